@@ -1,0 +1,123 @@
+"""Generate golden fixtures by running the REFERENCE's own Python (build container only).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Imports /root/reference/src/{models,utils_bc}.py (importable here: they only need torch/numpy)
+and torch.optim.RMSprop / LambdaLR / clip_grad_norm_ exactly as main_bc_2.py:80-90,209-227 uses
+them.  Inputs and weights come from pvr_habitat_amd.synth (regenerable on the GPU box), so only
+OUTPUTS are stored.  /root/reference is never read by tests at run time.
+"""
+import os, sys, random
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+from src.models import PolicyNet, PolicyNetWithConv            # noqa: E402  (the reference)
+from src import utils_bc as ref_utils                          # noqa: E402
+from pvr_habitat_amd import synth                              # noqa: E402
+
+
+bc_inputs = synth.bc_batches
+conv_inputs = synth.bc_conv_batches
+
+
+def run_reference(model, sd, batches, max_epochs, lr=1e-4, alpha=0.99, eps=1e-5, clip=40.0):
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model.train()
+    optimizer = torch.optim.RMSprop(model.parameters(), lr=lr, momentum=0, eps=eps, alpha=alpha)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: 1 - e / max_epochs)
+    obs, done, act = batches
+    rec = dict(loss=[], grad_norm=[], logits=[])
+    for s in range(obs.shape[0]):
+        o, d, a = torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s])
+        state = model.initial_state(batch_size=o.shape[1])
+        output, _ = model(dict(obs=o, done=d), state)
+        loss = F.nll_loss(F.log_softmax(torch.flatten(output['policy_logits'], 0, 1), dim=-1),
+                          target=torch.flatten(a, 0, 1).long())
+        scheduler.step()
+        optimizer.zero_grad()
+        loss.backward()
+        gn = 0.
+        for p in model.parameters():
+            if p.grad is not None and p.requires_grad:
+                gn += p.grad.detach().data.norm(2).item() ** 2
+        nn.utils.clip_grad_norm_(model.parameters(), clip)
+        optimizer.step()
+        rec['loss'].append(loss.item()); rec['grad_norm'].append(gn ** 0.5)
+        rec['logits'].append(output['policy_logits'].detach().numpy().copy())
+    # eval-mode forward (argmax branch, models.py:82) on the first batch with carried state
+    model.eval()
+    with torch.no_grad():
+        o, d = torch.from_numpy(obs[0]), torch.from_numpy(done[0])
+        out, st = model(dict(obs=o, done=d), model.initial_state(o.shape[1]))
+    rec['eval_logits'] = out['policy_logits'].numpy()
+    rec['eval_action'] = out['action'].numpy()
+    rec['eval_baseline'] = out['baseline'].numpy()
+    rec['eval_h'] = st[0].numpy(); rec['eval_c'] = st[1].numpy()
+    final = model.state_dict()
+    rec['param_sum'] = {k: float(v.double().sum()) for k, v in final.items()}
+    rec['param_sq'] = {k: float((v.double() ** 2).sum()) for k, v in final.items()}
+    return rec, {k: v.numpy() for k, v in final.items()}
+
+
+def save(name, rec, extra=None, keep_params=None):
+    flat = dict(loss=np.array(rec['loss']), grad_norm=np.array(rec['grad_norm']),
+                logits=np.stack(rec['logits']).astype(np.float32),
+                eval_logits=rec['eval_logits'], eval_action=rec['eval_action'],
+                eval_baseline=rec['eval_baseline'], eval_h=rec['eval_h'], eval_c=rec['eval_c'],
+                param_keys=np.array(list(rec['param_sum'].keys())),
+                param_sum=np.array(list(rec['param_sum'].values())),
+                param_sq=np.array(list(rec['param_sq'].values())))
+    if keep_params:
+        for k, v in keep_params.items():
+            flat['final/' + k] = v
+    if extra:
+        flat.update(extra)
+    np.savez_compressed(os.path.join(HERE, name), **flat)
+    print('wrote', name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in flat.items() if not k.startswith('final/')})
+
+
+def main():
+    torch.manual_seed(1); random.seed(1); np.random.seed(1)
+    torch.set_num_threads(8)
+    A = 3
+    # (1) tiny case, full tensors: T=5, B=2, obs=64, BN on
+    T, B, O, S = 5, 2, 64, 3
+    sd = synth.policy_state_dict(1, O, A, True)
+    rec, final = run_reference(PolicyNet((O,), A, True), sd, bc_inputs(1, T, B, O, A, S), max_epochs=10)
+    small = {k: final[k] for k in ('fc.1.bias', 'policy.weight', 'policy.bias', 'core.bias_hh_l1', 'fc.0.running_mean', 'fc.0.running_var')}
+    save('policy_small_bn.npz', rec, dict(T=T, B=B, O=O, A=A, steps=S, max_epochs=10), keep_params=small)
+    # (2) tiny case without BN (fc indices shift to fc.0 / fc.2)
+    sd = synth.policy_state_dict(2, O, A, False)
+    rec, final = run_reference(PolicyNet((O,), A, False), sd, bc_inputs(2, T, B, O, A, S), max_epochs=10)
+    save('policy_small_nobn.npz', rec, dict(T=T, B=B, O=O, A=A, steps=S, max_epochs=10),
+         keep_params={k: final[k] for k in ('fc.0.bias', 'policy.weight')})
+    # (3) the swept configuration: T=100, B=16, obs=4096 (2 x 2048), BN on (slurm_bc.py:121-128)
+    T, B, O, S = 100, 16, 4096, 3
+    sd = synth.policy_state_dict(1, O, A, True)
+    rec, final = run_reference(PolicyNet((O,), A, True), sd, bc_inputs(1, T, B, O, A, S), max_epochs=1000)
+    save('policy_full_bn.npz', rec, dict(T=T, B=B, O=O, A=A, steps=S, max_epochs=1000),
+         keep_params={k: final[k] for k in ('policy.weight', 'policy.bias', 'fc.1.bias')})
+    # (4) PolicyNetWithConv (finetune), tiny: T=4, B=2, 64x64x6 uint8
+    T, B, S = 4, 2, 2
+    sd = synth.policy_state_dict(3, 256, A, True, conv=True)
+    rec, final = run_reference(PolicyNetWithConv((64, 64, 6), A, True), sd, conv_inputs(3, T, B, S, A), max_epochs=10)
+    save('policy_conv_small.npz', rec, dict(T=T, B=B, A=A, steps=S, max_epochs=10),
+         keep_params={k: final[k] for k in ('feat_extract.0.bias', 'feat_extract.8.bias', 'policy.weight')})
+    # (5) sample_with_minimum_distance (utils_bc.py:24-29) under random.seed(1)
+    random.seed(1)
+    draws = [ref_utils.sample_with_minimum_distance(n=5000, k=16, d=100) for _ in range(3)]
+    random.seed(7)
+    draws2 = [ref_utils.sample_with_minimum_distance(n=40, k=4, d=10) for _ in range(3)]
+    ess = [[e, bool(ref_utils.is_essential_save(e, 12500, 200))] for e in range(0, 12500, 97)]
+    np.savez_compressed(os.path.join(HERE, 'sampler.npz'), seed1_n5000_k16_d100=np.array(draws),
+                        seed7_n40_k4_d10=np.array(draws2), essential=np.array(ess))
+    print('sampler', draws[0][:6])
+
+
+if __name__ == '__main__':
+    main()
