@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec embedded by the frozen ResNet50 (MoCo-v2 layout) PVR encoder.
+
+BASELINE.json metric "frames/sec embedded (ResNet50, 256x256)", workload = configs[1]:
+ResNet50 MoCo-v2 frozen, 256x256 uint8 frames, batch 256, bf16, synthetic frames + synthetic weights
+(no network).  A step = one pass of the hot path (resize/crop/normalise + 53 convs + pool) over one
+batch of 256 frames that is already resident in HBM.  Frames shard across ranks with no collective
+(SURVEY 8e): weak scaling, value = frames all ranks embedded / max-over-ranks time.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_FRAME = 8.174           # 2 x 4.0871 GMAC, 53 convs @ 224x224
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sd, frames_u8, budget_s=12.0):
+    """The oracle (torch fp32 eager restatement of the reference path) timed on this box's host cores,
+    batch 64 like the reference's 32 obs x 2 frames (save_embedded_obs.py:151-153)."""
+    from oracle import encoder_oracle as eo
+    torch.set_num_threads(os.cpu_count() or 1)
+    eo.embed(sd, frames_u8[:8], 'conv5')                      # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        eo.embed(sd, frames_u8[:64], 'conv5')
+        done += 64
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 64 * 8:
+            break
+    return dict(value=round(done / el, 2), unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d synthetic 256x256 frames in batches of 64, torch fp32 eager oracle, %.1f s' % (done, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--frame', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from pvr_habitat_amd import synth, _lib
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(1, 'conv5')               # MoCo-v2 encoder_q layout == torchvision resnet50
+    model = HipResNet50(sd, 'conv5', compute_dtype=args.dtype, max_batch=args.batch, chunk=args.chunk)
+    # each rank owns its own shard of the frame stream (different seed = different frames)
+    frames_np = synth.frames(1 + rank, args.batch, args.frame, args.frame)
+    frames = torch.from_numpy(frames_np).cuda()
+    out = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.forward_into(frames, out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.forward_into(frames, out)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # roofline of the dominant kernel (conv_igemm): HIP events between launches on the launch stream
+    chunk = args.chunk if args.chunk else args.batch
+    cap = 128
+    op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
+    conv_ms, conv_fl, other_ms = 0.0, 0.0, 0.0
+    reps = 3
+    for _ in range(reps):
+        _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(frames.data_ptr()), chunk, args.frame, args.frame,
+                                                  C.c_void_p(out.data_ptr()), out.stride(0), _lib.stream_ptr(), op_ms, op_fl,
+                                                  cap, C.byref(n_ops)))
+        for i in range(n_ops.value):
+            if i >= 3 and op_fl[i] > 0:
+                conv_ms += op_ms[i]; conv_fl += op_fl[i]
+            else:
+                other_ms += op_ms[i]
+    n_conv = n_ops.value - 4
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    barrier()
+
+    if rank == 0:
+        fps = world * args.steps * args.batch / el
+        line = {
+            'metric': 'frames/sec embedded (ResNet50, 256x256)', 'value': round(fps, 1), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: ResNet50 (MoCo-v2 layout) frozen, %dx%d uint8 frames resident in HBM, batch %d/GPU, '
+                                   'random-init synthetic weights' % (args.frame, args.frame, args.batch),
+                       'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk,
+                       'parallelism': 'frame shards, no collective (dp%d)' % world},
+            'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'conv_igemm_kernel (all %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
+                         'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
+                         'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd, frames_np)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,137 @@
+/*
+ * pvr_hip.h — C-ABI of libpvr_hip.so: the MI355X (gfx950) implementation of the PVR-embedding
+ * and behavioural-cloning hot path of sparisi/pvr_habitat.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class surface of
+ * src/embeddings.py (EmbeddingNet, :339-402) and src/models.py (PolicyNet :13-89,
+ * PolicyNetWithConv :96-197) plus the training loop of main_bc_2.py:186-227.  Every entry
+ * point below names the reference code it replaces.  Plain C types only: raw device/host
+ * pointers, sizes, an opaque hipStream_t passed as void*.  Status return: 0 = OK, non-zero =
+ * error (message via pvr_last_error, thread-local).  Nothing throws across the ABI.
+ *
+ * Ownership: the caller owns every buffer it passes (PyTorch-ROCm tensors on the Python
+ * side); the library borrows pointers for the duration of the enqueue and owns only its
+ * repacked weights and activation workspace (freed in *_destroy).  All work is enqueued on
+ * the caller's stream; no hidden synchronisation on the forward/step paths.
+ */
+#ifndef PVR_HIP_H
+#define PVR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int pvr_status;
+#define PVR_OK 0
+#define PVR_ERR_INVALID 1
+#define PVR_ERR_MISSING_WEIGHT 2
+#define PVR_ERR_HIP 3
+#define PVR_ERR_STATE 4
+
+/* storage / MFMA input type of the encoder ("throughput" = bf16, "parity" = f16); accumulation
+ * is always fp32 */
+#define PVR_BF16 0
+#define PVR_F16 1
+#define PVR_F32 2
+
+/* encoder architectures */
+#define PVR_ARCH_RESNET50 0      /* torchvision resnet50, fc=Identity  -> 2048 (embeddings.py:118-120, moco.py:6-26) */
+#define PVR_ARCH_RESNET50_L4 1   /* + BasicBlock(2048->42), no avgpool  -> 2058 (moco.py:73-113, resnet.py:47-83)   */
+#define PVR_ARCH_RESNET50_L3 2   /* layer3 + BasicBlock(1024->11)       -> 2156 (moco.py:29-70,  resnet.py:6-44)    */
+
+const char *pvr_version(void);
+/* copies the calling thread's last error message; returns its length */
+size_t pvr_last_error(char *buf, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Frozen encoder: replaces EmbeddingNet.forward (src/embeddings.py:386-402) = H2D'd uint8 NHWC
+ * frames -> Resize(256)/CenterCrop(224)/ConvertImageDtype/Normalize (:80-85) -> ResNet50-family
+ * eval forward -> flatten, fp32 (N, out_size).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pvr_encoder pvr_encoder;
+
+typedef struct pvr_encoder_desc {
+    int32_t arch;          /* PVR_ARCH_* */
+    int32_t dtype;         /* PVR_BF16 or PVR_F16 */
+    int32_t max_batch;     /* frames per forward call the workspace is sized for */
+    int32_t chunk;         /* frames pushed through the layer stack at a time (0 = max_batch) */
+    int32_t resize;        /* short-side target, 256 (embeddings.py:81) */
+    int32_t crop;          /* centre crop, 224 (embeddings.py:82); must be 224 for ResNet50 */
+    float mean[3];         /* Normalize mean (embeddings.py:84) */
+    float std_[3];         /* Normalize std */
+} pvr_encoder_desc;
+
+pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out);
+/* Hand over one fp32 host tensor under its torchvision state_dict name ("conv1.weight",
+ * "layer1.0.bn1.running_var", ...; the nesting of moco.py's nn.Sequential(layer, BasicBlock) is
+ * accepted as "layer4.0.<i>...." / "layer4.1....").  Unknown names are kept but unused
+ * (load_state_dict(strict=False) semantics, moco.py:23). */
+pvr_status pvr_encoder_load_weights(pvr_encoder *enc, const char *name, const float *host_data,
+                                    const int64_t *shape, int32_t ndim);
+/* Fold BN (eps 1e-5) and the input normalisation into the conv weights, repack to K-major
+ * 16-bit tiles, upload, allocate the workspace.  Fails with PVR_ERR_MISSING_WEIGHT naming the
+ * first absent key (the reference asserts len(missing_keys)==0, moco.py:24). */
+pvr_status pvr_encoder_finalize(pvr_encoder *enc);
+int32_t pvr_encoder_out_size(const pvr_encoder *enc);
+/* frames_dev: uint8 (n,h,w,3) on the device; out_dev: fp32, row i written at
+ * out_dev + i*out_stride (elements), out_size values — pass an offset pointer to build the
+ * UberModel concat (embeddings.py:55-57) without a cat kernel. n <= max_batch. */
+pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h,
+                               int32_t w, float *out_dev, int64_t out_stride, void *hip_stream);
+/* debug/parity tap: copy an intermediate activation of the last forward, converted to fp32
+ * NHWC, into out_dev. name: "pre","stem","pool","layer1".."layer4". Returns element count via *count. */
+pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out_dev, int64_t cap,
+                           int64_t *count, void *hip_stream);
+/* debug: make pvr_encoder_forward return right after the named tap has been produced (NULL/"" = off) */
+pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap);
+/* Instrumented forward of one chunk (n <= chunk): HIP events between launches on the caller's stream;
+ * synchronises.  op_ms[i] = duration of launch i (preprocess, stem, maxpool, convs..., pool/flatten),
+ * op_flops[i] = its algorithmic FLOPs (0 for byte kernels).  Used by bench.py's roofline block. */
+pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w,
+                               float *out_dev, int64_t out_stride, void *hip_stream, float *op_ms,
+                               double *op_flops, int32_t cap, int32_t *n_ops);
+void pvr_encoder_destroy(pvr_encoder *enc);
+
+/* ---------------------------------------------------------------------------------------------
+ * Single operators (unit-parity entry points; the encoder is built from these kernels).
+ * dtype = PVR_BF16 / PVR_F16 for activations and weights.
+ * ------------------------------------------------------------------------------------------- */
+/* transforms (embeddings.py:80-85) up to and including the uint8 crop; output is the stem's input
+ * image: (n, crop+6, crop+8, 4) 16-bit, pixel (y,x) at [y+3][x+3], channels (R,G,B,valid) holding the
+ * exact uint8 values (normalisation is folded into the stem weights), zero border. */
+pvr_status pvr_op_preprocess(const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, int32_t resize,
+                             int32_t crop, void *out_dev, int32_t dtype, void *hip_stream);
+/* conv1 7x7/2 + folded BN + ReLU on the padded image above. wgt: (64, 7*8*4) 16-bit, bias fp32(64).
+ * out: (n,112,112,64) NHWC 16-bit */
+pvr_status pvr_op_stem(const void *img_dev, const void *wgt_dev, const float *bias_dev, void *out_dev,
+                       int32_t n, int32_t dtype, void *hip_stream);
+/* maxpool 3x3/2 pad 1 on NHWC 16-bit */
+pvr_status pvr_op_maxpool(const void *in_dev, void *out_dev, int32_t n, int32_t h, int32_t w, int32_t c,
+                          int32_t dtype, void *hip_stream);
+/* implicit-GEMM convolution, NHWC, + bias (+ residual) (+ ReLU).  wgt: (cout_pad, kh*kw*cin) 16-bit,
+ * K index = (kh*KW+kw)*cin + c, cin % 64 == 0, cout_pad = cout rounded up to 64 (zero rows).
+ * out: (n,ho,wo,cout) 16-bit, or fp32 if out_f32. */
+pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *bias_dev,
+                         const void *residual_dev, void *out_dev, int32_t n, int32_t h, int32_t w,
+                         int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                         int32_t relu, int32_t out_f32, int32_t dtype, void *hip_stream);
+/* global average pool of NHWC (16-bit or fp32) -> fp32 rows at out + i*out_stride */
+pvr_status pvr_op_avgpool(const void *in_dev, float *out_dev, int64_t out_stride, int32_t n, int32_t hw,
+                          int32_t c, int32_t in_f32, int32_t dtype, void *hip_stream);
+
+/* host-only: the fp32 -> bf16/f16 round-to-nearest-even conversion finalize() applies to weights */
+pvr_status pvr_debug_convert(const float *src, uint16_t *dst, int64_t n, int32_t dtype);
+
+/* ---------------------------------------------------------------------------------------------
+ * BC policy: PolicyNet / PolicyNetWithConv forward (src/models.py:57-89,159-197) and one training
+ * iteration of main_bc_2.py:206-227 (loss, BPTT, grad-norm, clip, RMSprop with LambdaLR).  fp32.
+ * Declared in pvr_policy.h.
+ * ------------------------------------------------------------------------------------------- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVR_HIP_H */

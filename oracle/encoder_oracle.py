@@ -135,6 +135,7 @@ def resnet50_features(sd, x, variant='conv5', q=None, taps=None):
     stem = F.relu(_conv_bn(sd, 'conv1', 'bn1', x, 2, 3, q=None if q is None else q))
     x = F.max_pool2d(_q(stem, q), 3, 2, 1)
     if taps is not None:
+        taps['conv1'] = stem
         taps['stem'] = x
     stages = 4 if variant in ('conv5', 'conv4') else 3
     for li in range(stages):

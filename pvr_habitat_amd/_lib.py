@@ -1,0 +1,79 @@
+"""ctypes binding of libpvr_hip.so (include/pvr_hip.h).  No CPU fallback: if the library is
+missing the import of the product path fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpvr_hip.so')
+
+PVR_BF16, PVR_F16, PVR_F32 = 0, 1, 2
+ARCH_RESNET50, ARCH_RESNET50_L4, ARCH_RESNET50_L3 = 0, 1, 2
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [('arch', C.c_int32), ('dtype', C.c_int32), ('max_batch', C.c_int32), ('chunk', C.c_int32),
+                ('resize', C.c_int32), ('crop', C.c_int32), ('mean', C.c_float * 3), ('std_', C.c_float * 3)]
+
+
+_lib = None
+
+_SIGS = {
+    'pvr_version': (C.c_char_p, []),
+    'pvr_last_error': (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    'pvr_encoder_create': (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(C.c_void_p)]),
+    'pvr_encoder_load_weights': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    'pvr_encoder_finalize': (C.c_int, [C.c_void_p]),
+    'pvr_encoder_out_size': (C.c_int32, [C.c_void_p]),
+    'pvr_encoder_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    'pvr_encoder_tap': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    'pvr_encoder_debug_stop_after': (C.c_int, [C.c_void_p, C.c_char_p]),
+    'pvr_encoder_destroy': (None, [C.c_void_p]),
+    'pvr_encoder_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    'pvr_op_preprocess': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    'pvr_op_stem': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'pvr_op_maxpool': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    'pvr_op_conv2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_void_p]),
+    'pvr_op_avgpool': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    'pvr_debug_convert': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+}
+
+
+def lib():
+    """The loaded library (raises if it has not been built: run `python __graft_entry__.py build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError('libpvr_hip.so not found at %s: build it with `make -C pvr_habitat_amd/csrc` '
+                               '(there is no CPU fallback for the HIP path)' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            if not hasattr(l, name):
+                continue                      # optional groups (policy) are bound by their own modules
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(1024)
+    lib().pvr_last_error(buf, 1024)
+    return buf.value.decode(errors='replace')
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError('libpvr_hip: %s (status %d)' % (last_error(), status))
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('pvr_habitat_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU path')

@@ -1,0 +1,98 @@
+// C-ABI glue: error state, version, single-operator entry points (include/pvr_hip.h).
+#include <stdarg.h>
+#include "common.h"
+
+namespace pvr {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const std::string &last_error() { return g_err; }
+
+pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
+pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
+pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
+pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
+pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
+                       int, int, int, int, int, int, int, int, hipStream_t);
+
+static void *g_zero = nullptr;
+static pvr_status zero_page(void **out) {
+    if (!g_zero) {
+        PVR_HIP_TRY(hipMalloc(&g_zero, 256));
+        PVR_HIP_TRY(hipMemset(g_zero, 0, 256));
+    }
+    *out = g_zero;
+    return PVR_OK;
+}
+
+}  // namespace pvr
+
+using namespace pvr;
+
+extern "C" {
+
+const char *pvr_version(void) { return "pvr_hip 0.1.0 (gfx950)"; }
+
+size_t pvr_last_error(char *buf, size_t cap) {
+    const std::string &e = last_error();
+    if (buf && cap) {
+        size_t n = e.size() < cap - 1 ? e.size() : cap - 1;
+        memcpy(buf, e.data(), n);
+        buf[n] = 0;
+    }
+    return e.size();
+}
+
+pvr_status pvr_op_preprocess(const uint8_t *frames, int32_t n, int32_t h, int32_t w, int32_t resize, int32_t crop,
+                             void *out, int32_t dtype, void *stream) {
+    PVR_REQUIRE(frames && out, "pvr_op_preprocess: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    PVR_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n * (crop + 6) * (crop + 8) * 4 * 2, st));
+    return launch_preprocess(frames, n, h, w, resize, crop, out, dtype, st);
+}
+
+pvr_status pvr_op_stem(const void *img, const void *wgt, const float *bias, void *out, int32_t n, int32_t dtype,
+                       void *stream) {
+    PVR_REQUIRE(img && wgt && bias && out, "pvr_op_stem: null pointer");
+    return launch_stem(img, wgt, bias, out, n, 224, dtype, (hipStream_t)stream);
+}
+
+pvr_status pvr_op_maxpool(const void *in, void *out, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                          void *stream) {
+    PVR_REQUIRE(in && out, "pvr_op_maxpool: null pointer");
+    return launch_maxpool(in, out, n, h, w, c, dtype, (hipStream_t)stream);
+}
+
+pvr_status pvr_op_conv2d(const void *in, const void *wgt, const float *bias, const void *residual, void *out, int32_t n,
+                         int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                         int32_t pad, int32_t relu, int32_t out_f32, int32_t dtype, void *stream) {
+    PVR_REQUIRE(in && wgt && bias && out, "pvr_op_conv2d: null pointer");
+    void *z;
+    pvr_status s = zero_page(&z);
+    if (s) return s;
+    return launch_conv(in, wgt, bias, residual, out, z, n, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, dtype,
+                       (hipStream_t)stream);
+}
+
+pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_t n, int32_t hw, int32_t c, int32_t in_f32,
+                          int32_t dtype, void *stream) {
+    PVR_REQUIRE(in && out, "pvr_op_avgpool: null pointer");
+    return launch_avgpool(in, out, out_stride, n, hw, c, in_f32, dtype, (hipStream_t)stream);
+}
+
+// host-only helper used by the CPU tests: the weight conversion finalize() applies
+pvr_status pvr_debug_convert(const float *src, uint16_t *dst, int64_t n, int32_t dtype) {
+    PVR_REQUIRE(src && dst, "pvr_debug_convert: null pointer");
+    for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_h(src[i], dtype);
+    return PVR_OK;
+}
+
+}  // extern "C"

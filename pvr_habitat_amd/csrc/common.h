@@ -1,0 +1,111 @@
+// Shared host/device helpers for libpvr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "../../include/pvr_hip.h"
+
+namespace pvr {
+
+// ---- error plumbing (thread-local message, integer status across the ABI) -------------------
+void set_error(const char *fmt, ...);
+const std::string &last_error();
+
+#define PVR_HIP_TRY(expr)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            pvr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                           __LINE__);                                                          \
+            return PVR_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define PVR_LAUNCH_CHECK()                                                                     \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e != hipSuccess) {                                                                \
+            pvr::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),          \
+                           __FILE__, __LINE__);                                                \
+            return PVR_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define PVR_REQUIRE(cond, ...)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            pvr::set_error(__VA_ARGS__);                                                       \
+            return PVR_ERR_INVALID;                                                            \
+        }                                                                                      \
+    } while (0)
+
+// ---- 16-bit storage types --------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// host-side round-to-nearest-even conversions (weights are converted once at finalize)
+inline u16 f32_to_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+inline u16 f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (u16)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (u16)(sign | 0x7c00u);  // overflow -> inf (after rounding)
+    if (x < 0x38800000u) {                               // subnormal / zero in f16
+        if (x < 0x33000000u) return (u16)sign;
+        int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        int shift = 126 - e;                             // 14..24
+        uint32_t r = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) r++;
+        return (u16)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (u16)(sign | r);
+}
+inline u16 f32_to_h(float f, int dtype) { return dtype == PVR_F16 ? f32_to_f16_bits(f) : f32_to_bf16_bits(f); }
+
+// ---- device helpers --------------------------------------------------------------------------
+template <bool F16> struct HT;
+template <> struct HT<false> { typedef bf16_t T; typedef bf16x8 V8; };
+template <> struct HT<true> { typedef f16_t T; typedef f16x8 V8; };
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(typename HT<F16>::V8 a, typename HT<F16>::V8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool F16> __device__ __forceinline__ u16 to_h(float v) {
+    typename HT<F16>::T t = (typename HT<F16>::T)v;
+    return __builtin_bit_cast(u16, t);
+}
+template <bool F16> __device__ __forceinline__ float from_h(u16 b) {
+    return (float)__builtin_bit_cast(typename HT<F16>::T, b);
+}
+
+// bijective XCD-aware block remap (cdna_hip_programming.md, 256^2 template): blocks b and b+8 share
+// an XCD; give every XCD a contiguous run of tiles so neighbouring tiles share operand panels in L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace pvr

@@ -1,0 +1,244 @@
+// K5/K6/K7/K9: NHWC implicit-GEMM convolution on MFMA with fused bias (folded BN),
+// residual add and ReLU.  Serves every 1x1 and 3x3 convolution of the ResNet50 family
+// (torchvision Bottleneck / BasicBlock reached from reference src/embeddings.py:118-120,
+// src/vision_models/moco.py:11,34-50,78-94).
+//
+// GEMM view:  out[m][co] = sum_k  X[m][k] * W[co][k],   m = (n,ho,wo),  k = (kh,kw,c)
+//   * Cin % 64 == 0, so a BK=64 K-slice is ONE filter tap and 64 contiguous channels = 128 B
+//     contiguous in NHWC: no im2col, every staging load is a full 16-B lane load.
+//   * zero padding / tile tails read a 256-B zero page instead of branching.
+//   * LDS tiles are [rows][64] 16-bit (128-B rows), XOR-swizzled on the 16-B chunk index
+//     (chunk ^= (row>>1)&7) so the ds_read_b128 fragment reads are bank-conflict-free.
+//   * MFMA 16x16x32 (bf16 or f16 inputs, fp32 accumulate) with the WEIGHTS as the A operand, so a
+//     lane's 4 accumulator registers are 4 consecutive output channels of one pixel -> 8-B NHWC stores
+//     and 8-B residual loads.
+//   * 2-stage software pipeline: global loads for K-slice t+1 are issued before the MFMAs of slice t
+//     and written to the other LDS buffer after them (one barrier per slice).
+//   * block -> tile map is XCD-aware: consecutive tiles on one XCD share the activation rows (L2 reuse).
+#include "common.h"
+
+namespace pvr {
+
+struct ConvP {
+    const u16 *in;
+    const u16 *wgt;
+    const float *bias;
+    const u16 *res;
+    void *out;
+    const u16 *zero;      // >= 256 B of zeros
+    int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
+    int M, K;
+    int relu, out_f32;
+    int m_tiles, n_tiles;
+};
+
+template <int BM, int BN, bool F16>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int BK = 64;
+    constexpr int A_CH = BM / 32;                 // 16-B chunks per thread, activation tile
+    constexpr int B_CH = BN / 32;                 // 16-B chunks per thread, weight tile
+    constexpr int TM = BM / 32;                   // 16-pixel tiles per wave (2x2 waves)
+    constexpr int TN = BN / 32;                   // 16-cout tiles per wave
+    constexpr int STAGE = (BM + BN) * 128;        // bytes per pipeline stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = swz % p.n_tiles, tm = swz / p.n_tiles;
+    const int m0 = tm * BM, co0 = tn * BN;
+
+    // ---- staging assignment: chunk q = tid + 256*i -> LDS (row = q>>3, physical chunk = q&7) -------
+    const int srow = tid >> 3;                    // 0..31 (+32*i)
+    const int pch = tid & 7;
+    const u16 *a_base[A_CH];                      // pointer at tap (0,0), logical chunk applied
+    int a_hi0[A_CH], a_wi0[A_CH];
+    bool a_ok[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int row = srow + 32 * i;
+        const int lch = pch ^ ((row >> 1) & 7);   // logical chunk stored at this physical slot
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int wo = mm % p.Wo;
+        const int t = mm / p.Wo;
+        const int ho = t % p.Ho;
+        const int n = t / p.Ho;
+        a_hi0[i] = ho * p.stride - p.pad;
+        a_wi0[i] = wo * p.stride - p.pad;
+        a_base[i] = p.in + (((int64_t)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + lch * 8;
+    }
+    const u16 *b_base[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int row = srow + 32 * i;
+        const int lch = pch ^ ((row >> 1) & 7);
+        const int co = co0 + row;
+        b_ok[i] = co < p.CoutPad;
+        b_base[i] = p.wgt + (int64_t)(b_ok[i] ? co : 0) * p.K + lch * 8;
+    }
+    const int lds_st = srow * 128 + pch * 16;     // + 32*i*128 ; B tile after A tile
+
+    u32x4 ra[A_CH], rb[B_CH];                     // native vectors: HIP's uint4 struct went to scratch
+    const int cpt = p.Cin / BK;                   // K-slices per filter tap
+    const int nk = p.KH * p.KW * cpt;
+
+    int kh = 0, kw = 0, cs = 0;                   // position of the slice being LOADED
+    // (macros, not lambdas: by-reference lambda captures sent ra/rb to scratch memory)
+#define PVR_LOAD_SLICE(kt_)                                                                             \
+    {                                                                                                   \
+        const int tap_off = (kh * p.W + kw) * p.Cin + cs * BK;                                          \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                              \
+            const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                           \
+            const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;    \
+            const u16 *src = ok ? a_base[i] + tap_off : p.zero;                                         \
+            ra[i] = *reinterpret_cast<const u32x4 *>(src);                                              \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                              \
+            const u16 *src = b_ok[i] ? b_base[i] + (kt_) * BK : p.zero;                                 \
+            rb[i] = *reinterpret_cast<const u32x4 *>(src);                                              \
+        }                                                                                               \
+        if (++cs == cpt) { cs = 0; if (++kw == p.KW) { kw = 0; ++kh; } }                                \
+    }
+#define PVR_STORE_SLICE(buf_)                                                                           \
+    {                                                                                                   \
+        char *base = smem + (buf_) * STAGE + lds_st;                                                    \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + i * 32 * 128) = ra[i];                                    \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + BM * 128 + i * 32 * 128) = rb[i];                         \
+    }
+
+    // ---- wave tiling: 2x2 waves; wave (wm, wn) owns pixels [wm*BM/2,+BM/2) x couts [wn*BN/2,+BN/2) ----
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_rd[TM], b_rd[TN];                       // byte offsets of this lane's fragment rows
+    int a_sw[TM], b_sw[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int row = wm * (BM / 2) + j * 16 + fr;
+        a_rd[j] = row * 128;
+        a_sw[j] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * (BN / 2) + i * 16 + fr;
+        b_rd[i] = BM * 128 + row * 128;
+        b_sw[i] = (row >> 1) & 7;
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PVR_LOAD_SLICE(0);
+    PVR_STORE_SLICE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) PVR_LOAD_SLICE(kt + 1);
+        const char *sb = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 xa[TM], wb[TN];
+            const int lch = ks * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                xa[j] = *reinterpret_cast<const V8 *>(sb + a_rd[j] + ((lch ^ a_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                wb[i] = *reinterpret_cast<const V8 *>(sb + b_rd[i] + ((lch ^ b_sw[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = mfma16<F16>(wb[i], xa[j], acc[i][j]);
+        }
+        if (more) PVR_STORE_SLICE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#undef PVR_LOAD_SLICE
+#undef PVR_STORE_SLICE
+
+    // ---- epilogue: D row = 4*fq + reg = cout offset, D col = fr = pixel -------------------------------
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int co = co0 + wn * (BN / 2) + i * 16 + fq * 4;
+        if (co >= p.Cout) continue;
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * (BM / 2) + j * 16 + fr;
+            if (m >= p.M) continue;
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
+            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            const size_t o = (size_t)m * p.Cout + co;
+            if (p.res) {
+                const ushort4 r = *reinterpret_cast<const ushort4 *>(p.res + o);
+                v0 += from_h<F16>(r.x); v1 += from_h<F16>(r.y); v2 += from_h<F16>(r.z); v3 += from_h<F16>(r.w);
+            }
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            if (p.out_f32) {
+                *reinterpret_cast<float4 *>((float *)p.out + o) = make_float4(v0, v1, v2, v3);
+            } else {
+                ushort4 r;
+                r.x = to_h<F16>(v0); r.y = to_h<F16>(v1); r.z = to_h<F16>(v2); r.w = to_h<F16>(v3);
+                *reinterpret_cast<ushort4 *>((u16 *)p.out + o) = r;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static pvr_status launch_cfg(ConvP &p, int dtype, hipStream_t stream) {
+    p.m_tiles = (p.M + BM - 1) / BM;
+    p.n_tiles = (p.Cout + BN - 1) / BN;
+    const int grid = p.m_tiles * p.n_tiles;
+    const size_t lds = 2 * (BM + BN) * 128;
+    if (dtype == PVR_F16) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), dim3(grid), dim3(256), lds, stream, p);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), dim3(grid), dim3(256), lds, stream, p);
+    }
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const void *res, void *out, const void *zero,
+                       int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
+                       int out_f32, int dtype, hipStream_t stream) {
+    PVR_REQUIRE(cin % 64 == 0, "conv: cin %d not a multiple of 64", cin);
+    PVR_REQUIRE(cout % 4 == 0, "conv: cout %d not a multiple of 4", cout);
+    PVR_REQUIRE(zero != nullptr, "conv: zero page missing");
+    ConvP p;
+    p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;
+    p.zero = (const u16 *)zero;
+    p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
+    p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (h + 2 * pad - kh) / stride + 1;
+    p.Wo = (w + 2 * pad - kw) / stride + 1;
+    const int64_t M = (int64_t)n * p.Ho * p.Wo;
+    PVR_REQUIRE(M < (1ll << 31) && (int64_t)M * cout < (1ll << 40), "conv: problem too large");
+    p.M = (int)M; p.K = kh * kw * cin;
+    p.relu = relu; p.out_f32 = out_f32;
+    if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
+    return launch_cfg<128, 128>(p, dtype, stream);
+}
+
+}  // namespace pvr

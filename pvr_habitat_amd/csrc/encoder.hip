@@ -1,0 +1,420 @@
+// Frozen-encoder plan: ResNet50 family (conv5 / l4-compressed / l3-compressed) as a static list of
+// fused launches over a pre-allocated HBM workspace.
+//
+// Replaces: reference src/embeddings.py:386-402 (EmbeddingNet.forward), the model construction at
+// src/vision_models/moco.py:6-113 and resnet.py:6-104 (topology edits), and torchvision's
+// ResNet._forward_impl.  Weight names are torchvision's (SURVEY 8a "State-dict keys").
+//
+// Host-side work done once in finalize():
+//   * BN eval fold:  scale = gamma / sqrt(var + 1e-5),  W' = W*scale,  b' = beta - mean*scale (+ scale*conv_bias)
+//   * stem: Normalize + /255 folded into conv1 (see stem.hip), K laid out (kh, kw[8], c[4])
+//   * OIHW fp32 -> [cout_pad][kh][kw][cin_pad] 16-bit (bf16 or f16), zero padded
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include "common.h"
+
+namespace pvr {
+
+pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
+pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
+pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
+pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
+pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
+pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);
+pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
+                       int, int, int, int, int, int, int, int, hipStream_t);
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT };
+
+struct ConvOp {
+    std::string conv, bn;          // state_dict prefixes
+    int in_buf, out_buf, res_buf;
+    int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
+    u16 *d_w = nullptr;
+    float *d_b = nullptr;
+    std::string tap;               // non-empty: output of this op is the named tap
+};
+
+}  // namespace pvr
+
+using namespace pvr;
+
+struct pvr_encoder {
+    pvr_encoder_desc desc;
+    std::map<std::string, HostTensor> weights;
+    std::vector<ConvOp> ops;
+    bool finalized = false;
+    int out_size = 0;
+    int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation
+    // device
+    u16 *d_img = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_stem_w = nullptr, *d_zero = nullptr;
+    float *d_stem_b = nullptr;
+    void *d_buf[B_COUNT] = {nullptr};
+    size_t buf_elems = 0;
+    int last_n = 0;
+    std::string stop_after;                                          // debug: end the forward after this tap
+    std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
+};
+
+namespace pvr {
+
+static void add_conv(pvr_encoder *e, const std::string &conv, const std::string &bn, int in_buf, int out_buf,
+                     int res_buf, int h, int w, int cin, int cin_real, int cout, int cout_real, int k, int stride,
+                     int relu, int out_f32 = 0) {
+    ConvOp op;
+    op.conv = conv; op.bn = bn; op.in_buf = in_buf; op.out_buf = out_buf; op.res_buf = res_buf;
+    op.h = h; op.w = w; op.cin = cin; op.cin_real = cin_real; op.cout = cout; op.cout_real = cout_real;
+    op.k = k; op.stride = stride; op.pad = k / 2; op.relu = relu; op.out_f32 = out_f32;
+    e->ops.push_back(op);
+}
+
+// torchvision resnet50 v1.5: layers [3,4,6,3], stride on the 3x3 (conv2), downsample on block 0
+static void build_resnet50(pvr_encoder *e) {
+    const int arch = e->desc.arch;
+    const int stages = arch == PVR_ARCH_RESNET50_L3 ? 3 : 4;
+    const int nblk[4] = {3, 4, 6, 3};
+    int hw = 56, inpl = 64, x = B_X0;
+    for (int li = 0; li < stages; ++li) {
+        const int planes = 64 << li;
+        const bool nested = (arch == PVR_ARCH_RESNET50_L4 && li == 3) || (arch == PVR_ARCH_RESNET50_L3 && li == 2);
+        for (int bi = 0; bi < nblk[li]; ++bi) {
+            char pfx[64];
+            if (nested) snprintf(pfx, sizeof pfx, "layer%d.0.%d", li + 1, bi);
+            else snprintf(pfx, sizeof pfx, "layer%d.%d", li + 1, bi);
+            const std::string p = pfx;
+            const int stride = (bi == 0 && li > 0) ? 2 : 1;
+            const int ohw = hw / stride;
+            const int y = x == B_X0 ? B_X1 : B_X0;
+            const bool last = (li == stages - 1 && bi == nblk[li] - 1);
+            add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
+            add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_T2, B_NONE, hw, hw, planes, planes, planes, planes, 3, stride, 1);
+            int res = x;
+            if (bi == 0) {
+                add_conv(e, p + ".downsample.0", p + ".downsample.1", x, B_DS, B_NONE, hw, hw, inpl, inpl, planes * 4,
+                         planes * 4, 1, stride, 0);
+                res = B_DS;
+            }
+            // the trunk's last block feeds avgpool: keep fp32 (conv5 variant only)
+            const int f32 = (last && arch == PVR_ARCH_RESNET50) ? 1 : 0;
+            add_conv(e, p + ".conv3", p + ".bn3", B_T2, f32 ? B_F32 : y, res, ohw, ohw, planes, planes, planes * 4,
+                     planes * 4, 1, 1, 1, f32);
+            if (bi == nblk[li] - 1) {
+                char tn[16]; snprintf(tn, sizeof tn, "layer%d", li + 1);
+                e->ops.back().tap = tn;
+                e->taps[tn] = {f32 ? B_F32 : y, {ohw, ohw, planes * 4, f32}};
+            }
+            x = y; hw = ohw; inpl = planes * 4;
+        }
+    }
+    if (arch == PVR_ARCH_RESNET50) {
+        e->out_size = 2048; e->final_hw = 49; e->final_c = 2048; e->final_creal = 2048;
+        return;
+    }
+    // compression head: BasicBlock(C -> c) with a conv3x3(+bias)+BN downsample (moco.py:35-50 / 79-94)
+    const int cin = arch == PVR_ARCH_RESNET50_L3 ? 1024 : 2048;
+    const int c = arch == PVR_ARCH_RESNET50_L3 ? 11 : 42;
+    const std::string p = arch == PVR_ARCH_RESNET50_L3 ? "layer3.1" : "layer4.1";
+    add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, cin, cin, 64, c, 3, 1, 1);
+    add_conv(e, p + ".downsample.0", p + ".downsample.1", x, B_DS, B_NONE, hw, hw, cin, cin, 64, c, 3, 1, 0);
+    add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_F32, B_DS, hw, hw, 64, c, 64, c, 3, 1, 1, 1);
+    e->out_size = c * hw * hw; e->final_hw = hw * hw; e->final_c = 64; e->final_creal = c;
+}
+
+static const HostTensor *find(pvr_encoder *e, const std::string &name) {
+    auto it = e->weights.find(name);
+    return it == e->weights.end() ? nullptr : &it->second;
+}
+
+static pvr_status need(pvr_encoder *e, const std::string &name, const HostTensor **out, size_t numel) {
+    const HostTensor *t = find(e, name);
+    if (!t) { set_error("missing weight: %s", name.c_str()); return PVR_ERR_MISSING_WEIGHT; }
+    if (t->data.size() != numel) {
+        set_error("weight %s has %zu elements, expected %zu", name.c_str(), t->data.size(), numel);
+        return PVR_ERR_INVALID;
+    }
+    *out = t;
+    return PVR_OK;
+}
+
+static pvr_status bn_fold(pvr_encoder *e, const std::string &bn, int c, std::vector<float> &scale,
+                          std::vector<float> &shift) {
+    const HostTensor *g, *b, *m, *v;
+    pvr_status s;
+    if ((s = need(e, bn + ".weight", &g, c))) return s;
+    if ((s = need(e, bn + ".bias", &b, c))) return s;
+    if ((s = need(e, bn + ".running_mean", &m, c))) return s;
+    if ((s = need(e, bn + ".running_var", &v, c))) return s;
+    scale.resize(c); shift.resize(c);
+    for (int i = 0; i < c; ++i) {
+        scale[i] = g->data[i] / sqrtf(v->data[i] + 1e-5f);
+        shift[i] = b->data[i] - m->data[i] * scale[i];
+    }
+    return PVR_OK;
+}
+
+template <typename T>
+static pvr_status upload(T **dptr, const std::vector<T> &h) {
+    PVR_HIP_TRY(hipMalloc((void **)dptr, h.size() * sizeof(T)));
+    PVR_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PVR_OK;
+}
+
+static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
+    const int k = op.k, cr = op.cin_real, cor = op.cout_real;
+    const HostTensor *w;
+    pvr_status s;
+    if ((s = need(e, op.conv + ".weight", &w, (size_t)cor * cr * k * k))) return s;
+    std::vector<float> scale, shift;
+    if ((s = bn_fold(e, op.bn, cor, scale, shift))) return s;
+    if (const HostTensor *cb = find(e, op.conv + ".bias")) {
+        if ((int)cb->data.size() != cor) { set_error("bad bias size for %s", op.conv.c_str()); return PVR_ERR_INVALID; }
+        for (int i = 0; i < cor; ++i) shift[i] += scale[i] * cb->data[i];
+    }
+    const int cout_pad = (op.cout + 63) / 64 * 64;
+    const size_t K = (size_t)k * k * op.cin;
+    std::vector<u16> hw(cout_pad * K, 0);
+    for (int co = 0; co < cor; ++co)
+        for (int ci = 0; ci < cr; ++ci)
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) {
+                    const float v = w->data[(((size_t)co * cr + ci) * k + a) * k + b] * scale[co];
+                    hw[co * K + ((size_t)a * k + b) * op.cin + ci] = f32_to_h(v, e->desc.dtype);
+                }
+    std::vector<float> hb(cout_pad, 0.f);
+    for (int co = 0; co < cor; ++co) hb[co] = shift[co];
+    if ((s = upload(&op.d_w, hw))) return s;
+    return upload(&op.d_b, hb);
+}
+
+static pvr_status finalize_stem(pvr_encoder *e) {
+    const HostTensor *w;
+    pvr_status s;
+    if ((s = need(e, "conv1.weight", &w, 64 * 3 * 7 * 7))) return s;
+    std::vector<float> scale, shift;
+    if ((s = bn_fold(e, "bn1", 64, scale, shift))) return s;
+    std::vector<u16> hw(64 * 224, 0);
+    for (int co = 0; co < 64; ++co)
+        for (int a = 0; a < 7; ++a)
+            for (int b = 0; b < 7; ++b) {
+                double vsum = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    const double wv = (double)w->data[(((size_t)co * 3 + c) * 7 + a) * 7 + b] * scale[co];
+                    // (x/255 - mean)/std = x * 1/(255*std) - mean/std
+                    hw[co * 224 + (a * 8 + b) * 4 + c] = f32_to_h((float)(wv / (255.0 * e->desc.std_[c])), e->desc.dtype);
+                    vsum -= wv * e->desc.mean[c] / e->desc.std_[c];
+                }
+                hw[co * 224 + (a * 8 + b) * 4 + 3] = f32_to_h((float)vsum, e->desc.dtype);
+            }
+    if ((s = upload(&e->d_stem_w, hw))) return s;
+    return upload(&e->d_stem_b, shift);
+}
+
+}  // namespace pvr
+
+extern "C" {
+
+pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
+    PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_RESNET50_L3, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16, "dtype must be PVR_BF16 or PVR_F16");
+    PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
+    PVR_REQUIRE(desc->crop == 224, "crop must be 224 for the ResNet50 family (reference embeddings.py:82)");
+    PVR_REQUIRE(desc->resize >= desc->crop, "resize must be >= crop");
+    pvr_encoder *e = new pvr_encoder();
+    e->desc = *desc;
+    if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
+    build_resnet50(e);
+    *out = e;
+    return PVR_OK;
+}
+
+pvr_status pvr_encoder_load_weights(pvr_encoder *enc, const char *name, const float *host_data, const int64_t *shape,
+                                    int32_t ndim) {
+    PVR_REQUIRE(enc && name && host_data, "pvr_encoder_load_weights: null argument");
+    PVR_REQUIRE(!enc->finalized, "encoder already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    enc->weights[name] = std::move(t);
+    return PVR_OK;
+}
+
+pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
+    PVR_REQUIRE(enc, "null encoder");
+    PVR_REQUIRE(!enc->finalized, "encoder already finalized");
+    pvr_status s;
+    if ((s = finalize_stem(enc))) return s;
+    for (auto &op : enc->ops)
+        if ((s = finalize_conv(enc, op))) return s;
+    const int C = enc->desc.chunk, crop = enc->desc.crop;
+    const size_t img = (size_t)C * (crop + 6) * (crop + 8) * 4;
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_img, img * 2));
+    PVR_HIP_TRY(hipMemset(enc->d_img, 0, img * 2));            // zero border = conv1 padding, written once
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_stem, (size_t)C * 112 * 112 * 64 * 2));
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, 256));
+    PVR_HIP_TRY(hipMemset(enc->d_zero, 0, 256));
+    enc->buf_elems = (size_t)C * 56 * 56 * 256;                 // largest activation (layer1 output)
+    for (int b = 0; b < B_COUNT; ++b) {
+        size_t bytes = enc->buf_elems * 2;
+        if (b == B_F32) bytes = (size_t)C * enc->final_hw * enc->final_c * 4;
+        PVR_HIP_TRY(hipMalloc(&enc->d_buf[b], bytes));
+    }
+    enc->weights.clear();                                       // host copies no longer needed
+    enc->finalized = true;
+    return PVR_OK;
+}
+
+int32_t pvr_encoder_out_size(const pvr_encoder *enc) { return enc ? enc->out_size : 0; }
+
+}  // extern "C"
+
+// ev != nullptr: record one event before the first launch and one after every launch of the FIRST chunk
+static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
+                               int64_t out_stride, void *hip_stream, std::vector<hipEvent_t> *ev) {
+    PVR_REQUIRE(enc && frames && out, "pvr_encoder_forward: null argument");
+    if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
+    PVR_REQUIRE(n > 0 && n <= enc->desc.max_batch, "n=%d outside 1..max_batch=%d", n, enc->desc.max_batch);
+    PVR_REQUIRE(out_stride >= enc->out_size, "out_stride %lld < out_size %d", (long long)out_stride, enc->out_size);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int dt = enc->desc.dtype;
+    pvr_status s;
+    for (int f0 = 0; f0 < n; f0 += enc->desc.chunk) {
+        const int nb = (n - f0 < enc->desc.chunk) ? n - f0 : enc->desc.chunk;
+        const uint8_t *fr = frames + (size_t)f0 * h * w * 3;
+        auto mark = [&]() -> pvr_status {
+            if (ev && f0 == 0) {
+                hipEvent_t e;
+                PVR_HIP_TRY(hipEventCreate(&e));
+                PVR_HIP_TRY(hipEventRecord(e, st));
+                ev->push_back(e);
+            }
+            return PVR_OK;
+        };
+        if ((s = mark())) return s;
+        if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st))) return s;
+        if ((s = mark())) return s;
+        enc->last_n = nb;
+        if (enc->stop_after == "pre" || enc->stop_after == "stem") {
+            if (enc->stop_after == "stem")
+                if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, enc->desc.crop, dt, st))) return s;
+            return PVR_OK;
+        }
+        if ((s = launch_maxpool(enc->d_stem, enc->d_buf[B_X0], nb, 112, 112, 64, dt, st))) return s;
+        if (enc->stop_after == "pool") return PVR_OK;
+        bool stopped = false;
+        for (auto &op : enc->ops) {
+            const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
+            if ((s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h,
+                                 op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st)))
+                return s;
+            if ((s = mark())) return s;
+            if (!enc->stop_after.empty() && op.tap == enc->stop_after) { stopped = true; break; }
+        }
+        if (stopped) return PVR_OK;
+        float *o = out + (size_t)f0 * out_stride;
+        if (enc->desc.arch == PVR_ARCH_RESNET50)
+            s = launch_avgpool(enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c, 1, dt, st);
+        else
+            s = launch_nhwc_to_chw((const float *)enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c,
+                                   enc->final_creal, st);
+        if (s) return s;
+        if ((s = mark())) return s;
+    }
+    return PVR_OK;
+}
+
+extern "C" {
+
+pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
+                               int64_t out_stride, void *hip_stream) {
+    return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+}
+
+// Instrumented forward of ONE chunk: HIP events between launches on the caller's stream (synchronises).
+// op_ms[i] = duration of launch i, op_flops[i] = its algorithmic FLOPs (2*M*K_real*Cout_real; 0 for byte kernels),
+// launch order: preprocess, stem, maxpool, conv ops..., pool/flatten.
+pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
+                               int64_t out_stride, void *hip_stream, float *op_ms, double *op_flops, int32_t cap,
+                               int32_t *n_ops) {
+    PVR_REQUIRE(enc && op_ms && op_flops && n_ops, "pvr_encoder_profile: null argument");
+    PVR_REQUIRE(n <= enc->desc.chunk, "profile: n=%d must fit one chunk (%d)", n, enc->desc.chunk);
+    std::vector<hipEvent_t> ev;
+    pvr_status s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, &ev);
+    if (!s && hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) { set_error("profile: sync failed"); s = PVR_ERR_HIP; }
+    const int nl = (int)ev.size() - 1;
+    if (!s && nl > cap) { set_error("profile: %d launches > cap %d", nl, cap); s = PVR_ERR_INVALID; }
+    if (!s) {
+        for (int i = 0; i < nl; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            op_ms[i] = ms;
+            op_flops[i] = 0.0;
+        }
+        // stem: 118.0 MMAC/frame = 112*112*64*147
+        if (nl > 1) op_flops[1] = 2.0 * n * 112.0 * 112.0 * 64.0 * 147.0;
+        int i = 3;
+        for (auto &op : enc->ops) {
+            if (i >= nl) break;
+            const double ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
+            op_flops[i++] = 2.0 * n * ho * ho * (double)op.cout_real * op.k * op.k * op.cin_real;
+        }
+        *n_ops = nl;
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    return s;
+}
+
+pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap) {
+    PVR_REQUIRE(enc, "null encoder");
+    enc->stop_after = tap ? tap : "";
+    return PVR_OK;
+}
+
+pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64_t cap, int64_t *count, void *hip_stream) {
+    PVR_REQUIRE(enc && name && out && count, "pvr_encoder_tap: null argument");
+    if (!enc->finalized || enc->last_n == 0) { set_error("no forward has run"); return PVR_ERR_STATE; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int n = enc->last_n, crop = enc->desc.crop;
+    const std::string nm = name;
+    const void *src = nullptr;
+    size_t elems = 0;
+    int f32 = 0;
+    if (nm == "pre") { src = enc->d_img; elems = (size_t)n * (crop + 6) * (crop + 8) * 4; }
+    else if (nm == "stem") { src = enc->d_stem; elems = (size_t)n * 112 * 112 * 64; }
+    else if (nm == "pool") { src = enc->d_buf[B_X0]; elems = (size_t)n * 56 * 56 * 64; }
+    else {
+        auto it = enc->taps.find(nm);
+        PVR_REQUIRE(it != enc->taps.end(), "unknown tap %s", name);
+        // taps alias ping-pong buffers: only the LAST layer's tap is guaranteed intact after a full forward
+        const auto &g = it->second.second;
+        src = enc->d_buf[it->second.first];
+        elems = (size_t)n * g[0] * g[1] * g[2];
+        f32 = g[3];
+    }
+    PVR_REQUIRE((int64_t)elems <= cap, "tap %s needs %zu elements, cap %lld", name, elems, (long long)cap);
+    *count = (int64_t)elems;
+    if (f32) { PVR_HIP_TRY(hipMemcpyAsync(out, src, elems * 4, hipMemcpyDeviceToDevice, st)); return PVR_OK; }
+    return launch_h_to_f32(src, out, elems, enc->desc.dtype, st);
+}
+
+void pvr_encoder_destroy(pvr_encoder *enc) {
+    if (!enc) return;
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_b) (void)hipFree(op.d_b); }
+    for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
+    if (enc->d_img) (void)hipFree(enc->d_img);
+    if (enc->d_stem) (void)hipFree(enc->d_stem);
+    if (enc->d_stem_w) (void)hipFree(enc->d_stem_w);
+    if (enc->d_stem_b) (void)hipFree(enc->d_stem_b);
+    if (enc->d_zero) (void)hipFree(enc->d_zero);
+    delete enc;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// K3/K4/K8: ResNet50 stem conv1 7x7/2 + folded BN + ReLU on MFMA, maxpool 3x3/2,
+// global average pool, and the C-major flatten of the compression heads.
+//
+// Replaces torchvision ResNet.conv1/bn1/relu/maxpool/avgpool reached from reference
+// src/embeddings.py:118-120 and src/vision_models/moco.py:11-12.
+//
+// Stem as an implicit GEMM with NO im2col and NO bounds checks: the preprocess kernel writes a
+// zero-bordered (230 x 232 x 4) image whose 4th channel is a validity flag, so
+//   * K = 7 rows x 8 taps x 4 channels = 224 = 7 MFMA k-steps of 32 (tap 7 of each row has zero weight)
+//   * lane (px = lane&15, g = lane>>4) needs taps 2g,2g+1 of row s for output pixel px:
+//     image[2*ho+s][2*(wo0+px)+2g .. +1][0..3] = ONE aligned 16-byte load
+//   * Normalize((x/255-mean)/std) lives in the weights; the validity channel carries -sum(w*mean/std)
+//     per tap, so zero padding in the NORMALISED domain (what the reference pads) stays exact at the border.
+// Weights (64 x 224, 28 KB) stay in registers: 28 fragments per wave, reused over 7 pixel tiles.
+#include "common.h"
+
+namespace pvr {
+
+constexpr int STEM_K = 224;     // 7 * 8 * 4
+constexpr int STEM_CO = 64;
+
+template <bool F16>
+__global__ __launch_bounds__(256) void stem_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
+                                                   const float *__restrict__ bias, u16 *__restrict__ out,
+                                                   int crop) {
+    typedef typename HT<F16>::V8 V8;
+    const int PW = crop + 8, PH = crop + 6, OW = crop / 2;      // 232, 230, 112
+    const int n = blockIdx.y;
+    const int ho0 = blockIdx.x * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = lane & 15, g = lane >> 4;
+
+    // A operand = weights: lane holds W[co = i*16 + px][k = s*32 + g*8 .. +7]
+    V8 wf[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+            wf[i][s] = *reinterpret_cast<const V8 *>(wgt + (size_t)(i * 16 + px) * STEM_K + s * 32 + g * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + g * 4);
+
+    const int tiles_per_row = OW / 16;                           // 7
+    const int ntile = 4 * tiles_per_row;                         // 28 tiles per block
+    const u16 *imgn = img + (size_t)n * PH * PW * 4;
+    for (int t = wave; t < ntile; t += 4) {
+        const int ho = ho0 + t / tiles_per_row;
+        const int wo0 = (t % tiles_per_row) * 16;
+        if (ho >= OW) break;
+        // B operand = pixels: 7 aligned 16-B loads (2 pixels x 4 channels)
+        V8 xf[7];
+        const u16 *base = imgn + ((size_t)(2 * ho) * PW + 2 * (wo0 + px) + 2 * g) * 4;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) xf[s] = *reinterpret_cast<const V8 *>(base + (size_t)s * PW * 4);
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mfma16<F16>(wf[i][s], xf[s], acc[i]);
+        // D: row (cout in tile) = 4*g + reg, col = pixel px  ->  4 consecutive channels per lane
+        u16 *o = out + (((size_t)n * OW + ho) * OW + wo0 + px) * STEM_CO + g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ushort4 r;
+            r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
+            r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
+            r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
+            r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
+            *reinterpret_cast<ushort4 *>(o + i * 16) = r;
+        }
+    }
+}
+
+// maxpool 3x3 stride 2 pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are post-ReLU but the
+// kernel is general: out-of-range taps are skipped (-inf padding as torch does).
+template <bool F16>
+__global__ __launch_bounds__(256) void maxpool_kernel(const u16 *__restrict__ in, u16 *__restrict__ out, int n,
+                                                      int h, int w, int c, int ho, int wo) {
+    const int cg = c / 8;
+    const size_t total = (size_t)n * ho * wo * cg;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ch = (int)(idx % cg) * 8;
+        size_t r = idx / cg;
+        const int x = (int)(r % wo); r /= wo;
+        const int y = (int)(r % ho);
+        const int b = (int)(r / ho);
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * y - 1 + dy;
+            if (yy < 0 || yy >= h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * x - 1 + dx;
+                if (xx < 0 || xx >= w) continue;
+                const uint4 v = *reinterpret_cast<const uint4 *>(in + (((size_t)b * h + yy) * w + xx) * c + ch);
+                const u16 *e = reinterpret_cast<const u16 *>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], from_h<F16>(e[j]));
+            }
+        }
+        uint4 o;
+        u16 *oe = reinterpret_cast<u16 *>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oe[j] = to_h<F16>(m[j]);
+        *reinterpret_cast<uint4 *>(out + (((size_t)b * ho + y) * wo + x) * c + ch) = o;
+    }
+}
+
+// AdaptiveAvgPool2d(1)+flatten: NHWC (fp32 or 16-bit) -> fp32 row at out + b*out_stride
+template <bool F16, bool IN_F32>
+__global__ __launch_bounds__(256) void avgpool_kernel(const void *__restrict__ in, float *__restrict__ out,
+                                                      int64_t out_stride, int hw, int c) {
+    const int b = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    if constexpr (IN_F32) {
+        const float *p = (const float *)in + (size_t)b * hw * c + ch;
+        for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];
+    } else {
+        const u16 *p = (const u16 *)in + (size_t)b * hw * c + ch;
+        for (int i = 0; i < hw; ++i) s += from_h<F16>(p[(size_t)i * c]);
+    }
+    out[(size_t)b * out_stride + ch] = s / (float)hw;
+}
+
+// compression-head flatten (moco.py:57-60: avgpool/fc are empty Sequentials, so the reference
+// flattens (N,c,H,W) C-major): fp32 NHWC with padded channels -> out[b][ch*hw + i]
+__global__ __launch_bounds__(256) void nhwc_to_chw_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          int64_t out_stride, int hw, int cpad, int creal) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw * creal) return;
+    const int ch = idx / hw, i = idx % hw;
+    out[(size_t)b * out_stride + idx] = in[((size_t)b * hw + i) * cpad + ch];
+}
+
+// fp32 tap of a 16-bit activation buffer (parity debugging)
+template <bool F16>
+__global__ __launch_bounds__(256) void h_to_f32_kernel(const u16 *__restrict__ in, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = from_h<F16>(in[i]);
+}
+
+pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void *out, int n, int crop, int dtype,
+                       hipStream_t stream) {
+    PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);
+    dim3 grid((crop / 2 + 3) / 4, n);
+    if (dtype == PVR_F16)
+        hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
+    else
+        hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_maxpool(const void *in, void *out, int n, int h, int w, int c, int dtype, hipStream_t stream) {
+    PVR_REQUIRE(c % 8 == 0, "maxpool: channels %d not a multiple of 8", c);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)n * ho * wo * (c / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (dtype == PVR_F16)
+        hipLaunchKernelGGL(maxpool_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const u16 *)in, (u16 *)out, n, h, w, c, ho, wo);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const u16 *)in, (u16 *)out, n, h, w, c, ho, wo);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_avgpool(const void *in, float *out, int64_t out_stride, int n, int hw, int c, int in_f32, int dtype,
+                          hipStream_t stream) {
+    dim3 grid((c + 255) / 256, n);
+    if (in_f32)
+        hipLaunchKernelGGL((avgpool_kernel<false, true>), grid, dim3(256), 0, stream, in, out, out_stride, hw, c);
+    else if (dtype == PVR_F16)
+        hipLaunchKernelGGL((avgpool_kernel<true, false>), grid, dim3(256), 0, stream, in, out, out_stride, hw, c);
+    else
+        hipLaunchKernelGGL((avgpool_kernel<false, false>), grid, dim3(256), 0, stream, in, out, out_stride, hw, c);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_nhwc_to_chw(const float *in, float *out, int64_t out_stride, int n, int hw, int cpad, int creal,
+                              hipStream_t stream) {
+    dim3 grid((hw * creal + 255) / 256, n);
+    hipLaunchKernelGGL(nhwc_to_chw_kernel, grid, dim3(256), 0, stream, in, out, out_stride, hw, cpad, creal);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_h_to_f32(const void *in, float *out, size_t n, int dtype, hipStream_t stream) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == PVR_F16) hipLaunchKernelGGL(h_to_f32_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const u16 *)in, out, n);
+    else hipLaunchKernelGGL(h_to_f32_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const u16 *)in, out, n);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+}  // namespace pvr

@@ -1,0 +1,369 @@
+"""EmbeddingNet / UberModel / EmbeddingWrapper with the reference call surface, HIP inside.
+
+Mirrors reference src/embeddings.py:
+  * `_get_embedding(name, in_channels, pretrained, train)`  (:60-332)  name registry + transforms
+  * `UberModel`                                              (:44-57)   concat of separate models
+  * `EmbeddingNet(embedding_name, in_channels=3, pretrained=True, train=False, disable_cuda=False)`
+    `.forward(uint8 (N,H,W,3)) -> np.float32 (N,O).squeeze()`  (:339-402)
+  * `EmbeddingWrapper.observation`                           (:441-444)
+and the checkpoint loaders of src/vision_models/moco.py:6-113 / resnet.py:6-104 (key remapping and
+their asserts).  All arithmetic (transforms + network) runs in libpvr_hip.so on the MI355X; this
+module only owns names, state_dicts and tensors.  There is no CPU path: `disable_cuda=True` or a
+box without a GPU raises instead of silently computing something else.
+"""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, synth
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156}
+_ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3}
+
+# ---------------------------------------------------------------------------------------------
+# name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
+# ---------------------------------------------------------------------------------------------
+_SINGLE = {
+    'resnet50': ('torchvision', 'conv5', None),
+    'resnet50_places': ('resnet', 'conv5', 'resnet50_places.pth.tar'),
+    'resnet50_l4': ('resnet', 'conv4', 'resnet50_l4.pth.tar'),
+    'resnet50_l3': ('resnet', 'conv3', 'resnet50_l3.tar'),
+    'resnet50_places_l4': ('resnet', 'conv4', 'resnet50_places_l4.tar'),
+    'resnet50_places_l3': ('resnet', 'conv3', 'resnet50_places_l3.tar'),
+    'demy': ('moco', 'conv5', 'demy.pth'),
+    'moco_aug': ('moco', 'conv5', 'moco_aug.pth.tar'),
+    'moco_aug_habitat': ('moco', 'conv5', 'moco_aug_habitat_64.pth'),
+    'moco_aug_mujoco': ('moco', 'conv5', 'moco_aug_mujoco.pth'),
+    'moco_aug_uber': ('moco', 'conv5', 'moco_aug_uber.pth'),
+    'moco_aug_places': ('moco', 'conv5', 'moco_aug_places.pth.tar'),
+    'moco_aug_l4': ('moco', 'conv4', 'moco_aug_l4.pth'),
+    'moco_aug_places_l4': ('moco', 'conv4', 'moco_aug_places_l4.pth'),
+    'moco_aug_l3': ('moco', 'conv3', 'moco_aug_l3.pth'),
+    'moco_aug_places_l3': ('moco', 'conv3', 'moco_aug_places_l3.pth'),
+    'moco_croponly': ('moco', 'conv5', 'moco_croponly.pth'),
+    'moco_croponly_places': ('moco', 'conv5', 'moco_croponly_places.pth'),
+    'moco_croponly_habitat': ('moco', 'conv5', 'moco_croponly_habitat_64.pth'),
+    'moco_croponly_mujoco': ('moco', 'conv5', 'moco_croponly_mujoco.pth'),
+    'moco_croponly_uber': ('moco', 'conv5', 'moco_croponly_uber.pth'),
+    'moco_croponly_l4': ('moco', 'conv4', 'moco_croponly_l4.pth'),
+    'moco_croponly_l3': ('moco', 'conv3', 'moco_croponly_l3.pth'),
+    'moco_croponly_places_l4': ('moco', 'conv4', 'moco_croponly_places_l4.pth'),
+    'moco_croponly_places_l3': ('moco', 'conv3', 'moco_croponly_places_l3.pth'),
+    'moco_coloronly': ('moco', 'conv5', 'moco_coloronly.pth'),
+}
+_UBER = {}
+for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_croponly'):
+    _m = {'3': _base + '_l3', '4': _base + '_l4', '5': _base}
+    for _combo in ('345', '35', '34', '45'):
+        _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
+# names the reference registers but whose model families are not built yet
+_NOT_BUILT = ('random', 'resnet18', 'resnet34', 'mae_base', 'mae_large', 'mae_huge', 'maskrcnn_l3',
+              'clip_vit', 'clip_rn50')
+
+
+def _dtype_from_env(compute_dtype=None):
+    d = (compute_dtype or os.environ.get('PVR_DTYPE', 'bf16')).lower()
+    if d in ('bf16', 'bfloat16'):
+        return _lib.PVR_BF16
+    if d in ('f16', 'fp16', 'float16', 'half'):
+        return _lib.PVR_F16
+    raise ValueError('compute dtype must be bf16 or f16, got %r' % d)
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint -> torchvision-named state_dict (reference moco.py / resnet.py key handling)
+# ---------------------------------------------------------------------------------------------
+def _expected_keys(variant):
+    return [k for k in synth.resnet50_state_dict(0, variant, keys_only=True)]
+
+
+def remap_checkpoint(state_dict, family, variant):
+    """Apply the reference loaders' key remapping and asserts; returns {torchvision key: tensor}.
+
+    moco:   keep 'module.encoder_q.*' except 'module.encoder_q.fc*', strip the prefix (moco.py:14-21)
+    resnet: strip 'module.' (resnet.py:33-38, 95-99)
+    For the compressed variants the checkpoint stores the nn.Sequential nesting
+    ('layer4.0.<i>...', 'layer4.1....') because it was saved from the edited model."""
+    out = {}
+    for k, v in state_dict.items():
+        if family == 'moco':
+            if k.startswith('module.encoder_q') and not k.startswith('module.encoder_q.fc'):
+                out[k[len('module.encoder_q.'):]] = v
+        else:
+            if k.startswith('module.'):
+                out[k[len('module.'):]] = v
+    want = _expected_keys(variant)
+    missing = [k for k in want if k not in out]
+    unexpected = [k for k in out if k not in set(want)]
+    if family == 'moco' or variant == 'conv5':
+        assert len(missing) == 0, 'missing keys: %s' % missing[:5]                 # moco.py:24, resnet.py:102
+    if variant == 'conv3':
+        assert all(('fc.' in n or 'layer4.' in n or 'layer3.2' in n) for n in unexpected)   # moco.py:67
+    if variant == 'conv4':
+        assert all(('fc.' in n or 'layer4.2' in n) for n in unexpected)           # moco.py:110
+    return {k: out[k] for k in want if k in out}
+
+
+def _find_checkpoint(path):
+    for d in ('.', os.environ.get('PVR_CHECKPOINT_DIR', '')):
+        if d and os.path.isfile(os.path.join(d, path)):
+            return os.path.join(d, path)
+    return None
+
+
+def _load_named_state_dict(name, pretrained):
+    family, variant, ckpt = _SINGLE[name]
+    synthetic_ok = os.environ.get('PVR_SYNTHETIC_WEIGHTS', '0') == '1'
+    seed = zlib.crc32(name.encode()) & 0x7fffffff
+    if family == 'torchvision':
+        # torchvision hub weights cannot be downloaded here; a local torchvision-format file is used if present
+        f = _find_checkpoint('resnet50.pth') if pretrained else None
+        if f is not None:
+            sd = torch.load(f, map_location='cpu')
+            return {k: v for k, v in sd.items() if not k.startswith('fc.')}, variant
+        if pretrained and not synthetic_ok:
+            raise FileNotFoundError("pretrained torchvision resnet50 weights: put 'resnet50.pth' in . or "
+                                    "$PVR_CHECKPOINT_DIR (no network), or set PVR_SYNTHETIC_WEIGHTS=1")
+        return synth.resnet50_state_dict(seed, variant), variant
+    f = _find_checkpoint(ckpt)
+    if f is None:
+        if synthetic_ok:
+            return synth.resnet50_state_dict(seed, variant), variant
+        raise FileNotFoundError(ckpt)          # what torch.load(checkpoint_path) raises in the reference
+    checkpoint = torch.load(f, map_location=torch.device('cpu'))
+    return remap_checkpoint(checkpoint['state_dict'], family, variant), variant
+
+
+# ---------------------------------------------------------------------------------------------
+# module tree holding torchvision-named tensors, so state_dict() keys equal the reference's
+# ---------------------------------------------------------------------------------------------
+class _Node(nn.Module):
+    pass
+
+
+def _install(root, key, tensor):
+    parts = key.split('.')
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    leaf = parts[-1]
+    if leaf in ('running_mean', 'running_var', 'num_batches_tracked'):
+        node.register_buffer(leaf, tensor)
+    else:
+        node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+class HipResNet50(_Node):
+    """One frozen ResNet50-family model: fp32 host tensors (torchvision names) + a libpvr_hip encoder."""
+
+    def __init__(self, state_dict, variant='conv5', compute_dtype=None, max_batch=None, chunk=None):
+        super().__init__()
+        self.variant = variant
+        self.out_size = OUT_SIZE[variant]
+        self._dtype = _dtype_from_env(compute_dtype)
+        self._max_batch = int(max_batch or os.environ.get('PVR_MAX_BATCH', 256))
+        self._chunk = int(chunk or os.environ.get('PVR_CHUNK', 0))
+        self._handle = None
+        for k, v in state_dict.items():
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+            _install(self, k, t.detach().clone().cpu())
+        self.train(False)
+
+    # -- encoder lifetime ----------------------------------------------------------------------
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().pvr_encoder_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._release()                       # re-fold / re-upload on next use
+        return r
+
+    def _build(self):
+        L = _lib.lib()
+        desc = _lib.EncoderDesc(arch=_ARCH[self.variant], dtype=self._dtype, max_batch=self._max_batch,
+                                chunk=self._chunk, resize=256, crop=224)
+        desc.mean[:] = IMAGENET_MEAN
+        desc.std_[:] = IMAGENET_STD
+        h = C.c_void_p()
+        _lib.check(L.pvr_encoder_create(C.byref(desc), C.byref(h)))
+        try:
+            for k, v in self.state_dict().items():
+                if k.endswith('num_batches_tracked'):
+                    continue
+                a = np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32)
+                shp = (C.c_int64 * max(a.ndim, 1))(*(a.shape or (1,)))
+                _lib.check(L.pvr_encoder_load_weights(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
+            _lib.check(L.pvr_encoder_finalize(h))
+        except Exception:
+            L.pvr_encoder_destroy(h)
+            raise
+        self._handle = h
+
+    @property
+    def max_batch(self):
+        return self._max_batch
+
+    def forward_into(self, frames_u8, out):
+        """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0)."""
+        _lib.require_gpu()
+        if self._handle is None:
+            self._build()
+        n, h, w, c = frames_u8.shape
+        assert c == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+        assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[1] == self.out_size
+        L = _lib.lib()
+        for i in range(0, n, self._max_batch):
+            m = min(self._max_batch, n - i)
+            _lib.check(L.pvr_encoder_forward(self._handle, C.c_void_p(frames_u8[i:i + m].data_ptr()), m, h, w,
+                                             C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
+
+    def tap(self, name, n_elems):
+        """fp32 copy of an intermediate activation of the last forward (parity debugging)."""
+        buf = torch.empty(n_elems, dtype=torch.float32, device='cuda')
+        cnt = C.c_int64()
+        _lib.check(_lib.lib().pvr_encoder_tap(self._handle, name.encode(), C.c_void_p(buf.data_ptr()), n_elems,
+                                              C.byref(cnt), _lib.stream_ptr()))
+        return buf[:cnt.value]
+
+    def debug_stop_after(self, name):
+        if self._handle is None:
+            self._build()
+        _lib.check(_lib.lib().pvr_encoder_debug_stop_after(self._handle, name.encode() if name else None))
+
+    def forward(self, frames_u8):
+        out = torch.empty((frames_u8.shape[0], self.out_size), dtype=torch.float32, device=frames_u8.device)
+        self.forward_into(frames_u8, out)
+        return out
+
+
+class UberModel(nn.Module):
+    """reference src/embeddings.py:44-57.  `models` stays a plain list as in the reference (so, as there,
+    its weights are not part of state_dict()); each member writes its columns of one output buffer."""
+
+    def __init__(self, models):
+        super().__init__()
+        self.models = models
+        assert all(models[0].training == m.training for m in models)
+        self.training = models[0].training
+        self.out_size = sum(m.out_size for m in models)
+
+    def to(self, device):
+        return self
+
+    def forward_into(self, frames_u8, out):
+        col = 0
+        for m in self.models:
+            m.forward_into(frames_u8, out[:, col:col + m.out_size])
+            col += m.out_size
+
+    def forward(self, frames_u8):
+        out = torch.empty((frames_u8.shape[0], self.out_size), dtype=torch.float32, device=frames_u8.device)
+        self.forward_into(frames_u8, out)
+        return out
+
+
+class _Transforms(nn.Module):
+    """Stand-in for the reference's nn.Sequential of torchvision transforms (embeddings.py:80-85): the
+    Resize/CenterCrop/ConvertImageDtype/Normalize arithmetic is fused into the HIP preprocess + stem kernels."""
+    resize, crop, mean, std = 256, 224, IMAGENET_MEAN, IMAGENET_STD
+
+
+def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, train=False, **hip_kw):
+    assert in_channels == 3, 'Current models accept 3-channel inputs only.'          # embeddings.py:87
+    if embedding_name == 'true_state':
+        return nn.Sequential(nn.Identity()), nn.Sequential(nn.Identity())
+    if embedding_name in _SINGLE:
+        sd, variant = _load_named_state_dict(embedding_name, pretrained)
+        model = HipResNet50(sd, variant, **hip_kw)
+    elif embedding_name in _UBER:
+        model = UberModel([_get_embedding(n, in_channels, pretrained, train, **hip_kw)[0] for n in _UBER[embedding_name]])
+    elif embedding_name in _NOT_BUILT:
+        raise NotImplementedError("Requested model not available. ('%s' is registered by the reference but its "
+                                  "family is not built in pvr_habitat_amd yet)" % embedding_name)
+    else:
+        raise NotImplementedError("Requested model not available.")                 # embeddings.py:321
+    if train:
+        raise NotImplementedError('pvr_habitat_amd runs the encoder frozen (the reference scripts hard-code '
+                                  'train=False, main_bc_2.py:68-72); training the embedding is not built')
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model, _Transforms()
+
+
+class EmbeddingNet(nn.Module):
+    """
+    Input shape must be (N, H, W, 3), where N is the number of frames.
+    The output shape will be (N, O), where O is the embedding size.   (reference embeddings.py:339-402)
+    """
+
+    def __init__(self, embedding_name, in_channels=3, pretrained=True, train=False, disable_cuda=False,
+                 compute_dtype=None, max_batch=None, chunk=None):
+        super(EmbeddingNet, self).__init__()
+        self.embedding_name = embedding_name
+        if self.embedding_name == 'true_state':
+            return
+        self.in_channels = in_channels
+        self.embedding, self.transforms = _get_embedding(embedding_name, in_channels, pretrained, train,
+                                                         compute_dtype=compute_dtype, max_batch=max_batch, chunk=chunk)
+        # the reference discovers these with a dummy CPU forward (embeddings.py:359-363)
+        self.in_shape = torch.Size((in_channels, 224, 224))
+        self.out_size = int(self.embedding.out_size)
+        if disable_cuda:
+            raise NotImplementedError('disable_cuda=True: pvr_habitat_amd has no CPU path (HIP kernels only)')
+        self.device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        self.training = self.embedding.training
+
+    def _forward(self, observation_u8):
+        return self.embedding(observation_u8)
+
+    def embed_device(self, observation):
+        """uint8 (N,H,W,3) -> cuda fp32 (N, out_size); no host sync (for streaming callers)."""
+        _lib.require_gpu()
+        observation = observation.to(device=self.device, non_blocking=True).contiguous()
+        return self._forward(observation)
+
+    def forward(self, observation):
+        if self.embedding_name == 'true_state':
+            return observation.squeeze().cpu().numpy()
+        # observation.shape -> (N, H, W, 3); transposes + transforms + model are one HIP plan
+        with torch.no_grad():
+            out = self.embed_device(observation)
+            return out.view(-1, self.out_size).squeeze().cpu().numpy()
+
+
+class EmbeddingWrapper(object):
+    """reference src/embeddings.py:409-444 without the gym dependency: `observation((H,W,3n)) -> (n*O,)`.
+    If gym is importable the class can be mixed into gym.ObservationWrapper by the caller."""
+
+    def __init__(self, env, embedding):
+        self.env = env
+        in_channels = env.observation_space.shape[2]
+        assert in_channels % 3 == 0, \
+            """ Only RGB images are supported.
+                    Be sure that observation shape is (H, W, n * 3),
+                    where n is the number of frames per observation. """
+        self.in_channels = 3
+        self.n_frames = in_channels // 3
+        self.embedding = embedding
+        self.observation_shape = (self.embedding.out_size * self.n_frames,)
+
+    def observation(self, observation):
+        observation = np.stack(np.split(observation, self.n_frames, axis=-1))
+        return self.embedding(torch.from_numpy(observation)).flatten()

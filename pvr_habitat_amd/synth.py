@@ -82,7 +82,14 @@ def smooth_frames(seed, n, h, w, name='smooth'):
 RESNET50_LAYERS = (3, 4, 6, 3)
 
 
+_KEYS_ONLY = False
+
+
 def _bn(sd, seed, prefix, c, gamma=(0.8, 1.2)):
+    if _KEYS_ONLY:
+        for a in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+            sd[prefix + '.' + a] = None
+        return
     sd[prefix + '.weight'] = uniform(seed, prefix + '.weight', (c,), *gamma)
     sd[prefix + '.bias'] = uniform(seed, prefix + '.bias', (c,), -0.2, 0.2)
     sd[prefix + '.running_mean'] = uniform(seed, prefix + '.running_mean', (c,), -0.2, 0.2)
@@ -92,19 +99,33 @@ def _bn(sd, seed, prefix, c, gamma=(0.8, 1.2)):
 
 def _conv(sd, seed, name, co, ci, k, bias=False, gain=2.0):
     fan_in = ci * k * k
+    if _KEYS_ONLY:
+        sd[name + '.weight'] = None
+        if bias:
+            sd[name + '.bias'] = None
+        return
     sd[name + '.weight'] = normal(seed, name + '.weight', (co, ci, k, k), std=float(np.sqrt(gain / fan_in)))
     if bias:
         sd[name + '.bias'] = uniform(seed, name + '.bias', (co,), -0.1, 0.1)
 
 
-def resnet50_state_dict(seed=1, variant='conv5'):
-    """Synthetic state_dict with torchvision resnet50 keys.
+def resnet50_state_dict(seed=1, variant='conv5', keys_only=False):
+    """Synthetic state_dict with torchvision resnet50 keys (keys_only: names without data).
 
     variant: 'conv5' (-> 2048, moco.py:6-26), 'conv4' (layer4 + BasicBlock(2048->42),
     moco.py:73-113 -> 2058), 'conv3' (layer3 + BasicBlock(1024->11), moco.py:29-70 -> 2156).
     The last BN of every bottleneck gets a small gamma so 16 residual additions keep
     activations O(1) (random-init stand-in for a trained network's statistics).
     """
+    global _KEYS_ONLY
+    _KEYS_ONLY = bool(keys_only)
+    try:
+        return _resnet50_state_dict(seed, variant)
+    finally:
+        _KEYS_ONLY = False
+
+
+def _resnet50_state_dict(seed, variant):
     sd = {}
     _conv(sd, seed, 'conv1', 64, 3, 7)
     _bn(sd, seed, 'bn1', 64)

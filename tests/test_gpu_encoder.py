@@ -1,0 +1,227 @@
+"""GPU parity tests of the HIP encoder path against the CPU oracle (run on the MI355X box with -m gpu).
+
+Tolerances (stated per SURVEY D6 / BASELINE north_star):
+  * integer part of the transforms (resize/crop to uint8): bit-exact
+  * f16 "parity mode": relative L2 error and max-abs/max-ref of the embedding <= 1e-3 vs the fp32 oracle
+  * bf16 "throughput mode": measured, asserted <= 1e-2 (bf16 has eps 2^-8; 53 layers)
+"""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pvr_habitat_amd import synth, _lib
+
+gpu = pytest.mark.gpu
+pytestmark = [gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+
+DT = {'bf16': (torch.bfloat16, _lib.PVR_BF16), 'f16': (torch.float16, _lib.PVR_F16)}
+
+
+def _relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)), float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+# transforms
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('h,w', [(256, 256), (64, 64), (128, 128), (96, 64), (64, 96), (300, 256), (100, 75), (480, 640)])
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_preprocess_matches_oracle(h, w, dt):
+    from oracle import encoder_oracle as eo
+    tdt, cdt = DT[dt]
+    fr = synth.smooth_frames(11, 3, h, w)
+    ref = eo.preprocess_u8(fr).permute(0, 2, 3, 1).numpy()            # (N,224,224,3) uint8
+    d = torch.from_numpy(fr).cuda()
+    out = torch.empty((3, 230, 232, 4), dtype=tdt, device='cuda')
+    _lib.check(_lib.lib().pvr_op_preprocess(C.c_void_p(d.data_ptr()), 3, h, w, 256, 224, C.c_void_p(out.data_ptr()), cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    o = out.float().cpu().numpy()
+    inner = o[:, 3:227, 3:227, :3]
+    pow2 = (h, w) in ((256, 256), (64, 64), (128, 128))
+    diff = np.abs(inner - ref.astype(np.float32))
+    if pow2:
+        assert diff.max() == 0                                         # dyadic weights: bit-exact incl. ties
+    else:
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3            # rare .5 ties may round the other way
+    assert (o[:, 3:227, 3:227, 3] == 1).all()                          # validity channel
+    border = o.copy(); border[:, 3:227, 3:227, :] = 0
+    assert (border == 0).all()                                         # conv1 zero padding
+
+
+# ------------------------------------------------------------------------------------------------
+# implicit-GEMM convolution
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, relu, res, out_f32
+    (2, 56, 56, 64, 64, 1, 1, 1, 0, 0),
+    (2, 56, 56, 64, 64, 3, 1, 1, 0, 0),
+    (3, 56, 56, 64, 256, 1, 1, 1, 1, 0),
+    (2, 56, 56, 256, 128, 1, 1, 1, 0, 0),
+    (2, 56, 56, 128, 128, 3, 2, 1, 0, 0),
+    (2, 56, 56, 256, 512, 1, 2, 0, 0, 0),
+    (5, 14, 14, 256, 1024, 1, 1, 1, 1, 0),
+    (3, 14, 14, 512, 512, 3, 2, 1, 0, 0),
+    (3, 7, 7, 512, 2048, 1, 1, 1, 1, 1),
+    (1, 7, 7, 2048, 512, 1, 1, 1, 0, 0),
+    (1, 9, 11, 64, 64, 3, 1, 0, 1, 1),         # ragged M (99 rows), fp32 out
+    (2, 14, 14, 1024, 64, 3, 1, 1, 0, 0),      # compression head shape (cout padded to 64)
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_conv2d_matches_torch(case, dt):
+    n, h, w, cin, cout, k, stride, relu, res, out_f32 = case
+    tdt, cdt = DT[dt]
+    pad = k // 2
+    x = torch.from_numpy(synth.normal(3, 'cx%s' % (case,), (n, h, w, cin))).to(tdt)
+    wt = torch.from_numpy(synth.normal(3, 'cw%s' % (case,), (cout, cin, k, k), std=float(np.sqrt(2.0 / (cin * k * k))))).to(tdt)
+    b = torch.from_numpy(synth.uniform(3, 'cb%s' % (case,), (cout,), -0.5, 0.5))
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = torch.from_numpy(synth.normal(3, 'cr%s' % (case,), (n, ho, wo, cout))).to(tdt) if res else None
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), b, stride, pad).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.float()
+    if relu:
+        ref = F.relu(ref)
+    cout_pad = (cout + 63) // 64 * 64
+    wk = torch.zeros((cout_pad, k * k * cin), dtype=tdt)
+    wk[:cout] = wt.permute(0, 2, 3, 1).reshape(cout, -1)
+    bp = torch.zeros(cout_pad); bp[:cout] = b
+    xd, wd, bd = x.cuda().contiguous(), wk.cuda().contiguous(), bp.cuda()
+    rd = r.cuda().contiguous() if res else None
+    out = torch.full((n, ho, wo, cout), float('nan'), dtype=torch.float32 if out_f32 else tdt, device='cuda')
+    _lib.check(_lib.lib().pvr_op_conv2d(C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                        C.c_void_p(rd.data_ptr()) if res else None, C.c_void_p(out.data_ptr()),
+                                        n, h, w, cin, cout, k, k, stride, pad, relu, out_f32, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    l2, mx = _relerr(o.numpy(), ref.numpy())
+    tol = 2e-5 if out_f32 else (6e-3 if dt == 'bf16' else 8e-4)      # output rounding only (inputs pre-rounded)
+    assert l2 < tol and mx < 2 * tol + 1e-3 * (not out_f32), (l2, mx)
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_maxpool_avgpool(dt):
+    tdt, cdt = DT[dt]
+    x = torch.from_numpy(synth.normal(5, 'mp', (3, 112, 112, 64))).to(tdt)
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    xd = x.cuda(); out = torch.empty((3, 56, 56, 64), dtype=tdt, device='cuda')
+    _lib.check(_lib.lib().pvr_op_maxpool(C.c_void_p(xd.data_ptr()), C.c_void_p(out.data_ptr()), 3, 112, 112, 64, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), ref)                          # exact: max of representable values
+    y = torch.from_numpy(synth.normal(5, 'ap', (4, 49, 2048)))
+    yd = y.cuda(); o = torch.zeros((4, 2100), device='cuda')
+    _lib.check(_lib.lib().pvr_op_avgpool(C.c_void_p(yd.data_ptr()), C.c_void_p(o[:, 20:].data_ptr()), 2100, 4, 49, 2048, 1, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o[:, 20:2068].cpu().numpy(), y.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    assert (o[:, :20] == 0).all() and (o[:, 2068:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# whole encoder
+# ------------------------------------------------------------------------------------------------
+def _oracle_taps(sd, fr, variant='conv5'):
+    from oracle import encoder_oracle as eo
+    taps = {}
+    with torch.no_grad():
+        out = eo.resnet50_features(sd, eo.preprocess(fr), variant, taps=taps)
+    return out, taps
+
+
+@pytest.mark.parametrize('dt,tol', [('f16', 1e-3), ('bf16', 1e-2)])
+def test_resnet50_stagewise_parity(dt, tol):
+    """Every stage of the HIP plan against the fp32 oracle (conv1, pool, layer1..4, embedding)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    fr = synth.smooth_frames(21, 3, 256, 256)
+    ref_out, taps = _oracle_taps(sd, fr)
+    m = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=8)
+    d = torch.from_numpy(fr).cuda()
+    report = {}
+    for name, key in (('stem', 'conv1'), ('pool', 'stem'), ('layer1', 'layer1'), ('layer2', 'layer2'), ('layer3', 'layer3'), ('layer4', 'layer4')):
+        m.debug_stop_after(name)
+        m(d)
+        ref = taps[key].permute(0, 2, 3, 1).contiguous().numpy()
+        got = m.tap(name, ref.size).cpu().numpy().reshape(ref.shape)
+        report[name] = _relerr(got, ref)
+    m.debug_stop_after('')
+    out = m(d).cpu().numpy()
+    report['embedding'] = _relerr(out, ref_out.reshape(3, 2048).numpy())
+    print('\n[%s] stage rel-L2 / max-norm errors:' % dt, {k: ('%.2e' % v[0], '%.2e' % v[1]) for k, v in report.items()})
+    for k, v in report.items():
+        assert v[0] < tol * (1.5 if k != 'embedding' else 1.0), (k, v)
+    assert report['embedding'][1] < tol
+
+
+@pytest.mark.parametrize('variant,osz', [('conv3', 2156), ('conv4', 2058)])
+def test_compressed_variants(variant, osz):
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(2, variant)
+    fr = synth.smooth_frames(22, 2, 128, 128)
+    ref = eo.embed(sd, fr, variant)
+    m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert out.shape == (2, osz)
+    l2, mx = _relerr(out, ref)
+    print('\n[%s f16] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
+    assert l2 < 1e-3 and mx < 2e-3
+
+
+def test_embeddingnet_surface_and_uber(monkeypatch):
+    """EmbeddingNet call surface (embeddings.py:386-402): numpy fp32, squeeze of N=1, Uber concat order,
+    save_embedded_obs split/concat (save_embedded_obs.py:151-156)."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import EmbeddingNet, _SINGLE
+    import zlib
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    monkeypatch.setenv('PVR_DTYPE', 'f16')
+    monkeypatch.setenv('PVR_MAX_BATCH', '8')
+    torch.set_num_threads(8)
+    net = EmbeddingNet('moco_aug_uber_345')
+    assert net.out_size == 6262 and tuple(net.in_shape) == (3, 224, 224) and net.training is False
+    fr = synth.smooth_frames(23, 2, 64, 64)
+    out = net(torch.from_numpy(fr))
+    assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == (2, 6262)
+    members = []
+    for nme in ('moco_aug_l3', 'moco_aug_l4', 'moco_aug'):
+        seed = zlib.crc32(nme.encode()) & 0x7fffffff
+        members.append((synth.resnet50_state_dict(seed, _SINGLE[nme][1]), _SINGLE[nme][1]))
+    ref = eo.embed_uber(members, fr)
+    l2, mx = _relerr(out, ref)
+    assert l2 < 1e-3, (l2, mx)
+    one = net(torch.from_numpy(fr[:1]))
+    assert one.shape == (6262,)                                        # .squeeze() of N=1
+    np.testing.assert_array_equal(one, out[0])                         # batch-size invariance, bit-exact
+    # 6-channel observations: all current frames first, then all goal frames
+    net1 = EmbeddingNet('resnet50', pretrained=False)
+    obs = np.concatenate([fr, fr[::-1]], axis=3)                       # (2,64,64,6)
+    e = eo.split_embed_concat(lambda o: net1(torch.from_numpy(o)), obs, 2)
+    assert e.shape == (2, 4096)
+    np.testing.assert_array_equal(e[0, :2048], e[1, 2048:])
+    with pytest.raises(NotImplementedError):
+        EmbeddingNet('not_a_model')
+
+
+def test_full_batch_properties():
+    """BASELINE config-2 sizes (batch 256 @ 256x256): determinism and batch-composition invariance."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    m = HipResNet50(sd, 'conv5', compute_dtype='bf16', max_batch=256)
+    fr = torch.from_numpy(synth.frames(1, 256, 256, 256)).cuda()
+    a = m(fr); b = m(fr)
+    assert torch.equal(a, b)                                           # deterministic
+    perm = torch.randperm(256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0))
+    c = m(fr[perm].contiguous())
+    assert torch.equal(c, a[perm])                                     # each frame embedded independently
+    small = HipResNet50(sd, 'conv5', compute_dtype='bf16', max_batch=32)
+    d = small(fr[:70].contiguous())                                    # chunked path (3 forwards: 32+32+6)
+    assert torch.equal(d, a[:70])
+    assert torch.isfinite(a).all() and float(a.std()) > 0
