@@ -28,6 +28,7 @@ static pvr_status zero_page(void **out) {
     if (!g_zero) {
         PVR_HIP_TRY(hipMalloc(&g_zero, 256));
         PVR_HIP_TRY(hipMemset(g_zero, 0, 256));
+        PVR_HIP_TRY(hipDeviceSynchronize());
     }
     *out = g_zero;
     return PVR_OK;

@@ -166,31 +166,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
 
-    // ---- epilogue: D row = 4*fq + reg = cout offset, D col = fr = pixel -------------------------------
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // (1) acc + bias -> LDS as an fp32 [BM pixels][BN couts] tile (reuses the pipeline buffers; every wave is
+    //     past the loop's last barrier).  D row = 4*fq + reg = cout, D col = fr = pixel, so a lane owns one
+    //     16-B chunk per MFMA tile; chunks are XOR-swizzled with (pixel & 7) against ds_write bank conflicts.
+    // (2) the whole block walks the tile in 8-cout units: coalesced 16-B residual loads and 16-B stores
+    //     (a pixel's BN couts are contiguous in NHWC), instead of 8-B stores at a 2*Cout-byte stride.
+    static_assert(BM * BN * 4 <= 2 * STAGE, "epilogue tile must fit the pipeline buffers");
+    float *ep = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const int co = co0 + wn * (BN / 2) + i * 16 + fq * 4;
-        if (co >= p.Cout) continue;
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
+        const int cl = wn * (BN / 2) + i * 16 + fq * 4;          // cout within the tile
+        const int co = co0 + cl;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < p.Cout) bv = *reinterpret_cast<const float4 *>(p.bias + co);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wm * (BM / 2) + j * 16 + fr;
-            if (m >= p.M) continue;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
-            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            const size_t o = (size_t)m * p.Cout + co;
-            if (p.res) {
-                const ushort4 r = *reinterpret_cast<const ushort4 *>(p.res + o);
-                v0 += from_h<F16>(r.x); v1 += from_h<F16>(r.y); v2 += from_h<F16>(r.z); v3 += from_h<F16>(r.w);
+            const int pl = wm * (BM / 2) + j * 16 + fr;          // pixel within the tile
+            f32x4 v = acc[i][j];
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            *reinterpret_cast<f32x4 *>(ep + pl * BN + (((cl >> 2) ^ (pl & 7)) << 2)) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
+#pragma unroll
+    for (int it = 0; it < BM * UPR / 256; ++it) {
+        const int u = tid + it * 256;
+        const int pl = u / UPR, cu = u % UPR;
+        const int m = m0 + pl, co = co0 + cu * 8;
+        if (m >= p.M || co >= p.Cout) continue;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + pl * BN + (((2 * cu) ^ (pl & 7)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + pl * BN + (((2 * cu + 1) ^ (pl & 7)) << 2));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const size_t o = (size_t)m * p.Cout + co;
+        if (p.res) {
+            const u32x4 r = *reinterpret_cast<const u32x4 *>(p.res + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu));
+                v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16));
             }
-            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            if (p.out_f32) {
-                *reinterpret_cast<float4 *>((float *)p.out + o) = make_float4(v0, v1, v2, v3);
-            } else {
-                ushort4 r;
-                r.x = to_h<F16>(v0); r.y = to_h<F16>(v1); r.z = to_h<F16>(v2); r.w = to_h<F16>(v3);
-                *reinterpret_cast<ushort4 *>((u16 *)p.out + o) = r;
-            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.out_f32) {
+            float *op = (float *)p.out + o;
+            *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4 *>((u16 *)p.out + o) = r;
         }
     }
 }
@@ -224,7 +255,7 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
                        int out_f32, int dtype, hipStream_t stream) {
     PVR_REQUIRE(cin % 64 == 0, "conv: cin %d not a multiple of 64", cin);
-    PVR_REQUIRE(cout % 4 == 0, "conv: cout %d not a multiple of 4", cout);
+    PVR_REQUIRE(cout % 8 == 0, "conv: cout %d not a multiple of 8", cout);
     PVR_REQUIRE(zero != nullptr, "conv: zero page missing");
     ConvP p;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;

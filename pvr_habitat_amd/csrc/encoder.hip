@@ -267,6 +267,9 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
         if (b == B_F32) bytes = (size_t)C * enc->final_hw * enc->final_c * 4;
         PVR_HIP_TRY(hipMalloc(&enc->d_buf[b], bytes));
     }
+    // the memsets above run on the null stream; forwards run on the caller's stream (torch's current
+    // stream need not be ordered against it), so drain the device once here, off the hot path
+    PVR_HIP_TRY(hipDeviceSynchronize());
     enc->weights.clear();                                       // host copies no longer needed
     enc->finalized = true;
     return PVR_OK;
@@ -302,12 +305,12 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st))) return s;
         if ((s = mark())) return s;
         enc->last_n = nb;
-        if (enc->stop_after == "pre" || enc->stop_after == "stem") {
-            if (enc->stop_after == "stem")
-                if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, enc->desc.crop, dt, st))) return s;
-            return PVR_OK;
-        }
+        if (enc->stop_after == "pre") return PVR_OK;
+        if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, enc->desc.crop, dt, st))) return s;
+        if ((s = mark())) return s;
+        if (enc->stop_after == "stem") return PVR_OK;
         if ((s = launch_maxpool(enc->d_stem, enc->d_buf[B_X0], nb, 112, 112, 64, dt, st))) return s;
+        if ((s = mark())) return s;
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false;
         for (auto &op : enc->ops) {

@@ -233,6 +233,18 @@ class HipResNet50(_Node):
             _lib.check(L.pvr_encoder_forward(self._handle, C.c_void_p(frames_u8[i:i + m].data_ptr()), m, h, w,
                                              C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
 
+    def op_names(self):
+        """conv launch order of the HIP plan (mirrors build_resnet50 in csrc/encoder.hip)."""
+        names = []
+        stages = 3 if self.variant == 'conv3' else 4
+        for li in range(stages):
+            for bi in range((3, 4, 6, 3)[li]):
+                p = 'layer%d.%d' % (li + 1, bi)
+                names += [p + '.conv1', p + '.conv2'] + ([p + '.downsample'] if bi == 0 else []) + [p + '.conv3']
+        if self.variant != 'conv5':
+            names += ['head.conv1', 'head.downsample', 'head.conv2']
+        return names
+
     def tap(self, name, n_elems):
         """fp32 copy of an intermediate activation of the last forward (parity debugging)."""
         buf = torch.empty(n_elems, dtype=torch.float32, device='cuda')

@@ -172,7 +172,9 @@ def test_compressed_variants(variant, osz):
     assert out.shape == (2, osz)
     l2, mx = _relerr(out, ref)
     print('\n[%s f16] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
-    assert l2 < 1e-3 and mx < 2e-3
+    # no averaging at the end of the compressed variants: the f16 trunk error (~9e-4, see stagewise test) reaches
+    # the output un-averaged, so the bound here is 1.5e-3 (the split-f16 parity mode is the tighter path)
+    assert l2 < 1.5e-3 and mx < 3e-3
 
 
 def test_embeddingnet_surface_and_uber(monkeypatch):
