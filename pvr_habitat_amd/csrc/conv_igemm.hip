@@ -32,8 +32,10 @@ struct ConvP {
     int m_tiles, n_tiles;
 };
 
-template <int BM, int BN, bool F16>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+// STAGES = 2: double-buffered K loop.  STAGES = 1: single K-slice convolutions (1x1, Cin = 64): half the LDS, so
+// three blocks per CU overlap each other's load / MFMA / store phases (there is no K loop to pipeline).
+template <int BM, int BN, bool F16, int STAGES, bool HAS_RES>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BK = 64;
     constexpr int A_CH = BM / 32;                 // 16-B chunks per thread, activation tile
@@ -136,11 +138,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     PVR_LOAD_SLICE(0);
+    // residual prefetch: issue the epilogue's 16-B residual loads now so their latency hides under the K loop
+    constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
+    constexpr int EP_IT = BM * UPR / 256;
+    u32x4 rres[HAS_RES ? EP_IT : 1];
+    if constexpr (HAS_RES) {
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int u = tid + it * 256;
+            const int m = m0 + u / UPR, co = co0 + (u % UPR) * 8;
+            const bool ok = m < p.M && co < p.Cout;
+            rres[it] = *reinterpret_cast<const u32x4 *>(ok ? p.res + (size_t)m * p.Cout + co : p.zero);
+        }
+    }
     PVR_STORE_SLICE(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
+        const bool more = STAGES > 1 && kt + 1 < nk;
         if (more) PVR_LOAD_SLICE(kt + 1);
         const char *sb = smem + cur * STAGE;
 #pragma unroll
@@ -167,88 +182,104 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #undef PVR_STORE_SLICE
 
     // ---- epilogue ------------------------------------------------------------------------------------------
-    // (1) acc + bias -> LDS as an fp32 [BM pixels][BN couts] tile (reuses the pipeline buffers; every wave is
+    // (1) acc + bias -> LDS as an fp32 [pixels][BN couts] tile (reuses the pipeline buffers; every wave is
     //     past the loop's last barrier).  D row = 4*fq + reg = cout, D col = fr = pixel, so a lane owns one
     //     16-B chunk per MFMA tile; chunks are XOR-swizzled with (pixel & 7) against ds_write bank conflicts.
-    // (2) the whole block walks the tile in 8-cout units: coalesced 16-B residual loads and 16-B stores
-    //     (a pixel's BN couts are contiguous in NHWC), instead of 8-B stores at a 2*Cout-byte stride.
-    static_assert(BM * BN * 4 <= 2 * STAGE, "epilogue tile must fit the pipeline buffers");
+    // (2) the whole block walks the tile in 8-cout units: coalesced 16-B stores (a pixel's BN couts are
+    //     contiguous in NHWC) with the prefetched residual, instead of 8-B stores at a 2*Cout-byte stride.
+    // The tile is staged in EP_PASS passes of EP_ROWS pixel rows when it exceeds the pipeline buffers.
+    constexpr int EP_FIT = STAGES * STAGE / (BN * 4);           // pixel rows the pipeline buffers can hold as fp32
+    constexpr int EP_ROWS = EP_FIT >= BM ? BM : (EP_FIT >= BM / 2 ? BM / 2 : BM / 4);
+    constexpr int EP_PASS = BM / EP_ROWS;
+    static_assert(EP_ROWS % 16 == 0 && EP_ROWS <= EP_FIT, "epilogue pass must align to MFMA tiles and fit LDS");
     float *ep = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int cl = wn * (BN / 2) + i * 16 + fq * 4;          // cout within the tile
-        const int co = co0 + cl;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (co < p.Cout) bv = *reinterpret_cast<const float4 *>(p.bias + co);
+    for (int pass = 0; pass < EP_PASS; ++pass) {
+        if (pass > 0) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int pl = wm * (BM / 2) + j * 16 + fr;          // pixel within the tile
-            f32x4 v = acc[i][j];
-            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            *reinterpret_cast<f32x4 *>(ep + pl * BN + (((cl >> 2) ^ (pl & 7)) << 2)) = v;
-        }
-    }
-    __syncthreads();
-    constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
+        for (int i = 0; i < TN; ++i) {
+            const int cl = wn * (BN / 2) + i * 16 + fq * 4;      // cout within the tile
+            const int co = co0 + cl;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.Cout) bv = *reinterpret_cast<const float4 *>(p.bias + co);
 #pragma unroll
-    for (int it = 0; it < BM * UPR / 256; ++it) {
-        const int u = tid + it * 256;
-        const int pl = u / UPR, cu = u % UPR;
-        const int m = m0 + pl, co = co0 + cu * 8;
-        if (m >= p.M || co >= p.Cout) continue;
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + pl * BN + (((2 * cu) ^ (pl & 7)) << 2));
-        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + pl * BN + (((2 * cu + 1) ^ (pl & 7)) << 2));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const size_t o = (size_t)m * p.Cout + co;
-        if (p.res) {
-            const u32x4 r = *reinterpret_cast<const u32x4 *>(p.res + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu));
-                v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16));
+            for (int j = 0; j < TM; ++j) {
+                const int pl = wm * (BM / 2) + j * 16 + fr;      // pixel within the tile
+                if (pl / EP_ROWS != pass) continue;              // wave-uniform (EP_ROWS % 16 == 0)
+                const int pr = pl - pass * EP_ROWS;
+                f32x4 v = acc[i][j];
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                *reinterpret_cast<f32x4 *>(ep + pr * BN + (((cl >> 2) ^ (pr & 7)) << 2)) = v;
             }
         }
-        if (p.relu) {
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.out_f32) {
-            float *op = (float *)p.out + o;
-            *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-            u32x4 r;
+        for (int it = 0; it < EP_IT / EP_PASS; ++it) {
+            const int itg = pass * (EP_IT / EP_PASS) + it;       // index into the prefetched residual
+            const int u = tid + itg * 256;
+            const int pl = u / UPR, cu = u % UPR;
+            const int pr = pl - pass * EP_ROWS;
+            const int m = m0 + pl, co = co0 + cu * 8;
+            if (m >= p.M || co >= p.Cout) continue;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + pr * BN + (((2 * cu) ^ (pr & 7)) << 2));
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + pr * BN + (((2 * cu + 1) ^ (pr & 7)) << 2));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const size_t o = (size_t)m * p.Cout + co;
+            if constexpr (HAS_RES) {
+                const u32x4 r = rres[itg];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
-            *reinterpret_cast<u32x4 *>((u16 *)p.out + o) = r;
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu));
+                    v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.out_f32) {
+                float *op = (float *)p.out + o;
+                *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                u32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+                *reinterpret_cast<u32x4 *>((u16 *)p.out + o) = r;
+            }
         }
     }
+}
+
+template <int BM, int BN, bool F16, int STAGES, bool HAS_RES>
+static pvr_status launch_inst2(ConvP &p, hipStream_t stream) {
+    const int grid = p.m_tiles * p.n_tiles;
+    const size_t lds = STAGES * (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, HAS_RES>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, HAS_RES>), dim3(grid), dim3(256), lds, stream, p);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+template <int BM, int BN, bool F16, int STAGES>
+static pvr_status launch_inst(ConvP &p, hipStream_t stream) {
+    return p.res ? launch_inst2<BM, BN, F16, STAGES, true>(p, stream) : launch_inst2<BM, BN, F16, STAGES, false>(p, stream);
 }
 
 template <int BM, int BN>
 static pvr_status launch_cfg(ConvP &p, int dtype, hipStream_t stream) {
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
-    const int grid = p.m_tiles * p.n_tiles;
-    const size_t lds = 2 * (BM + BN) * 128;
-    if (dtype == PVR_F16) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), dim3(grid), dim3(256), lds, stream, p);
-    } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), dim3(grid), dim3(256), lds, stream, p);
-    }
-    PVR_LAUNCH_CHECK();
-    return PVR_OK;
+    const bool single = p.K == 64;
+    if (dtype == PVR_F16)
+        return single ? launch_inst<BM, BN, true, 1>(p, stream) : launch_inst<BM, BN, true, 2>(p, stream);
+    return single ? launch_inst<BM, BN, false, 1>(p, stream) : launch_inst<BM, BN, false, 2>(p, stream);
 }
 
 pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const void *res, void *out, const void *zero,
