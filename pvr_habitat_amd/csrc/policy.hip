@@ -1,0 +1,314 @@
+// BC policy plan (fp32): PolicyNet forward and one fused training iteration as a static sequence of launches
+// over a pre-allocated workspace.  C-ABI in include/pvr_policy.h.
+//
+// Replaces reference src/models.py:57-89 (forward) and main_bc_2.py:206-227 (loss / backward / clip / RMSprop).
+// The reference steps nn.LSTM one timestep at a time from Python (models.py:66-73: 100 x cuDNN calls with M = 16);
+// here the input projections of all T steps are hoisted into one GEMM per layer and only the recurrent product
+// stays sequential (one launch per layer-step, weights served from L2 / Infinity Cache: 16.8 MB per layer).
+#include <map>
+#include <string>
+#include <vector>
+#include "policy_kernels.h"
+#include "../../include/pvr_policy.h"
+
+using namespace pvr;
+
+namespace {
+struct Slot { int64_t off, numel; };
+}
+
+struct pvr_policy {
+    pvr_policy_desc d;
+    std::map<std::string, Slot> slots;
+    int64_t n_total = 0, n_train = 0;
+    // offsets (elements) into the flat parameter / gradient buffers
+    int64_t o_bnw = -1, o_bnb = -1, o_fc1w, o_fc1b, o_fc2w, o_fc2b, o_wih[2], o_whh[2], o_bih[2], o_bhh[2], o_pw, o_pb, o_bw, o_bb;
+    // workspace
+    float *a0 = nullptr, *bn_mean = nullptr, *bn_invstd = nullptr, *a1 = nullptr, *a2 = nullptr;
+    float *G[2] = {nullptr, nullptr}, *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr}, *WT[2] = {nullptr, nullptr};
+    float *hprev = nullptr, *nd = nullptr, *zeros = nullptr, *dc_carry = nullptr;
+    float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
+    long long *action = nullptr;
+    float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
+    float *grads = nullptr;
+    bool have_grads = false;
+};
+
+namespace {
+
+int64_t add_slot(pvr_policy *p, const std::string &name, int64_t numel) {
+    const int64_t off = p->n_total;
+    p->slots[name] = Slot{off, numel};
+    p->n_total += (numel + 3) / 4 * 4;            // every tensor starts on a 16-byte boundary
+    return off;
+}
+
+template <typename T>
+pvr_status dalloc(T **ptr, size_t n) {
+    PVR_HIP_TRY(hipMalloc((void **)ptr, n * sizeof(T)));
+    PVR_HIP_TRY(hipMemset(*ptr, 0, n * sizeof(T)));
+    return PVR_OK;
+}
+
+pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
+                bool a_km, bool b_kn, int relu, hipStream_t st) {
+    GemmP g;
+    g.A = A; g.B = B; g.bias = bias; g.mask = mask; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.lda = a_km ? M : K; g.ldb = b_kn ? N : K; g.ldc = N; g.relu = relu;
+    PVR_REQUIRE(((a_km && b_kn) || K % 4 == 0) && (!a_km || M % 4 == 0) && (!b_kn || N % 4 == 0),
+                "gemm_f32: contiguous dims must be multiples of 4 (M=%d N=%d K=%d)", M, N, K);
+    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+    if (!a_km && !b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(grid), dim3(256), 0, st, g);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status colsum(const float *X, float *out0, float *out1, int R, int C, hipStream_t st) {
+    ColP c = {};
+    c.X = X; c.out0 = out0; c.out1 = out1; c.R = R; c.C = C;
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3((C + 31) / 32), dim3(256), 0, st, c);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+inline int blocks_for(size_t n, int cap = 4096) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+
+#define TRY(x) do { pvr_status _s = (x); if (_s) return _s; } while (0)
+
+// forward through the workspace; logits/baseline/action land in pol->logits etc.  `target` non-null also
+// produces dlogits and per-row losses.
+pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn, const float *obs, const uint8_t *done,
+                        const float *h0, const float *c0, int T, int B, int training, const long long *target,
+                        hipStream_t st) {
+    const auto &d = pol->d;
+    const int N = T * B, H = d.hidden, O = d.obs_size;
+    hipLaunchKernelGGL(notdone_kernel, dim3((N + 255) / 256), dim3(256), 0, st, done, pol->nd, N);
+    const float *x0 = obs;
+    if (d.batch_norm) {
+        PVR_REQUIRE(bn && bn->running_mean && bn->running_var, "policy: batch_norm=1 needs the BN buffers");
+        if (training) {
+            PVR_REQUIRE(N > 1, "BatchNorm1d training needs more than one row");
+            ColP c = {};
+            c.X = obs; c.out0 = pol->bn_mean; c.out1 = pol->bn_invstd; c.running_mean = bn->running_mean;
+            c.running_var = bn->running_var; c.nbt = (long long *)bn->num_batches_tracked; c.R = N; c.C = O;
+            hipLaunchKernelGGL(colreduce_kernel<1>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)N * O / 4)), dim3(256), 0, st, obs, pol->bn_mean, pol->bn_invstd,
+                               P + pol->o_bnw, P + pol->o_bnb, pol->a0, (size_t)N * O / 4, O, 0);
+        } else {
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)N * O / 4)), dim3(256), 0, st, obs, bn->running_mean,
+                               bn->running_var, P + pol->o_bnw, P + pol->o_bnb, pol->a0, (size_t)N * O / 4, O, 1);
+        }
+        PVR_LAUNCH_CHECK();
+        x0 = pol->a0;
+    }
+    TRY(gemm(x0, P + pol->o_fc1w, P + pol->o_fc1b, nullptr, pol->a1, N, H, O, false, false, 1, st));
+    TRY(gemm(pol->a1, P + pol->o_fc2w, P + pol->o_fc2b, nullptr, pol->a2, N, H, H, false, false, 1, st));
+    const float *xin = pol->a2;
+    for (int l = 0; l < 2; ++l) {
+        // hoisted input projection of all T steps: Gx = x W_ih^T + b_ih (b_hh is added in the recurrent step)
+        TRY(gemm(xin, P + pol->o_wih[l], P + pol->o_bih[l], nullptr, pol->G[l], N, 4 * H, H, false, false, 0, st));
+        for (int t = 0; t < T; ++t) {
+            LstmFwdP f;
+            f.G = pol->G[l] + (size_t)t * B * 4 * H;
+            f.h_prev = t == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t - 1) * B * H;
+            f.c_prev = t == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t - 1) * B * H;
+            f.nd = pol->nd + (size_t)t * B;
+            f.W = P + pol->o_whh[l];
+            f.bhh = P + pol->o_bhh[l];
+            f.h_out = pol->Hs[l] + (size_t)t * B * H;
+            f.c_out = pol->Cs[l] + (size_t)t * B * H;
+            f.B = B; f.H = H;
+            hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, st, f);
+        }
+        PVR_LAUNCH_CHECK();
+        xin = pol->Hs[l];
+    }
+    HeadP hp;
+    hp.out = pol->Hs[1]; hp.Wp = P + pol->o_pw; hp.bp = P + pol->o_pb; hp.Wb = P + pol->o_bw; hp.bb = P + pol->o_bb;
+    hp.logits = pol->logits; hp.baseline = pol->baseline; hp.dlogits = pol->dlogits; hp.loss_row = pol->loss_row;
+    hp.action = pol->action; hp.target = target; hp.N = N; hp.H = H; hp.A = d.num_actions;
+    hipLaunchKernelGGL(heads_kernel, dim3((N + 3) / 4), dim3(256), 0, st, hp);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
+    PVR_REQUIRE(desc && out, "pvr_policy_create: null argument");
+    PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 64 == 0, "hidden must be a positive multiple of 64 (got %d)", desc->hidden);
+    PVR_REQUIRE(desc->obs_size > 0 && desc->obs_size % 4 == 0, "obs_size must be a positive multiple of 4 (got %d)", desc->obs_size);
+    PVR_REQUIRE(desc->num_actions > 0 && desc->num_actions <= 16, "num_actions must be in 1..16");
+    PVR_REQUIRE(desc->max_t > 0 && desc->max_b > 0 && desc->max_b <= 64, "max_t > 0 and 0 < max_b <= 64 required");
+    pvr_policy *p = new pvr_policy();
+    p->d = *desc;
+    const int64_t O = desc->obs_size, H = desc->hidden, A = desc->num_actions;
+    const int o = desc->batch_norm ? 1 : 0;
+    char nm[64];
+    if (desc->batch_norm) { p->o_bnw = add_slot(p, "fc.0.weight", O); p->o_bnb = add_slot(p, "fc.0.bias", O); }
+    snprintf(nm, sizeof nm, "fc.%d.weight", o); p->o_fc1w = add_slot(p, nm, H * O);
+    snprintf(nm, sizeof nm, "fc.%d.bias", o); p->o_fc1b = add_slot(p, nm, H);
+    snprintf(nm, sizeof nm, "fc.%d.weight", o + 2); p->o_fc2w = add_slot(p, nm, H * H);
+    snprintf(nm, sizeof nm, "fc.%d.bias", o + 2); p->o_fc2b = add_slot(p, nm, H);
+    for (int l = 0; l < 2; ++l) {
+        snprintf(nm, sizeof nm, "core.weight_ih_l%d", l); p->o_wih[l] = add_slot(p, nm, 4 * H * H);
+        snprintf(nm, sizeof nm, "core.weight_hh_l%d", l); p->o_whh[l] = add_slot(p, nm, 4 * H * H);
+        snprintf(nm, sizeof nm, "core.bias_ih_l%d", l); p->o_bih[l] = add_slot(p, nm, 4 * H);
+        snprintf(nm, sizeof nm, "core.bias_hh_l%d", l); p->o_bhh[l] = add_slot(p, nm, 4 * H);
+    }
+    p->o_pw = add_slot(p, "policy.weight", A * H);
+    p->o_pb = add_slot(p, "policy.bias", A);
+    p->n_train = p->n_total;                       // the baseline head gets no gradient from the BC loss
+    p->o_bw = add_slot(p, "baseline.weight", H);
+    p->o_bb = add_slot(p, "baseline.bias", 1);
+
+    const size_t N = (size_t)desc->max_t * desc->max_b, B = desc->max_b;
+    pvr_status s = PVR_OK;
+#define A_(ptr, n) if (!s) s = dalloc(&p->ptr, (n))
+    A_(a0, N * O); A_(bn_mean, O); A_(bn_invstd, O); A_(a1, N * H); A_(a2, N * H);
+    for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); A_(WT[l], (size_t)4 * H * H); }
+    A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H);
+    A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
+    A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
+#undef A_
+    if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("policy: device sync failed"); s = PVR_ERR_HIP; }
+    if (s) { pvr_policy_destroy(p); return s; }
+    *out = p;
+    return PVR_OK;
+}
+
+void pvr_policy_destroy(pvr_policy *p) {
+    if (!p) return;
+    void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
+                    p->WT[0], p->WT[1], p->hprev, p->nd, p->zeros, p->dc_carry, p->logits, p->baseline, p->dlogits,
+                    p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int64_t pvr_policy_param_count(const pvr_policy *p) { return p ? p->n_total : 0; }
+int64_t pvr_policy_trainable_count(const pvr_policy *p) { return p ? p->n_train : 0; }
+
+int64_t pvr_policy_param_offset(const pvr_policy *p, const char *name, int64_t *numel) {
+    if (!p || !name) return -1;
+    auto it = p->slots.find(name);
+    if (it == p->slots.end()) return -1;
+    if (numel) *numel = it->second.numel;
+    return it->second.off;
+}
+
+pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const float *obs,
+                              const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
+                              float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
+    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
+    const float *h_in = h0 ? h0 : pol->zeros, *c_in = c0 ? c0 : pol->zeros;
+    TRY(forward_core(pol, params, bn, obs, done, h_in, c_in, T, B, training, nullptr, st));
+    if (logits) PVR_HIP_TRY(hipMemcpyAsync(logits, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
+    if (baseline) PVR_HIP_TRY(hipMemcpyAsync(baseline, pol->baseline, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    if (action) PVR_HIP_TRY(hipMemcpyAsync(action, pol->action, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < 2; ++l) {
+        if (h_out) PVR_HIP_TRY(hipMemcpyAsync(h_out + (size_t)l * B * H, pol->Hs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
+        if (c_out) PVR_HIP_TRY(hipMemcpyAsync(c_out + (size_t)l * B * H, pol->Cs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, const pvr_policy_bn *bn, const float *obs,
+                           const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
+                           float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const auto &d = pol->d;
+    const int N = T * B, H = d.hidden, O = d.obs_size, A = d.num_actions;
+    const float *P = params;
+    float *Gd = pol->grads;
+    // ---- forward (training mode, zero initial state: main_bc_2.py:207-209) + loss --------------------------------
+    TRY(forward_core(pol, P, bn, obs, done, pol->zeros, pol->zeros, T, B, 1, (const long long *)actions, st));
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, pol->loss_row, N, 1.0f / (float)N, pol->stats);
+    if (logits_out) PVR_HIP_TRY(hipMemcpyAsync(logits_out, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
+    // ---- heads backward --------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(head_dw_kernel, dim3((H + 1 + 31) / 32), dim3(256), 0, st, pol->dlogits, pol->Hs[1], Gd + pol->o_pw, Gd + pol->o_pb, N, H, A);
+    hipLaunchKernelGGL(head_dx_kernel, dim3(blocks_for((size_t)N * H)), dim3(256), 0, st, pol->dlogits, P + pol->o_pw, pol->dA, N, H, A);
+    PVR_LAUNCH_CHECK();
+    // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
+    float *dh_ext = pol->dA, *dx = pol->dB;
+    for (int l = 1; l >= 0; --l) {
+        hipLaunchKernelGGL(transpose_kernel, dim3(H / 32, 4 * H / 32), dim3(256), 0, st, P + pol->o_whh[l], pol->WT[l], 4 * H, H);
+        for (int t = T - 1; t >= 0; --t) {
+            LstmBwdP b;
+            b.dG_next = t == T - 1 ? nullptr : pol->G[l] + (size_t)(t + 1) * B * 4 * H;
+            b.nd_next = t == T - 1 ? nullptr : pol->nd + (size_t)(t + 1) * B;
+            b.WT = pol->WT[l];
+            b.dh_ext = dh_ext + (size_t)t * B * H;
+            b.dc_carry = pol->dc_carry;
+            b.G = pol->G[l] + (size_t)t * B * 4 * H;
+            b.c_t = pol->Cs[l] + (size_t)t * B * H;
+            b.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
+            b.nd = pol->nd + (size_t)t * B;
+            b.B = B; b.H = H;
+            hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3(H / 16), dim3(1024), 0, st, b);
+        }
+        PVR_LAUNCH_CHECK();
+        const float *xin = l == 0 ? pol->a2 : pol->Hs[0];
+        // dW_hh = dG^T (nd * h_prev), dW_ih = dG^T x_in, db_ih = db_hh = colsum(dG)
+        hipLaunchKernelGGL(hprev_kernel, dim3(blocks_for((size_t)N * H / 4)), dim3(256), 0, st, pol->Hs[l], pol->zeros, pol->nd, pol->hprev, T, B, H);
+        TRY(gemm(pol->G[l], pol->hprev, nullptr, nullptr, Gd + pol->o_whh[l], 4 * H, H, N, true, true, 0, st));
+        TRY(gemm(pol->G[l], xin, nullptr, nullptr, Gd + pol->o_wih[l], 4 * H, H, N, true, true, 0, st));
+        TRY(colsum(pol->G[l], Gd + pol->o_bih[l], Gd + pol->o_bhh[l], N, 4 * H, st));
+        // dx_in = dG W_ih; for layer 0 the ReLU of fc2 is applied as a mask (a2 > 0)
+        TRY(gemm(pol->G[l], P + pol->o_wih[l], nullptr, l == 0 ? pol->a2 : nullptr, dx, N, H, 4 * H, false, true, 0, st));
+        float *tmp = dh_ext; dh_ext = dx; dx = tmp;
+    }
+    // dh_ext now holds dz2 = d(fc2 pre-activation) [N][H]
+    float *dz2 = dh_ext, *dz1 = dx;
+    const float *x0 = d.batch_norm ? pol->a0 : obs;
+    TRY(gemm(dz2, pol->a1, nullptr, nullptr, Gd + pol->o_fc2w, H, H, N, true, true, 0, st));
+    TRY(colsum(dz2, Gd + pol->o_fc2b, nullptr, N, H, st));
+    TRY(gemm(dz2, P + pol->o_fc2w, nullptr, pol->a1, dz1, N, H, H, false, true, 0, st));      // masked by a1 > 0
+    TRY(gemm(dz1, x0, nullptr, nullptr, Gd + pol->o_fc1w, H, O, N, true, true, 0, st));
+    TRY(colsum(dz1, Gd + pol->o_fc1b, nullptr, N, H, st));
+    if (d.batch_norm) {
+        TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
+        ColP c = {};
+        c.X = obs; c.dY = pol->da0; c.mean_in = pol->bn_mean; c.invstd_in = pol->bn_invstd;
+        c.out0 = Gd + pol->o_bnw; c.out1 = Gd + pol->o_bnb; c.R = N; c.C = O;
+        hipLaunchKernelGGL(colreduce_kernel<2>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+        PVR_LAUNCH_CHECK();
+    }
+    pol->have_grads = true;
+    // ---- grad norm, clip, RMSprop -----------------------------------------------------------------------------------
+    const size_t nt = (size_t)pol->n_train;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, st, Gd, nt, pol->partial);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, pol->partial, 1024, max_grad_norm, pol->stats);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, square_avg, Gd, pol->stats, nt / 4, lr, alpha, eps);
+    PVR_LAUNCH_CHECK();
+    if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out, pol->stats, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_stream) {
+    PVR_REQUIRE(pol && grads_out, "pvr_policy_last_grads: null argument");
+    if (!pol->have_grads) { set_error("no training step has run"); return PVR_ERR_STATE; }
+    PVR_HIP_TRY(hipMemcpyAsync(grads_out, pol->grads, (size_t)pol->n_train * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    return PVR_OK;
+}
+
+pvr_status pvr_op_gemm_f32(const float *A, const float *B, const float *bias, float *C, int32_t M, int32_t N, int32_t K,
+                           int32_t a_km, int32_t b_kn, int32_t relu, void *hip_stream) {
+    PVR_REQUIRE(A && B && C, "pvr_op_gemm_f32: null pointer");
+    return gemm(A, B, bias, nullptr, C, M, N, K, a_km != 0, b_kn != 0, relu, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// Device kernels of the BC policy path (fp32).  Included only by policy.hip.
+//
+// Reference arithmetic: src/models.py:57-89 (PolicyNet.forward), main_bc_2.py:211-227 (loss, clip, RMSprop).
+// Everything here is deterministic: no float atomics; every reduction has a fixed order, so two runs give
+// bit-identical parameters (the reference's own run-to-run behaviour with cudnn.deterministic=True).
+//
+// Matrix work uses the f32-input MFMA v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, MI355X_MICROARCH.md
+// "Matrix cores"): lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D col = l&15, row = 4*(l>>4)+reg.
+#pragma once
+#include "common.h"
+
+namespace pvr {
+
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 GEMM, 64x64x32 tiles, 2x2 waves, 2-stage LDS pipeline.
+//   C[m][n] = sum_k A'(m,k) * B'(n,k)  (+ bias[n]) (relu) (zero where mask[m][n] <= 0)
+//   ATR: A stored [K][M] (lda = row stride) else [M][K];  BTR: B stored [K][N] else [N][K].
+// Used for: FC layers and LSTM input projections (NT), dX = dY W (NN), dW = dY^T X (TN).
+// ---------------------------------------------------------------------------------------------------------
+struct GemmP {
+    const float *A, *B, *bias, *mask;
+    float *C;
+    int M, N, K, lda, ldb, ldc, relu;
+};
+
+template <bool ATR, bool BTR>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int LDN = 36;        // [rows][k] stride (floats) of a k-contiguous operand tile
+    constexpr int LDT = 80;        // [k][rows] stride of a row-contiguous operand tile (== 16 mod 32: conflict-free)
+    constexpr int TILE = 2560;     // max(64*36, 32*80)
+    __shared__ __attribute__((aligned(16))) float sm[2][2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (swz / n_tiles) * BM, n0 = (swz % n_tiles) * BN;
+    const int nk = (p.K + BK - 1) / BK;
+
+    f32x4 ra[2], rb[2];
+#define PVR_G_LOAD(kt_)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+            const int idx = tid + 256 * i;                                                                \
+            if (!ATR) {                                                                                   \
+                const int gm = m0 + (idx >> 3), gk = (kt_) * BK + (idx & 7) * 4;                          \
+                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gm * p.lda + gk) \
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
+            } else {                                                                                      \
+                const int gk = (kt_) * BK + (idx >> 4), gm = m0 + (idx & 15) * 4;                         \
+                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gk * p.lda + gm) \
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
+            }                                                                                             \
+            if (!BTR) {                                                                                   \
+                const int gn = n0 + (idx >> 3), gk = (kt_) * BK + (idx & 7) * 4;                          \
+                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gn * p.ldb + gk) \
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
+            } else {                                                                                      \
+                const int gk = (kt_) * BK + (idx >> 4), gn = n0 + (idx & 15) * 4;                         \
+                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gk * p.ldb + gn) \
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define PVR_G_STORE(buf_)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+            const int idx = tid + 256 * i;                                                                \
+            float *da = !ATR ? &sm[buf_][0][(idx >> 3) * LDN + (idx & 7) * 4] : &sm[buf_][0][(idx >> 4) * LDT + (idx & 15) * 4]; \
+            float *db = !BTR ? &sm[buf_][1][(idx >> 3) * LDN + (idx & 7) * 4] : &sm[buf_][1][(idx >> 4) * LDT + (idx & 15) * 4]; \
+            *reinterpret_cast<f32x4 *>(da) = ra[i];                                                       \
+            *reinterpret_cast<f32x4 *>(db) = rb[i];                                                       \
+        }                                                                                                 \
+    }
+
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PVR_G_LOAD(0);
+    PVR_G_STORE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) PVR_G_LOAD(kt + 1);
+        const float *As = sm[cur][0], *Bs = sm[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int k = ks * 4 + fq;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 32 + i * 16 + fr;
+                a[i] = !ATR ? As[row * LDN + k] : As[k * LDT + row];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 32 + j * 16 + fr;
+                b[j] = !BTR ? Bs[row * LDN + k] : Bs[k * LDT + row];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32(a[i], b[j], acc[i][j]);
+        }
+        if (more) PVR_G_STORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef PVR_G_LOAD
+#undef PVR_G_STORE
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask && p.mask[(size_t)m * p.ldc + n] <= 0.f) v = 0.f;
+                p.C[(size_t)m * p.ldc + n] = v;
+            }
+    }
+}
+
+// [R][C] -> [C][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(size_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) out[(size_t)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column reductions over the N = T*B rows (fixed order: 8 row groups per column, then an LDS tree)
+//   MODE 0: out[c] = sum_r X[r][c]
+//   MODE 1: BN statistics (models.py:31-34, training): mean, 1/sqrt(var_biased+eps), running-stat update
+//   MODE 2: BN affine grads: dgamma[c] = sum_r dY[r][c]*(X[r][c]-mean[c])*invstd[c], dbeta[c] = sum_r dY[r][c]
+// ---------------------------------------------------------------------------------------------------------
+struct ColP {
+    const float *X, *dY, *mean_in, *invstd_in;
+    float *out0, *out1, *running_mean, *running_var;
+    long long *nbt;
+    int R, C;
+    int out_stride;   // MODE 0 with two outputs (bias_ih and bias_hh get the same sum): out1 optional
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
+    __shared__ float s0[8][33], s1[8][33];
+    const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < p.C;
+    float a0 = 0.f, a1 = 0.f;
+    if (MODE == 0) {
+        if (ok) for (int r = g; r < p.R; r += 8) a0 += p.X[(size_t)r * p.C + c];
+    } else if (MODE == 1) {
+        if (ok) for (int r = g; r < p.R; r += 8) a0 += p.X[(size_t)r * p.C + c];
+    } else {
+        if (ok) {
+            const float mu = p.mean_in[c], is = p.invstd_in[c];
+            for (int r = g; r < p.R; r += 8) {
+                const float dy = p.dY[(size_t)r * p.C + c];
+                a0 += dy * ((p.X[(size_t)r * p.C + c] - mu) * is);
+                a1 += dy;
+            }
+        }
+    }
+    s0[g][cx] = a0; s1[g][cx] = a1;
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t0 += s0[i][cx]; t1 += s1[i][cx]; }
+    if (MODE == 0) {
+        if (ok && g == 0) { p.out0[c] = t0; if (p.out1) p.out1[c] = t0; }
+    } else if (MODE == 2) {
+        if (ok && g == 0) { p.out0[c] = t0; p.out1[c] = t1; }
+    } else {
+        const float mean = t0 / (float)p.R;
+        __syncthreads();
+        float v = 0.f;
+        if (ok) for (int r = g; r < p.R; r += 8) { const float d = p.X[(size_t)r * p.C + c] - mean; v += d * d; }
+        s0[g][cx] = v;
+        __syncthreads();
+        if (ok && g == 0) {
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vs += s0[i][cx];
+            const float var_b = vs / (float)p.R;
+            p.out0[c] = mean;
+            p.out1[c] = 1.0f / sqrtf(var_b + 1e-5f);
+            // momentum 0.1, unbiased variance in the running estimate (torch BatchNorm1d)
+            p.running_mean[c] = 0.9f * p.running_mean[c] + 0.1f * mean;
+            p.running_var[c] = 0.9f * p.running_var[c] + 0.1f * (var_b * (float)p.R / (float)(p.R - 1));
+            if (c == 0 && p.nbt) *p.nbt += 1;
+        }
+    }
+}
+
+// y = (x - mean) * invstd * gamma + beta  (training: batch stats; eval: running stats, invstd computed here)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd_or_var, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ y, size_t total4,
+                                                       int C, int is_var) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % (size_t)C);
+        const f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float is = is_var ? 1.0f / sqrtf(invstd_or_var[c + e] + 1e-5f) : invstd_or_var[c + e];
+            o[e] = (xv[e] - mean[c + e]) * is * gamma[c + e] + beta[c + e];
+        }
+        reinterpret_cast<f32x4 *>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void notdone_kernel(const uint8_t *__restrict__ done, float *__restrict__ nd, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) nd[i] = fabsf(1.0f - (done[i] ? 1.0f : 0.0f));      // models.py:66
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTM forward, one launch per (layer, timestep): gates = Gx[t] + (nd*h_prev) W_hh^T, cell update.
+// Block = 4 hidden units (16 gate rows i,f,g,o); wave w contracts k in [w*H/4, (w+1)*H/4) on the f32 MFMA.
+// G is overwritten in place with the activated gates (saved for BPTT).
+// ---------------------------------------------------------------------------------------------------------
+struct LstmFwdP {
+    float *G;                  // [B][4H] at t: in = input projection (+ both biases), out = i,f,g,o
+    const float *h_prev, *c_prev, *nd, *W, *bhh;   // [B][H], [B][H], [B], [4H][H], [4H]
+    float *h_out, *c_out;      // [B][H]
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
+    __shared__ float part[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int u0 = blockIdx.x * 4, H = p.H;
+    const float *wrow = p.W + (size_t)((fr >> 2) * H + u0 + (fr & 3)) * H;
+    const int kbeg = wave * (H / 4);
+    for (int b0 = 0; b0 < p.B; b0 += 16) {
+        const int b = b0 + fr;
+        const bool bok = b < p.B;
+        const float ndb = bok ? p.nd[b] : 0.f;
+        const float *hrow = p.h_prev + (size_t)(bok ? b : 0) * H;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < H / 64; ++c) {
+            const int k = kbeg + c * 16 + fq * 4;
+            f32x4 hv = *reinterpret_cast<const f32x4 *>(hrow + k);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + k);
+            hv *= ndb;                                   // state * notdone (models.py:69); 0 for padded batch rows
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma_f32(hv[e], wv[e], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
+        __syncthreads();
+        if (tid < 64) {
+            const int bb = tid >> 2, j = tid & 3, bi = b0 + bb;
+            if (bi < p.B) {
+                float s[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    s[g] = ((part[0][bb][g * 4 + j] + part[1][bb][g * 4 + j]) + (part[2][bb][g * 4 + j] + part[3][bb][g * 4 + j])) +
+                           (p.G[(size_t)bi * 4 * H + g * H + u0 + j] + p.bhh[g * H + u0 + j]);
+                const float ig = sigmoidf_(s[0]), fg = sigmoidf_(s[1]), gg = tanhf(s[2]), og = sigmoidf_(s[3]);
+                const float cm = p.nd[bi] * p.c_prev[(size_t)bi * H + u0 + j];
+                const float c = fg * cm + ig * gg;
+                const float h = og * tanhf(c);
+                float *g = p.G + (size_t)bi * 4 * H + u0 + j;
+                g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+                p.c_out[(size_t)bi * H + u0 + j] = c;
+                p.h_out[(size_t)bi * H + u0 + j] = h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTM backward (BPTT), one launch per (layer, timestep), t descending.  Block = 16 hidden units, 16 waves:
+//   (a) dh_rec[b][u] = nd[t+1][b] * sum_k dG[t+1][b][k] * W_hh[k][u]   (WT = W_hh^T, row u contiguous in k)
+//   (b) for its own units: dh = dh_ext[t] + dh_rec, dc = dh*o*(1-tanh^2 c) + dc_carry, gate grads -> dG[t]
+//       (in place over the saved gates), dc_carry = nd[t] * dc * f
+// ---------------------------------------------------------------------------------------------------------
+struct LstmBwdP {
+    const float *dG_next, *nd_next, *WT, *dh_ext;    // [B][4H] (nullptr at t=T-1), [B], [H][4H], [B][H]
+    float *dc_carry;                                  // [B][H] in/out
+    float *G;                                         // [B][4H] at t: gates in, dG out
+    const float *c_t, *c_prev, *nd;                   // [B][H], [B][H], [B]
+    int B, H;
+};
+
+__global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(LstmBwdP p) {
+    __shared__ float part[16][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int u0 = blockIdx.x * 16, H = p.H, K = 4 * p.H;
+    const float *wrow = p.WT + (size_t)(u0 + fr) * K;
+    const int kbeg = wave * (K / 16);
+    for (int b0 = 0; b0 < p.B; b0 += 16) {
+        if (p.dG_next) {
+            const int b = b0 + fr;
+            const bool bok = b < p.B;
+            const float *drow = p.dG_next + (size_t)(bok ? b : 0) * K;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < K / 256; ++c) {
+                const int k = kbeg + c * 16 + fq * 4;
+                f32x4 dv = *reinterpret_cast<const f32x4 *>(drow + k);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + k);
+                if (!bok) dv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32(dv[e], wv[e], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int bb = tid >> 4, j = tid & 15, bi = b0 + bb, u = u0 + j;
+            if (bi < p.B) {
+                float dh = p.dh_ext[(size_t)bi * H + u];
+                float dc_in = 0.f;
+                if (p.dG_next) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) s += part[w][bb][j];
+                    dh += p.nd_next[bi] * s;
+                    dc_in = p.dc_carry[(size_t)bi * H + u];
+                }
+                float *g = p.G + (size_t)bi * K + u;
+                const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+                const float tc = tanhf(p.c_t[(size_t)bi * H + u]);
+                const float cm = p.nd[bi] * p.c_prev[(size_t)bi * H + u];
+                const float dog = dh * tc * og * (1.f - og);
+                const float dc = dh * og * (1.f - tc * tc) + dc_in;
+                g[0] = dc * gg * ig * (1.f - ig);
+                g[H] = dc * cm * fg * (1.f - fg);
+                g[2 * H] = dc * ig * (1.f - gg * gg);
+                g[3 * H] = dog;
+                p.dc_carry[(size_t)bi * H + u] = p.nd[bi] * dc * fg;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh
+__global__ __launch_bounds__(256) void hprev_kernel(const float *__restrict__ hs, const float *__restrict__ h_init,
+                                                    const float *__restrict__ nd, float *__restrict__ out, int T, int B, int H) {
+    const size_t total4 = (size_t)T * B * H / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const int row = (int)(e / H);                    // t*B + b
+        const int t = row / B, b = row % B;
+        const float *src = t == 0 ? h_init + (size_t)b * H + (e % H) : hs + (size_t)(row - B) * H + (e % H);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+        v *= nd[row];
+        reinterpret_cast<f32x4 *>(out)[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// heads (models.py:75-82) + BC loss (main_bc_2.py:211-214): one wave per row
+//   logits = out W_p^T + b_p, baseline = out W_b^T + b_b, action = argmax (first max on ties, as torch.argmax)
+//   with targets: loss_row = -log_softmax(logits)[target], dlogits = (softmax - onehot) / N   (mean reduction)
+// dlogits rows are padded to 16 floats.
+// ---------------------------------------------------------------------------------------------------------
+struct HeadP {
+    const float *out, *Wp, *bp, *Wb, *bb;
+    float *logits, *baseline, *dlogits, *loss_row;
+    long long *action;
+    const long long *target;
+    int N, H, A;
+};
+
+__global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const float *x = p.out + (size_t)n * p.H;
+    float l[17];
+    for (int a = 0; a <= p.A; ++a) {
+        const float *w = a < p.A ? p.Wp + (size_t)a * p.H : p.Wb;
+        float s = 0.f;
+        for (int k = lane * 4; k < p.H; k += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + k), wv = *reinterpret_cast<const f32x4 *>(w + k);
+            s += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        l[a] = s + (a < p.A ? p.bp[a] : p.bb[0]);
+    }
+    if (lane != 0) return;
+    int best = 0;
+    float mx = l[0];
+    for (int a = 1; a < p.A; ++a) if (l[a] > mx) { mx = l[a]; best = a; }
+    for (int a = 0; a < p.A; ++a) p.logits[(size_t)n * p.A + a] = l[a];
+    p.baseline[n] = l[p.A];
+    p.action[n] = best;
+    if (p.target) {
+        float se = 0.f;
+        for (int a = 0; a < p.A; ++a) se += expf(l[a] - mx);
+        const float lse = mx + logf(se);
+        const int tg = (int)p.target[n];
+        p.loss_row[n] = lse - l[tg];
+        const float inv = 1.0f / (float)p.N;
+        for (int a = 0; a < 16; ++a)
+            p.dlogits[(size_t)n * 16 + a] = a < p.A ? (expf(l[a] - lse) - (a == tg ? 1.f : 0.f)) * inv : 0.f;
+    }
+}
+
+// fixed-order sum of n values scaled by `scale` -> out[0]  (loss mean; 1 block)
+__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int n, float scale, float *__restrict__ out) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0] * scale;
+}
+
+// dout[n][k] = sum_a dlogits[n][a] * Wp[a][k]
+__global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dl, const float *__restrict__ Wp,
+                                                      float *__restrict__ dout, int N, int H, int A) {
+    const size_t total = (size_t)N * H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / H), k = (int)(i % H);
+        float s = 0.f;
+        for (int a = 0; a < A; ++a) s += dl[(size_t)n * 16 + a] * Wp[(size_t)a * H + k];
+        dout[i] = s;
+    }
+}
+
+// dWp[a][k] = sum_n dlogits[n][a] * out[n][k];  dbp[a] = sum_n dlogits[n][a]   (32 columns x 8 row groups / block)
+__global__ __launch_bounds__(256) void head_dw_kernel(const float *__restrict__ dl, const float *__restrict__ out,
+                                                      float *__restrict__ dWp, float *__restrict__ dbp, int N, int H, int A) {
+    __shared__ float s[8][33];
+    const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cx;                  // k == H -> bias column (out == 1)
+    for (int a = 0; a < A; ++a) {
+        float acc = 0.f;
+        if (k <= H)
+            for (int n = g; n < N; n += 8) acc += dl[(size_t)n * 16 + a] * (k < H ? out[(size_t)n * H + k] : 1.f);
+        s[g][cx] = acc;
+        __syncthreads();
+        if (g == 0 && k <= H) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += s[i][cx];
+            if (k < H) dWp[(size_t)a * H + k] = t; else dbp[a] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// grad norm + clip + RMSprop (main_bc_2.py:220-227; torch.optim.RMSprop momentum=0, centered=False)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial) {
+    __shared__ float s[256];
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t beg = (size_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float a = 0.f;
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) a += g[i] * g[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+// stats[1] = ||g||, stats[2] = clip coefficient min(1, max_norm / (norm + 1e-6))
+__global__ __launch_bounds__(256) void norm_final_kernel(const float *__restrict__ partial, int n, float max_norm, float *__restrict__ stats) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(s[0]);
+        stats[1] = nrm;
+        const float coef = max_norm / (nrm + 1e-6f);
+        stats[2] = coef < 1.f ? coef : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__ p, float *__restrict__ v, const float *__restrict__ g,
+                                                      const float *__restrict__ stats, size_t n4, float lr, float alpha, float eps) {
+    const float coef = stats[2];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 vv = reinterpret_cast<f32x4 *>(v)[i];
+        f32x4 pv = reinterpret_cast<f32x4 *>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * coef;
+            vv[e] = vv[e] * alpha + (1.f - alpha) * (ge * ge);
+            pv[e] = pv[e] - lr * (ge / (sqrtf(vv[e]) + eps));
+        }
+        reinterpret_cast<f32x4 *>(v)[i] = vv;
+        reinterpret_cast<f32x4 *>(p)[i] = pv;
+    }
+}
+
+}  // namespace pvr

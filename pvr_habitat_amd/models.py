@@ -1,0 +1,302 @@
+"""PolicyNet with the reference call surface; forward and the BC training step run in libpvr_hip.so.
+
+Mirrors reference src/models.py:13-89 (`PolicyNet(observation_shape, num_actions, batch_norm=False)`,
+`.device`, `.initial_state(B)`, `.forward(inputs, core_state) -> (dict, core_state)`), the optimiser set-up of
+main_bc_2.py:80-90 (`RMSprop` + `LambdaLR(1 - epoch/max_epochs)`) and the update of main_bc_2.py:206-227.
+
+All parameters are views of ONE flat fp32 buffer (layout from `pvr_policy_param_offset`), so the fused
+HIP step (forward, loss, BPTT, grad-norm, clip, RMSprop) updates them in place while `state_dict()` keeps
+the reference's keys and shapes (`fc.0.*` BatchNorm, `fc.1/fc.3` linears, `core.*_l{0,1}`, `policy.*`,
+`baseline.*`).  There is no autograd graph: training goes through `HipRMSprop.step(...)`, not `loss.backward()`.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import _lib
+
+HIDDEN = 1024
+
+
+class PolicyBN(C.Structure):
+    _fields_ = [('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p)]
+
+
+class PolicyDesc(C.Structure):
+    _fields_ = [('obs_size', C.c_int32), ('hidden', C.c_int32), ('num_actions', C.c_int32), ('batch_norm', C.c_int32),
+                ('max_t', C.c_int32), ('max_b', C.c_int32)]
+
+
+def _plib():
+    L = _lib.lib()
+    if not getattr(L, '_policy_bound', False):
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        L.pvr_policy_create.restype = C.c_int
+        L.pvr_policy_create.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp)]
+        L.pvr_policy_destroy.restype = None
+        L.pvr_policy_destroy.argtypes = [vp]
+        L.pvr_policy_param_count.restype = i64
+        L.pvr_policy_param_count.argtypes = [vp]
+        L.pvr_policy_trainable_count.restype = i64
+        L.pvr_policy_trainable_count.argtypes = [vp]
+        L.pvr_policy_param_offset.restype = i64
+        L.pvr_policy_param_offset.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+        L.pvr_policy_forward.restype = C.c_int
+        L.pvr_policy_forward.argtypes = [vp, vp, C.POINTER(PolicyBN), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.pvr_policy_step.restype = C.c_int
+        L.pvr_policy_step.argtypes = [vp, vp, vp, C.POINTER(PolicyBN), vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp]
+        L.pvr_policy_last_grads.restype = C.c_int
+        L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
+        L.pvr_op_gemm_f32.restype = C.c_int
+        L.pvr_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+        L._policy_bound = True
+    return L
+
+
+class _Holder(nn.Module):
+    """Plain container so parameter names nest like the reference modules (fc.1.weight, core.weight_ih_l0)."""
+
+
+def _init(module, weight_init, bias_init, gain=1):
+    weight_init(module.weight.data, gain=gain)
+    bias_init(module.bias.data)
+    return module
+
+
+def _reference_init(obs_size, num_actions, batch_norm, hidden):
+    """Same torch modules, construction order and init calls as reference src/models.py:17-44, so that a given
+    torch seed yields the reference's initial weights bit for bit.  Returns {state_dict key: tensor}."""
+    init_ = lambda m: _init(m, nn.init.orthogonal_, lambda x: nn.init.constant_(x, 0), nn.init.calculate_gain('relu'))
+    fc = nn.Sequential(init_(nn.Linear(obs_size, hidden)), nn.ReLU(), init_(nn.Linear(hidden, hidden)), nn.ReLU())
+    if batch_norm:
+        fc = nn.Sequential(nn.BatchNorm1d(obs_size), *list(fc))
+    core = nn.LSTM(hidden, hidden, 2)
+    init_ = lambda m: _init(m, nn.init.orthogonal_, lambda x: nn.init.constant_(x, 0))
+    policy = init_(nn.Linear(hidden, num_actions))
+    baseline = init_(nn.Linear(hidden, 1))
+    sd = {}
+    for pfx, mod in (('fc', fc), ('core', core), ('policy', policy), ('baseline', baseline)):
+        for k, v in mod.state_dict().items():
+            sd[pfx + '.' + k] = v.detach().clone()
+    return sd
+
+
+class PolicyNet(nn.Module):
+    def __init__(self, observation_shape, num_actions, batch_norm=False, max_unroll=100, max_batch=32):
+        super(PolicyNet, self).__init__()
+        self.obs_size = int(observation_shape[0])
+        self.num_actions = int(num_actions)
+        self.batch_norm = bool(batch_norm)
+        self.hidden = HIDDEN
+        self._max_t, self._max_b = int(max_unroll), int(max_batch)
+        self._handle = None
+        self._layout = None          # name -> (offset, shape), filled from the library on first GPU use
+        sd = _reference_init(self.obs_size, self.num_actions, self.batch_norm, self.hidden)
+        # flat buffer with the library's layout (computed here without the GPU: same rule as policy.hip add_slot)
+        self._order = [k for k in sd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+        base = [k for k in self._order if k.startswith('baseline.')]
+        self._order = [k for k in self._order if not k.startswith('baseline.')] + base
+        off, self._slots = 0, {}
+        for k in self._order:
+            self._slots[k] = (off, tuple(sd[k].shape))
+            if k == 'policy.bias':
+                self._n_train = off + (sd[k].numel() + 3) // 4 * 4
+            off += (sd[k].numel() + 3) // 4 * 4
+        self._flat = torch.zeros(off, dtype=torch.float32)
+        for k in self._order:
+            o, shp = self._slots[k]
+            self._flat[o:o + sd[k].numel()].copy_(sd[k].reshape(-1))
+        # module tree with the reference names; parameters are views of the flat buffer
+        for k in self._order:
+            self._install(k, nn.Parameter(self._view(k), requires_grad=True))
+        if self.batch_norm:
+            bn = self._modules['fc']._modules['0']
+            bn.register_buffer('running_mean', sd['fc.0.running_mean'])
+            bn.register_buffer('running_var', sd['fc.0.running_var'])
+            bn.register_buffer('num_batches_tracked', sd['fc.0.num_batches_tracked'])
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def _view(self, k):
+        o, shp = self._slots[k]
+        return self._flat[o:o + int(np.prod(shp))].view(shp)
+
+    def _install(self, key, param):
+        parts = key.split('.')
+        node = self
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Holder())
+            node = node._modules[p]
+        node.register_parameter(parts[-1], param)
+
+    def _param(self, key):
+        node = self
+        parts = key.split('.')
+        for p in parts[:-1]:
+            node = node._modules[p]
+        return node, parts[-1]
+
+    def _apply(self, fn, recurse=True):
+        # move the flat buffer once and re-point every parameter view at it (nn.Module._apply would break the aliasing)
+        self._flat = fn(self._flat)
+        for k in self._order:
+            node, leaf = self._param(k)
+            node._parameters[leaf].data = self._view(k)
+        if self.batch_norm:
+            bn = self._modules['fc']._modules['0']
+            for b in ('running_mean', 'running_var', 'num_batches_tracked'):
+                bn._buffers[b] = fn(bn._buffers[b])
+        self._release()
+        return self
+
+    def _release(self):
+        if self._handle is not None:
+            _plib().pvr_policy_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure(self, T, B):
+        _lib.require_gpu()
+        if not self._flat.is_cuda:
+            raise RuntimeError('PolicyNet parameters are on %s: call .to(device="cuda") first (no CPU path)' % self._flat.device)
+        if self._handle is not None and T <= self._max_t and B <= self._max_b:
+            return
+        self._release()
+        self._max_t, self._max_b = max(self._max_t, T), max(self._max_b, B)
+        L = _plib()
+        d = PolicyDesc(self.obs_size, self.hidden, self.num_actions, int(self.batch_norm), self._max_t, self._max_b)
+        h = C.c_void_p()
+        _lib.check(L.pvr_policy_create(C.byref(d), C.byref(h)))
+        self._handle = h
+        assert L.pvr_policy_param_count(h) == self._flat.numel(), 'flat layout mismatch with libpvr_hip'
+        assert L.pvr_policy_trainable_count(h) == self._n_train
+        for k in self._order:
+            n = C.c_int64()
+            assert L.pvr_policy_param_offset(h, k.encode(), C.byref(n)) == self._slots[k][0], k
+
+    def _bn_struct(self):
+        if not self.batch_norm:
+            return None
+        bn = self._modules['fc']._modules['0']
+        return PolicyBN(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr())
+
+    # -- reference surface ------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._flat.device
+
+    def initial_state(self, batch_size):
+        return tuple(torch.zeros(2, batch_size, self.hidden) for _ in range(2))
+
+    def forward(self, inputs, core_state=()):
+        x = inputs['obs']                                     # (unroll_length, batch_size, obs_size)
+        T, B = x.shape[0], x.shape[1]
+        self._ensure(T, B)
+        dev = self.device
+        x = torch.flatten(x, 0, 1).float().to(device=dev).contiguous()
+        done = inputs['done'].to(device=dev).to(torch.uint8).contiguous()
+        if len(core_state) == 2:
+            h0 = core_state[0].to(device=dev, dtype=torch.float32).contiguous()
+            c0 = core_state[1].to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            h0 = c0 = None
+        A = self.num_actions
+        logits = torch.empty((T, B, A), dtype=torch.float32, device=dev)
+        baseline = torch.empty((T, B), dtype=torch.float32, device=dev)
+        action = torch.empty((T, B), dtype=torch.int64, device=dev)
+        h = torch.empty((2, B, self.hidden), dtype=torch.float32, device=dev)
+        c = torch.empty_like(h)
+        bn = self._bn_struct()
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(_plib().pvr_policy_forward(self._handle, vp(self._flat), C.byref(bn) if bn else None, vp(x), vp(done),
+                                              vp(h0), vp(c0), T, B, int(self.training), vp(logits), vp(baseline), vp(action),
+                                              vp(h), vp(c), _lib.stream_ptr()))
+        if self.training:                                     # models.py:78-80 (sample is unused by the BC loss)
+            action = torch.multinomial(F.softmax(logits.view(T * B, A), dim=1), num_samples=1).view(T, B)
+        return dict(policy_logits=logits, baseline=baseline, action=action), (h, c)
+
+    def last_grads(self):
+        """Flat pre-clip gradient of the last fused step as {state_dict key: tensor} (parity tests)."""
+        g = torch.empty(self._n_train, dtype=torch.float32, device=self.device)
+        _lib.check(_plib().pvr_policy_last_grads(self._handle, C.c_void_p(g.data_ptr()), _lib.stream_ptr()))
+        out = {}
+        for k in self._order:
+            o, shp = self._slots[k]
+            if o < self._n_train:
+                out[k] = g[o:o + int(np.prod(shp))].view(shp)
+        return out
+
+
+class HipRMSprop(object):
+    """torch.optim.RMSprop(momentum=0, centered=False) + LambdaLR(1 - epoch/max_epochs) as used by
+    main_bc_2.py:80-90, fused with the forward/backward of the BC loss (main_bc_2.py:206-227).
+
+    `scheduler_step()` mirrors the reference's `scheduler.step()` call, which precedes `optimizer.step()`
+    (main_bc_2.py:216), so update k uses lr * (1 - (k+1)/max_epochs)."""
+
+    def __init__(self, model, lr=1e-4, alpha=0.99, eps=1e-5, momentum=0, max_grad_norm=40.0, max_epochs=None):
+        assert momentum == 0, 'momentum != 0 is not built (reference default is 0, src/arguments.py:63-64)'
+        self.model, self.lr0, self.alpha, self.eps = model, float(lr), float(alpha), float(eps)
+        self.max_grad_norm, self.max_epochs = float(max_grad_norm), max_epochs
+        self.last_epoch = 0
+        self.square_avg = torch.zeros_like(model._flat)
+        self.steps = 0
+        self._stats = None
+
+    def scheduler_step(self):
+        self.last_epoch += 1
+
+    def current_lr(self):
+        if self.max_epochs is None:
+            return self.lr0
+        return self.lr0 * (1 - self.last_epoch / self.max_epochs)
+
+    def step(self, obs, done, actions, return_logits=False):
+        """obs (T,B,obs) float, done (T,B) bool, actions (T,B) int -> (loss, grad_norm) device scalars."""
+        m = self.model
+        T, B = obs.shape[0], obs.shape[1]
+        m._ensure(T, B)
+        dev = m.device
+        if self.square_avg.device != dev:
+            self.square_avg = self.square_avg.to(dev)
+        x = torch.flatten(obs, 0, 1).float().to(device=dev).contiguous()
+        d = done.to(device=dev).to(torch.uint8).contiguous()
+        a = actions.to(device=dev).long().contiguous()
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        logits = torch.empty((T, B, m.num_actions), dtype=torch.float32, device=dev) if return_logits else None
+        bn = m._bn_struct()
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(_plib().pvr_policy_step(m._handle, vp(m._flat), vp(self.square_avg), C.byref(bn) if bn else None, vp(x), vp(d),
+                                           vp(a), T, B, self.current_lr(), self.alpha, self.eps, self.max_grad_norm, vp(stats),
+                                           vp(logits), _lib.stream_ptr()))
+        self.steps += 1
+        return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
+
+    # torch-compatible checkpoint layout (main_bc_2.py:255-257)
+    def state_dict(self):
+        state = {}
+        for i, k in enumerate(k for k in self.model._order):
+            o, shp = self.model._slots[k]
+            if o < self.model._n_train:
+                state[i] = {'step': torch.tensor(float(self.steps)), 'square_avg': self.square_avg[o:o + int(np.prod(shp))].view(shp).clone()}
+        return {'state': state, 'param_groups': [{'lr': self.current_lr(), 'initial_lr': self.lr0, 'momentum': 0, 'alpha': self.alpha,
+                                                  'eps': self.eps, 'centered': False, 'weight_decay': 0,
+                                                  'params': list(range(len(self.model._order)))}],
+                'last_epoch': self.last_epoch}
+
+    def load_state_dict(self, sd):
+        for i, k in enumerate(self.model._order):
+            if i in sd['state']:
+                o, shp = self.model._slots[k]
+                self.square_avg[o:o + int(np.prod(shp))].copy_(sd['state'][i]['square_avg'].reshape(-1))
+                self.steps = int(sd['state'][i]['step'])
+        self.last_epoch = sd.get('last_epoch', self.last_epoch)

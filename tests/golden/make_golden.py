@@ -117,7 +117,27 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'sampler.npz'), seed1_n5000_k16_d100=np.array(draws),
                         seed7_n40_k4_d10=np.array(draws2), essential=np.array(ess))
     print('sampler', draws[0][:6])
+    init_fixture()
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') != '1':
     main()
+
+
+def init_fixture():
+    """Reference constructor under torch.manual_seed(1): per-tensor checksums of the initial weights."""
+    out = {}
+    for bn in (True, False):
+        torch.manual_seed(1)
+        m = PolicyNet((64,), 3, bn)
+        sd = m.state_dict()
+        out['keys_bn%d' % bn] = np.array(list(sd.keys()))
+        out['shapes_bn%d' % bn] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out['sum_bn%d' % bn] = np.array([float(v.double().sum()) for v in sd.values()])
+        out['sq_bn%d' % bn] = np.array([float((v.double() ** 2).sum()) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, 'policy_init_seed1.npz'), **out)
+    print('wrote policy_init_seed1.npz')
+
+
+if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1':
+    init_fixture()
