@@ -51,6 +51,48 @@ def cpu_baseline(sd, frames_u8, budget_s=12.0):
                 sample='%d synthetic 256x256 frames in batches of 64, torch fp32 eager oracle, %.1f s' % (done, el))
 
 
+BC_GFLOP_PER_STEP = 211.4         # PolicyNet T=100,B=16,obs 4096: 3 x fwd of 22.02 MMAC x 1600
+
+
+def bc_bench(steps, warmup, with_cpu):
+    """Second half of the BASELINE metric: BC steps/sec (main_bc_2.py:186-227 iteration, slurm_bc.py:121-128
+    configuration T=100, B=16, obs 4096, BatchNorm on, RMSprop) on one GPU, batches resident in HBM."""
+    from pvr_habitat_amd import synth
+    from pvr_habitat_amd.models import PolicyNet, HipRMSprop
+    T, B, O, A = 100, 16, 4096, 3
+    m = PolicyNet((O,), A, True, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(1, O, A, True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to('cuda').train()
+    opt = HipRMSprop(m, max_epochs=10 ** 6)
+    obs, done, act = synth.bc_batches(1, T, B, O, A, 2)
+    obs_d, done_d, act_d = torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), torch.from_numpy(act).cuda()
+    for i in range(warmup):
+        opt.scheduler_step(); opt.step(obs_d[i % 2], done_d[i % 2], act_d[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        opt.scheduler_step(); loss, gn = opt.step(obs_d[i % 2], done_d[i % 2], act_d[i % 2])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res = {'metric': 'BC steps/sec (PolicyNet T=100 B=16 obs=4096 BN, fp32)', 'value': round(steps / el, 2), 'unit': 'steps/s',
+           'ms_per_step': round(el / steps * 1e3, 3), 'tflops': round(BC_GFLOP_PER_STEP * steps / el / 1e3, 2),
+           'dtype': 'f32', 'final_loss': round(float(loss), 5)}
+    if with_cpu:
+        from oracle import policy_oracle as po
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        p = po.to_params(sd)
+        o = po.RMSpropState(p, max_epochs=10 ** 6)
+        po.bc_step(p, o, torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(act[0]), True)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 8.0 and n < 5:
+            po.bc_step(p, o, torch.from_numpy(obs[n % 2]), torch.from_numpy(done[n % 2]), torch.from_numpy(act[n % 2]), True); n += 1
+        res['cpu_baseline'] = {'value': round(n / (time.perf_counter() - t0), 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                               'kind': 'port', 'sample': '%d oracle steps (torch fp32 autograd restatement)' % n}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -61,6 +103,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
     args = ap.parse_args()
 
@@ -146,6 +189,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, frames_np)
+        if world == 1 and not args.no_bc:
+            line['bc'] = bc_bench(max(args.steps, 10), args.warmup, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -26,7 +26,7 @@ typedef struct pvr_policy pvr_policy;
 
 typedef struct pvr_policy_desc {
     int32_t obs_size;      /* observation_shape[0] (models.py:22) */
-    int32_t hidden;        /* 1024 in the reference; multiple of 64 */
+    int32_t hidden;        /* 1024 in the reference; multiple of 1024 */
     int32_t num_actions;   /* <= 16 */
     int32_t batch_norm;    /* BatchNorm1d in front of the MLP (models.py:30-34) */
     int32_t max_t;         /* unroll_length the workspace is sized for */

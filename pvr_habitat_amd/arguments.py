@@ -1,0 +1,55 @@
+"""Command-line flags of the hot-path scripts.  Names and defaults are the reference's
+(src/arguments.py:3-68, plus behavioral_cloning/save_embedded_obs.py:25-26); the only additions are the
+MI355X knobs at the end.  A fresh parser is built per call (the reference mutates one module-level parser,
+which makes a second import of a script fail with an argparse conflict, cf. main_test.py:14)."""
+import argparse
+
+
+def make_parser():
+    parser = argparse.ArgumentParser(description='PyTorch Scalable Agent')
+    # Behavioral Cloning Settings.
+    parser.add_argument('--max_frames', type=int, default=200000000)
+    parser.add_argument('--n_episodes_test', type=int, default=50)
+    parser.add_argument('--eval_frequency', type=int, default=200)
+    parser.add_argument('--to_env', type=str, default='HabitatImageNav-apartment_0')
+    parser.add_argument('--debug', action='store_true')
+    parser.add_argument('--disable_save', action='store_true')
+    parser.add_argument('--essential_save_only', action='store_true')
+    parser.add_argument('--save_path', type=str, default='bc')
+    parser.add_argument('--data_path', type=str, default='behavioral_cloning')
+    # Embedding Settings.
+    parser.add_argument('--embedding_name', type=str, default='resnet50')
+    parser.add_argument('--train_embedding', action='store_true')
+    parser.add_argument('--disable_pretrained_embedding', action='store_false', dest='pretrained_embedding')
+    parser.add_argument('--batch_norm', action='store_true')
+    # Environment Settings.
+    parser.add_argument('--env', type=str, default='HabitatImageNav-apartment_0')
+    parser.add_argument('--num_input_frames', type=int, default=1)
+    # General Settings.
+    parser.add_argument('--xpid', default=None)
+    parser.add_argument('--run_id', default=1, type=int)
+    parser.add_argument('--seed', default=1, type=int)
+    # Training settings.
+    parser.add_argument('--total_frames', default=50000000, type=int)
+    parser.add_argument('--batch_size', default=32, type=int)
+    parser.add_argument('--unroll_length', default=100, type=int)
+    parser.add_argument('--mp_start', default='spawn', type=str)
+    parser.add_argument('--disable_cuda', action='store_true')
+    # Optimizer settings.
+    parser.add_argument('--learning_rate', default=0.0001, type=float)
+    parser.add_argument('--alpha', default=0.99, type=float)
+    parser.add_argument('--momentum', default=0, type=float)
+    parser.add_argument('--epsilon', default=1e-5, type=float)
+    parser.add_argument('--max_grad_norm', default=40., type=float)
+    # save_embedded_obs.py:25-26
+    parser.add_argument('--n_trajectories', type=int, default=-1)
+    parser.add_argument('--source', type=str, default='png', choices=['png', 'pickle'])
+    # MI355X additions (not in the reference)
+    parser.add_argument('--compute_dtype', type=str, default=None, choices=[None, 'bf16', 'f16'],
+                        help='encoder storage/MFMA input type (default: $PVR_DTYPE or bf16)')
+    parser.add_argument('--embed_batch', type=int, default=256, help='frames per encoder launch (the reference '
+                        'pushes batch_size x n_frames = 64 per forward, save_embedded_obs.py:151-153)')
+    return parser
+
+
+parser = make_parser()

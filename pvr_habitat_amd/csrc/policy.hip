@@ -144,7 +144,7 @@ extern "C" {
 
 pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     PVR_REQUIRE(desc && out, "pvr_policy_create: null argument");
-    PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 64 == 0, "hidden must be a positive multiple of 64 (got %d)", desc->hidden);
+    PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 1024 == 0, "hidden must be a positive multiple of 1024 (got %d)", desc->hidden);
     PVR_REQUIRE(desc->obs_size > 0 && desc->obs_size % 4 == 0, "obs_size must be a positive multiple of 4 (got %d)", desc->obs_size);
     PVR_REQUIRE(desc->num_actions > 0 && desc->num_actions <= 16, "num_actions must be in 1..16");
     PVR_REQUIRE(desc->max_t > 0 && desc->max_b > 0 && desc->max_b <= 64, "max_t > 0 and 0 < max_b <= 64 required");

@@ -262,13 +262,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
         const float ndb = bok ? p.nd[b] : 0.f;
         const float *hrow = p.h_prev + (size_t)(bok ? b : 0) * H;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < H / 64; ++c) {
-            const int k = kbeg + c * 16 + fq * 4;
-            f32x4 hv = *reinterpret_cast<const f32x4 *>(hrow + k);
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + k);
-            hv *= ndb;                                   // state * notdone (models.py:69); 0 for padded batch rows
+        // every load of the wave's K range is issued before the MFMA chain, so the L2 / Infinity-Cache latency of
+        // the weight stream is paid once, not once per 16-k chunk (the launch is latency-bound)
+        for (int c0 = 0; c0 < H / 64; c0 += 16) {
+            f32x4 hv[16], wv[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma_f32(hv[e], wv[e], acc);
+            for (int c = 0; c < 16; ++c) {
+                const int k = kbeg + (c0 + c) * 16 + fq * 4;
+                hv[c] = *reinterpret_cast<const f32x4 *>(hrow + k);
+                wv[c] = *reinterpret_cast<const f32x4 *>(wrow + k);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the 32 loads ahead of the MFMA chain (hipcc otherwise
+                                                         // re-serialises them: load, vmcnt(0), 2 MFMAs, load, ...)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                hv[c] *= ndb;                            // state * notdone (models.py:69); 0 for padded batch rows
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32(hv[c][e], wv[c][e], acc);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
@@ -322,13 +333,21 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(LstmBwdP p) {
             const bool bok = b < p.B;
             const float *drow = p.dG_next + (size_t)(bok ? b : 0) * K;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < K / 256; ++c) {
-                const int k = kbeg + c * 16 + fq * 4;
-                f32x4 dv = *reinterpret_cast<const f32x4 *>(drow + k);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + k);
-                if (!bok) dv = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c0 = 0; c0 < K / 256; c0 += 8) {
+                f32x4 dv[8], wv[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma_f32(dv[e], wv[e], acc);
+                for (int c = 0; c < 8; ++c) {
+                    const int k = kbeg + (c0 + c) * 16 + fq * 4;
+                    dv[c] = *reinterpret_cast<const f32x4 *>(drow + k);
+                    wv[c] = *reinterpret_cast<const f32x4 *>(wrow + k);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // 16 loads in flight before the MFMA chain (see forward)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (!bok) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma_f32(dv[c][e], wv[c][e], acc);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];

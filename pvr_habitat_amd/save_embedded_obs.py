@@ -1,0 +1,163 @@
+"""Offline embedding of saved trajectories: same `run(flags)` contract, flags and output files as reference
+behavioral_cloning/save_embedded_obs.py:96-172, with the frames pushed through the HIP encoder in large
+batches and, under torch.distributed, sharded across the GPUs of one node with NO collective on the data
+path (each rank embeds a contiguous row range; rank 0 concatenates in rank order and writes the pickle).
+
+  pickle source: <data_path>/<env>.pickle  {obs:[(L,H,W,3n) u8], action, reward, done, true_state}  (:29-47)
+  png source:    <data_path>/<env>/<t>_<s>.png, <t>_goal.png, <t>.pickle                             (:50-93)
+  output:        <data_path>/<env>_<embedding_name>.pickle {obs f32 (N, n*O), action, reward, done, true_state}
+                 <data_path>/<embedding_name>[_<run_id>].tar  {'embedding_model_state_dict': ...}      (:126-131)
+"""
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+from .arguments import make_parser
+from .embeddings import EmbeddingNet
+from .utils_bc import shard_bounds
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def read_habitat_data_from_pickle(data_path, n_trajectories=-1):
+    print('loading %s ...' % data_path)
+    with open(data_path + '.pickle', 'rb') as f:
+        data = pickle.load(f)
+    if n_trajectories == -1:
+        n_trajectories = len(data['reward'])
+    for k in ('obs', 'action', 'reward', 'done', 'true_state'):
+        data[k] = np.concatenate(data[k][:n_trajectories])
+    n_samples = len(data['reward'])
+    print('  ', '%d trajectories for a total of %d samples' % (n_trajectories, n_samples))
+    print('  ', 'avg. return is', data['reward'].sum() / n_trajectories)
+    return data
+
+
+def _imread(path):
+    """cv2.imread equivalent (the reference writes RGB arrays with cv2.imwrite and reads them back with
+    cv2.imread, so the array round-trips; PIL returns the file's RGB, i.e. the array reversed)."""
+    try:
+        import cv2
+        return cv2.imread(path)
+    except ImportError:
+        from PIL import Image
+        if not os.path.isfile(path):
+            return None
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[..., ::-1])
+
+
+def embed_rows(embed_fn, obs, n_frames, batch):
+    """save_embedded_obs.py:151-157: (N,H,W,3n) -> per batch: split frames, stack on the batch axis (all first
+    frames, then all second frames, ...), embed, re-split, concat on the feature axis -> (N, n*O)."""
+    out = []
+    for i in range(0, obs.shape[0], batch):
+        o = obs[i:i + batch]
+        m = o.shape[0]
+        o = np.concatenate(np.split(o, n_frames, axis=3), axis=0)
+        e = embed_fn(torch.from_numpy(np.ascontiguousarray(o)))
+        e = np.asarray(e).reshape(n_frames * m, -1)            # undo the N=1 squeeze of EmbeddingNet.forward
+        out.append(np.concatenate(np.split(e, n_frames, axis=0), axis=-1))
+    return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
+
+
+def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256):
+    """PNG layout of save_opt_trajectories_png.py:44-58.  The reference embeds one frame per forward (:69-77);
+    here a trajectory's frames are decoded on the host and embedded together (same rows, same order)."""
+    print('loading %s ...' % data_path)
+    data = dict(obs=[], action=[], reward=[], done=[], true_state=[], png=[])
+    if n_trajectories == -1:
+        n_trajectories = 100000
+    t = 0
+    for t in range(n_trajectories):
+        meta_path = os.path.join(data_path, '%d.pickle' % t)
+        goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
+        if goal is None:
+            break
+        with open(meta_path, 'rb') as f:
+            tmp = pickle.load(f)
+        for k in data.keys():
+            if k in tmp:
+                data[k].append(tmp[k])
+        frames, names = [], []
+        for s in range(500):                                   # max steps per trajectory (habitat_config/nav_task.yaml:4)
+            p = os.path.join(data_path, '%d_%d.png' % (t, s))
+            f = _imread(p) if os.path.isfile(p) else None
+            if f is None:
+                break
+            frames.append(f); names.append(p)
+        if not frames:
+            continue
+        frames = np.stack(frames)
+        if model is not None:
+            g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
+            e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
+                                for i in range(0, len(frames), batch)])
+            data['obs'].extend(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+        else:
+            data['obs'].extend(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
+        data['png'] += names
+    n_trajectories = t
+    data['obs'] = np.stack(data['obs'])
+    for k in ('action', 'reward', 'done', 'true_state'):
+        data[k] = np.concatenate(data[k])
+    n_samples = len(data['reward'])
+    print('  ', '%d trajectories for a total of %d samples' % (n_trajectories, n_samples))
+    return data
+
+
+def run(flags):
+    save_name = os.path.join(flags.data_path, flags.env + '_' + flags.embedding_name + '.pickle')
+    if os.path.isfile(save_name):
+        return                                                  # idempotent skip (:97-101)
+    dist, rank, world = _dist()
+    torch.manual_seed(flags.run_id)
+    np.random.seed(flags.run_id)
+    random.seed(flags.run_id)
+    flags.device = torch.device('cuda') if torch.cuda.is_available() and not flags.disable_cuda else torch.device('cpu')
+    embedding_model = EmbeddingNet(flags.embedding_name, in_channels=3, pretrained=flags.pretrained_embedding,
+                                   train=flags.train_embedding, disable_cuda=flags.disable_cuda,
+                                   compute_dtype=getattr(flags, 'compute_dtype', None),
+                                   max_batch=getattr(flags, 'embed_batch', 256))
+    if rank == 0:
+        emb_path = os.path.join(flags.data_path, flags.embedding_name)
+        if flags.embedding_name == 'random':
+            emb_path += '_' + str(flags.run_id)
+        torch.save({'embedding_model_state_dict': embedding_model.state_dict()}, emb_path + '.tar')
+    print('=== Loading trajectories ===')
+    batch = getattr(flags, 'embed_batch', 256)
+    if flags.source == 'png':
+        assert world == 1, 'png source: shard by trajectory directory, one process per shard'
+        data = read_habitat_data_from_png(os.path.join(flags.data_path, flags.env), embedding_model, flags.n_trajectories, batch)
+        data.pop('png', None)
+    else:
+        data = read_habitat_data_from_pickle(os.path.join(flags.data_path, flags.env), flags.n_trajectories)
+        print('  ', 'passing observations through embedding model')
+        n_samples = data['obs'].shape[0]
+        n_frames = max(data['obs'].shape[3] // 3, 1)
+        lo, hi = shard_bounds(n_samples, rank, world)
+        mine = embed_rows(embedding_model, data['obs'][lo:hi], n_frames, max(1, batch // n_frames))
+        if world > 1:
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)              # host-side concat only; no device collective
+            if rank != 0:
+                return
+            mine = np.concatenate(parts)
+        data = dict(obs=np.array(mine), action=data['action'][:n_samples], reward=data['reward'][:n_samples],
+                    done=data['done'][:n_samples], true_state=data['true_state'][:n_samples])
+    n_samples = len(data['reward'])
+    assert n_samples > 0, 'no data found'
+    print('  ', 'total number of samples', n_samples)
+    with open(save_name, 'wb') as handle:
+        pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+if __name__ == '__main__':
+    run(make_parser().parse_args())

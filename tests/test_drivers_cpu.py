@@ -1,0 +1,110 @@
+"""CPU tests of the host logic around the hot path: flags, batch assembly, row sharding (gloo, world size 2),
+save_embedded_obs split/concat order with a stand-in embedder."""
+import os
+import pickle
+import subprocess
+import sys
+import numpy as np
+import pytest
+import torch
+
+from pvr_habitat_amd import utils_bc
+from pvr_habitat_amd.arguments import make_parser
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flag_names_and_defaults_match_reference():
+    f = make_parser().parse_args([])
+    ref = dict(max_frames=200000000, n_episodes_test=50, eval_frequency=200, to_env='HabitatImageNav-apartment_0', debug=False,
+               disable_save=False, essential_save_only=False, save_path='bc', data_path='behavioral_cloning',
+               embedding_name='resnet50', train_embedding=False, pretrained_embedding=True, batch_norm=False,
+               env='HabitatImageNav-apartment_0', num_input_frames=1, xpid=None, run_id=1, seed=1, total_frames=50000000,
+               batch_size=32, unroll_length=100, mp_start='spawn', disable_cuda=False, learning_rate=0.0001, alpha=0.99,
+               momentum=0, epsilon=1e-5, max_grad_norm=40., n_trajectories=-1, source='png')      # src/arguments.py:3-68
+    for k, v in ref.items():
+        assert getattr(f, k) == v, k
+
+
+def test_gather_unrolls_matches_reference_loop():
+    rng = np.random.default_rng(0)
+    obs, act = rng.standard_normal((50, 7)).astype(np.float32), rng.integers(0, 3, 50)
+    starts = [3, 47, 20]
+    o, a = utils_bc.gather_unrolls([obs, act], starts, 10, 50)
+    ro = np.stack([obs[np.mod(np.arange(i, i + 10), 50)] for i in starts], axis=1)      # main_bc_2.py:194-201
+    ra = np.stack([act[np.mod(np.arange(i, i + 10), 50)] for i in starts], axis=1)
+    assert np.array_equal(o, ro) and np.array_equal(a, ra) and o.shape == (10, 3, 7)
+
+
+def test_sampler_raises_like_reference_when_data_too_short():
+    import random
+    random.seed(1)
+    with pytest.raises(ValueError):
+        utils_bc.sample_with_minimum_distance(n=500, k=16, d=100)      # negative population
+
+
+def test_embed_rows_order_and_shapes():
+    from pvr_habitat_amd.save_embedded_obs import embed_rows
+    obs = np.arange(5 * 4 * 4 * 6, dtype=np.uint8).reshape(5, 4, 4, 6)
+    calls = []
+
+    def fake(t):
+        calls.append(tuple(t.shape))
+        e = t.numpy().reshape(t.shape[0], -1)[:, :3].astype(np.float32)
+        return e.squeeze()                                     # EmbeddingNet squeezes N=1
+
+    out = embed_rows(fake, obs, 2, 2)
+    assert out.shape == (5, 6) and calls == [(4, 4, 4, 3), (4, 4, 4, 3), (2, 4, 4, 3)]
+    np.testing.assert_array_equal(out[:, :3], obs[..., :3].reshape(5, -1)[:, :3])
+    np.testing.assert_array_equal(out[:, 3:], obs[..., 3:].reshape(5, -1)[:, :3])
+
+
+def test_shard_bounds_cover_rows_in_order():
+    for n in (0, 1, 7, 100000):
+        for w in (1, 2, 3, 8):
+            b = [utils_bc.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+_WORKER = r'''
+import os, sys, pickle, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+import pvr_habitat_amd.save_embedded_obs as S
+class Fake:                                    # stand-in embedder: deterministic function of the frame bytes
+    out_size = 4
+    def __init__(self, *a, **k): pass
+    def state_dict(self): return {}
+    def __call__(self, t):
+        x = t.numpy().astype(np.float32).reshape(t.shape[0], -1)
+        return np.stack([x.sum(1), x[:, 0], x[:, -1], x.mean(1)], 1).squeeze()
+S.EmbeddingNet = Fake
+flags = S.make_parser().parse_args(['--data_path', sys.argv[1], '--env', 'scene', '--embedding_name', 'fake', '--source', 'pickle', '--embed_batch', '6'])
+S.run(flags)
+dist.barrier()
+'''
+
+
+def test_save_embedded_obs_sharded_gloo_world2(tmp_path):
+    """N>1 path: two gloo ranks embed contiguous row shards; rank 0 writes the same pickle a single process does."""
+    rng = np.random.default_rng(1)
+    trajs = [rng.integers(0, 255, (L, 8, 8, 6), dtype=np.uint8) for L in (5, 9, 3)]
+    raw = dict(obs=trajs, action=[rng.integers(0, 3, len(t)) for t in trajs], reward=[np.zeros(len(t)) for t in trajs],
+               done=[np.zeros(len(t), bool) for t in trajs], true_state=[np.zeros((len(t), 12)) for t in trajs])
+    outs = []
+    for world in (1, 2):
+        d = tmp_path / ('w%d' % world)
+        d.mkdir()
+        pickle.dump(raw, open(d / 'scene.pickle', 'wb'))
+        script = d / 'worker.py'
+        script.write_text(_WORKER % dict(root=ROOT))
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29731 + world))
+            procs.append(subprocess.Popen([sys.executable, str(script), str(d)], env=env))
+        assert all(p.wait(timeout=120) == 0 for p in procs)
+        outs.append(pickle.load(open(d / 'scene_fake.pickle', 'rb')))
+    assert outs[0]['obs'].shape == (17, 8) and outs[0]['obs'].dtype == np.float32
+    np.testing.assert_array_equal(outs[0]['obs'], outs[1]['obs'])
+    np.testing.assert_array_equal(outs[0]['action'], outs[1]['action'])
+    assert set(outs[0]) == {'obs', 'action', 'reward', 'done', 'true_state'}      # save_embedded_obs.py:165

@@ -1,0 +1,51 @@
+"""End-to-end plumbing on the GPU (BASELINE config 0 shape): synthetic Replica-like trajectories ->
+save_embedded_obs.run -> main_bc_2.run, through the reference's file formats and flags."""
+import os
+import pickle
+import numpy as np
+import pytest
+import torch
+
+from pvr_habitat_amd import synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+
+
+def test_embed_then_bc_pipeline(tmp_path, monkeypatch):
+    from pvr_habitat_amd import save_embedded_obs as S, main_bc_2 as M
+    from pvr_habitat_amd.arguments import make_parser
+    from oracle import encoder_oracle as eo
+    import zlib
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    lens = (90, 120, 70)                                        # 280 observations = 560 frames of 128x128
+    fr = synth.smooth_frames(31, 2 * sum(lens), 128, 128)
+    obs_all = np.concatenate([fr[:sum(lens)], fr[sum(lens):]], axis=3)           # (N,128,128,6): frame + goal
+    cuts = np.cumsum((0,) + lens)
+    rng = np.random.default_rng(0)
+    raw = dict(obs=[obs_all[a:b] for a, b in zip(cuts[:-1], cuts[1:])],
+               action=[rng.integers(0, 3, L) for L in lens], reward=[np.zeros(L, np.float32) for L in lens],
+               done=[np.eye(1, L, L - 1, dtype=bool)[0] for L in lens], true_state=[np.zeros((L, 12), np.float32) for L in lens])
+    pickle.dump(raw, open(tmp_path / 'scene.pickle', 'wb'))
+    args = ['--data_path', str(tmp_path), '--save_path', str(tmp_path / 'bc'), '--env', 'scene', '--to_env', 'scene',
+            '--embedding_name', 'resnet50', '--source', 'pickle', '--compute_dtype', 'f16', '--embed_batch', '64',
+            '--unroll_length', '10', '--batch_size', '4', '--batch_norm', '--max_frames', '800', '--eval_frequency', '5']
+    S.run(make_parser().parse_args(args))
+    out = pickle.load(open(tmp_path / 'scene_resnet50.pickle', 'rb'))
+    assert out['obs'].shape == (280, 4096) and out['obs'].dtype == np.float32
+    assert os.path.isfile(tmp_path / 'resnet50.tar')
+    sd = synth.resnet50_state_dict(zlib.crc32(b'resnet50') & 0x7fffffff, 'conv5')
+    torch.set_num_threads(8)
+    ref = eo.split_embed_concat(lambda o: eo.embed(sd, o, 'conv5', squeeze=False), obs_all[:3], 2)
+    assert np.linalg.norm(out['obs'][:3] - ref) / np.linalg.norm(ref) < 1e-3
+    S.run(make_parser().parse_args(args))                       # second call: idempotent skip (save_embedded_obs.py:97-101)
+    stats = M.run(make_parser().parse_args(args))
+    st = stats['scene']
+    assert set(st) == {'episode_return', 'episode_success', 'frames', 'training_loss', 'gradient_norm'}
+    assert len(st['frames']) == 1 + 4 and st['frames'][0] == 0 and np.isnan(st['training_loss'][0])
+    assert all(np.isfinite(st['training_loss'][1:])) and all(np.isfinite(st['gradient_norm'][1:]))
+    ck = torch.load(tmp_path / 'bc' / 'scene_emresnet50_s1_scene.tar', weights_only=False)
+    assert set(ck) == {'embedding_model_state_dict', 'actor_model_state_dict', 'actor_model_optimizer_state_dict', 'scheduler_state_dict', 'flags'}
+    assert ck['actor_model_state_dict']['fc.1.weight'].shape == (1024, 4096)
+    # resume: finished run returns immediately with the saved stats (main_bc_2.py:49-56)
+    again = M.run(make_parser().parse_args(args))
+    assert again['scene']['frames'] == st['frames']
