@@ -46,6 +46,10 @@ def test_embed_then_bc_pipeline(tmp_path, monkeypatch):
     ck = torch.load(tmp_path / 'bc' / 'scene_emresnet50_s1_scene.tar', weights_only=False)
     assert set(ck) == {'embedding_model_state_dict', 'actor_model_state_dict', 'actor_model_optimizer_state_dict', 'scheduler_state_dict', 'flags'}
     assert ck['actor_model_state_dict']['fc.1.weight'].shape == (1024, 4096)
-    # resume: finished run returns immediately with the saved stats (main_bc_2.py:49-56)
+    # resume (main_bc_2.py:49-56, 154-162): last saved frame count 760 < max_frames, so the run restarts from the
+    # checkpoint at frames=760 and appends one more evaluation point, exactly as the reference's range() does
     again = M.run(make_parser().parse_args(args))
-    assert again['scene']['frames'] == st['frames']
+    assert again['scene']['frames'] == st['frames'] + [760]
+    done_args = [a if a != '800' else '700' for a in args]
+    finished = M.run(make_parser().parse_args(done_args))       # frames[-1] >= max_frames: returns without training
+    assert finished['scene']['frames'] == again['scene']['frames']
