@@ -41,6 +41,8 @@ typedef int pvr_status;
 #define PVR_ARCH_RESNET50 0      /* torchvision resnet50, fc=Identity  -> 2048 (embeddings.py:118-120, moco.py:6-26) */
 #define PVR_ARCH_RESNET50_L4 1   /* + BasicBlock(2048->42), no avgpool  -> 2058 (moco.py:73-113, resnet.py:47-83)   */
 #define PVR_ARCH_RESNET50_L3 2   /* layer3 + BasicBlock(1024->11)       -> 2156 (moco.py:29-70,  resnet.py:6-44)    */
+#define PVR_ARCH_CLIP_VIT_B32 3  /* openai/CLIP visual ViT-B/32 encode_image -> 512 (embeddings.py:303-304,375-376) */
+#define PVR_ARCH_CLIP_VIT_B16 4  /* same block layout, patch 16 (197 tokens) -> 512 (BASELINE config 3)          */
 
 const char *pvr_version(void);
 /* copies the calling thread's last error message; returns its length */
@@ -100,8 +102,8 @@ void pvr_encoder_destroy(pvr_encoder *enc);
  * dtype = PVR_BF16 / PVR_F16 for activations and weights.
  * ------------------------------------------------------------------------------------------- */
 /* transforms (embeddings.py:80-85) up to and including the uint8 crop; output is the stem's input
- * image: (n, crop+6, crop+8, 4) 16-bit, pixel (y,x) at [y+3][x+3], channels (R,G,B,valid) holding the
- * exact uint8 values (normalisation is folded into the stem weights), zero border. */
+ * image: (n, crop+6, crop+8, 4) 16-bit, pixel (y,x) at [y+3][x+3], channels (R-128,G-128,B-128,valid): exact
+ * centred uint8 values (normalisation is folded into the stem weights), zero border (valid=0). */
 pvr_status pvr_op_preprocess(const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, int32_t resize,
                              int32_t crop, void *out_dev, int32_t dtype, void *hip_stream);
 /* conv1 7x7/2 + folded BN + ReLU on the padded image above. wgt: (64, 7*8*4) 16-bit, bias fp32(64).

@@ -1,0 +1,99 @@
+"""CPU fp32 restatement of the reference's CLIP branch (test infrastructure).
+
+Follows reference src/embeddings.py:298-314 (clip.load("ViT-B/32"), transforms Resize(res, BICUBIC,
+antialias=True) -> CenterCrop(res) -> ConvertImageDtype(float) -> Normalize(CLIP mean/std)) and :375-376
+(`encode_image`).  openai/CLIP (requirements.txt:19, unpinned git HEAD, NOT under /root/reference) is restated
+from its published model.py `VisionTransformer`:
+    conv1 (k = s = patch, no bias) -> [class_embedding ; patches] + positional_embedding -> ln_pre ->
+    12 x { x += MHA(ln_1(x)) ; x += c_proj(QuickGELU(c_fc(ln_2(x)))) } -> ln_post(x[:,0]) @ proj
+with LayerNorm eps 1e-5 computed in fp32, QuickGELU(x) = x * sigmoid(1.702 x), nn.MultiheadAttention packing
+(in_proj rows = [q;k;v], heads split the 768 features into 12 x 64, scores scaled by 1/sqrt(64)).
+
+PARITY PINNING: CLIP is not installable here and has no reference test -> "parity unpinned" at this boundary;
+the restatement is cross-checked against transformers.CLIPVisionModelWithProjection (quick_gelu, same
+parameter count, name-remapped synthetic weights) in tests/test_oracle_vit.py.
+torchvision's antialiased bicubic Resize on uint8 = float32 interpolate(bicubic, antialias=True), clamp(0,255)
+(bicubic overshoots), round, cast back to uint8 (restated, not executed).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _t(a):
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
+
+
+def resize_size(h, w, size):
+    short, long_ = (w, h) if w <= h else (h, w)
+    if short == size:
+        return h, w
+    ns, nl = size, int(size * long_ / short)
+    return (nl, ns) if w <= h else (ns, nl)
+
+
+def preprocess_u8(frames_nhwc_u8, res=224):
+    x = _t(frames_nhwc_u8).transpose(1, 2).transpose(1, 3).contiguous()
+    n, c, h, w = x.shape
+    nh, nw = resize_size(h, w, res)
+    if (nh, nw) != (h, w):
+        y = F.interpolate(x.float(), size=(nh, nw), mode='bicubic', align_corners=False, antialias=True)
+        x = y.clamp(0, 255).round().to(torch.uint8)
+    top, left = int(round((nh - res) / 2.0)), int(round((nw - res) / 2.0))
+    return x[..., top:top + res, left:left + res]
+
+
+def preprocess(frames_nhwc_u8, res=224):
+    x = preprocess_u8(frames_nhwc_u8, res).float() / 255.0
+    m = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    return (x - m) / s
+
+
+def _ln(x, w, b):
+    return F.layer_norm(x.float(), (x.shape[-1],), _t(w), _t(b), 1e-5)
+
+
+def encode_image(sd, x, heads=12, taps=None):
+    """x: fp32 (N,3,R,R) normalised -> (N, out_dim)."""
+    pre = 'visual.'
+    w1 = _t(sd[pre + 'conv1.weight'])
+    patch = w1.shape[-1]
+    x = F.conv2d(x, w1, None, patch)                              # (N, width, g, g)
+    n, width = x.shape[0], x.shape[1]
+    x = x.reshape(n, width, -1).permute(0, 2, 1)
+    cls = _t(sd[pre + 'class_embedding']).view(1, 1, -1).expand(n, 1, width)
+    x = torch.cat([cls, x], dim=1) + _t(sd[pre + 'positional_embedding'])
+    x = _ln(x, sd[pre + 'ln_pre.weight'], sd[pre + 'ln_pre.bias'])
+    if taps is not None:
+        taps['ln_pre'] = x
+    T, hd = x.shape[1], width // heads
+    i = 0
+    while (pre + 'transformer.resblocks.%d.ln_1.weight' % i) in sd:
+        p = pre + 'transformer.resblocks.%d.' % i
+        y = _ln(x, sd[p + 'ln_1.weight'], sd[p + 'ln_1.bias'])
+        qkv = y @ _t(sd[p + 'attn.in_proj_weight']).t() + _t(sd[p + 'attn.in_proj_bias'])
+        q, k, v = qkv.split(width, dim=-1)
+        sh = lambda t: t.reshape(n, T, heads, hd).permute(0, 2, 1, 3)
+        a = torch.softmax((sh(q) @ sh(k).transpose(-1, -2)) / (hd ** 0.5), dim=-1) @ sh(v)
+        a = a.permute(0, 2, 1, 3).reshape(n, T, width)
+        x = x + a @ _t(sd[p + 'attn.out_proj.weight']).t() + _t(sd[p + 'attn.out_proj.bias'])
+        y = _ln(x, sd[p + 'ln_2.weight'], sd[p + 'ln_2.bias'])
+        y = y @ _t(sd[p + 'mlp.c_fc.weight']).t() + _t(sd[p + 'mlp.c_fc.bias'])
+        y = y * torch.sigmoid(1.702 * y)                          # QuickGELU
+        x = x + y @ _t(sd[p + 'mlp.c_proj.weight']).t() + _t(sd[p + 'mlp.c_proj.bias'])
+        if taps is not None:
+            taps['block%d' % i] = x
+        i += 1
+    x = _ln(x[:, 0, :], sd[pre + 'ln_post.weight'], sd[pre + 'ln_post.bias'])
+    return x @ _t(sd[pre + 'proj'])
+
+
+def embed(sd, frames_nhwc_u8, squeeze=True):
+    with torch.no_grad():
+        out = encode_image(sd, preprocess(frames_nhwc_u8))
+        out = out.reshape(out.shape[0], -1)
+        return (out.squeeze() if squeeze else out).numpy()

@@ -28,13 +28,15 @@ struct ConvP {
     const u16 *zero;      // >= 256 B of zeros
     int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
     int M, K;
-    int relu, out_f32;
+    int res_f32;          // residual buffer is fp32 (out_f32 layout) instead of 16-bit
+    int act, out_f32;     // act: 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x), 3 GELU (erf)
     int m_tiles, n_tiles;
 };
 
 // STAGES = 2: double-buffered K loop.  STAGES = 1: single K-slice convolutions (1x1, Cin = 64): half the LDS, so
 // three blocks per CU overlap each other's load / MFMA / store phases (there is no K loop to pipeline).
-template <int BM, int BN, bool F16, int STAGES, bool HAS_RES>
+// RES: 0 no residual, 1 16-bit residual (ResNet), 2 fp32 residual (transformer residual stream)
+template <int BM, int BN, bool F16, int STAGES, int RES>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BK = 64;
@@ -141,14 +143,25 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     // residual prefetch: issue the epilogue's 16-B residual loads now so their latency hides under the K loop
     constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
     constexpr int EP_IT = BM * UPR / 256;
-    u32x4 rres[HAS_RES ? EP_IT : 1];
-    if constexpr (HAS_RES) {
+    u32x4 rres[RES == 0 ? 1 : (RES == 1 ? EP_IT : 2 * EP_IT)];
+    if constexpr (RES == 1) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
             const int u = tid + it * 256;
             const int m = m0 + u / UPR, co = co0 + (u % UPR) * 8;
             const bool ok = m < p.M && co < p.Cout;
             rres[it] = *reinterpret_cast<const u32x4 *>(ok ? p.res + (size_t)m * p.Cout + co : p.zero);
+        }
+    } else if constexpr (RES == 2) {
+        const float *resf = reinterpret_cast<const float *>(p.res);
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int u = tid + it * 256;
+            const int m = m0 + u / UPR, co = co0 + (u % UPR) * 8;
+            const bool ok = m < p.M && co < p.Cout;
+            const float *src = ok ? resf + (size_t)m * p.Cout + co : reinterpret_cast<const float *>(p.zero);
+            rres[2 * it] = *reinterpret_cast<const u32x4 *>(src);
+            rres[2 * it + 1] = *reinterpret_cast<const u32x4 *>(src + 4);
         }
     }
     PVR_STORE_SLICE(0);
@@ -225,17 +238,31 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + pr * BN + (((2 * cu + 1) ^ (pr & 7)) << 2));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const size_t o = (size_t)m * p.Cout + co;
-            if constexpr (HAS_RES) {
+            if constexpr (RES == 1) {
                 const u32x4 r = rres[itg];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu));
                     v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16));
                 }
+            } else if constexpr (RES == 2) {
+                // (bit_cast of a single vector ELEMENT lvalue is mis-folded to element 0 by hipcc: cast whole vectors)
+                const f32x4 r0 = __builtin_bit_cast(f32x4, rres[2 * itg]), r1 = __builtin_bit_cast(f32x4, rres[2 * itg + 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += r0[e];
+                    v[4 + e] += r1[e];
+                }
             }
-            if (p.relu) {
+            if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+            } else if (p.act == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
             if (p.out_f32) {
                 float *op = (float *)p.out + o;
@@ -252,24 +279,25 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     }
 }
 
-template <int BM, int BN, bool F16, int STAGES, bool HAS_RES>
+template <int BM, int BN, bool F16, int STAGES, int RES>
 static pvr_status launch_inst2(ConvP &p, hipStream_t stream) {
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = STAGES * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, HAS_RES>,
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, RES>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, HAS_RES>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
 
 template <int BM, int BN, bool F16, int STAGES>
 static pvr_status launch_inst(ConvP &p, hipStream_t stream) {
-    return p.res ? launch_inst2<BM, BN, F16, STAGES, true>(p, stream) : launch_inst2<BM, BN, F16, STAGES, false>(p, stream);
+    if (!p.res) return launch_inst2<BM, BN, F16, STAGES, 0>(p, stream);
+    return p.res_f32 ? launch_inst2<BM, BN, F16, STAGES, 2>(p, stream) : launch_inst2<BM, BN, F16, STAGES, 1>(p, stream);
 }
 
 template <int BM, int BN>
@@ -298,7 +326,7 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     const int64_t M = (int64_t)n * p.Ho * p.Wo;
     PVR_REQUIRE(M < (1ll << 31) && (int64_t)M * cout < (1ll << 40), "conv: problem too large");
     p.M = (int)M; p.K = kh * kw * cin;
-    p.relu = relu; p.out_f32 = out_f32;
+    p.act = relu; p.out_f32 = out_f32 & 1; p.res_f32 = (out_f32 >> 1) & 1;   // out_f32 bit1: residual is fp32
     if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
     return launch_cfg<128, 128>(p, dtype, stream);
 }

@@ -9,59 +9,7 @@
 //   * BN eval fold:  scale = gamma / sqrt(var + 1e-5),  W' = W*scale,  b' = beta - mean*scale (+ scale*conv_bias)
 //   * stem: Normalize + /255 folded into conv1 (see stem.hip), K laid out (kh, kw[8], c[4])
 //   * OIHW fp32 -> [cout_pad][kh][kw][cin_pad] 16-bit (bf16 or f16), zero padded
-#include <map>
-#include <string>
-#include <vector>
-#include <cmath>
-#include "common.h"
-
-namespace pvr {
-
-pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
-pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
-pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
-pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
-pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
-pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);
-pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
-                       int, int, int, int, int, int, int, int, hipStream_t);
-
-struct HostTensor {
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-};
-
-enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT };
-
-struct ConvOp {
-    std::string conv, bn;          // state_dict prefixes
-    int in_buf, out_buf, res_buf;
-    int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
-    u16 *d_w = nullptr;
-    float *d_b = nullptr;
-    std::string tap;               // non-empty: output of this op is the named tap
-};
-
-}  // namespace pvr
-
-using namespace pvr;
-
-struct pvr_encoder {
-    pvr_encoder_desc desc;
-    std::map<std::string, HostTensor> weights;
-    std::vector<ConvOp> ops;
-    bool finalized = false;
-    int out_size = 0;
-    int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation
-    // device
-    u16 *d_img = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_stem_w = nullptr, *d_zero = nullptr;
-    float *d_stem_b = nullptr;
-    void *d_buf[B_COUNT] = {nullptr};
-    size_t buf_elems = 0;
-    int last_n = 0;
-    std::string stop_after;                                          // debug: end the forward after this tap
-    std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
-};
+#include "encoder_internal.h"
 
 namespace pvr {
 
@@ -127,13 +75,13 @@ static void build_resnet50(pvr_encoder *e) {
     e->out_size = c * hw * hw; e->final_hw = hw * hw; e->final_c = 64; e->final_creal = c;
 }
 
-static const HostTensor *find(pvr_encoder *e, const std::string &name) {
+const HostTensor *enc_find(pvr_encoder *e, const std::string &name) {
     auto it = e->weights.find(name);
     return it == e->weights.end() ? nullptr : &it->second;
 }
 
-static pvr_status need(pvr_encoder *e, const std::string &name, const HostTensor **out, size_t numel) {
-    const HostTensor *t = find(e, name);
+pvr_status enc_need(pvr_encoder *e, const std::string &name, const HostTensor **out, size_t numel) {
+    const HostTensor *t = enc_find(e, name);
     if (!t) { set_error("missing weight: %s", name.c_str()); return PVR_ERR_MISSING_WEIGHT; }
     if (t->data.size() != numel) {
         set_error("weight %s has %zu elements, expected %zu", name.c_str(), t->data.size(), numel);
@@ -147,10 +95,10 @@ static pvr_status bn_fold(pvr_encoder *e, const std::string &bn, int c, std::vec
                           std::vector<float> &shift) {
     const HostTensor *g, *b, *m, *v;
     pvr_status s;
-    if ((s = need(e, bn + ".weight", &g, c))) return s;
-    if ((s = need(e, bn + ".bias", &b, c))) return s;
-    if ((s = need(e, bn + ".running_mean", &m, c))) return s;
-    if ((s = need(e, bn + ".running_var", &v, c))) return s;
+    if ((s = enc_need(e, bn + ".weight", &g, c))) return s;
+    if ((s = enc_need(e, bn + ".bias", &b, c))) return s;
+    if ((s = enc_need(e, bn + ".running_mean", &m, c))) return s;
+    if ((s = enc_need(e, bn + ".running_var", &v, c))) return s;
     scale.resize(c); shift.resize(c);
     for (int i = 0; i < c; ++i) {
         scale[i] = g->data[i] / sqrtf(v->data[i] + 1e-5f);
@@ -159,21 +107,15 @@ static pvr_status bn_fold(pvr_encoder *e, const std::string &bn, int c, std::vec
     return PVR_OK;
 }
 
-template <typename T>
-static pvr_status upload(T **dptr, const std::vector<T> &h) {
-    PVR_HIP_TRY(hipMalloc((void **)dptr, h.size() * sizeof(T)));
-    PVR_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    return PVR_OK;
-}
 
 static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
     const int k = op.k, cr = op.cin_real, cor = op.cout_real;
     const HostTensor *w;
     pvr_status s;
-    if ((s = need(e, op.conv + ".weight", &w, (size_t)cor * cr * k * k))) return s;
+    if ((s = enc_need(e, op.conv + ".weight", &w, (size_t)cor * cr * k * k))) return s;
     std::vector<float> scale, shift;
     if ((s = bn_fold(e, op.bn, cor, scale, shift))) return s;
-    if (const HostTensor *cb = find(e, op.conv + ".bias")) {
+    if (const HostTensor *cb = enc_find(e, op.conv + ".bias")) {
         if ((int)cb->data.size() != cor) { set_error("bad bias size for %s", op.conv.c_str()); return PVR_ERR_INVALID; }
         for (int i = 0; i < cor; ++i) shift[i] += scale[i] * cb->data[i];
     }
@@ -189,14 +131,14 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
                 }
     std::vector<float> hb(cout_pad, 0.f);
     for (int co = 0; co < cor; ++co) hb[co] = shift[co];
-    if ((s = upload(&op.d_w, hw))) return s;
-    return upload(&op.d_b, hb);
+    if ((s = enc_upload(&op.d_w, hw))) return s;
+    return enc_upload(&op.d_b, hb);
 }
 
 static pvr_status finalize_stem(pvr_encoder *e) {
     const HostTensor *w;
     pvr_status s;
-    if ((s = need(e, "conv1.weight", &w, 64 * 3 * 7 * 7))) return s;
+    if ((s = enc_need(e, "conv1.weight", &w, 64 * 3 * 7 * 7))) return s;
     std::vector<float> scale, shift;
     if ((s = bn_fold(e, "bn1", 64, scale, shift))) return s;
     std::vector<u16> hw(64 * 224, 0);
@@ -206,14 +148,14 @@ static pvr_status finalize_stem(pvr_encoder *e) {
                 double vsum = 0.0;
                 for (int c = 0; c < 3; ++c) {
                     const double wv = (double)w->data[(((size_t)co * 3 + c) * 7 + a) * 7 + b] * scale[co];
-                    // (x/255 - mean)/std = x * 1/(255*std) - mean/std
+                    // (x/255 - mean)/std with x = xc + 128:  xc/(255 std) + (128 - 255 mean)/(255 std)
                     hw[co * 224 + (a * 8 + b) * 4 + c] = f32_to_h((float)(wv / (255.0 * e->desc.std_[c])), e->desc.dtype);
-                    vsum -= wv * e->desc.mean[c] / e->desc.std_[c];
+                    vsum += wv * (128.0 - 255.0 * e->desc.mean[c]) / (255.0 * e->desc.std_[c]);
                 }
                 hw[co * 224 + (a * 8 + b) * 4 + 3] = f32_to_h((float)vsum, e->desc.dtype);
             }
-    if ((s = upload(&e->d_stem_w, hw))) return s;
-    return upload(&e->d_stem_b, shift);
+    if ((s = enc_upload(&e->d_stem_w, hw))) return s;
+    return enc_upload(&e->d_stem_b, shift);
 }
 
 }  // namespace pvr
@@ -222,15 +164,20 @@ extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
-    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_RESNET50_L3, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_CLIP_VIT_B16, "unknown arch %d", desc->arch);
     PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16, "dtype must be PVR_BF16 or PVR_F16");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
-    PVR_REQUIRE(desc->crop == 224, "crop must be 224 for the ResNet50 family (reference embeddings.py:82)");
+    PVR_REQUIRE(desc->crop == 224, "crop must be 224 (reference embeddings.py:82; CLIP input_resolution 224)");
     PVR_REQUIRE(desc->resize >= desc->crop, "resize must be >= crop");
     pvr_encoder *e = new pvr_encoder();
     e->desc = *desc;
     if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
-    build_resnet50(e);
+    if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32) {
+        pvr_status s = vit_create(e);
+        if (s) { delete e; return s; }
+    } else {
+        build_resnet50(e);
+    }
     *out = e;
     return PVR_OK;
 }
@@ -251,6 +198,13 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     PVR_REQUIRE(enc, "null encoder");
     PVR_REQUIRE(!enc->finalized, "encoder already finalized");
     pvr_status s;
+    if (enc->vit) {
+        if ((s = vit_finalize(enc))) return s;
+        PVR_HIP_TRY(hipDeviceSynchronize());
+        enc->weights.clear();
+        enc->finalized = true;
+        return PVR_OK;
+    }
     if ((s = finalize_stem(enc))) return s;
     for (auto &op : enc->ops)
         if ((s = finalize_conv(enc, op))) return s;
@@ -289,6 +243,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
     hipStream_t st = (hipStream_t)hip_stream;
     const int dt = enc->desc.dtype;
     pvr_status s;
+    if (enc->vit) return vit_forward(enc, frames, n, h, w, out, out_stride, st);
     for (int f0 = 0; f0 < n; f0 += enc->desc.chunk) {
         const int nb = (n - f0 < enc->desc.chunk) ? n - f0 : enc->desc.chunk;
         const uint8_t *fr = frames + (size_t)f0 * h * w * 3;
@@ -385,6 +340,7 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
     PVR_REQUIRE(enc && name && out && count, "pvr_encoder_tap: null argument");
     if (!enc->finalized || enc->last_n == 0) { set_error("no forward has run"); return PVR_ERR_STATE; }
     hipStream_t st = (hipStream_t)hip_stream;
+    if (enc->vit) return vit_tap(enc, name, out, cap, count, st);
     const int n = enc->last_n, crop = enc->desc.crop;
     const std::string nm = name;
     const void *src = nullptr;
@@ -410,6 +366,7 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
 
 void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
+    if (enc->vit) vit_destroy(enc);
     for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_b) (void)hipFree(op.d_b); }
     for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
     if (enc->d_img) (void)hipFree(enc->d_img);

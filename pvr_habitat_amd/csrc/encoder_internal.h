@@ -1,0 +1,74 @@
+// Internal declarations shared by encoder.hip (ResNet50 family) and vit.hip (CLIP ViT).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include "common.h"
+
+namespace pvr {
+
+pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
+pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
+pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
+pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
+pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
+pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);
+pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
+                       int, int, int, int, int, int, int, int, hipStream_t);
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT };
+
+struct ConvOp {
+    std::string conv, bn;          // state_dict prefixes
+    int in_buf, out_buf, res_buf;
+    int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
+    u16 *d_w = nullptr;
+    float *d_b = nullptr;
+    std::string tap;               // non-empty: output of this op is the named tap
+};
+
+}  // namespace pvr
+
+using namespace pvr;
+
+struct pvr_encoder {
+    pvr_encoder_desc desc;
+    std::map<std::string, HostTensor> weights;
+    std::vector<ConvOp> ops;
+    bool finalized = false;
+    int out_size = 0;
+    int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation
+    // device
+    u16 *d_img = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_stem_w = nullptr, *d_zero = nullptr;
+    float *d_stem_b = nullptr;
+    void *d_buf[B_COUNT] = {nullptr};
+    size_t buf_elems = 0;
+    int last_n = 0;
+    std::string stop_after;                                          // debug: end the forward after this tap
+    std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
+    struct pvr_vit *vit = nullptr;                                   // CLIP ViT plan (vit.hip) when arch >= PVR_ARCH_CLIP_VIT_B32
+};
+
+
+namespace pvr {
+const HostTensor *enc_find(pvr_encoder *e, const std::string &name);
+pvr_status enc_need(pvr_encoder *e, const std::string &name, const HostTensor **out, size_t numel);
+template <typename T>
+pvr_status enc_upload(T **dptr, const std::vector<T> &h) {
+    PVR_HIP_TRY(hipMalloc((void **)dptr, h.size() * sizeof(T)));
+    PVR_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PVR_OK;
+}
+// vit.hip
+pvr_status vit_create(pvr_encoder *e);
+pvr_status vit_finalize(pvr_encoder *e);
+pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st);
+void vit_destroy(pvr_encoder *e);
+pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, int64_t *count, hipStream_t st);
+}  // namespace pvr

@@ -2,15 +2,15 @@
 //
 // Replaces reference src/embeddings.py:391-393 (.to(device), NHWC->NCHW transposes, the
 // T.Resize/T.CenterCrop part of the transforms at :80-85).  ConvertImageDtype(/255) and
-// Normalize are NOT applied here: they are folded into the stem weights (encoder.cpp), so this
-// kernel hands the stem the exact uint8 values (0..255 are exact in bf16 and f16).
+// Normalize are NOT applied here: they are folded into the stem weights (encoder.hip), so this
+// kernel hands the stem the exact centred uint8 values x-128 (integers -128..127 are exact in bf16 and f16).
 //
 // torchvision 0.10 tensor Resize on uint8 = float32 bilinear (align_corners=False) then
 // round-half-even back to uint8; restated in oracle/encoder_oracle.py:resize_u8.
 //
 // HBM-bound byte kernel: 3 B read (or 12 B for the 4 bilinear taps) + 8 B written per pixel.
 // Output layout: (n, crop+6, crop+8, 4) 16-bit, pixel (y,x) at [y+3][x+3], channels
-// (R,G,B,valid=1); the 3-pixel zero border (valid=0) is the conv1 padding and is never written.
+// (R-128,G-128,B-128,valid=1); the 3-pixel zero border (valid=0) is the conv1 padding and is never written.
 #include "common.h"
 
 namespace pvr {
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreP p) {
     }
     const int PW = p.crop + 8, PH = p.crop + 6;
     ushort4 o;
-    o.x = to_h<F16>(v[0]); o.y = to_h<F16>(v[1]); o.z = to_h<F16>(v[2]); o.w = to_h<F16>(1.0f);
+    // centred values (x - 128, exact integers in bf16/f16): keeps the folded-Normalize products small, so the
+    // 16-bit rounding of the stem weights is not amplified by the common-mode ~128 of every pixel
+    o.x = to_h<F16>(v[0] - 128.f); o.y = to_h<F16>(v[1] - 128.f); o.z = to_h<F16>(v[2] - 128.f); o.w = to_h<F16>(1.0f);
     *reinterpret_cast<ushort4 *>(p.dst + (((size_t)n * PH + (y + 3)) * PW + (x + 3)) * 4) = o;
 }
 

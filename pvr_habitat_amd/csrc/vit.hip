@@ -1,0 +1,481 @@
+// CLIP visual transformer (ViT-B/32, ViT-B/16) encode_image as a HIP plan.
+//
+// Replaces reference src/embeddings.py:298-314 (clip.load + transforms) and :375-376 (encode_image) with openai/CLIP's
+// VisionTransformer restated in oracle/vit_oracle.py.  Plan per chunk of frames:
+//   patchify (uint8 crop -> [N*g*g][P*P*3] 16-bit, Normalize and /255 folded into the patch-embed weights)
+//   -> patch-embed GEMM (conv_igemm as a 1x1 conv over "pixels" = patches, fp32 out)
+//   -> [CLS ; patches] + positional embedding -> ln_pre  (assemble_ln_kernel, fp32 residual stream)
+//   -> 12 x { ln_1 -> QKV GEMM(+bias) -> attention_kernel -> out_proj GEMM(+bias, += fp32 residual)
+//             ln_2 -> c_fc GEMM(+bias, QuickGELU) -> c_proj GEMM(+bias, += fp32 residual) }
+//   -> ln_post(CLS) @ proj (cls_head_kernel, fp32)
+// GEMMs: conv_igemm_kernel (MFMA 16x16x32, bf16 or f16 inputs, fp32 accumulate); the residual stream stays fp32.
+// Attention: one workgroup per (image, head); scores are computed TRANSPOSED (S^T = K Q^T) so that the softmaxed
+// accumulator tile is already the B operand of the second product (O^T = V^T P^T) — no LDS round trip for P
+// (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"); softmax reductions are wave shuffles.
+#include "encoder_internal.h"
+
+namespace pvr {
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+// uint8 (n,h,w,3) centre crop -> A[(n*g*g + gy*g + gx)][(py*P + px)*3 + c] as 16-bit (exact centred values x-128)
+template <bool F16>
+__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t *__restrict__ frames, u16 *__restrict__ A, int n, int h,
+                                                       int w, int top, int left, int res, int P) {
+    const int g = res / P, K = P * P * 3;
+    const size_t total = (size_t)n * g * g * (K / 8);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k8 = (int)(i % (K / 8)) * 8;
+        const size_t row = i / (K / 8);
+        const int gx = (int)(row % g), gy = (int)((row / g) % g), b = (int)(row / ((size_t)g * g));
+        u32x4 o;
+        u16 *oe = reinterpret_cast<u16 *>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k8 + e, c = k % 3, px = (k / 3) % P, py = k / (3 * P);
+            const int y = top + gy * P + py, x = left + gx * P + px;
+            oe[e] = to_h<F16>((float)frames[(((size_t)b * h + y) * w + x) * 3 + c] - 128.f);     // centred, exact
+        }
+        *reinterpret_cast<u32x4 *>(A + row * K + k8) = o;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per token row of width W (multiple of 256): LayerNorm (eps 1e-5, fp32) of x (+ optional assembly of the
+// token sequence: row t = 0 -> cls, t > 0 -> patch_emb[n*g2 + t-1], plus pos[t]).  Writes fp32 (residual stream)
+// and/or 16-bit (GEMM operand).
+template <bool F16, int W>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ patch_emb,
+                                                        const float *__restrict__ cls, const float *__restrict__ pos,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ out_f32, u16 *__restrict__ out_h, int rows, int T) {
+    constexpr int PER = W / 64;                   // 12 for 768
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[PER];
+    if (patch_emb) {
+        const int t = row % T, b = row / T;
+        const float *src = t == 0 ? cls : patch_emb + ((size_t)b * (T - 1) + t - 1) * W;
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) {
+            const int k = (i * 64 + lane) * 4;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + k), p = *reinterpret_cast<const f32x4 *>(pos + (size_t)t * W + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i * 4 + e] = a[e] + p[e];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(x + (size_t)row * W + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i * 4 + e] = a[e];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + k), bt = *reinterpret_cast<const f32x4 *>(beta + k);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i * 4 + e] - mean) * rstd * gm[e] + bt[e];
+        if (out_f32) *reinterpret_cast<f32x4 *>(out_f32 + (size_t)row * W + k) = o;
+        if (out_h) {
+            ushort4 r;
+            r.x = to_h<F16>(o[0]); r.y = to_h<F16>(o[1]); r.z = to_h<F16>(o[2]); r.w = to_h<F16>(o[3]);
+            *reinterpret_cast<ushort4 *>(out_h + (size_t)row * W + k) = r;
+        }
+    }
+}
+
+// Multi-head attention, head dim 64.  qkv: [N*T][3W] 16-bit (q | k | v, head h at columns h*64..), out: [N*T][W].
+// grid (heads, N), 4 waves.  Keys are padded to TK (multiple of 32): padded scores are -inf, padded V rows zero.
+template <bool F16>
+__global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ qkv, u16 *__restrict__ out, int T, int TK, int W) {
+    typedef typename HT<F16>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VS = TK + 4;                                        // V^T row stride (elements)
+    char *Ks = smem;                                              // [TK][64] 16-bit, 128-B rows, chunk-swizzled
+    u16 *Vt = reinterpret_cast<u16 *>(smem + (size_t)TK * 128);   // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int hd = blockIdx.x, b = blockIdx.y;
+    const size_t rs = (size_t)3 * W;
+    const u16 *base = qkv + (size_t)b * T * rs + hd * 64;
+    for (int idx = tid; idx < TK * 8; idx += 256) {
+        const int row = idx >> 3, ch = idx & 7;
+        u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+        if (row < T) {
+            kv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + W + ch * 8);
+            vv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + 2 * W + ch * 8);
+        }
+        *reinterpret_cast<u32x4 *>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
+        const u16 *ve = reinterpret_cast<const u16 *>(&vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+    }
+    __syncthreads();
+    const int NT = TK / 16;                                       // key tiles (<= 14)
+    for (int qt = wave; qt * 16 < T; qt += 4) {
+        const int query = qt * 16 + fr;
+        const bool qok = query < T;
+        // B operand of S^T = K Q^T : Q[query = fr][d = ks*32 + 8*fq + j]
+        V8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 t = u32x4{0u, 0u, 0u, 0u};
+            if (qok) t = *reinterpret_cast<const u32x4 *>(base + (size_t)query * rs + ks * 32 + fq * 8);
+            qf[ks] = __builtin_bit_cast(V8, t);
+        }
+        f32x4 s[14];
+#pragma unroll
+        for (int nt = 0; nt < 14; ++nt) {
+            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nt < NT) {
+                const int krow = nt * 16 + fr;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const V8 kf = *reinterpret_cast<const V8 *>(Ks + krow * 128 + (((ks * 4 + fq) ^ ((krow >> 1) & 7)) << 4));
+                    s[nt] = mfma16<F16>(kf, qf[ks], s[nt]);
+                }
+            }
+        }
+        // s[nt][r] = S^T[key = nt*16 + 4*fq + r][query = fr]; softmax over keys (scores / sqrt(64))
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 14; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + fq * 4 + r;
+                const float v = (nt < NT && key < T) ? s[nt][r] * 0.125f : -INFINITY;
+                s[nt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 14; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[nt][r] - mx);            // exp(-inf) = 0 for padded keys
+                s[nt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // O^T = V^T P^T : k-slot (fq, j) <-> key 32*ks + 16*(j>>2) + 4*fq + (j&3), identical for both operands
+        f32x4 o[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            if (ks * 32 < TK) {
+                u16 pe[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pe[j] = to_h<F16>(s[2 * ks + (j >> 2)][j & 3]);
+                u32x4 pw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pw[e] = (unsigned)pe[2 * e] | ((unsigned)pe[2 * e + 1] << 16);
+                const V8 pf = __builtin_bit_cast(V8, pw);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const u16 *vr = Vt + (size_t)(mt * 16 + fr) * VS + ks * 32 + fq * 4;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(vr), hi = *reinterpret_cast<const uint2 *>(vr + 16);
+                    const u32x4 vw = u32x4{lo.x, lo.y, hi.x, hi.y};
+                    o[mt] = mfma16<F16>(__builtin_bit_cast(V8, vw), pf, o[mt]);
+                }
+            }
+        }
+        if (qok) {
+            u16 *orow = out + ((size_t)b * T + query) * W + hd * 64 + fq * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                ushort4 r;
+                r.x = to_h<F16>(o[mt][0] * inv); r.y = to_h<F16>(o[mt][1] * inv);
+                r.z = to_h<F16>(o[mt][2] * inv); r.w = to_h<F16>(o[mt][3] * inv);
+                *reinterpret_cast<ushort4 *>(orow + mt * 16) = r;
+            }
+        }
+    }
+}
+
+// ln_post(x[:,0,:]) @ proj  (W -> out_dim), one block per image, fp32
+template <int W>
+__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, const float *__restrict__ proj,
+                                                       float *__restrict__ out, int64_t out_stride, int T, int out_dim) {
+    __shared__ float y[W];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float *row = x + (size_t)b * T * W;
+    float v[W / 256];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < W / 256; ++i) { v[i] = row[tid + i * 256]; s += v[i]; }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < W / 256; ++i) { const float d = v[i] - mean; q += d * d; }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < W / 256; ++i) y[tid + i * 256] = (v[i] - mean) * rstd * gamma[tid + i * 256] + beta[tid + i * 256];
+    __syncthreads();
+    for (int j = tid; j < out_dim; j += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < W; ++k) acc += y[k] * proj[(size_t)k * out_dim + j];
+        out[(size_t)b * out_stride + j] = acc;
+    }
+}
+
+}  // namespace pvr
+
+// ------------------------------------------------------------------------------------------------------------------
+// host plan
+// ------------------------------------------------------------------------------------------------------------------
+using namespace pvr;
+
+struct VitBlock {
+    u16 *w_qkv = nullptr, *w_out = nullptr, *w_fc = nullptr, *w_proj = nullptr;
+    float *b_qkv = nullptr, *b_out = nullptr, *b_fc = nullptr, *b_proj = nullptr;
+    float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+};
+
+struct pvr_vit {
+    int patch = 32, width = 768, layers = 12, heads = 12, out_dim = 512, res = 224, grid = 7, T = 50, TK = 64;
+    std::vector<VitBlock> blocks;
+    u16 *w_patch = nullptr;
+    float *b_patch = nullptr, *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr,
+          *lnpost_b = nullptr, *proj = nullptr;
+    // workspace (chunk frames)
+    u16 *A = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *zero = nullptr;
+    float *pe = nullptr, *x0 = nullptr, *x1 = nullptr;
+    std::vector<void *> owned;
+};
+
+namespace pvr {
+
+static pvr_status up_f32(pvr_encoder *e, const std::string &name, size_t numel, float **dptr) {
+    const HostTensor *t;
+    pvr_status s = enc_need(e, name, &t, numel);
+    if (s) return s;
+    if ((s = enc_upload(dptr, t->data))) return s;
+    e->vit->owned.push_back(*dptr);
+    return PVR_OK;
+}
+
+// nn.Linear weight [out][in] -> 16-bit rows (already K-major), rows padded to a multiple of 64
+static pvr_status up_linear(pvr_encoder *e, const std::string &wname, const std::string &bname, int out_f, int in_f, u16 **dw, float **db) {
+    const HostTensor *w, *b;
+    pvr_status s;
+    if ((s = enc_need(e, wname, &w, (size_t)out_f * in_f))) return s;
+    if ((s = enc_need(e, bname, &b, (size_t)out_f))) return s;
+    const int pad = (out_f + 63) / 64 * 64;
+    std::vector<u16> hw((size_t)pad * in_f, 0);
+    for (size_t i = 0; i < (size_t)out_f * in_f; ++i) hw[i] = f32_to_h(w->data[i], e->desc.dtype);
+    std::vector<float> hb(pad, 0.f);
+    for (int i = 0; i < out_f; ++i) hb[i] = b->data[i];
+    if ((s = enc_upload(dw, hw))) return s;
+    e->vit->owned.push_back(*dw);
+    if ((s = enc_upload(db, hb))) return s;
+    e->vit->owned.push_back(*db);
+    return PVR_OK;
+}
+
+pvr_status vit_create(pvr_encoder *e) {
+    pvr_vit *v = new pvr_vit();
+    v->patch = e->desc.arch == PVR_ARCH_CLIP_VIT_B16 ? 16 : 32;
+    v->res = e->desc.crop;
+    v->grid = v->res / v->patch;
+    v->T = v->grid * v->grid + 1;
+    v->TK = (v->T + 31) / 32 * 32;
+    if (v->TK > 224) { delete v; set_error("vit: more than 224 tokens not supported"); return PVR_ERR_INVALID; }
+    e->vit = v;
+    e->out_size = v->out_dim;
+    return PVR_OK;
+}
+
+pvr_status vit_finalize(pvr_encoder *e) {
+    pvr_vit *v = e->vit;
+    const int W = v->width, P = v->patch, K = P * P * 3, dt = e->desc.dtype;
+    pvr_status s;
+    // patch embedding: conv1 [W][3][P][P] (no bias) -> [W][(py,px,c)], Normalize + /255 folded:
+    //   sum w*((x/255-mean)/std) = sum (w/(255 std)) (x-128) + sum w (128 - 255 mean)/(255 std)
+    const HostTensor *w;
+    if ((s = enc_need(e, "visual.conv1.weight", &w, (size_t)W * K))) return s;
+    {
+        std::vector<u16> hw((size_t)W * K);
+        std::vector<float> hb(W, 0.f);
+        for (int co = 0; co < W; ++co) {
+            double bsum = 0.0;
+            for (int c = 0; c < 3; ++c)
+                for (int py = 0; py < P; ++py)
+                    for (int px = 0; px < P; ++px) {
+                        const double wv = w->data[(((size_t)co * 3 + c) * P + py) * P + px];
+                        hw[(size_t)co * K + (py * P + px) * 3 + c] = f32_to_h((float)(wv / (255.0 * e->desc.std_[c])), dt);
+                        bsum += wv * (128.0 - 255.0 * e->desc.mean[c]) / (255.0 * e->desc.std_[c]);   // x = xc + 128
+                    }
+            hb[co] = (float)bsum;
+        }
+        if ((s = enc_upload(&v->w_patch, hw))) return s;
+        v->owned.push_back(v->w_patch);
+        if ((s = enc_upload(&v->b_patch, hb))) return s;
+        v->owned.push_back(v->b_patch);
+    }
+    if ((s = up_f32(e, "visual.class_embedding", W, &v->cls))) return s;
+    if ((s = up_f32(e, "visual.positional_embedding", (size_t)v->T * W, &v->pos))) return s;
+    if ((s = up_f32(e, "visual.ln_pre.weight", W, &v->lnpre_w))) return s;
+    if ((s = up_f32(e, "visual.ln_pre.bias", W, &v->lnpre_b))) return s;
+    if ((s = up_f32(e, "visual.ln_post.weight", W, &v->lnpost_w))) return s;
+    if ((s = up_f32(e, "visual.ln_post.bias", W, &v->lnpost_b))) return s;
+    if ((s = up_f32(e, "visual.proj", (size_t)W * v->out_dim, &v->proj))) return s;
+    v->blocks.resize(v->layers);
+    for (int i = 0; i < v->layers; ++i) {
+        VitBlock &b = v->blocks[i];
+        const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
+        if ((s = up_linear(e, p + "attn.in_proj_weight", p + "attn.in_proj_bias", 3 * W, W, &b.w_qkv, &b.b_qkv))) return s;
+        if ((s = up_linear(e, p + "attn.out_proj.weight", p + "attn.out_proj.bias", W, W, &b.w_out, &b.b_out))) return s;
+        if ((s = up_linear(e, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", 4 * W, W, &b.w_fc, &b.b_fc))) return s;
+        if ((s = up_linear(e, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", W, 4 * W, &b.w_proj, &b.b_proj))) return s;
+        if ((s = up_f32(e, p + "ln_1.weight", W, &b.ln1_w))) return s;
+        if ((s = up_f32(e, p + "ln_1.bias", W, &b.ln1_b))) return s;
+        if ((s = up_f32(e, p + "ln_2.weight", W, &b.ln2_w))) return s;
+        if ((s = up_f32(e, p + "ln_2.bias", W, &b.ln2_b))) return s;
+    }
+    const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid;
+    auto alloc = [&](void **ptr, size_t bytes) -> pvr_status {
+        PVR_HIP_TRY(hipMalloc(ptr, bytes));
+        v->owned.push_back(*ptr);
+        return PVR_OK;
+    };
+    if ((s = alloc((void **)&v->A, prow * K * 2))) return s;
+    if ((s = alloc((void **)&v->pe, prow * W * 4))) return s;
+    if ((s = alloc((void **)&v->x0, rows * W * 4))) return s;
+    if ((s = alloc((void **)&v->x1, rows * W * 4))) return s;
+    if ((s = alloc((void **)&v->y, rows * W * 2))) return s;
+    if ((s = alloc((void **)&v->qkv, rows * 3 * W * 2))) return s;
+    if ((s = alloc((void **)&v->att, rows * W * 2))) return s;
+    if ((s = alloc((void **)&v->hid, rows * 4 * W * 2))) return s;
+    if ((s = alloc((void **)&v->zero, 256))) return s;
+    PVR_HIP_TRY(hipMemset(v->zero, 0, 256));
+    return PVR_OK;
+}
+
+void vit_destroy(pvr_encoder *e) {
+    if (!e->vit) return;
+    for (void *p : e->vit->owned) (void)hipFree(p);
+    delete e->vit;
+    e->vit = nullptr;
+}
+
+template <bool F16>
+static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
+    pvr_vit *v = e->vit;
+    const int W = v->width, P = v->patch, K = P * P * 3, T = v->T, g2 = v->grid * v->grid, dt = e->desc.dtype;
+    PVR_REQUIRE(W == 768, "vit: width %d not built", W);
+    // transforms (embeddings.py:309-314): Resize(res, BICUBIC, antialias) is the identity when the short side is res
+    const int sh = w <= h ? w : h;
+    PVR_REQUIRE(sh == v->res, "CLIP path: frames with short side %d need the antialiased bicubic Resize(%d), which is not built yet "
+                "(pass %dx%d frames)", sh, v->res, v->res, v->res);
+    const int top = (int)nearbyint((h - v->res) / 2.0), left = (int)nearbyint((w - v->res) / 2.0);
+    pvr_status s;
+    for (int f0 = 0; f0 < n; f0 += e->desc.chunk) {
+        const int nb = (n - f0 < e->desc.chunk) ? n - f0 : e->desc.chunk;
+        const int rows = nb * T, prow = nb * g2;
+        const uint8_t *fr = frames + (size_t)f0 * h * w * 3;
+        const size_t tot = (size_t)prow * (K / 8);
+        hipLaunchKernelGGL(patchify_kernel<F16>, dim3((int)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, st,
+                           fr, v->A, nb, h, w, top, left, v->res, P);
+        PVR_LAUNCH_CHECK();
+        // patch embedding GEMM -> fp32 [prow][W]
+        if ((s = launch_conv(v->A, v->w_patch, v->b_patch, nullptr, v->pe, v->zero, prow, 1, 1, K, W, 1, 1, 1, 0, 0, 1, dt, st))) return s;
+        // tokens + positional embedding + ln_pre -> residual stream x0 (fp32)
+        hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *)nullptr, v->pe, v->cls,
+                           v->pos, v->lnpre_w, v->lnpre_b, v->x0, (u16 *)nullptr, rows, T);
+        PVR_LAUNCH_CHECK();
+        e->last_n = nb;
+        const std::string &stop = e->stop_after;
+        if (stop == "pe" || stop == "ln_pre") return PVR_OK;
+        float *x = v->x0, *xn = v->x1;
+        int bi = 0;
+        const size_t att_lds = (size_t)v->TK * 128 + (size_t)64 * (v->TK + 4) * 2;
+        for (auto &b : v->blocks) {
+            hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T);
+            if ((s = launch_conv(v->y, b.w_qkv, b.b_qkv, nullptr, v->qkv, v->zero, rows, 1, 1, W, 3 * W, 1, 1, 1, 0, 0, 0, dt, st))) return s;
+            if (bi == 0 && stop == "qkv0") return PVR_OK;
+            hipLaunchKernelGGL(attention_kernel<F16>, dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
+            PVR_LAUNCH_CHECK();
+            if (bi == 0 && stop == "att0") return PVR_OK;
+            // x' = x + out_proj(att): fp32 residual in (bit1), fp32 out (bit0)
+            if ((s = launch_conv(v->att, b.w_out, b.b_out, x, xn, v->zero, rows, 1, 1, W, W, 1, 1, 1, 0, 0, 3, dt, st))) return s;
+            if (bi == 0 && stop == "res0") return PVR_OK;
+            hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, xn, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, b.ln2_w, b.ln2_b, (float *)nullptr, v->y, rows, T);
+            if ((s = launch_conv(v->y, b.w_fc, b.b_fc, nullptr, v->hid, v->zero, rows, 1, 1, W, 4 * W, 1, 1, 1, 0, 2, 0, dt, st))) return s;   // QuickGELU
+            if (bi == 0 && stop == "fc0") return PVR_OK;
+            if ((s = launch_conv(v->hid, b.w_proj, b.b_proj, xn, x, v->zero, rows, 1, 1, 4 * W, W, 1, 1, 1, 0, 0, 3, dt, st))) return s;
+            if (stop == "block" + std::to_string(bi)) return PVR_OK;
+            ++bi;
+        }
+        hipLaunchKernelGGL((cls_head_kernel<768>), dim3(nb), dim3(256), 0, st, x, v->lnpost_w, v->lnpost_b, v->proj,
+                           out + (size_t)f0 * out_stride, out_stride, T, v->out_dim);
+        PVR_LAUNCH_CHECK();
+        e->last_n = nb;
+    }
+    return PVR_OK;
+}
+
+// parity taps (after a forward stopped with pvr_encoder_debug_stop_after): fp32 copies of plan buffers
+pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, int64_t *count, hipStream_t st) {
+    pvr_vit *v = e->vit;
+    const std::string nm = name;
+    const size_t rows = (size_t)e->last_n * v->T, W = v->width;
+    const void *src = nullptr;
+    size_t elems = 0;
+    bool f32 = true;
+    if (nm == "pe") { src = v->pe; elems = (size_t)e->last_n * v->grid * v->grid * W; }
+    else if (nm == "ln_pre" || nm.rfind("block", 0) == 0) { src = v->x0; elems = rows * W; }
+    else if (nm == "qkv0") { src = v->qkv; elems = rows * 3 * W; f32 = false; }
+    else if (nm == "att0") { src = v->att; elems = rows * W; f32 = false; }
+    else if (nm == "res0") { src = v->x1; elems = rows * W; }
+    else if (nm == "fc0") { src = v->hid; elems = rows * 4 * W; f32 = false; }
+    else { set_error("unknown vit tap %s", name); return PVR_ERR_INVALID; }
+    PVR_REQUIRE((int64_t)elems <= cap, "tap %s needs %zu elements", name, elems);
+    *count = (int64_t)elems;
+    if (f32) { PVR_HIP_TRY(hipMemcpyAsync(out, src, elems * 4, hipMemcpyDeviceToDevice, st)); return PVR_OK; }
+    return launch_h_to_f32(src, out, elems, e->desc.dtype, st);
+}
+
+pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_done = true;
+    }
+    return e->desc.dtype == PVR_F16 ? vit_forward_t<true>(e, frames, n, h, w, out, out_stride, st)
+                                    : vit_forward_t<false>(e, frames, n, h, w, out, out_stride, st);
+}
+
+}  // namespace pvr

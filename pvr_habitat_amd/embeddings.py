@@ -23,8 +23,11 @@ from . import _lib, synth
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156}
-_ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3}
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512}
+_ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3,
+         'clip_b32': 3, 'clip_b16': 4}
 
 # ---------------------------------------------------------------------------------------------
 # name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
@@ -63,8 +66,10 @@ for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_cropo
     for _combo in ('345', '35', '34', '45'):
         _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
 # names the reference registers but whose model families are not built yet
-_NOT_BUILT = ('random', 'resnet18', 'resnet34', 'mae_base', 'mae_large', 'mae_huge', 'maskrcnn_l3',
-              'clip_vit', 'clip_rn50')
+_NOT_BUILT = ('random', 'resnet18', 'resnet34', 'mae_base', 'mae_large', 'mae_huge', 'maskrcnn_l3', 'clip_rn50')
+# CLIP visual towers: 'clip_vit' is the reference's name (ViT-B/32, embeddings.py:303-304); 'clip_vit_b16' is the
+# same block layout at patch 16 (BASELINE config 3), not a reference registry name
+_CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16)}
 
 
 def _dtype_from_env(compute_dtype=None):
@@ -157,17 +162,22 @@ def _install(root, key, tensor):
     leaf = parts[-1]
     if leaf in ('running_mean', 'running_var', 'num_batches_tracked'):
         node.register_buffer(leaf, tensor)
+    elif leaf in node._modules:                      # e.g. 'visual.proj' next to nothing else: keep as parameter
+        raise KeyError(key)
     else:
         node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
 
 
 class HipResNet50(_Node):
-    """One frozen ResNet50-family model: fp32 host tensors (torchvision names) + a libpvr_hip encoder."""
+    """One frozen encoder: fp32 host tensors under the reference's state_dict names + a libpvr_hip encoder handle.
+    variant: 'conv5' | 'conv4' | 'conv3' (ResNet50 family, torchvision names) or 'clip_b32' | 'clip_b16'
+    (openai/CLIP visual tower, `visual.*` names)."""
 
     def __init__(self, state_dict, variant='conv5', compute_dtype=None, max_batch=None, chunk=None):
         super().__init__()
         self.variant = variant
         self.out_size = OUT_SIZE[variant]
+        self._clip = variant.startswith('clip')
         self._dtype = _dtype_from_env(compute_dtype)
         self._max_batch = int(max_batch or os.environ.get('PVR_MAX_BATCH', 256))
         self._chunk = int(chunk or os.environ.get('PVR_CHUNK', 0))
@@ -197,9 +207,9 @@ class HipResNet50(_Node):
     def _build(self):
         L = _lib.lib()
         desc = _lib.EncoderDesc(arch=_ARCH[self.variant], dtype=self._dtype, max_batch=self._max_batch,
-                                chunk=self._chunk, resize=256, crop=224)
-        desc.mean[:] = IMAGENET_MEAN
-        desc.std_[:] = IMAGENET_STD
+                                chunk=self._chunk, resize=224 if self._clip else 256, crop=224)
+        desc.mean[:] = CLIP_MEAN if self._clip else IMAGENET_MEAN          # embeddings.py:313 / :84
+        desc.std_[:] = CLIP_STD if self._clip else IMAGENET_STD
         h = C.c_void_p()
         _lib.check(L.pvr_encoder_create(C.byref(desc), C.byref(h)))
         try:
@@ -302,6 +312,17 @@ def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, trai
         return nn.Sequential(nn.Identity()), nn.Sequential(nn.Identity())
     if embedding_name in _SINGLE:
         sd, variant = _load_named_state_dict(embedding_name, pretrained)
+        model = HipResNet50(sd, variant, **hip_kw)
+    elif embedding_name in _CLIP:
+        variant, ckpt, patch = _CLIP[embedding_name]
+        f = _find_checkpoint(ckpt) if pretrained else None
+        if f is not None:                             # OpenAI's TorchScript archive: keep the visual tower only
+            full = torch.jit.load(f, map_location='cpu').state_dict()
+            sd = {k: v.float() for k, v in full.items() if k.startswith('visual.')}
+        elif os.environ.get('PVR_SYNTHETIC_WEIGHTS', '0') == '1' or not pretrained:
+            sd = synth.clip_vit_state_dict(zlib.crc32(embedding_name.encode()) & 0x7fffffff, patch=patch)
+        else:
+            raise FileNotFoundError(ckpt)
         model = HipResNet50(sd, variant, **hip_kw)
     elif embedding_name in _UBER:
         model = UberModel([_get_embedding(n, in_channels, pretrained, train, **hip_kw)[0] for n in _UBER[embedding_name]])

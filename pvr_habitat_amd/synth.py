@@ -210,3 +210,34 @@ def bc_conv_batches(seed, T, B, steps, A):
     done = uniform(seed, 'bc_done', (steps, T, B)) < 0.02
     act = (uniform(seed, 'bc_act', (steps, T, B)) * A).astype(np.int64).clip(0, A - 1)
     return obs, done, act
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP visual transformer (openai/CLIP model.py VisionTransformer; reference src/embeddings.py:303-304
+# loads "ViT-B/32": width 768, 12 layers, 12 heads, patch 32, output 512).  Keys as in clip's state_dict.
+# ------------------------------------------------------------------------------------------
+def clip_vit_state_dict(seed=1, patch=32, width=768, layers=12, out_dim=512, resolution=224):
+    sd = {}
+    grid = resolution // patch
+    s = width ** -0.5
+    sd['visual.class_embedding'] = normal(seed, 'vit.cls', (width,), std=s)
+    sd['visual.positional_embedding'] = normal(seed, 'vit.pos', (grid * grid + 1, width), std=s)
+    sd['visual.proj'] = normal(seed, 'vit.proj', (width, out_dim), std=s)
+    sd['visual.conv1.weight'] = normal(seed, 'vit.conv1', (width, 3, patch, patch), std=float(np.sqrt(1.0 / (3 * patch * patch))))
+    for nm in ('ln_pre', 'ln_post'):
+        sd['visual.%s.weight' % nm] = uniform(seed, 'vit.%s.w' % nm, (width,), 0.8, 1.2)
+        sd['visual.%s.bias' % nm] = uniform(seed, 'vit.%s.b' % nm, (width,), -0.1, 0.1)
+    for i in range(layers):
+        p = 'visual.transformer.resblocks.%d.' % i
+        sd[p + 'attn.in_proj_weight'] = normal(seed, p + 'inw', (3 * width, width), std=s)
+        sd[p + 'attn.in_proj_bias'] = uniform(seed, p + 'inb', (3 * width,), -0.05, 0.05)
+        sd[p + 'attn.out_proj.weight'] = normal(seed, p + 'outw', (width, width), std=s * 0.5)
+        sd[p + 'attn.out_proj.bias'] = uniform(seed, p + 'outb', (width,), -0.05, 0.05)
+        for ln in ('ln_1', 'ln_2'):
+            sd[p + ln + '.weight'] = uniform(seed, p + ln + 'w', (width,), 0.8, 1.2)
+            sd[p + ln + '.bias'] = uniform(seed, p + ln + 'b', (width,), -0.1, 0.1)
+        sd[p + 'mlp.c_fc.weight'] = normal(seed, p + 'fcw', (4 * width, width), std=s)
+        sd[p + 'mlp.c_fc.bias'] = uniform(seed, p + 'fcb', (4 * width,), -0.05, 0.05)
+        sd[p + 'mlp.c_proj.weight'] = normal(seed, p + 'pjw', (width, 4 * width), std=float((4 * width) ** -0.5) * 0.5)
+        sd[p + 'mlp.c_proj.bias'] = uniform(seed, p + 'pjb', (width,), -0.05, 0.05)
+    return sd

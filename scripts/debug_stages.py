@@ -25,7 +25,7 @@ for (h, n, mb) in ((64, 4, 4), (64, 3, 8), (256, 4, 4), (256, 2, 4), (128, 2, 4)
     res = {}
     m.debug_stop_after('pre'); m(d)
     pre = m.tap('pre', n * 230 * 232 * 4).cpu().numpy().reshape(n, 230, 232, 4)
-    res['pre'] = float(np.abs(pre[:, 3:227, 3:227, :3] - u8).max())
+    res['pre'] = float(np.abs(pre[:, 3:227, 3:227, :3] + 128.0 - u8).max())
     for name, key in (('stem', 'conv1'), ('pool', 'stem'), ('layer1', 'layer1'), ('layer2', 'layer2'), ('layer3', 'layer3'), ('layer4', 'layer4')):
         m.debug_stop_after(name); m(d)
         r = taps[key].permute(0, 2, 3, 1).contiguous().numpy()

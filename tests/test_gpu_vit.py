@@ -1,0 +1,44 @@
+"""GPU parity of the CLIP ViT path (B/32 as the reference loads it, B/16 as BASELINE config 3) vs the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from pvr_habitat_amd import synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b)), float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize('patch,variant', [(32, 'clip_b32'), (16, 'clip_b16')])
+@pytest.mark.parametrize('dt,tol', [('f16', 1e-3), ('bf16', 1e-2)])
+def test_clip_vit_matches_oracle(patch, variant, dt, tol):
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.clip_vit_state_dict(1, patch=patch)
+    fr = synth.smooth_frames(41, 3, 224, 224)
+    ref = vo.embed(sd, fr, squeeze=False)
+    m = HipResNet50(sd, variant, compute_dtype=dt, max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert out.shape == (3, 512) and np.isfinite(out).all()
+    l2, mx = _rel(out, ref)
+    print('\n[%s %s] rel-L2 %.2e max-norm %.2e' % (variant, dt, l2, mx))
+    assert l2 < tol and mx < 2 * tol
+    one = m(torch.from_numpy(fr[1:2]).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(one[0], out[1])                # batch-composition invariance, bit-exact
+
+
+def test_clip_embeddingnet_surface(monkeypatch):
+    from pvr_habitat_amd.embeddings import EmbeddingNet
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    monkeypatch.setenv('PVR_DTYPE', 'f16')
+    net = EmbeddingNet('clip_vit', max_batch=8)
+    assert net.out_size == 512
+    fr = synth.frames(3, 2, 256, 224)                            # centre crop of the long side, no resize needed
+    out = net(torch.from_numpy(fr))
+    assert out.shape == (2, 512) and out.dtype == np.float32
+    with pytest.raises(RuntimeError, match='bicubic'):
+        net(torch.from_numpy(synth.frames(3, 1, 64, 64)))        # loud failure, not a silent wrong resize

@@ -1,0 +1,59 @@
+"""Pin oracle/vit_oracle.py against an independent CLIP vision tower (transformers) with remapped weights."""
+import numpy as np
+import torch
+
+from pvr_habitat_amd import synth
+from oracle import vit_oracle as vo
+
+
+def _hf_clip(sd, patch):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    cfg = CLIPVisionConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                           image_size=224, patch_size=patch, hidden_act='quick_gelu', layer_norm_eps=1e-5, projection_dim=512)
+    m = CLIPVisionModelWithProjection(cfg).eval()
+    t = lambda k: torch.from_numpy(np.array(sd[k]))
+    new = {'vision_model.embeddings.class_embedding': t('visual.class_embedding'),
+           'vision_model.embeddings.patch_embedding.weight': t('visual.conv1.weight'),
+           'vision_model.embeddings.position_embedding.weight': t('visual.positional_embedding'),
+           'vision_model.pre_layrnorm.weight': t('visual.ln_pre.weight'), 'vision_model.pre_layrnorm.bias': t('visual.ln_pre.bias'),
+           'vision_model.post_layernorm.weight': t('visual.ln_post.weight'), 'vision_model.post_layernorm.bias': t('visual.ln_post.bias'),
+           'visual_projection.weight': t('visual.proj').t().contiguous()}
+    for i in range(12):
+        p, q = 'visual.transformer.resblocks.%d.' % i, 'vision_model.encoder.layers.%d.' % i
+        w, b = t(p + 'attn.in_proj_weight'), t(p + 'attn.in_proj_bias')
+        for j, nm in enumerate(('q_proj', 'k_proj', 'v_proj')):
+            new[q + 'self_attn.%s.weight' % nm] = w[j * 768:(j + 1) * 768].clone()
+            new[q + 'self_attn.%s.bias' % nm] = b[j * 768:(j + 1) * 768].clone()
+        new[q + 'self_attn.out_proj.weight'] = t(p + 'attn.out_proj.weight'); new[q + 'self_attn.out_proj.bias'] = t(p + 'attn.out_proj.bias')
+        new[q + 'layer_norm1.weight'] = t(p + 'ln_1.weight'); new[q + 'layer_norm1.bias'] = t(p + 'ln_1.bias')
+        new[q + 'layer_norm2.weight'] = t(p + 'ln_2.weight'); new[q + 'layer_norm2.bias'] = t(p + 'ln_2.bias')
+        new[q + 'mlp.fc1.weight'] = t(p + 'mlp.c_fc.weight'); new[q + 'mlp.fc1.bias'] = t(p + 'mlp.c_fc.bias')
+        new[q + 'mlp.fc2.weight'] = t(p + 'mlp.c_proj.weight'); new[q + 'mlp.fc2.bias'] = t(p + 'mlp.c_proj.bias')
+    missing, unexpected = m.load_state_dict(new, strict=False)
+    assert not [k for k in missing if 'position_ids' not in k] and not unexpected, (missing, unexpected)
+    return m
+
+
+def test_vit_b32_matches_independent_implementation():
+    torch.set_num_threads(8)
+    sd = synth.clip_vit_state_dict(1, patch=32)
+    assert sum(v.size for v in sd.values()) == 87849216          # OpenAI ViT-B/32 visual tower
+    fr = synth.smooth_frames(4, 2, 224, 224)
+    x = vo.preprocess(fr)
+    with torch.no_grad():
+        ours = vo.encode_image(sd, x).numpy()
+        hf = _hf_clip(sd, 32)(pixel_values=x).image_embeds.numpy()
+    assert ours.shape == (2, 512)
+    np.testing.assert_allclose(ours, hf, rtol=2e-4, atol=2e-5)
+
+
+def test_vit_b16_tokens_and_transforms():
+    torch.set_num_threads(8)
+    sd = synth.clip_vit_state_dict(2, patch=16)
+    assert sd['visual.positional_embedding'].shape == (197, 768)
+    fr = synth.frames(3, 1, 224, 224)
+    u8 = vo.preprocess_u8(fr)
+    assert np.array_equal(u8.numpy(), np.transpose(fr, (0, 3, 1, 2)))      # 224 input: resize + crop are identities
+    assert vo.embed(sd, fr).shape == (512,)
+    up = vo.preprocess_u8(synth.smooth_frames(3, 1, 64, 64))                # 64 -> 224 antialiased bicubic, clamped
+    assert up.shape == (1, 3, 224, 224) and up.dtype == torch.uint8
