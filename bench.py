@@ -93,6 +93,31 @@ def bc_bench(steps, warmup, with_cpu):
     return res
 
 
+VIT_GFLOP = {'clip_b32': 8.82, 'clip_b16': 35.13}      # per frame
+
+
+def vit_bench(variant, batch, steps, warmup, dtype):
+    """BASELINE config 3: CLIP-layout ViT frozen, 224x224 frames resident in HBM, frames/s on one GPU."""
+    from pvr_habitat_amd import synth
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.clip_vit_state_dict(1, patch=16 if variant == 'clip_b16' else 32)
+    m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=batch)
+    fr = torch.from_numpy(synth.frames(3, batch, 224, 224)).cuda()
+    out = torch.empty((batch, 512), dtype=torch.float32, device='cuda')
+    for _ in range(warmup):
+        m.forward_into(fr, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.forward_into(fr, out)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    fps = steps * batch / el
+    return {'metric': 'frames/sec embedded (%s, 224x224)' % variant, 'value': round(fps, 1), 'unit': 'frames/s', 'dtype': dtype,
+            'ms_per_step': round(el / steps * 1e3, 3), 'batch': batch, 'tflops': round(fps * VIT_GFLOP[variant] / 1e3, 1),
+            'frac_of_mfma_peak': round(fps * VIT_GFLOP[variant] / 1e3 / PEAK_BF16_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +129,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
+    ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
     args = ap.parse_args()
 
@@ -189,6 +215,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, frames_np)
+        if world == 1 and not args.no_vit:
+            line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, args.dtype), vit_bench('clip_b32', args.batch, 5, 2, args.dtype)]
         if world == 1 and not args.no_bc:
             line['bc'] = bc_bench(max(args.steps, 10), args.warmup, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)

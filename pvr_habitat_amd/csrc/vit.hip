@@ -41,6 +41,45 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t *__restrict
     }
 }
 
+// Antialiased bicubic Resize (embeddings.py:310: T.Resize(res, BICUBIC, antialias=True) on a uint8 tensor =
+// float32 separable resampling, horizontal pass first, then vertical, clamp(0,255), round-half-even, uint8).
+// Restates ATen's _upsample_bicubic2d_aa: per output index a window [xmin, xmin+xsize) and normalised weights of
+// the a=-0.5 cubic evaluated at (j + xmin - center + 0.5) * invscale (tables built on the host, aa_tables()).
+__global__ __launch_bounds__(256) void aa_resize_h_kernel(const uint8_t *__restrict__ src, float *__restrict__ tmp,
+                                                          const int *__restrict__ xmin, const int *__restrict__ xsize,
+                                                          const float *__restrict__ wts, int maxk, int n, int h, int w,
+                                                          int left, int res) {
+    const size_t total = (size_t)n * h * res * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % 3), xo = (int)((i / 3) % res);
+        const size_t row = i / ((size_t)3 * res);                   // b*h + y
+        const int X = xo + left, x0 = xmin[X], k = xsize[X];
+        const uint8_t *s = src + (row * w + x0) * 3 + c;
+        const float *wt = wts + (size_t)X * maxk;
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += wt[j] * (float)s[j * 3];
+        tmp[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_resize_v_kernel(const float *__restrict__ tmp, uint8_t *__restrict__ dst,
+                                                          const int *__restrict__ ymin, const int *__restrict__ ysize,
+                                                          const float *__restrict__ wts, int maxk, int n, int h, int top, int res) {
+    const size_t total = (size_t)n * res * res * 3;
+    const size_t rowlen = (size_t)res * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t xc = i % rowlen;
+        const int yo = (int)((i / rowlen) % res), b = (int)(i / (rowlen * res));
+        const int Y = yo + top, y0 = ymin[Y], k = ysize[Y];
+        const float *t = tmp + ((size_t)b * h + y0) * rowlen + xc;
+        const float *wt = wts + (size_t)Y * maxk;
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += wt[j] * t[(size_t)j * rowlen];
+        acc = fminf(fmaxf(acc, 0.f), 255.f);                        // bicubic overshoots: clamp before the uint8 cast
+        dst[i] = (uint8_t)rintf(acc);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -270,6 +309,11 @@ struct pvr_vit {
     // workspace (chunk frames)
     u16 *A = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *zero = nullptr;
     float *pe = nullptr, *x0 = nullptr, *x1 = nullptr;
+    // antialiased-bicubic resize state, rebuilt when the frame size changes
+    int rs_h = 0, rs_w = 0, rs_rh = 0, rs_rw = 0, rs_maxk_h = 0, rs_maxk_w = 0;
+    int *rs_xmin = nullptr, *rs_xsize = nullptr, *rs_ymin = nullptr, *rs_ysize = nullptr;
+    float *rs_wx = nullptr, *rs_wy = nullptr, *rs_tmp = nullptr;
+    uint8_t *rs_u8 = nullptr;
     std::vector<void *> owned;
 };
 
@@ -384,8 +428,60 @@ pvr_status vit_finalize(pvr_encoder *e) {
 void vit_destroy(pvr_encoder *e) {
     if (!e->vit) return;
     for (void *p : e->vit->owned) (void)hipFree(p);
+    pvr_vit *v = e->vit;
+    void *rs[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp, v->rs_u8};
+    for (void *q : rs) if (q) (void)hipFree(q);
     delete e->vit;
     e->vit = nullptr;
+}
+
+// ATen _compute_indices_weights_aa for one dimension (float arithmetic as in the fp32 kernel)
+static void aa_tables(int in, int out, std::vector<int> &mn, std::vector<int> &sz, std::vector<float> &wt, int &maxk) {
+    const float scale = (float)in / (float)out;
+    const float support = scale >= 1.f ? 2.f * scale : 2.f;        // bicubic interp_size 4
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    maxk = (int)ceilf(support) * 2 + 1;
+    mn.assign(out, 0); sz.assign(out, 0); wt.assign((size_t)out * maxk, 0.f);
+    auto cubic = [](float x) {
+        const float a = -0.5f;
+        x = fabsf(x);
+        if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+        if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+        return 0.f;
+    };
+    for (int i = 0; i < out; ++i) {
+        const float center = scale * ((float)i + 0.5f);
+        int lo = (int)(center - support + 0.5f); if (lo < 0) lo = 0;
+        int hi = (int)(center + support + 0.5f); if (hi > in) hi = in;
+        const int k = hi - lo;
+        float total = 0.f;
+        for (int j = 0; j < k; ++j) { const float w = cubic(((float)(j + lo) - center + 0.5f) * invscale); wt[(size_t)i * maxk + j] = w; total += w; }
+        for (int j = 0; j < k; ++j) if (total != 0.f) wt[(size_t)i * maxk + j] /= total;
+        mn[i] = lo; sz[i] = k;
+    }
+}
+
+static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
+    pvr_vit *v = e->vit;
+    if (v->rs_h == h && v->rs_w == w) return PVR_OK;
+    const int sh = w <= h ? w : h, lg = w <= h ? h : w;
+    const int ns = v->res, nl = (int)((double)v->res * (double)lg / (double)sh);     // torchvision resize(int size)
+    v->rs_rw = w <= h ? ns : nl; v->rs_rh = w <= h ? nl : ns;
+    std::vector<int> xm, xs, ym, ys;
+    std::vector<float> wx, wy;
+    aa_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
+    aa_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
+    void *old[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp, v->rs_u8};
+    PVR_HIP_TRY(hipDeviceSynchronize());
+    for (void *q : old) if (q) (void)hipFree(q);
+    pvr_status s;
+    if ((s = enc_upload(&v->rs_xmin, xm)) || (s = enc_upload(&v->rs_xsize, xs)) || (s = enc_upload(&v->rs_ymin, ym)) ||
+        (s = enc_upload(&v->rs_ysize, ys)) || (s = enc_upload(&v->rs_wx, wx)) || (s = enc_upload(&v->rs_wy, wy))) return s;
+    PVR_HIP_TRY(hipMalloc((void **)&v->rs_tmp, (size_t)e->desc.chunk * h * v->res * 3 * sizeof(float)));
+    PVR_HIP_TRY(hipMalloc((void **)&v->rs_u8, (size_t)e->desc.chunk * v->res * v->res * 3));
+    PVR_HIP_TRY(hipDeviceSynchronize());
+    v->rs_h = h; v->rs_w = w;
+    return PVR_OK;
 }
 
 template <bool F16>
@@ -395,17 +491,28 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
     PVR_REQUIRE(W == 768, "vit: width %d not built", W);
     // transforms (embeddings.py:309-314): Resize(res, BICUBIC, antialias) is the identity when the short side is res
     const int sh = w <= h ? w : h;
-    PVR_REQUIRE(sh == v->res, "CLIP path: frames with short side %d need the antialiased bicubic Resize(%d), which is not built yet "
-                "(pass %dx%d frames)", sh, v->res, v->res, v->res);
-    const int top = (int)nearbyint((h - v->res) / 2.0), left = (int)nearbyint((w - v->res) / 2.0);
+    const bool resize = sh != v->res;
     pvr_status s;
+    if (resize && (s = aa_prepare(e, h, w))) return s;
+    const int eh = resize ? v->rs_rh : h, ew = resize ? v->rs_rw : w;              // size after Resize
+    const int top = (int)nearbyint((eh - v->res) / 2.0), left = (int)nearbyint((ew - v->res) / 2.0);
     for (int f0 = 0; f0 < n; f0 += e->desc.chunk) {
         const int nb = (n - f0 < e->desc.chunk) ? n - f0 : e->desc.chunk;
         const int rows = nb * T, prow = nb * g2;
         const uint8_t *fr = frames + (size_t)f0 * h * w * 3;
         const size_t tot = (size_t)prow * (K / 8);
-        hipLaunchKernelGGL(patchify_kernel<F16>, dim3((int)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, st,
-                           fr, v->A, nb, h, w, top, left, v->res, P);
+        if (resize) {
+            const size_t t1 = (size_t)nb * h * v->res * 3, t2 = (size_t)nb * v->res * v->res * 3;
+            hipLaunchKernelGGL(aa_resize_h_kernel, dim3((int)((t1 + 255) / 256 > 8192 ? 8192 : (t1 + 255) / 256)), dim3(256), 0, st, fr,
+                               v->rs_tmp, v->rs_xmin, v->rs_xsize, v->rs_wx, v->rs_maxk_w, nb, h, w, left, v->res);
+            hipLaunchKernelGGL(aa_resize_v_kernel, dim3((int)((t2 + 255) / 256 > 8192 ? 8192 : (t2 + 255) / 256)), dim3(256), 0, st,
+                               v->rs_tmp, v->rs_u8, v->rs_ymin, v->rs_ysize, v->rs_wy, v->rs_maxk_h, nb, h, top, v->res);
+            hipLaunchKernelGGL(patchify_kernel<F16>, dim3((int)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, st,
+                               v->rs_u8, v->A, nb, v->res, v->res, 0, 0, v->res, P);
+        } else {
+            hipLaunchKernelGGL(patchify_kernel<F16>, dim3((int)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, st,
+                               fr, v->A, nb, h, w, top, left, v->res, P);
+        }
         PVR_LAUNCH_CHECK();
         // patch embedding GEMM -> fp32 [prow][W]
         if ((s = launch_conv(v->A, v->w_patch, v->b_patch, nullptr, v->pe, v->zero, prow, 1, 1, K, W, 1, 1, 1, 0, 0, 1, dt, st))) return s;
@@ -446,6 +553,15 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
     return PVR_OK;
 }
 
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+static pvr_status launch_u8_to_f32(const uint8_t *in, float *out, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
 // parity taps (after a forward stopped with pvr_encoder_debug_stop_after): fp32 copies of plan buffers
 pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, int64_t *count, hipStream_t st) {
     pvr_vit *v = e->vit;
@@ -460,6 +576,13 @@ pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, in
     else if (nm == "att0") { src = v->att; elems = rows * W; f32 = false; }
     else if (nm == "res0") { src = v->x1; elems = rows * W; }
     else if (nm == "fc0") { src = v->hid; elems = rows * 4 * W; f32 = false; }
+    else if (nm == "resized") {                      // uint8 crop after the antialiased Resize, as fp32
+        PVR_REQUIRE(v->rs_u8 != nullptr, "no resize has run");
+        elems = (size_t)e->last_n * v->res * v->res * 3;
+        PVR_REQUIRE((int64_t)elems <= cap, "tap resized needs %zu elements", elems);
+        *count = (int64_t)elems;
+        return launch_u8_to_f32(v->rs_u8, out, elems, st);
+    }
     else { set_error("unknown vit tap %s", name); return PVR_ERR_INVALID; }
     PVR_REQUIRE((int64_t)elems <= cap, "tap %s needs %zu elements", name, elems);
     *count = (int64_t)elems;

@@ -40,5 +40,23 @@ def test_clip_embeddingnet_surface(monkeypatch):
     fr = synth.frames(3, 2, 256, 224)                            # centre crop of the long side, no resize needed
     out = net(torch.from_numpy(fr))
     assert out.shape == (2, 512) and out.dtype == np.float32
-    with pytest.raises(RuntimeError, match='bicubic'):
-        net(torch.from_numpy(synth.frames(3, 1, 64, 64)))        # loud failure, not a silent wrong resize
+
+
+@pytest.mark.parametrize('h,w', [(64, 64), (256, 256), (100, 75), (128, 160)])
+def test_clip_antialiased_bicubic_resize(h, w):
+    """embeddings.py:310: Resize(224, BICUBIC, antialias=True) on uint8 frames (Habitat renders 64x64)."""
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.clip_vit_state_dict(1, patch=32)
+    fr = synth.smooth_frames(43, 2, h, w)
+    m = HipResNet50(sd, 'clip_b32', compute_dtype='f16', max_batch=4)
+    d = torch.from_numpy(fr).cuda()
+    out = m(d).cpu().numpy()
+    u8 = vo.preprocess_u8(fr).permute(0, 2, 3, 1).numpy().astype(np.float32)      # (N,224,224,3)
+    got = m.tap('resized', u8.size).cpu().numpy().reshape(u8.shape)
+    diff = np.abs(got - u8)
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3          # .5 ties may round the other way (fp32 summation order)
+    ref = vo.embed(sd, fr, squeeze=False)
+    l2 = float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+    assert l2 < 1e-3, l2
