@@ -31,6 +31,8 @@ typedef struct pvr_policy_desc {
     int32_t batch_norm;    /* BatchNorm1d in front of the MLP (models.py:30-34) */
     int32_t max_t;         /* unroll_length the workspace is sized for */
     int32_t max_b;         /* batch_size the workspace is sized for (<= 64) */
+    int32_t conv_frames;   /* 0: vector observations (PolicyNet).  n > 0: PolicyNetWithConv (models.py:96-197) on raw uint8
+                              (T,B,64,64,3n) observations; obs_size must be 128*n and `obs` arguments are uint8 */
 } pvr_policy_desc;
 
 pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out);
@@ -50,10 +52,10 @@ typedef struct pvr_policy_bn {
     int64_t *num_batches_tracked;
 } pvr_policy_bn;
 
-/* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32, done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
+/* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32 (uint8 (T,B,64,64,3n) when conv_frames = n > 0), done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
  * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82), h_out/c_out
  * (2,B,hidden) are device outputs.  training != 0 uses batch statistics and updates the BN buffers (:31-34). */
-pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const float *obs,
+pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B,
                               int32_t training, float *logits, float *baseline, int64_t *action, float *h_out,
                               float *c_out, void *hip_stream);
@@ -63,9 +65,20 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
  * lr = learning_rate * LambdaLR factor for this update.  stats_out (device, 2 floats): loss, grad norm (pre-clip).
  * logits_out (optional, may be NULL): (T,B,A) training-mode logits. */
 pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, const pvr_policy_bn *bn,
-                           const float *obs, const uint8_t *done, const int64_t *actions, int32_t T, int32_t B,
+                           const void *obs, const uint8_t *done, const int64_t *actions, int32_t T, int32_t B,
                            float lr, float alpha, float eps, float max_grad_norm, float *stats_out,
                            float *logits_out, void *hip_stream);
+
+/* Data-parallel training (finetune configuration): the same iteration in two halves so the caller can
+ * all-reduce the flat gradient (RCCL / torch.distributed) between them.  pvr_policy_backward leaves the UNCLIPPED
+ * local gradient of the mean loss in grads (device, trainable_count floats, caller-owned) and the loss in
+ * stats_out[0]; pvr_policy_apply computes the norm of whatever grads now holds (e.g. the rank average), clips and
+ * applies RMSprop; stats_out[1] = that norm. */
+pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
+                               const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float *grads,
+                               float *stats_out, float *logits_out, void *hip_stream);
+pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr,
+                            float alpha, float eps, float max_grad_norm, float *stats_out, void *hip_stream);
 
 /* parity/debug: copy the flat gradient of the last pvr_policy_step (pre-clip) to grads_out (device, trainable_count) */
 pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_stream);

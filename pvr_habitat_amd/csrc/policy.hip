@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "policy_kernels.h"
+#include "policy_conv.h"
 #include "../../include/pvr_policy.h"
 
 using namespace pvr;
@@ -22,6 +23,7 @@ struct pvr_policy {
     std::map<std::string, Slot> slots;
     int64_t n_total = 0, n_train = 0;
     // offsets (elements) into the flat parameter / gradient buffers
+    int64_t o_cw[5] = {-1, -1, -1, -1, -1}, o_cb[5] = {-1, -1, -1, -1, -1};
     int64_t o_bnw = -1, o_bnb = -1, o_fc1w, o_fc1b, o_fc2w, o_fc2b, o_wih[2], o_whh[2], o_bih[2], o_bhh[2], o_pw, o_pb, o_bw, o_bb;
     // workspace
     float *a0 = nullptr, *bn_mean = nullptr, *bn_invstd = nullptr, *a1 = nullptr, *a2 = nullptr;
@@ -32,6 +34,10 @@ struct pvr_policy {
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
     float *grads = nullptr;
     bool have_grads = false;
+    // PolicyNetWithConv front end (conv_frames > 0)
+    float *act[5] = {nullptr}, *dact[5] = {nullptr}, *wp[5] = {nullptr}, *wt[5] = {nullptr}, *feat = nullptr, *dfeat = nullptr;
+    float *cpartial = nullptr, *cgpacked = nullptr, *bpartial = nullptr;
+    std::vector<void *> conv_owned;
 };
 
 namespace {
@@ -83,12 +89,33 @@ inline int blocks_for(size_t n, int cap = 4096) {
 
 // forward through the workspace; logits/baseline/action land in pol->logits etc.  `target` non-null also
 // produces dlogits and per-row losses.
-pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn, const float *obs, const uint8_t *done,
+pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn, const void *obs_in, const uint8_t *done,
                         const float *h0, const float *c0, int T, int B, int training, const long long *target,
                         hipStream_t st) {
     const auto &d = pol->d;
     const int N = T * B, H = d.hidden, O = d.obs_size;
     hipLaunchKernelGGL(notdone_kernel, dim3((N + 255) / 256), dim3(256), 0, st, done, pol->nd, N);
+    const float *obs = (const float *)obs_in;
+    if (d.conv_frames > 0) {
+        // models.py:163-170: x/255, per-frame transpose(1,3), 5 x (conv3x3 s2 p1 + ELU), cat(-1), view(T*B,-1)
+        const int nf = d.conv_frames, F = N * nf;
+        const void *in = obs_in;
+        int S = 64;
+        for (int l = 0; l < 5; ++l) {
+            const int So = S / 2;
+            if (l == 0) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(5), dim3(256), 0, st, P + pol->o_cw[l], pol->wp[l], 1);
+            else hipLaunchKernelGGL(conv_pack_kernel<32>, dim3(36), dim3(256), 0, st, P + pol->o_cw[l], pol->wp[l], 1);
+            ConvFP c;
+            c.in = in; c.W = pol->wp[l]; c.bias = P + pol->o_cb[l]; c.out = pol->act[l]; c.F = F; c.Sin = S; c.So = So; c.nf = nf;
+            const long long tiles = ((long long)F * So * So + 15) / 16;
+            if (l == 0) hipLaunchKernelGGL(conv_s2_fwd_kernel<3>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
+            else hipLaunchKernelGGL(conv_s2_fwd_kernel<32>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
+            in = pol->act[l]; S = So;
+        }
+        hipLaunchKernelGGL(conv_feat_kernel, dim3(blocks_for((size_t)N * 128 * nf)), dim3(256), 0, st, pol->act[4], pol->feat, N, nf, 1);
+        PVR_LAUNCH_CHECK();
+        obs = pol->feat;
+    }
     const float *x0 = obs;
     if (d.batch_norm) {
         PVR_REQUIRE(bn && bn->running_mean && bn->running_var, "policy: batch_norm=1 needs the BN buffers");
@@ -140,104 +167,11 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
 
 }  // namespace
 
-extern "C" {
-
-pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
-    PVR_REQUIRE(desc && out, "pvr_policy_create: null argument");
-    PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 1024 == 0, "hidden must be a positive multiple of 1024 (got %d)", desc->hidden);
-    PVR_REQUIRE(desc->obs_size > 0 && desc->obs_size % 4 == 0, "obs_size must be a positive multiple of 4 (got %d)", desc->obs_size);
-    PVR_REQUIRE(desc->num_actions > 0 && desc->num_actions <= 16, "num_actions must be in 1..16");
-    PVR_REQUIRE(desc->max_t > 0 && desc->max_b > 0 && desc->max_b <= 64, "max_t > 0 and 0 < max_b <= 64 required");
-    pvr_policy *p = new pvr_policy();
-    p->d = *desc;
-    const int64_t O = desc->obs_size, H = desc->hidden, A = desc->num_actions;
-    const int o = desc->batch_norm ? 1 : 0;
-    char nm[64];
-    if (desc->batch_norm) { p->o_bnw = add_slot(p, "fc.0.weight", O); p->o_bnb = add_slot(p, "fc.0.bias", O); }
-    snprintf(nm, sizeof nm, "fc.%d.weight", o); p->o_fc1w = add_slot(p, nm, H * O);
-    snprintf(nm, sizeof nm, "fc.%d.bias", o); p->o_fc1b = add_slot(p, nm, H);
-    snprintf(nm, sizeof nm, "fc.%d.weight", o + 2); p->o_fc2w = add_slot(p, nm, H * H);
-    snprintf(nm, sizeof nm, "fc.%d.bias", o + 2); p->o_fc2b = add_slot(p, nm, H);
-    for (int l = 0; l < 2; ++l) {
-        snprintf(nm, sizeof nm, "core.weight_ih_l%d", l); p->o_wih[l] = add_slot(p, nm, 4 * H * H);
-        snprintf(nm, sizeof nm, "core.weight_hh_l%d", l); p->o_whh[l] = add_slot(p, nm, 4 * H * H);
-        snprintf(nm, sizeof nm, "core.bias_ih_l%d", l); p->o_bih[l] = add_slot(p, nm, 4 * H);
-        snprintf(nm, sizeof nm, "core.bias_hh_l%d", l); p->o_bhh[l] = add_slot(p, nm, 4 * H);
-    }
-    p->o_pw = add_slot(p, "policy.weight", A * H);
-    p->o_pb = add_slot(p, "policy.bias", A);
-    p->n_train = p->n_total;                       // the baseline head gets no gradient from the BC loss
-    p->o_bw = add_slot(p, "baseline.weight", H);
-    p->o_bb = add_slot(p, "baseline.bias", 1);
-
-    const size_t N = (size_t)desc->max_t * desc->max_b, B = desc->max_b;
-    pvr_status s = PVR_OK;
-#define A_(ptr, n) if (!s) s = dalloc(&p->ptr, (n))
-    A_(a0, N * O); A_(bn_mean, O); A_(bn_invstd, O); A_(a1, N * H); A_(a2, N * H);
-    for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); A_(WT[l], (size_t)4 * H * H); }
-    A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H);
-    A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
-    A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
-#undef A_
-    if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("policy: device sync failed"); s = PVR_ERR_HIP; }
-    if (s) { pvr_policy_destroy(p); return s; }
-    *out = p;
-    return PVR_OK;
-}
-
-void pvr_policy_destroy(pvr_policy *p) {
-    if (!p) return;
-    void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
-                    p->WT[0], p->WT[1], p->hprev, p->nd, p->zeros, p->dc_carry, p->logits, p->baseline, p->dlogits,
-                    p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
-    delete p;
-}
-
-int64_t pvr_policy_param_count(const pvr_policy *p) { return p ? p->n_total : 0; }
-int64_t pvr_policy_trainable_count(const pvr_policy *p) { return p ? p->n_train : 0; }
-
-int64_t pvr_policy_param_offset(const pvr_policy *p, const char *name, int64_t *numel) {
-    if (!p || !name) return -1;
-    auto it = p->slots.find(name);
-    if (it == p->slots.end()) return -1;
-    if (numel) *numel = it->second.numel;
-    return it->second.off;
-}
-
-pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const float *obs,
-                              const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
-                              float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
-    PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
-    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
-    hipStream_t st = (hipStream_t)hip_stream;
-    const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
-    const float *h_in = h0 ? h0 : pol->zeros, *c_in = c0 ? c0 : pol->zeros;
-    TRY(forward_core(pol, params, bn, obs, done, h_in, c_in, T, B, training, nullptr, st));
-    if (logits) PVR_HIP_TRY(hipMemcpyAsync(logits, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
-    if (baseline) PVR_HIP_TRY(hipMemcpyAsync(baseline, pol->baseline, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
-    if (action) PVR_HIP_TRY(hipMemcpyAsync(action, pol->action, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
-    for (int l = 0; l < 2; ++l) {
-        if (h_out) PVR_HIP_TRY(hipMemcpyAsync(h_out + (size_t)l * B * H, pol->Hs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
-        if (c_out) PVR_HIP_TRY(hipMemcpyAsync(c_out + (size_t)l * B * H, pol->Cs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
-    }
-    return PVR_OK;
-}
-
-pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, const pvr_policy_bn *bn, const float *obs,
-                           const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
-                           float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
-    PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
-    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
-    hipStream_t st = (hipStream_t)hip_stream;
+// backward of everything after the forward in the workspace; leaves the unclipped gradient in Gd
+static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs_in, int T, int B, float *Gd, hipStream_t st) {
     const auto &d = pol->d;
     const int N = T * B, H = d.hidden, O = d.obs_size, A = d.num_actions;
-    const float *P = params;
-    float *Gd = pol->grads;
-    // ---- forward (training mode, zero initial state: main_bc_2.py:207-209) + loss --------------------------------
-    TRY(forward_core(pol, P, bn, obs, done, pol->zeros, pol->zeros, T, B, 1, (const long long *)actions, st));
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, pol->loss_row, N, 1.0f / (float)N, pol->stats);
-    if (logits_out) PVR_HIP_TRY(hipMemcpyAsync(logits_out, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
+    const float *obs = d.conv_frames > 0 ? pol->feat : (const float *)obs_in;
     // ---- heads backward --------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(head_dw_kernel, dim3((H + 1 + 31) / 32), dim3(256), 0, st, pol->dlogits, pol->Hs[1], Gd + pol->o_pw, Gd + pol->o_pb, N, H, A);
     hipLaunchKernelGGL(head_dx_kernel, dim3(blocks_for((size_t)N * H)), dim3(256), 0, st, pol->dlogits, P + pol->o_pw, pol->dA, N, H, A);
@@ -279,21 +213,206 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
     TRY(gemm(dz2, P + pol->o_fc2w, nullptr, pol->a1, dz1, N, H, H, false, true, 0, st));      // masked by a1 > 0
     TRY(gemm(dz1, x0, nullptr, nullptr, Gd + pol->o_fc1w, H, O, N, true, true, 0, st));
     TRY(colsum(dz1, Gd + pol->o_fc1b, nullptr, N, H, st));
+    const bool need_dobs = d.conv_frames > 0;
+    if (d.batch_norm || need_dobs) TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
+    const float *dfeat = pol->da0;
     if (d.batch_norm) {
-        TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
         ColP c = {};
         c.X = obs; c.dY = pol->da0; c.mean_in = pol->bn_mean; c.invstd_in = pol->bn_invstd;
         c.out0 = Gd + pol->o_bnw; c.out1 = Gd + pol->o_bnb; c.R = N; c.C = O;
         hipLaunchKernelGGL(colreduce_kernel<2>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+        if (need_dobs) {
+            hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks_for((size_t)N * O)), dim3(256), 0, st, obs, pol->da0, pol->bn_mean, pol->bn_invstd,
+                               P + pol->o_bnw, Gd + pol->o_bnw, Gd + pol->o_bnb, pol->dfeat, N, O);
+            dfeat = pol->dfeat;
+        }
         PVR_LAUNCH_CHECK();
     }
+    if (need_dobs) {
+        // ---- conv stack backward (models.py:107-118) ----------------------------------------------------------------
+        const int nf = d.conv_frames, F = N * nf;
+        hipLaunchKernelGGL(conv_feat_kernel, dim3(blocks_for((size_t)N * 128 * nf)), dim3(256), 0, st, pol->dact[4], const_cast<float *>(dfeat), N, nf, 0);
+        const int WAVES = 256;
+        for (int l = 4; l >= 0; --l) {
+            const int So = 64 >> (l + 1), Sin = So * 2;
+            const size_t ne = (size_t)F * So * So * 32;
+            hipLaunchKernelGGL(elu_bwd_kernel, dim3(blocks_for(ne / 4)), dim3(256), 0, st, pol->dact[l], pol->act[l], ne / 4);
+            // bias gradient: per-block partial column sums over a row range, then a fixed-order sum of the partials
+            {
+                const int R = F * So * So, G = R < 1024 ? 1 : 256, per = (R + G - 1) / G;
+                for (int g = 0; g < G; ++g) (void)g;
+                ColP c = {};
+                c.X = pol->dact[l]; c.out0 = pol->bpartial; c.out1 = nullptr; c.R = per; c.C = 32;
+                // one launch per partial would be slow: view [R][32] as G row blocks through a strided colreduce
+                hipLaunchKernelGGL(rowblock_colsum_kernel, dim3(G), dim3(256), 0, st, pol->dact[l], pol->bpartial, R, per);
+                TRY(colsum(pol->bpartial, Gd + pol->o_cb[l], nullptr, G, 32, st));
+            }
+            ConvWP w;
+            w.in = l == 0 ? obs_in : (const void *)pol->act[l - 1]; w.dpre = pol->dact[l]; w.partial = pol->cpartial;
+            w.F = F; w.Sin = Sin; w.So = So; w.nf = nf; w.waves = WAVES;
+            const int cols = l == 0 ? 32 * 9 * 4 : 32 * 9 * 32;
+            if (l == 0) hipLaunchKernelGGL(conv_s2_wgrad_kernel<3>, dim3(WAVES / 4), dim3(256), 0, st, w);
+            else hipLaunchKernelGGL(conv_s2_wgrad_kernel<32>, dim3(WAVES / 4), dim3(256), 0, st, w);
+            TRY(colsum(pol->cpartial, pol->cgpacked, nullptr, WAVES, cols, st));
+            if (l == 0) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(5), dim3(256), 0, st, Gd + pol->o_cw[l], pol->cgpacked, 0);
+            else hipLaunchKernelGGL(conv_pack_kernel<32>, dim3(36), dim3(256), 0, st, Gd + pol->o_cw[l], pol->cgpacked, 0);
+            if (l > 0) {
+                hipLaunchKernelGGL(conv_wt_kernel, dim3(36), dim3(256), 0, st, pol->wp[l], pol->wt[l]);
+                ConvDP g;
+                g.dpre = pol->dact[l]; g.Wt = pol->wt[l]; g.din = pol->dact[l - 1]; g.F = F; g.Sin = Sin; g.So = So;
+                const long long tiles = ((long long)F * Sin * Sin + 15) / 16;
+                hipLaunchKernelGGL(conv_s2_dgrad_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g);
+            }
+            PVR_LAUNCH_CHECK();
+        }
+    }
     pol->have_grads = true;
-    // ---- grad norm, clip, RMSprop -----------------------------------------------------------------------------------
+    return PVR_OK;
+}
+
+static pvr_status apply_core(pvr_policy *pol, float *params, float *square_avg, const float *Gd, float lr, float alpha, float eps,
+                             float max_grad_norm, hipStream_t st) {
     const size_t nt = (size_t)pol->n_train;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, st, Gd, nt, pol->partial);
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, pol->partial, 1024, max_grad_norm, pol->stats);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, square_avg, Gd, pol->stats, nt / 4, lr, alpha, eps);
     PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+extern "C" {
+
+pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
+    PVR_REQUIRE(desc && out, "pvr_policy_create: null argument");
+    PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 1024 == 0, "hidden must be a positive multiple of 1024 (got %d)", desc->hidden);
+    PVR_REQUIRE(desc->obs_size > 0 && desc->obs_size % 4 == 0, "obs_size must be a positive multiple of 4 (got %d)", desc->obs_size);
+    PVR_REQUIRE(desc->num_actions > 0 && desc->num_actions <= 16, "num_actions must be in 1..16");
+    PVR_REQUIRE(desc->max_t > 0 && desc->max_b > 0 && desc->max_b <= 64, "max_t > 0 and 0 < max_b <= 64 required");
+    PVR_REQUIRE(desc->conv_frames >= 0 && (desc->conv_frames == 0 || desc->obs_size == 128 * desc->conv_frames),
+                "conv_frames=%d needs obs_size=%d", desc->conv_frames, 128 * desc->conv_frames);
+    pvr_policy *p = new pvr_policy();
+    p->d = *desc;
+    const int64_t O = desc->obs_size, H = desc->hidden, A = desc->num_actions;
+    const int o = desc->batch_norm ? 1 : 0;
+    char nm[64];
+    if (desc->conv_frames > 0)
+        for (int l = 0; l < 5; ++l) {                  // reference parameter order: feat_extract first (models.py:107-118)
+            snprintf(nm, sizeof nm, "feat_extract.%d.weight", 2 * l); p->o_cw[l] = add_slot(p, nm, 32 * (l == 0 ? 3 : 32) * 9);
+            snprintf(nm, sizeof nm, "feat_extract.%d.bias", 2 * l); p->o_cb[l] = add_slot(p, nm, 32);
+        }
+    if (desc->batch_norm) { p->o_bnw = add_slot(p, "fc.0.weight", O); p->o_bnb = add_slot(p, "fc.0.bias", O); }
+    snprintf(nm, sizeof nm, "fc.%d.weight", o); p->o_fc1w = add_slot(p, nm, H * O);
+    snprintf(nm, sizeof nm, "fc.%d.bias", o); p->o_fc1b = add_slot(p, nm, H);
+    snprintf(nm, sizeof nm, "fc.%d.weight", o + 2); p->o_fc2w = add_slot(p, nm, H * H);
+    snprintf(nm, sizeof nm, "fc.%d.bias", o + 2); p->o_fc2b = add_slot(p, nm, H);
+    for (int l = 0; l < 2; ++l) {
+        snprintf(nm, sizeof nm, "core.weight_ih_l%d", l); p->o_wih[l] = add_slot(p, nm, 4 * H * H);
+        snprintf(nm, sizeof nm, "core.weight_hh_l%d", l); p->o_whh[l] = add_slot(p, nm, 4 * H * H);
+        snprintf(nm, sizeof nm, "core.bias_ih_l%d", l); p->o_bih[l] = add_slot(p, nm, 4 * H);
+        snprintf(nm, sizeof nm, "core.bias_hh_l%d", l); p->o_bhh[l] = add_slot(p, nm, 4 * H);
+    }
+    p->o_pw = add_slot(p, "policy.weight", A * H);
+    p->o_pb = add_slot(p, "policy.bias", A);
+    p->n_train = p->n_total;                       // the baseline head gets no gradient from the BC loss
+    p->o_bw = add_slot(p, "baseline.weight", H);
+    p->o_bb = add_slot(p, "baseline.bias", 1);
+
+    const size_t N = (size_t)desc->max_t * desc->max_b, B = desc->max_b;
+    pvr_status s = PVR_OK;
+#define A_(ptr, n) if (!s) s = dalloc(&p->ptr, (n))
+    A_(a0, N * O); A_(bn_mean, O); A_(bn_invstd, O); A_(a1, N * H); A_(a2, N * H);
+    for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); A_(WT[l], (size_t)4 * H * H); }
+    A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H);
+    A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
+    A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
+    if (desc->conv_frames > 0) {
+        const size_t F = N * desc->conv_frames;
+        for (int l = 0; l < 5; ++l) {
+            const size_t So = 64 >> (l + 1);
+            A_(act[l], F * So * So * 32); A_(dact[l], F * So * So * 32); A_(wp[l], 32 * 9 * 32); A_(wt[l], 32 * 9 * 32);
+        }
+        A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)256 * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, 256 * 32);
+    }
+#undef A_
+    if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("policy: device sync failed"); s = PVR_ERR_HIP; }
+    if (s) { pvr_policy_destroy(p); return s; }
+    *out = p;
+    return PVR_OK;
+}
+
+void pvr_policy_destroy(pvr_policy *p) {
+    if (!p) return;
+    void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
+                    p->WT[0], p->WT[1], p->hprev, p->nd, p->zeros, p->dc_carry, p->logits, p->baseline, p->dlogits,
+                    p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
+                    p->cpartial, p->cgpacked, p->bpartial};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (int l = 0; l < 5; ++l) { void *c[] = {p->act[l], p->dact[l], p->wp[l], p->wt[l]}; for (void *q : c) if (q) (void)hipFree(q); }
+    delete p;
+}
+
+int64_t pvr_policy_param_count(const pvr_policy *p) { return p ? p->n_total : 0; }
+int64_t pvr_policy_trainable_count(const pvr_policy *p) { return p ? p->n_train : 0; }
+
+int64_t pvr_policy_param_offset(const pvr_policy *p, const char *name, int64_t *numel) {
+    if (!p || !name) return -1;
+    auto it = p->slots.find(name);
+    if (it == p->slots.end()) return -1;
+    if (numel) *numel = it->second.numel;
+    return it->second.off;
+}
+
+pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
+                              const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
+                              float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
+    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
+    const float *h_in = h0 ? h0 : pol->zeros, *c_in = c0 ? c0 : pol->zeros;
+    TRY(forward_core(pol, params, bn, obs, done, h_in, c_in, T, B, training, nullptr, st));
+    if (logits) PVR_HIP_TRY(hipMemcpyAsync(logits, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
+    if (baseline) PVR_HIP_TRY(hipMemcpyAsync(baseline, pol->baseline, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    if (action) PVR_HIP_TRY(hipMemcpyAsync(action, pol->action, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < 2; ++l) {
+        if (h_out) PVR_HIP_TRY(hipMemcpyAsync(h_out + (size_t)l * B * H, pol->Hs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
+        if (c_out) PVR_HIP_TRY(hipMemcpyAsync(c_out + (size_t)l * B * H, pol->Cs[l] + (size_t)(T - 1) * B * H, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs, const uint8_t *done,
+                               const int64_t *actions, int32_t T, int32_t B, float *grads, float *stats_out, float *logits_out,
+                               void *hip_stream) {
+    PVR_REQUIRE(pol && params && obs && done && actions && grads, "pvr_policy_backward: null argument");
+    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = T * B, A = pol->d.num_actions;
+    // forward (training mode, zero initial state: main_bc_2.py:207-209) + loss
+    TRY(forward_core(pol, params, bn, obs, done, pol->zeros, pol->zeros, T, B, 1, (const long long *)actions, st));
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, pol->loss_row, N, 1.0f / (float)N, pol->stats);
+    if (logits_out) PVR_HIP_TRY(hipMemcpyAsync(logits_out, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
+    TRY(backward_core(pol, params, obs, T, B, grads, st));
+    if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out, pol->stats, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr, float alpha, float eps,
+                            float max_grad_norm, float *stats_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && square_avg && grads, "pvr_policy_apply: null argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    TRY(apply_core(pol, params, square_avg, grads, lr, alpha, eps, max_grad_norm, st));
+    if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out + 1, pol->stats + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, const pvr_policy_bn *bn, const void *obs,
+                           const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
+                           float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    TRY(pvr_policy_backward(pol, params, bn, obs, done, actions, T, B, pol->grads, nullptr, logits_out, hip_stream));
+    TRY(apply_core(pol, params, square_avg, pol->grads, lr, alpha, eps, max_grad_norm, st));
     if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out, pol->stats, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return PVR_OK;
 }

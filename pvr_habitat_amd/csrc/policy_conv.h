@@ -1,0 +1,258 @@
+// PolicyNetWithConv feature extractor (reference src/models.py:107-118, 159-170), fp32, forward and backward.
+//   x/255 -> per 3-channel frame: transpose(1,3) (H<->W swap) -> 5 x [Conv2d(k3, s2, p1, ->32) + ELU] -> cat on the
+//   last axis -> view(T*B, -1)
+// Activations are NHWC fp32 [frame][S][S][32] in the TRANSPOSED spatial domain the reference convolves in
+// (row index a = original column, column index b = original row).  All three kernels are implicit GEMMs on the
+// f32 MFMA (16x16x4); reductions are fixed-order (per-wave partials + colreduce), no atomics.
+#pragma once
+#include "policy_kernels.h"
+
+namespace pvr {
+
+struct ConvFP {
+    const void *in;          // CIN==3: uint8 obs (N,64,64,3*nf); else fp32 NHWC [F][Sin][Sin][32]
+    const float *W, *bias;   // [32][9][CINP] (CINP = 4 or 32), [32]
+    float *out;              // [F][So][So][32] post-ELU
+    int F, Sin, So, nf;      // F frames (= N*nf)
+};
+
+// forward: wave = 16 output pixels x 32 channels
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
+    constexpr int CP = CIN == 3 ? 4 : 32;
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long npix = (long long)p.F * p.So * p.So;
+    if (tile * 16 >= npix) return;
+    const long long pix = tile * 16 + fr;                 // A-operand row of this lane
+    const bool pok = pix < npix;
+    const long long pp = pok ? pix : 0;
+    const int ox = (int)(pp % p.So), oy = (int)((pp / p.So) % p.So);
+    const int f = (int)(pp / ((long long)p.So * p.So));
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = 2 * oy + tap / 3 - 1, ix = 2 * ox + tap % 3 - 1;
+        const bool ok = pok && (unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin;
+        if constexpr (CIN == 3) {
+            // k-slot fq = input channel; conv input I'[iy][ix][c] = x[n][ix][iy][3*fr_ + c] / 255  (H<->W swap)
+            float a = 0.f;
+            if (ok && fq < 3) {
+                const int n = f / p.nf, fi = f % p.nf;
+                const uint8_t *x = (const uint8_t *)p.in;
+                a = (float)x[(((size_t)n * p.Sin + ix) * p.Sin + iy) * (3 * p.nf) + 3 * fi + fq] / 255.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
+        } else {
+            const float *src = (const float *)p.in + (((size_t)f * p.Sin + iy) * p.Sin + ix) * 32;
+#pragma unroll
+            for (int c0 = 0; c0 < 32; c0 += 16) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + ((size_t)(j * 16 + fr) * 9 + tap) * CP + c0 + fq * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j] = mfma_f32(a[e], w[e], acc[j]);
+                }
+            }
+        }
+    }
+    // D: row = 4*fq + r = pixel in tile, col = fr = channel (+16 j)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float b = p.bias[j * 16 + fr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long q = tile * 16 + fq * 4 + r;
+            if (q >= npix) continue;
+            const float v = acc[j][r] + b;
+            p.out[(size_t)q * 32 + j * 16 + fr] = v > 0.f ? v : expf(v) - 1.f;      // ELU (alpha 1)
+        }
+    }
+}
+
+// d(pre-activation) = d(out) * (out > 0 ? 1 : out + 1)   in place  (elu'(x) = exp(x) = out + 1 for x <= 0)
+__global__ __launch_bounds__(256) void elu_bwd_kernel(float *__restrict__ d, const float *__restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 g = reinterpret_cast<f32x4 *>(d)[i];
+        const f32x4 o = reinterpret_cast<const f32x4 *>(out)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= o[e] > 0.f ? 1.f : o[e] + 1.f;
+        reinterpret_cast<f32x4 *>(d)[i] = g;
+    }
+}
+
+// weight gradient partials: wave w accumulates dW[co][tap][ci] over its pixel range; partial[w][co*9*CP + tap*CP + ci]
+struct ConvWP {
+    const void *in;          // layer input (uint8 obs for CIN==3, else fp32 NHWC)
+    const float *dpre;       // [F][So][So][32]
+    float *partial;          // [waves][32*9*CP]
+    int F, Sin, So, nf, waves;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
+    constexpr int CP = CIN == 3 ? 4 : 32;
+    constexpr int NT = CIN == 3 ? 3 : 18;                 // 16-column tiles over the 9*CP columns (36 / 288)
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long npix = (long long)p.F * p.So * p.So;
+    const long long per = ((npix + p.waves - 1) / p.waves + 3) / 4 * 4;
+    const long long beg = (long long)wv * per, end = beg + per < npix ? beg + per : npix;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long p0 = beg; p0 < end; p0 += 4) {
+        const long long pix = p0 + fq;                    // k-slot fq = pixel
+        const bool pok = pix < end;
+        const long long pp = pok ? pix : 0;
+        const int ox = (int)(pp % p.So), oy = (int)((pp / p.So) % p.So);
+        const int f = (int)(pp / ((long long)p.So * p.So));
+        float a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = pok ? p.dpre[(size_t)pp * 32 + i * 16 + fr] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = j * 16 + fr, tap = col / CP, ci = col % CP;
+            float b = 0.f;
+            if (pok && tap < 9) {
+                const int iy = 2 * oy + tap / 3 - 1, ix = 2 * ox + tap % 3 - 1;
+                if ((unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin) {
+                    if constexpr (CIN == 3) {
+                        if (ci < 3) {
+                            const int n = f / p.nf, fi = f % p.nf;
+                            b = (float)((const uint8_t *)p.in)[(((size_t)n * p.Sin + ix) * p.Sin + iy) * (3 * p.nf) + 3 * fi + ci] / 255.0f;
+                        }
+                    } else {
+                        b = ((const float *)p.in)[(((size_t)f * p.Sin + iy) * p.Sin + ix) * 32 + ci];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = mfma_f32(a[i], b, acc[i][j]);
+        }
+    }
+    // D: row = co (4*fq + r + 16 i), col = column fr + 16 j
+    float *out = p.partial + (size_t)wv * 32 * 9 * CP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = j * 16 + fr;
+            if (col >= 9 * CP) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(i * 16 + fq * 4 + r) * 9 * CP + col] = acc[i][j][r];
+        }
+}
+
+// input gradient (layers 2..5): dIn[f][iy][ix][ci] = sum_{taps with matching parity} dPre[f][oy][ox][:] . Wt[tap][ci][:]
+struct ConvDP {
+    const float *dpre, *Wt;  // [F][So][So][32], [9][32 ci][32 co]
+    float *din;              // [F][Sin][Sin][32]
+    int F, Sin, So;
+};
+
+__global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long npix = (long long)p.F * p.Sin * p.Sin;
+    if (tile * 16 >= npix) return;
+    const long long pix = tile * 16 + fr;
+    const bool pok = pix < npix;
+    const long long pp = pok ? pix : 0;
+    const int ix = (int)(pp % p.Sin), iy = (int)((pp / p.Sin) % p.Sin);
+    const int f = (int)(pp / ((long long)p.Sin * p.Sin));
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ty = iy + 1 - tap / 3, tx = ix + 1 - tap % 3;     // = 2*oy, 2*ox when this tap reached the pixel
+        const bool ok = pok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.So && (tx >> 1) < p.So;
+        const float *src = p.dpre + (((size_t)f * p.So + (ty >> 1)) * p.So + (tx >> 1)) * 32;
+#pragma unroll
+        for (int c0 = 0; c0 < 32; c0 += 16) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(p.Wt + ((size_t)tap * 32 + j * 16 + fr) * 32 + c0 + fq * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j] = mfma_f32(a[e], w[e], acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long q = tile * 16 + fq * 4 + r;
+            if (q < npix) p.din[(size_t)q * 32 + j * 16 + fr] = acc[j][r];
+        }
+}
+
+// W [32 co][9][32 ci] -> Wt [9][32 ci][32 co]
+__global__ __launch_bounds__(256) void conv_wt_kernel(const float *__restrict__ W, float *__restrict__ Wt) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 9 * 32 * 32; i += gridDim.x * 256) {
+        const int co = i % 32, ci = (i / 32) % 32, tap = i / 1024;
+        Wt[i] = W[(co * 9 + tap) * 32 + ci];
+    }
+}
+
+// OIHW (32,CIN,3,3) <-> [32][9][CP] packing of the reference parameter (and back for gradients)
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ oihw, float *__restrict__ packed, int to_packed) {
+    constexpr int CP = CIN == 3 ? 4 : 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 32 * 9 * CP; i += gridDim.x * 256) {
+        const int ci = i % CP, tap = (i / CP) % 9, co = i / (9 * CP);
+        if (ci >= CIN) { if (to_packed) packed[i] = 0.f; continue; }
+        const int o = (co * CIN + ci) * 9 + tap;
+        if (to_packed) packed[i] = oihw[o]; else const_cast<float *>(oihw)[o] = packed[i];
+    }
+}
+
+// features: feat[n][c*(4*nf) + a*(2*nf) + fi*2 + b] = act5[n*nf + fi][a][b][c]   (torch.cat(..., -1).view(T*B, -1))
+__global__ __launch_bounds__(256) void conv_feat_kernel(float *__restrict__ act5, float *__restrict__ feat, int N, int nf, int to_feat) {
+    const int per = 32 * 4 * nf;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * per; i += gridDim.x * 256) {
+        const int n = i / per, k = i % per;
+        const int b = k % 2, fi = (k / 2) % nf, a = (k / (2 * nf)) % 2, c = k / (4 * nf);
+        const size_t src = ((((size_t)n * nf + fi) * 2 + a) * 2 + b) * 32 + c;
+        if (to_feat) feat[i] = act5[src]; else act5[src] = feat[i];
+    }
+}
+
+// partial[g][c] = sum over rows [g*per, min((g+1)*per, R)) of X[r][c], C = 32 (bias gradients of the conv stack)
+__global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float *__restrict__ X, float *__restrict__ partial, int R, int per) {
+    __shared__ float s[8][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int beg = blockIdx.x * per, end = beg + per < R ? beg + per : R;
+    float a = 0.f;
+    for (int r = beg + g; r < end; r += 8) a += X[(size_t)r * 32 + c];
+    s[g][c] = a;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += s[i][c];
+        partial[blockIdx.x * 32 + c] = t;
+    }
+}
+
+// BatchNorm1d input gradient: dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N)
+__global__ __launch_bounds__(256) void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
+                                                    const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                    const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                                                    float *__restrict__ dx, int N, int C) {
+    const size_t total = (size_t)N * C;
+    const float inv_n = 1.0f / (float)N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float xh = (x[i] - mean[c]) * invstd[c];
+        dx[i] = gamma[c] * invstd[c] * (dy[i] - dbeta[c] * inv_n - xh * dgamma[c] * inv_n);
+    }
+}
+
+}  // namespace pvr

@@ -28,7 +28,7 @@ class PolicyBN(C.Structure):
 
 class PolicyDesc(C.Structure):
     _fields_ = [('obs_size', C.c_int32), ('hidden', C.c_int32), ('num_actions', C.c_int32), ('batch_norm', C.c_int32),
-                ('max_t', C.c_int32), ('max_b', C.c_int32)]
+                ('max_t', C.c_int32), ('max_b', C.c_int32), ('conv_frames', C.c_int32)]
 
 
 def _plib():
@@ -49,6 +49,10 @@ def _plib():
         L.pvr_policy_forward.argtypes = [vp, vp, C.POINTER(PolicyBN), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         L.pvr_policy_step.restype = C.c_int
         L.pvr_policy_step.argtypes = [vp, vp, vp, C.POINTER(PolicyBN), vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp]
+        L.pvr_policy_backward.restype = C.c_int
+        L.pvr_policy_backward.argtypes = [vp, vp, C.POINTER(PolicyBN), vp, vp, vp, i32, i32, vp, vp, vp, vp]
+        L.pvr_policy_apply.restype = C.c_int
+        L.pvr_policy_apply.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, vp, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
         L.pvr_op_gemm_f32.restype = C.c_int
@@ -67,10 +71,18 @@ def _init(module, weight_init, bias_init, gain=1):
     return module
 
 
-def _reference_init(obs_size, num_actions, batch_norm, hidden):
-    """Same torch modules, construction order and init calls as reference src/models.py:17-44, so that a given
-    torch seed yields the reference's initial weights bit for bit.  Returns {state_dict key: tensor}."""
+def _reference_init(obs_size, num_actions, batch_norm, hidden, conv=False):
+    """Same torch modules, construction order and init calls as reference src/models.py:17-44 (and :104-148 for the
+    conv variant), so that a given torch seed yields the reference's initial weights bit for bit.
+    Returns {state_dict key: tensor}."""
     init_ = lambda m: _init(m, nn.init.orthogonal_, lambda x: nn.init.constant_(x, 0), nn.init.calculate_gain('relu'))
+    feat = None
+    if conv:
+        layers, cin = [], 3
+        for _ in range(5):
+            layers += [init_(nn.Conv2d(in_channels=cin, out_channels=32, kernel_size=(3, 3), stride=2, padding=1)), nn.ELU()]
+            cin = 32
+        feat = nn.Sequential(*layers)
     fc = nn.Sequential(init_(nn.Linear(obs_size, hidden)), nn.ReLU(), init_(nn.Linear(hidden, hidden)), nn.ReLU())
     if batch_norm:
         fc = nn.Sequential(nn.BatchNorm1d(obs_size), *list(fc))
@@ -79,23 +91,30 @@ def _reference_init(obs_size, num_actions, batch_norm, hidden):
     policy = init_(nn.Linear(hidden, num_actions))
     baseline = init_(nn.Linear(hidden, 1))
     sd = {}
-    for pfx, mod in (('fc', fc), ('core', core), ('policy', policy), ('baseline', baseline)):
+    for pfx, mod in ((('feat_extract', feat),) if conv else ()) + (('fc', fc), ('core', core), ('policy', policy), ('baseline', baseline)):
         for k, v in mod.state_dict().items():
             sd[pfx + '.' + k] = v.detach().clone()
     return sd
 
 
 class PolicyNet(nn.Module):
+    _conv_frames = 0
+
     def __init__(self, observation_shape, num_actions, batch_norm=False, max_unroll=100, max_batch=32):
         super(PolicyNet, self).__init__()
-        self.obs_size = int(observation_shape[0])
+        if self._conv_frames_from(observation_shape):
+            self._conv_frames = self._conv_frames_from(observation_shape)
+            assert tuple(observation_shape[:2]) == (64, 64), 'PolicyNetWithConv is built for 64x64 frames (habitat_config/nav_task.yaml:11-12)'
+            self.obs_size = 128 * self._conv_frames      # 32 channels x 2 x 2 per frame (models.py:120-121)
+        else:
+            self.obs_size = int(observation_shape[0])
         self.num_actions = int(num_actions)
         self.batch_norm = bool(batch_norm)
         self.hidden = HIDDEN
         self._max_t, self._max_b = int(max_unroll), int(max_batch)
         self._handle = None
         self._layout = None          # name -> (offset, shape), filled from the library on first GPU use
-        sd = _reference_init(self.obs_size, self.num_actions, self.batch_norm, self.hidden)
+        sd = _reference_init(self.obs_size, self.num_actions, self.batch_norm, self.hidden, conv=self._conv_frames > 0)
         # flat buffer with the library's layout (computed here without the GPU: same rule as policy.hip add_slot)
         self._order = [k for k in sd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
         base = [k for k in self._order if k.startswith('baseline.')]
@@ -118,6 +137,9 @@ class PolicyNet(nn.Module):
             bn.register_buffer('running_mean', sd['fc.0.running_mean'])
             bn.register_buffer('running_var', sd['fc.0.running_var'])
             bn.register_buffer('num_batches_tracked', sd['fc.0.num_batches_tracked'])
+
+    def _conv_frames_from(self, observation_shape):
+        return 0
 
     # -- plumbing ---------------------------------------------------------------------------------------------
     def _view(self, k):
@@ -173,7 +195,8 @@ class PolicyNet(nn.Module):
         self._release()
         self._max_t, self._max_b = max(self._max_t, T), max(self._max_b, B)
         L = _plib()
-        d = PolicyDesc(self.obs_size, self.hidden, self.num_actions, int(self.batch_norm), self._max_t, self._max_b)
+        d = PolicyDesc(self.obs_size, self.hidden, self.num_actions, int(self.batch_norm), self._max_t, self._max_b,
+                       self._conv_frames)
         h = C.c_void_p()
         _lib.check(L.pvr_policy_create(C.byref(d), C.byref(h)))
         self._handle = h
@@ -202,7 +225,7 @@ class PolicyNet(nn.Module):
         T, B = x.shape[0], x.shape[1]
         self._ensure(T, B)
         dev = self.device
-        x = torch.flatten(x, 0, 1).float().to(device=dev).contiguous()
+        x = self._prep_obs(x, dev)
         done = inputs['done'].to(device=dev).to(torch.uint8).contiguous()
         if len(core_state) == 2:
             h0 = core_state[0].to(device=dev, dtype=torch.float32).contiguous()
@@ -224,6 +247,12 @@ class PolicyNet(nn.Module):
             action = torch.multinomial(F.softmax(logits.view(T * B, A), dim=1), num_samples=1).view(T, B)
         return dict(policy_logits=logits, baseline=baseline, action=action), (h, c)
 
+    def _prep_obs(self, x, dev):
+        if self._conv_frames:
+            assert x.dtype == torch.uint8 and tuple(x.shape[2:]) == (64, 64, 3 * self._conv_frames), x.shape
+            return torch.flatten(x, 0, 1).to(device=dev).contiguous()     # raw uint8 frames; /255 happens in the kernel
+        return torch.flatten(x, 0, 1).float().to(device=dev).contiguous()
+
     def last_grads(self):
         """Flat pre-clip gradient of the last fused step as {state_dict key: tensor} (parity tests)."""
         g = torch.empty(self._n_train, dtype=torch.float32, device=self.device)
@@ -234,6 +263,26 @@ class PolicyNet(nn.Module):
             if o < self._n_train:
                 out[k] = g[o:o + int(np.prod(shp))].view(shp)
         return out
+
+
+def average_gradients(flat_grads, stats, group=None):
+    """Sum the flat gradient (and the loss) over ranks, divide by the world size.  One collective for the whole
+    model: 18.1 M fp32 = 72.6 MB for PolicyNetWithConv.  Works on any backend (gloo in the CPU tests)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    flat_grads.div_(world)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    stats.div_(world)
+    return flat_grads
+
+
+class PolicyNetWithConv(PolicyNet):
+    """reference src/models.py:96-197: raw uint8 (T,B,64,64,3n) observations -> 5 x (conv3x3 s2 + ELU) per frame ->
+    the same BN / FC / LSTM / heads.  Extra state_dict keys `feat_extract.{0,2,4,6,8}.{weight,bias}`."""
+
+    def _conv_frames_from(self, observation_shape):
+        return int(observation_shape[2]) // 3
 
 
 class HipRMSprop(object):
@@ -251,6 +300,7 @@ class HipRMSprop(object):
         self.square_avg = torch.zeros_like(model._flat)
         self.steps = 0
         self._stats = None
+        self._grads = None            # caller-owned flat gradient (data-parallel path)
 
     def scheduler_step(self):
         self.last_epoch += 1
@@ -268,7 +318,7 @@ class HipRMSprop(object):
         dev = m.device
         if self.square_avg.device != dev:
             self.square_avg = self.square_avg.to(dev)
-        x = torch.flatten(obs, 0, 1).float().to(device=dev).contiguous()
+        x = m._prep_obs(obs, dev)
         d = done.to(device=dev).to(torch.uint8).contiguous()
         a = actions.to(device=dev).long().contiguous()
         stats = torch.empty(2, dtype=torch.float32, device=dev)
@@ -280,6 +330,37 @@ class HipRMSprop(object):
                                            vp(logits), _lib.stream_ptr()))
         self.steps += 1
         return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
+
+    def step_data_parallel(self, obs, done, actions, group=None):
+        """Finetune configuration: every rank runs forward/backward on its slice of the batch, the flat
+        gradient is summed over ranks with ONE all-reduce (RCCL over xGMI under backend 'nccl') and divided by the
+        world size (loss is a mean over the global batch), then every rank applies the identical clipped RMSprop
+        update.  BatchNorm statistics are per-rank (torch DDP default); see DESIGN.md."""
+        import torch.distributed as dist
+        m = self.model
+        T, B = obs.shape[0], obs.shape[1]
+        m._ensure(T, B)
+        dev = m.device
+        if self.square_avg.device != dev:
+            self.square_avg = self.square_avg.to(dev)
+        if self._grads is None or self._grads.device != dev:
+            self._grads = torch.zeros(m._n_train, dtype=torch.float32, device=dev)
+        x = m._prep_obs(obs, dev)
+        d = done.to(device=dev).to(torch.uint8).contiguous()
+        a = actions.to(device=dev).long().contiguous()
+        stats = torch.zeros(2, dtype=torch.float32, device=dev)
+        bn = m._bn_struct()
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        L = _plib()
+        _lib.check(L.pvr_policy_backward(m._handle, vp(m._flat), C.byref(bn) if bn else None, vp(x), vp(d), vp(a), T, B,
+                                         vp(self._grads), vp(stats), None, _lib.stream_ptr()))
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world > 1:
+            average_gradients(self._grads, stats, group)
+        _lib.check(L.pvr_policy_apply(m._handle, vp(m._flat), vp(self.square_avg), vp(self._grads), self.current_lr(), self.alpha,
+                                      self.eps, self.max_grad_norm, vp(stats), _lib.stream_ptr()))
+        self.steps += 1
+        return stats[0], stats[1]
 
     # torch-compatible checkpoint layout (main_bc_2.py:255-257)
     def state_dict(self):

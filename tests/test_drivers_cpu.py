@@ -108,3 +108,29 @@ def test_save_embedded_obs_sharded_gloo_world2(tmp_path):
     np.testing.assert_array_equal(outs[0]['obs'], outs[1]['obs'])
     np.testing.assert_array_equal(outs[0]['action'], outs[1]['action'])
     assert set(outs[0]) == {'obs', 'action', 'reward', 'done', 'true_state'}      # save_embedded_obs.py:165
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pvr_habitat_amd.models import average_gradients
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+r = dist.get_rank()
+g = torch.arange(10, dtype=torch.float32) * (r + 1)           # rank 0: k, rank 1: 2k -> mean 1.5k
+stats = torch.tensor([float(r + 1), 0.0])
+average_gradients(g, stats)
+assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * 1.5), g
+assert float(stats[0]) == 1.5
+dist.barrier()
+'''
+
+
+def test_gradient_averaging_gloo_world2(tmp_path):
+    """The one exchange step of the finetune configuration (SURVEY 8e): sum over ranks / world size, on gloo."""
+    script = tmp_path / 'dp.py'
+    script.write_text(_DP_WORKER % dict(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29741')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    assert all(p.wait(timeout=120) == 0 for p in procs)

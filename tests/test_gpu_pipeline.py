@@ -53,3 +53,23 @@ def test_embed_then_bc_pipeline(tmp_path, monkeypatch):
     done_args = [a if a != '800' else '700' for a in args]
     finished = M.run(make_parser().parse_args(done_args))       # frames[-1] >= max_frames: returns without training
     assert finished['scene']['frames'] == again['scene']['frames']
+
+
+def test_finetune_pipeline(tmp_path):
+    """main_bc_finetune.run on a synthetic raw-frame scene pickle (reference format, main_bc_finetune.py:102-128)."""
+    from pvr_habitat_amd import main_bc_finetune as Fz
+    from pvr_habitat_amd.arguments import make_parser
+    lens = (40, 50)
+    fr = synth.frames(7, sum(lens), 64, 128).reshape(sum(lens), 64, 64, 6)
+    cuts = np.cumsum((0,) + lens)
+    rng = np.random.default_rng(0)
+    raw = dict(obs=[fr[a:b] for a, b in zip(cuts[:-1], cuts[1:])], action=[rng.integers(0, 3, L) for L in lens],
+               reward=[np.zeros(L, np.float32) for L in lens], done=[np.eye(1, L, L - 1, dtype=bool)[0] for L in lens],
+               true_state=[np.zeros((L, 12), np.float32) for L in lens])
+    pickle.dump(raw, open(tmp_path / 'scene.pickle', 'wb'))
+    args = ['--data_path', str(tmp_path), '--save_path', str(tmp_path / 'ft'), '--env', 'scene', '--to_env', 'scene', '--batch_norm',
+            '--unroll_length', '8', '--batch_size', '4', '--max_frames', '320', '--eval_frequency', '5']
+    stats = Fz.run(make_parser().parse_args(args))['scene']
+    assert len(stats['frames']) == 3 and all(np.isfinite(stats['training_loss'][1:]))
+    ck = torch.load(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar', weights_only=False)
+    assert ck['actor_model_state_dict']['feat_extract.8.weight'].shape == (32, 32, 3, 3)

@@ -33,26 +33,27 @@ def test_gemm_f32(M, N, K, a_km, b_kn):
     np.testing.assert_allclose(Cd.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-4 * np.sqrt(K / 1024.0))
 
 
-def _model(seed, O, A, bn, T, B):
-    from pvr_habitat_amd.models import PolicyNet
-    m = PolicyNet((O,), A, bn, max_unroll=T, max_batch=B)
-    sd = synth.policy_state_dict(seed, O, A, bn)
+def _model(seed, O, A, bn, T, B, conv=False):
+    from pvr_habitat_amd.models import PolicyNet, PolicyNetWithConv
+    m = PolicyNetWithConv((64, 64, 6), A, bn, max_unroll=T, max_batch=B) if conv else PolicyNet((O,), A, bn, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(seed, O, A, bn, conv=conv)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     return m.to(device='cuda'), sd
 
 
-def _run_case(golden_dir, name, seed, bn):
+def _run_case(golden_dir, name, seed, bn, conv=False):
     from pvr_habitat_amd.models import HipRMSprop
     from oracle import policy_oracle as po
     g = np.load(os.path.join(golden_dir, name))
-    T, B, A, S, O = int(g['T']), int(g['B']), int(g['A']), int(g['steps']), int(g['O'])
-    m, sd = _model(seed, O, A, bn, T, B)
-    obs, done, act = synth.bc_batches(seed, T, B, O, A, S)
+    T, B, A, S = int(g['T']), int(g['B']), int(g['A']), int(g['steps'])
+    O = 256 if conv else int(g['O'])
+    m, sd = _model(seed, O, A, bn, T, B, conv)
+    obs, done, act = synth.bc_conv_batches(seed, T, B, S, A) if conv else synth.bc_batches(seed, T, B, O, A, S)
     opt = HipRMSprop(m, lr=1e-4, alpha=0.99, eps=1e-5, max_grad_norm=40.0, max_epochs=int(g['max_epochs']))
     m.train()
     # oracle gradients of the first step, tensor by tensor (pins the hand-written backward)
     p = po.to_params(sd)
-    out, _ = po.forward(p, torch.from_numpy(obs[0]), torch.from_numpy(done[0]), (torch.zeros(2, B, 1024), torch.zeros(2, B, 1024)), bn, training=True)
+    out, _ = po.forward(p, torch.from_numpy(obs[0]), torch.from_numpy(done[0]), (torch.zeros(2, B, 1024), torch.zeros(2, B, 1024)), bn, training=True, conv=conv)
     loss0 = torch.nn.functional.nll_loss(torch.log_softmax(out['policy_logits'].flatten(0, 1), -1), torch.from_numpy(act[0]).flatten().long())
     loss0.backward()
     for s in range(S):
@@ -105,6 +106,29 @@ def test_policy_small_bn(golden_dir):
 
 def test_policy_small_nobn(golden_dir):
     _run_case(golden_dir, 'policy_small_nobn.npz', 2, False)
+
+
+def test_policy_with_conv_small(golden_dir):
+    """PolicyNetWithConv (finetune path, models.py:96-197): raw uint8 frames, conv stack fwd/bwd, BN input gradient."""
+    _run_case(golden_dir, 'policy_conv_small.npz', 3, True, conv=True)
+
+
+def test_policy_data_parallel_halves_match_fused_step():
+    """pvr_policy_backward + pvr_policy_apply (the data-parallel split, world size 1) == pvr_policy_step, bit for bit."""
+    from pvr_habitat_amd.models import HipRMSprop
+    T, B, O, A = 12, 8, 256, 3
+    obs, done, act = synth.bc_batches(5, T, B, O, A, 2)
+    outs = []
+    for dp in (False, True):
+        m, _ = _model(5, O, A, True, T, B)
+        opt = HipRMSprop(m, max_epochs=50)
+        m.train()
+        for s in range(2):
+            opt.scheduler_step()
+            f = opt.step_data_parallel if dp else opt.step
+            loss, gn = f(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+        outs.append((m._flat.clone(), float(loss), float(gn)))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
 
 
 def test_policy_full_bn(golden_dir):
