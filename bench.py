@@ -27,6 +27,23 @@ GFLOP_PER_FRAME = 8.174           # 2 x 4.0871 GMAC, 53 convs @ 224x224 (SURVEY 
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 
 
+def conv_algorithmic_bytes(n):
+    """Sum over the 52 bottleneck convs of input + output (+ residual) activation bytes at 16-bit for n frames."""
+    tot, hw, inpl = 0, 56, 64
+    for li, nb in enumerate((3, 4, 6, 3)):
+        planes = 64 << li
+        for bi in range(nb):
+            s = 2 if (bi == 0 and li > 0) else 1
+            o = hw // s
+            tot += hw * hw * inpl + hw * hw * planes                     # conv1
+            tot += hw * hw * planes + o * o * planes                     # conv2
+            if bi == 0:
+                tot += hw * hw * inpl + o * o * planes * 4               # downsample
+            tot += o * o * planes + 2 * o * o * planes * 4               # conv3 (+ residual)
+            hw, inpl = o, planes * 4
+    return tot * 2 * n
+
+
 def cpu_baseline(sd, frames_u8, budget_s=12.0):
     """The oracle (torch fp32 eager restatement of the reference path) timed on this box's host cores,
     batch 64 like the reference's 32 obs x 2 frames (save_embedded_obs.py:151-153)."""
@@ -177,6 +194,7 @@ def main():
     cap = 128
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
     conv_ms, conv_fl, other_ms = 0.0, 0.0, 0.0
+    algo_bytes = conv_algorithmic_bytes(chunk)
     reps = 3
     for _ in range(reps):
         _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(frames.data_ptr()), chunk, args.frame, args.frame,
@@ -188,6 +206,10 @@ def main():
             else:
                 other_ms += op_ms[i]
     n_conv = n_ops.value - 4
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'pmc_conv_traffic.json')
+    if os.path.isfile(tf):                                   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+        traffic = round(json.load(open(tf))['avg_hbm_bytes_per_launch'])
     if args.per_op and rank == 0:
         names = ['preprocess', 'stem', 'maxpool'] + [op for op in model.op_names()] + ['pool/flatten']
         for i in range(n_ops.value):
@@ -208,7 +230,9 @@ def main():
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
             'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': 'avg HBM bytes per conv launch, rocprofv3 PMC passes (profiles/pmc_conv_traffic.json); algorithmic '
+                                         'in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
                          'kernel': 'conv_igemm_kernel (all %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},

@@ -27,8 +27,8 @@ struct pvr_policy {
     int64_t o_bnw = -1, o_bnb = -1, o_fc1w, o_fc1b, o_fc2w, o_fc2b, o_wih[2], o_whh[2], o_bih[2], o_bhh[2], o_pw, o_pb, o_bw, o_bb;
     // workspace
     float *a0 = nullptr, *bn_mean = nullptr, *bn_invstd = nullptr, *a1 = nullptr, *a2 = nullptr;
-    float *G[2] = {nullptr, nullptr}, *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr}, *WT[2] = {nullptr, nullptr};
-    float *hprev = nullptr, *nd = nullptr, *zeros = nullptr, *dc_carry = nullptr;
+    float *G[2] = {nullptr, nullptr}, *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};
+    float *hprev = nullptr, *nd = nullptr, *zeros = nullptr, *dc_carry = nullptr, *rec_partial = nullptr;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
@@ -179,20 +179,24 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
     float *dh_ext = pol->dA, *dx = pol->dB;
     for (int l = 1; l >= 0; --l) {
-        hipLaunchKernelGGL(transpose_kernel, dim3(H / 32, 4 * H / 32), dim3(256), 0, st, P + pol->o_whh[l], pol->WT[l], 4 * H, H);
         for (int t = T - 1; t >= 0; --t) {
-            LstmBwdP b;
-            b.dG_next = t == T - 1 ? nullptr : pol->G[l] + (size_t)(t + 1) * B * 4 * H;
-            b.nd_next = t == T - 1 ? nullptr : pol->nd + (size_t)(t + 1) * B;
-            b.WT = pol->WT[l];
-            b.dh_ext = dh_ext + (size_t)t * B * H;
-            b.dc_carry = pol->dc_carry;
-            b.G = pol->G[l] + (size_t)t * B * 4 * H;
-            b.c_t = pol->Cs[l] + (size_t)t * B * H;
-            b.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
-            b.nd = pol->nd + (size_t)t * B;
-            b.B = B; b.H = H;
-            hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3(H / 16), dim3(1024), 0, st, b);
+            const bool has_next = t < T - 1;
+            if (has_next) {
+                LstmRecP r;
+                r.dG_next = pol->G[l] + (size_t)(t + 1) * B * 4 * H; r.W = P + pol->o_whh[l]; r.partial = pol->rec_partial; r.B = B; r.H = H;
+                hipLaunchKernelGGL(lstm_bwd_rec_kernel, dim3(256), dim3(256), 0, st, r);
+            }
+            LstmCellBP c;
+            c.partial = has_next ? pol->rec_partial : nullptr;
+            c.nd_next = has_next ? pol->nd + (size_t)(t + 1) * B : nullptr;
+            c.dh_ext = dh_ext + (size_t)t * B * H;
+            c.dc_carry = pol->dc_carry;
+            c.G = pol->G[l] + (size_t)t * B * 4 * H;
+            c.c_t = pol->Cs[l] + (size_t)t * B * H;
+            c.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
+            c.nd = pol->nd + (size_t)t * B;
+            c.B = B; c.H = H;
+            hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, c);
         }
         PVR_LAUNCH_CHECK();
         const float *xin = l == 0 ? pol->a2 : pol->Hs[0];
@@ -321,8 +325,8 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     pvr_status s = PVR_OK;
 #define A_(ptr, n) if (!s) s = dalloc(&p->ptr, (n))
     A_(a0, N * O); A_(bn_mean, O); A_(bn_invstd, O); A_(a1, N * H); A_(a2, N * H);
-    for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); A_(WT[l], (size_t)4 * H * H); }
-    A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H);
+    for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); }
+    A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H); A_(rec_partial, 16 * B * H);
     A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
     A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
     if (desc->conv_frames > 0) {
@@ -343,7 +347,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
 void pvr_policy_destroy(pvr_policy *p) {
     if (!p) return;
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
-                    p->WT[0], p->WT[1], p->hprev, p->nd, p->zeros, p->dc_carry, p->logits, p->baseline, p->dlogits,
+                    p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
                     p->cpartial, p->cgpacked, p->bpartial};
     for (void *q : ptrs) if (q) (void)hipFree(q);

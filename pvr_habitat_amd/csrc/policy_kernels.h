@@ -261,6 +261,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
         const bool bok = b < p.B;
         const float ndb = bok ? p.nd[b] : 0.f;
         const float *hrow = p.h_prev + (size_t)(bok ? b : 0) * H;
+        // operands of the cell update (threads < 64): issued now so their latency overlaps the weight stream
+        const int tb = tid >> 2, tj = tid & 3, tbi = b0 + tb;
+        const bool tok = tid < 64 && tbi < p.B;
+        float gx[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f, ndt = 0.f;
+        if (tok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gx[g] = p.G[(size_t)tbi * 4 * H + g * H + u0 + tj] + p.bhh[g * H + u0 + tj];
+            cprev = p.c_prev[(size_t)tbi * H + u0 + tj];
+            ndt = p.nd[tbi];
+        }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         // every load of the wave's K range is issued before the MFMA chain, so the L2 / Infinity-Cache latency of
         // the weight stream is paid once, not once per 16-k chunk (the launch is latency-bound)
@@ -284,102 +294,115 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
         __syncthreads();
-        if (tid < 64) {
-            const int bb = tid >> 2, j = tid & 3, bi = b0 + bb;
-            if (bi < p.B) {
-                float s[4];
+        if (tok) {
+            float s[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    s[g] = ((part[0][bb][g * 4 + j] + part[1][bb][g * 4 + j]) + (part[2][bb][g * 4 + j] + part[3][bb][g * 4 + j])) +
-                           (p.G[(size_t)bi * 4 * H + g * H + u0 + j] + p.bhh[g * H + u0 + j]);
-                const float ig = sigmoidf_(s[0]), fg = sigmoidf_(s[1]), gg = tanhf(s[2]), og = sigmoidf_(s[3]);
-                const float cm = p.nd[bi] * p.c_prev[(size_t)bi * H + u0 + j];
-                const float c = fg * cm + ig * gg;
-                const float h = og * tanhf(c);
-                float *g = p.G + (size_t)bi * 4 * H + u0 + j;
-                g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
-                p.c_out[(size_t)bi * H + u0 + j] = c;
-                p.h_out[(size_t)bi * H + u0 + j] = h;
-            }
+            for (int g = 0; g < 4; ++g)
+                s[g] = ((part[0][tb][g * 4 + tj] + part[1][tb][g * 4 + tj]) + (part[2][tb][g * 4 + tj] + part[3][tb][g * 4 + tj])) + gx[g];
+            const float ig = sigmoidf_(s[0]), fg = sigmoidf_(s[1]), gg = tanhf(s[2]), og = sigmoidf_(s[3]);
+            const float cm = ndt * cprev;
+            const float c = fg * cm + ig * gg;
+            const float h = og * tanhf(c);
+            float *g = p.G + (size_t)tbi * 4 * H + u0 + tj;
+            g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+            p.c_out[(size_t)tbi * H + u0 + tj] = c;
+            p.h_out[(size_t)tbi * H + u0 + tj] = h;
         }
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LSTM backward (BPTT), one launch per (layer, timestep), t descending.  Block = 16 hidden units, 16 waves:
-//   (a) dh_rec[b][u] = nd[t+1][b] * sum_k dG[t+1][b][k] * W_hh[k][u]   (WT = W_hh^T, row u contiguous in k)
-//   (b) for its own units: dh = dh_ext[t] + dh_rec, dc = dh*o*(1-tanh^2 c) + dc_carry, gate grads -> dG[t]
-//       (in place over the saved gates), dc_carry = nd[t] * dc * f
+// LSTM backward (BPTT), two launches per (layer, timestep), t descending, 2-D partition of the recurrent product:
+//   phase A  lstm_bwd_rec_kernel : partial[kg][b][u] = sum_{k in group kg} dG[t+1][b][k] * W_hh[k][u]
+//            grid 16 k-groups x 16 u-groups = 256 blocks; a block reads a 256 x 64 slab of the ORIGINAL [4H][H]
+//            weights (64 KB, 256-B row segments) and 16 KB of gate gradients - every CU streams 1/256 of W_hh,
+//            instead of 64 blocks each re-reading all 256 KB of dG[t+1]
+//   phase B  lstm_bwd_cell_kernel: dh = dh_ext + nd[t+1] * sum_kg partial (fixed order), gate gradients, dc carry
+// MFMA roles in phase A: A[i = batch][k] = dG, B[k][j] = W with j <-> u = u0 + 4*fr + e (float4 along u).
 // ---------------------------------------------------------------------------------------------------------
-struct LstmBwdP {
-    const float *dG_next, *nd_next, *WT, *dh_ext;    // [B][4H] (nullptr at t=T-1), [B], [H][4H], [B][H]
-    float *dc_carry;                                  // [B][H] in/out
-    float *G;                                         // [B][4H] at t: gates in, dG out
-    const float *c_t, *c_prev, *nd;                   // [B][H], [B][H], [B]
+struct LstmRecP {
+    const float *dG_next, *W;      // [B][4H], [4H][H]
+    float *partial;                // [16][B][H]
     int B, H;
 };
 
-__global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(LstmBwdP p) {
-    __shared__ float part[16][16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int u0 = blockIdx.x * 16, H = p.H, K = 4 * p.H;
-    const float *wrow = p.WT + (size_t)(u0 + fr) * K;
-    const int kbeg = wave * (K / 16);
+__global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) {
+    __shared__ float part[4][4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int H = p.H, K = 4 * p.H;
+    const int kg = blockIdx.x >> 4, ug = blockIdx.x & 15;
+    const int kper = K / 16, uper = H / 16;                     // 256 and 64 for H = 1024
+    const int u0 = ug * uper, kbeg = kg * kper + wave * (kper / 4);
     for (int b0 = 0; b0 < p.B; b0 += 16) {
-        if (p.dG_next) {
-            const int b = b0 + fr;
-            const bool bok = b < p.B;
-            const float *drow = p.dG_next + (size_t)(bok ? b : 0) * K;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < K / 256; c0 += 8) {
-                f32x4 dv[8], wv[8];
+        const int b = b0 + fr;
+        const bool bok = b < p.B;
+        const float *drow = p.dG_next + (size_t)(bok ? b : 0) * K;
+        for (int ub = 0; ub < uper; ub += 64) {
+            f32x4 acc[4];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int k = kbeg + (c0 + c) * 16 + fq * 4;
-                    dv[c] = *reinterpret_cast<const f32x4 *>(drow + k);
-                    wv[c] = *reinterpret_cast<const f32x4 *>(wrow + k);
-                }
-                __builtin_amdgcn_sched_barrier(0);       // 16 loads in flight before the MFMA chain (see forward)
+            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < kper / 64; ++c) {               // 16-k chunks of this wave
+                const int k0 = kbeg + c * 16;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(drow + k0 + fq * 4);
+                if (!bok) a = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 w[4];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (!bok) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int e1 = 0; e1 < 4; ++e1)
+                    w[e1] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)(k0 + fq * 4 + e1) * H + u0 + ub + fr * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = mfma_f32(dv[c][e], wv[c][e], acc);
-                }
+                for (int e1 = 0; e1 < 4; ++e1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = mfma_f32(a[e1], w[e1][e], acc[e]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
-        }
-        __syncthreads();
-        if (tid < 256) {
-            const int bb = tid >> 4, j = tid & 15, bi = b0 + bb, u = u0 + j;
-            if (bi < p.B) {
-                float dh = p.dh_ext[(size_t)bi * H + u];
-                float dc_in = 0.f;
-                if (p.dG_next) {
-                    float s = 0.f;
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int w = 0; w < 16; ++w) s += part[w][bb][j];
-                    dh += p.nd_next[bi] * s;
-                    dc_in = p.dc_carry[(size_t)bi * H + u];
-                }
-                float *g = p.G + (size_t)bi * K + u;
-                const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
-                const float tc = tanhf(p.c_t[(size_t)bi * H + u]);
-                const float cm = p.nd[bi] * p.c_prev[(size_t)bi * H + u];
-                const float dog = dh * tc * og * (1.f - og);
-                const float dc = dh * og * (1.f - tc * tc) + dc_in;
-                g[0] = dc * gg * ig * (1.f - ig);
-                g[H] = dc * cm * fg * (1.f - fg);
-                g[2 * H] = dc * ig * (1.f - gg * gg);
-                g[3 * H] = dog;
-                p.dc_carry[(size_t)bi * H + u] = p.nd[bi] * dc * fg;
+                for (int r = 0; r < 4; ++r) part[wave][e][fq * 4 + r][fr] = acc[e][r];
+            __syncthreads();
+            // 16 batch x 64 u outputs, 4 per thread: u = u0 + ub + 4*j + e
+            for (int o = tid; o < 16 * 64; o += 256) {
+                const int bb = o >> 6, uu = o & 63, j = uu >> 2, e = uu & 3;
+                if (b0 + bb < p.B)
+                    p.partial[((size_t)kg * p.B + b0 + bb) * H + u0 + ub + uu] =
+                        (part[0][e][bb][j] + part[1][e][bb][j]) + (part[2][e][bb][j] + part[3][e][bb][j]);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
+}
+
+struct LstmCellBP {
+    const float *partial, *nd_next, *dh_ext;      // [16][B][H] (nullptr at t = T-1), [B], [B][H]
+    float *dc_carry, *G;                          // [B][H] in/out, [B][4H] gates in / dG out
+    const float *c_t, *c_prev, *nd;
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int H = p.H;
+    if (i >= p.B * H) return;
+    const int bi = i / H, u = i % H;
+    float dh = p.dh_ext[i], dc_in = 0.f;
+    if (p.partial) {
+        float s = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) s += p.partial[((size_t)kg * p.B + bi) * H + u];
+        dh += p.nd_next[bi] * s;
+        dc_in = p.dc_carry[i];
+    }
+    float *g = p.G + (size_t)bi * 4 * H + u;
+    const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+    const float tc = tanhf(p.c_t[i]);
+    const float cm = p.nd[bi] * p.c_prev[i];
+    const float dog = dh * tc * og * (1.f - og);
+    const float dc = dh * og * (1.f - tc * tc) + dc_in;
+    g[0] = dc * gg * ig * (1.f - ig);
+    g[H] = dc * cm * fg * (1.f - fg);
+    g[2 * H] = dc * ig * (1.f - gg * gg);
+    g[3 * H] = dog;
+    p.dc_carry[i] = p.nd[bi] * dc * fg;
 }
 
 // Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh
