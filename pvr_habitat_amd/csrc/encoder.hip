@@ -261,11 +261,14 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;
         enc->last_n = nb;
         if (enc->stop_after == "pre") return PVR_OK;
-        if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, enc->desc.crop, dt, st))) return s;
+        if (enc->stop_after == "stem") {             // debug tap of the un-pooled conv1 output: unfused kernel
+            if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, enc->desc.crop, dt, st))) return s;
+            return PVR_OK;
+        }
+        // conv1 + bn1 + relu + maxpool fused: the 112x112x64 activation stays in LDS
+        if ((s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st))) return s;
         if ((s = mark())) return s;
-        if (enc->stop_after == "stem") return PVR_OK;
-        if ((s = launch_maxpool(enc->d_stem, enc->d_buf[B_X0], nb, 112, 112, 64, dt, st))) return s;
-        if ((s = mark())) return s;
+        if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false;
         for (auto &op : enc->ops) {

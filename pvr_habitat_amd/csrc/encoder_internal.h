@@ -11,6 +11,7 @@ namespace pvr {
 pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
+pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
 pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
 pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);

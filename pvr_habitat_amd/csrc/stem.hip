@@ -18,6 +18,7 @@ namespace pvr {
 
 constexpr int STEM_K = 224;     // 7 * 8 * 4
 constexpr int STEM_CO = 64;
+constexpr int STEM_IPB = 4;     // images per block of the fused stem+pool kernel
 
 template <bool F16>
 __global__ __launch_bounds__(256) void stem_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
@@ -71,6 +72,108 @@ __global__ __launch_bounds__(256) void stem_kernel(const u16 *__restrict__ img, 
             r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
             *reinterpret_cast<ushort4 *>(o + i * 16) = r;
         }
+    }
+}
+
+// Fused conv1 + bn1 + relu + maxpool(3x3/2, pad 1): a block produces 2 pooled rows (x 56 cols x 64 ch) of one image.
+// It computes the 5 conv rows they need (25 % recompute of a 3 %-of-FLOPs layer) into an LDS tile
+// [5][112][64] 16-bit (70 KB, 16-byte chunks XOR-swizzled with the column), then pools from LDS and writes
+// 16-byte coalesced NHWC rows.  Replaces stem_kernel + maxpool_kernel on the encoder path: the 1.6 MB/frame
+// conv1 activation never goes to HBM (write 411 MB + read 411 MB per 256 frames saved).
+template <bool F16>
+__global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
+                                                        const float *__restrict__ bias, u16 *__restrict__ out, int nimg) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [5][112] pixels x 128 B
+    const int pr0 = blockIdx.x * 2;                                  // pooled rows pr0, pr0+1
+    const int cr0 = 2 * pr0 - 1;                                     // first conv row held (may be -1: above the image)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 15, g = lane >> 4;
+    V8 wf[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+            wf[i][s] = *reinterpret_cast<const V8 *>(wgt + (size_t)(i * 16 + px) * STEM_K + s * 32 + g * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + g * 4);
+    // the 28 weight fragments (112 VGPRs) are loaded once and reused over STEM_IPB images of this row pair
+    for (int n = blockIdx.y * STEM_IPB; n < nimg && n < (int)(blockIdx.y + 1) * STEM_IPB; ++n) {
+    const u16 *imgn = img + (size_t)n * PH * PW * 4;
+    // software pipeline: the 7 pixel fragments of this wave's NEXT tile are in flight while the current tile's 28
+    // MFMAs run (the kernel is latency-bound: 9 dependent load->MFMA rounds per wave otherwise)
+    auto tile_base = [&](int t) -> const u16 * {
+        const int lr = t / 7, ho = cr0 + lr, wo0 = (t % 7) * 16;
+        const int hc = ho < 0 ? 0 : (ho >= OW ? OW - 1 : ho);      // clamped: rows outside the image are loaded but unused
+        return imgn + ((size_t)(2 * hc) * PW + 2 * (wo0 + px) + 2 * g) * 4;
+    };
+    V8 xn[7];
+    {
+        const u16 *b0 = tile_base(wave);
+#pragma unroll
+        for (int s = 0; s < 7; ++s) xn[s] = *reinterpret_cast<const V8 *>(b0 + (size_t)s * PW * 4);
+    }
+    for (int t = wave; t < 35; t += 4) {                             // 5 rows x 7 tiles of 16 columns
+        const int lr = t / 7, ho = cr0 + lr, wo0 = (t % 7) * 16;
+        V8 xf[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) xf[s] = xn[s];
+        if (t + 4 < 35) {
+            const u16 *b1 = tile_base(t + 4);
+#pragma unroll
+            for (int s = 0; s < 7; ++s) xn[s] = *reinterpret_cast<const V8 *>(b1 + (size_t)s * PW * 4);
+        }
+        if (ho < 0 || ho >= OW) continue;                            // rows outside the image are never pooled
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mfma16<F16>(wf[i][s], xf[s], acc[i]);
+        const int col = wo0 + px;
+        char *prow = smem + ((size_t)lr * OW + col) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ushort4 r;
+            r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
+            r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
+            r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
+            r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
+            const int c16 = i * 2 + (g >> 1);                        // 16-byte chunk of channels 16i+4g .. +3
+            *reinterpret_cast<ushort4 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
+        }
+    }
+    __syncthreads();
+    // pooling: 2 rows x 56 cols x 8 channel-chunks = 896 outputs of 16 B
+    for (int o = tid; o < 2 * PO * 8; o += 256) {
+        const int k = o & 7, pc = (o >> 3) % PO, pr = o / (8 * PO);
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = 0.f;                      // inputs are post-ReLU (>= 0): 0 is the identity
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int lr = 2 * pr + dy, ho = cr0 + lr;
+            if (ho < 0 || ho >= OW) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int col = 2 * pc - 1 + dx;
+                if (col < 0 || col >= OW) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + ((size_t)lr * OW + col) * 128 + ((k ^ (col & 7)) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[2 * e] = fmaxf(m[2 * e], from_h<F16>((u16)(v[e] & 0xffffu)));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], from_h<F16>((u16)(v[e] >> 16)));
+                }
+            }
+        }
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (unsigned)to_h<F16>(m[2 * e]) | ((unsigned)to_h<F16>(m[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pc) * STEM_CO + k * 8) = r;
+    }
+    __syncthreads();                                                 // LDS tile is rewritten for the next image
     }
 }
 
@@ -156,6 +259,25 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
         hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
     else
         hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias, void *out, int n, int crop, int dtype,
+                            hipStream_t stream) {
+    PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);
+    const size_t lds = 5 * 112 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(28, (n + STEM_IPB - 1) / STEM_IPB);
+    if (dtype == PVR_F16)
+        hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n);
+    else
+        hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
