@@ -28,6 +28,7 @@ struct ConvP {
     const u16 *zero;      // >= 256 B of zeros
     int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
     int M, K;
+    unsigned in_bytes, w_bytes;   // buffer sizes for the raw-buffer range check
     int res_f32;          // residual buffer is fp32 (out_f32 layout) instead of 16-bit
     int act, out_f32;     // act: 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x), 3 GELU (erf)
     int m_tiles, n_tiles;
@@ -53,35 +54,45 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     const int m0 = tm * BM, co0 = tn * BN;
 
     // ---- staging assignment: chunk q = tid + 256*i -> LDS (row = q>>3, physical chunk = q&7) -------
+    // Address arithmetic is kept OUT of the K loop (a first version spent ~480 VALU instructions per K-slice per
+    // wave on 64-bit pointers, bounds tests and swizzles against 512 MFMA cycles - rocprofv3 SQ_INSTS_VALU):
+    //   * loads are raw buffer loads: one 32-bit byte offset per chunk, precomputed at tap (0,0); per slice it costs
+    //     one add of the wave-uniform tap offset and one select; out-of-image taps and tile tails take an offset past
+    //     num_records, for which the hardware returns zeros (no zero page, no branches)
+    //   * per-row 9-bit masks say which filter taps fall inside the image
+    //   * LDS addresses are per-thread constants plus compile-time stage offsets (the loop is unrolled by two)
     const int srow = tid >> 3;                    // 0..31 (+32*i)
     const int pch = tid & 7;
-    const u16 *a_base[A_CH];                      // pointer at tap (0,0), logical chunk applied
-    int a_hi0[A_CH], a_wi0[A_CH];
-    bool a_ok[A_CH];
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;               // >= num_records for every buffer (< 2 GiB, checked by the launcher)
+    int a_off[A_CH], a_mask[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int row = srow + 32 * i;
         const int lch = pch ^ ((row >> 1) & 7);   // logical chunk stored at this physical slot
         const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int wo = mm % p.Wo;
         const int t = mm / p.Wo;
         const int ho = t % p.Ho;
         const int n = t / p.Ho;
-        a_hi0[i] = ho * p.stride - p.pad;
-        a_wi0[i] = wo * p.stride - p.pad;
-        a_base[i] = p.in + (((int64_t)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + lch * 8;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_off[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
+        int mask = 0;
+        for (int th = 0; th < p.KH; ++th)
+            for (int tw = 0; tw < p.KW; ++tw)
+                if (ok && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mask |= 1 << (th * p.KW + tw);
+        a_mask[i] = mask;
     }
-    const u16 *b_base[B_CH];
-    bool b_ok[B_CH];
+    int b_off[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         const int row = srow + 32 * i;
         const int lch = pch ^ ((row >> 1) & 7);
         const int co = co0 + row;
-        b_ok[i] = co < p.CoutPad;
-        b_base[i] = p.wgt + (int64_t)(b_ok[i] ? co : 0) * p.K + lch * 8;
+        b_off[i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
     }
     const int lds_st = srow * 128 + pch * 16;     // + 32*i*128 ; B tile after A tile
 
@@ -89,22 +100,17 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     const int cpt = p.Cin / BK;                   // K-slices per filter tap
     const int nk = p.KH * p.KW * cpt;
 
-    int kh = 0, kw = 0, cs = 0;                   // position of the slice being LOADED
-    // (macros, not lambdas: by-reference lambda captures sent ra/rb to scratch memory)
+    int kh = 0, kw = 0, cs = 0, tap = 0;          // position of the slice being LOADED (wave-uniform)
 #define PVR_LOAD_SLICE(kt_)                                                                             \
     {                                                                                                   \
-        const int tap_off = (kh * p.W + kw) * p.Cin + cs * BK;                                          \
+        const int tap_off = ((kh * p.W + kw) * p.Cin + cs * BK) * 2;                                    \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                              \
-            const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                           \
-            const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;    \
-            const u16 *src = ok ? a_base[i] + tap_off : p.zero;                                         \
-            ra[i] = *reinterpret_cast<const u32x4 *>(src);                                              \
+            const int vo = ((a_mask[i] >> tap) & 1) ? a_off[i] + tap_off : OOB;                         \
+            ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0));  \
         }                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                              \
-            const u16 *src = b_ok[i] ? b_base[i] + (kt_) * BK : p.zero;                                 \
-            rb[i] = *reinterpret_cast<const u32x4 *>(src);                                              \
-        }                                                                                               \
-        if (++cs == cpt) { cs = 0; if (++kw == p.KW) { kw = 0; ++kh; } }                                \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt_) * (BK * 2), 0)); \
+        if (++cs == cpt) { cs = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }                         \
     }
 #define PVR_STORE_SLICE(buf_)                                                                           \
     {                                                                                                   \
@@ -118,19 +124,19 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     // ---- wave tiling: 2x2 waves; wave (wm, wn) owns pixels [wm*BM/2,+BM/2) x couts [wn*BN/2,+BN/2) ----
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    int a_rd[TM], b_rd[TN];                       // byte offsets of this lane's fragment rows
-    int a_sw[TM], b_sw[TN];
+    int a_rd[2][TM], b_rd[2][TN];                 // byte offsets of this lane's fragments inside a stage, per k-step
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int row = wm * (BM / 2) + j * 16 + fr;
-        a_rd[j] = row * 128;
-        a_sw[j] = (row >> 1) & 7;
-    }
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int row = wn * (BN / 2) + i * 16 + fr;
-        b_rd[i] = BM * 128 + row * 128;
-        b_sw[i] = (row >> 1) & 7;
+        for (int j = 0; j < TM; ++j) {
+            const int row = wm * (BM / 2) + j * 16 + fr;
+            a_rd[ks][j] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int row = wn * (BN / 2) + i * 16 + fr;
+            b_rd[ks][i] = BM * 128 + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
     }
 
     f32x4 acc[TN][TM];
@@ -166,31 +172,28 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     }
     PVR_STORE_SLICE(0);
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = STAGES > 1 && kt + 1 < nk;
-        if (more) PVR_LOAD_SLICE(kt + 1);
-        const char *sb = smem + cur * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            V8 xa[TM], wb[TN];
-            const int lch = ks * 4 + fq;
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-                xa[j] = *reinterpret_cast<const V8 *>(sb + a_rd[j] + ((lch ^ a_sw[j]) << 4));
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-                wb[i] = *reinterpret_cast<const V8 *>(sb + b_rd[i] + ((lch ^ b_sw[i]) << 4));
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = mfma16<F16>(wb[i], xa[j], acc[i][j]);
-        }
-        if (more) PVR_STORE_SLICE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    // one K-slice: loads of slice kt+1 are issued first, the MFMAs of slice kt run, then slice kt+1 is written to the
+    // other stage.  CUR_ is a literal so every LDS access is base register + immediate.
+#define PVR_K_STEP(kt_, CUR_)                                                                           \
+    {                                                                                                   \
+        const bool more = STAGES > 1 && (kt_) + 1 < nk;                                                 \
+        if (more) PVR_LOAD_SLICE((kt_) + 1);                                                            \
+        const char *sb = smem + (CUR_) * STAGE;                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+            V8 xa[TM], wb[TN];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(sb + a_rd[ks][j]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(sb + b_rd[ks][i]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                              \
+                _Pragma("unroll") for (int j = 0; j < TM; ++j) acc[i][j] = mfma16<F16>(wb[i], xa[j], acc[i][j]); \
+        }                                                                                               \
+        if (more) PVR_STORE_SLICE((STAGES > 1 ? 1 - (CUR_) : 0));                                       \
+        __syncthreads();                                                                                \
     }
-
+    for (int kt = 0; kt < nk; kt += 2) {
+        PVR_K_STEP(kt, 0);
+        if (kt + 1 < nk) PVR_K_STEP(kt + 1, 1);
+    }
+#undef PVR_K_STEP
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
 
@@ -326,6 +329,9 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     const int64_t M = (int64_t)n * p.Ho * p.Wo;
     PVR_REQUIRE(M < (1ll << 31) && (int64_t)M * cout < (1ll << 40), "conv: problem too large");
     p.M = (int)M; p.K = kh * kw * cin;
+    const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2;
+    PVR_REQUIRE(inb < 0x7ffffff0ll && wb < 0x7ffffff0ll && kh * kw <= 25, "conv: operand larger than 2 GiB (chunk the batch)");
+    p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb;
     p.act = relu; p.out_f32 = out_f32 & 1; p.res_f32 = (out_f32 >> 1) & 1;   // out_f32 bit1: residual is fp32
     if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
     return launch_cfg<128, 128>(p, dtype, stream);
