@@ -80,10 +80,16 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
         const int n = t / p.Ho;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
         a_off[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
+        // branch-free tap mask (KH, KW <= 3): bit th*KW+tw set when tap (th,tw) of this row falls inside the image
+        int hb = 0, wb = 0;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            hb |= (int)(ok && t3 < p.KH && (unsigned)(hi0 + t3) < (unsigned)p.H) << t3;
+            wb |= (int)(t3 < p.KW && (unsigned)(wi0 + t3) < (unsigned)p.W) << t3;
+        }
         int mask = 0;
-        for (int th = 0; th < p.KH; ++th)
-            for (int tw = 0; tw < p.KW; ++tw)
-                if (ok && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mask |= 1 << (th * p.KW + tw);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
         a_mask[i] = mask;
     }
     int b_off[B_CH];
@@ -330,7 +336,7 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     PVR_REQUIRE(M < (1ll << 31) && (int64_t)M * cout < (1ll << 40), "conv: problem too large");
     p.M = (int)M; p.K = kh * kw * cin;
     const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2;
-    PVR_REQUIRE(inb < 0x7ffffff0ll && wb < 0x7ffffff0ll && kh * kw <= 25, "conv: operand larger than 2 GiB (chunk the batch)");
+    PVR_REQUIRE(inb < 0x7ffffff0ll && wb < 0x7ffffff0ll && kh <= 3 && kw <= 3, "conv: operand larger than 2 GiB or filter larger than 3x3");
     p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb;
     p.act = relu; p.out_f32 = out_f32 & 1; p.res_f32 = (out_f32 >> 1) & 1;   // out_f32 bit1: residual is fp32
     if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
