@@ -135,6 +135,32 @@ def vit_bench(variant, batch, steps, warmup, dtype):
             'frac_of_mfma_peak': round(fps * VIT_GFLOP[variant] / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 
+def pcie_bench(model_sd, batch, frame, dtype, nbatches=8):
+    """PCIe-inclusive rate (never the headline `value`): host-resident uint8 frames -> pinned staging -> H2D ->
+    encoder -> D2H fp32 embeddings, overlapped on separate HIP streams (embeddings.stream_embed)."""
+    from pvr_habitat_amd import synth
+    from pvr_habitat_amd.embeddings import HipResNet50, stream_embed
+
+    class _Net:                                           # minimal EmbeddingNet-like holder
+        pass
+    net = _Net()
+    net.embedding = HipResNet50(model_sd, 'conv5', compute_dtype=dtype, max_batch=batch)
+    net.out_size = net.embedding.out_size
+    fr = torch.from_numpy(synth.frames(9, batch, frame, frame)).repeat(nbatches, 1, 1, 1)
+    stream_embed(net, fr[:2 * batch], batch)              # warm-up (allocations, first launches)
+    res = {}
+    for kind, src in (('pageable_source', fr), ('pinned_source', fr.pin_memory())):
+        stream_embed(net, src, batch)                     # first pass touches / page-locks the host pages
+        t0 = time.perf_counter()
+        out = stream_embed(net, src, batch)
+        el = time.perf_counter() - t0
+        assert np.isfinite(out).all()
+        res[kind] = {'value': round(fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(fr.numel() / el / 1e9, 2)}
+    res['frames'] = int(fr.shape[0])
+    res['note'] = 'host uint8 frames -> (pinned double buffer ->) H2D -> encode -> D2H fp32, copies overlapped with compute on separate HIP streams'
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -146,6 +172,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
+    ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
     args = ap.parse_args()
@@ -239,6 +266,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, frames_np)
+        if world == 1 and not args.no_pcie:
+            line['pcie_inclusive'] = pcie_bench(sd, args.batch, args.frame, args.dtype)
         if world == 1 and not args.no_vit:
             line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, args.dtype), vit_bench('clip_b32', args.batch, 5, 2, args.dtype)]
         if world == 1 and not args.no_bc:

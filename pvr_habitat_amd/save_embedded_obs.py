@@ -143,7 +143,16 @@ def run(flags):
         n_samples = data['obs'].shape[0]
         n_frames = max(data['obs'].shape[3] // 3, 1)
         lo, hi = shard_bounds(n_samples, rank, world)
-        mine = embed_rows(embedding_model, data['obs'][lo:hi], n_frames, max(1, batch // n_frames))
+        if hasattr(getattr(embedding_model, 'embedding', None), 'forward_into'):
+            # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU
+            # test), so the per-batch split/stack/concat of save_embedded_obs.py:151-156 is reproduced by streaming
+            # each 3-channel frame plane through the overlapped H2D/compute/D2H path and concatenating on features
+            from .embeddings import stream_embed
+            shard = data['obs'][lo:hi]
+            mine = np.concatenate([stream_embed(embedding_model, np.ascontiguousarray(shard[..., 3 * f:3 * f + 3]), batch)
+                                   for f in range(n_frames)], axis=-1) if hi > lo else np.zeros((0, 0), np.float32)
+        else:
+            mine = embed_rows(embedding_model, data['obs'][lo:hi], n_frames, max(1, batch // n_frames))
         if world > 1:
             parts = [None] * world if rank == 0 else None
             dist.gather_object(mine, parts, dst=0)              # host-side concat only; no device collective

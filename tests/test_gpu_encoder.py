@@ -227,3 +227,14 @@ def test_full_batch_properties():
     d = small(fr[:70].contiguous())                                    # chunked path (3 forwards: 32+32+6)
     assert torch.equal(d, a[:70])
     assert torch.isfinite(a).all() and float(a.std()) > 0
+
+
+def test_stream_embed_matches_batched_calls(monkeypatch):
+    """Overlapped H2D / compute / D2H path returns the same rows in the same order, bit for bit."""
+    from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    net = EmbeddingNet('resnet50', pretrained=False, compute_dtype='bf16', max_batch=16)
+    fr = synth.frames(4, 70, 64, 64)
+    a = stream_embed(net, fr, batch=16)
+    b = np.concatenate([net(torch.from_numpy(fr[i:i + 16])).reshape(-1, 2048) for i in range(0, 70, 16)])
+    assert a.shape == (70, 2048) and np.array_equal(a, b)
