@@ -97,3 +97,72 @@ def embed(sd, frames_nhwc_u8, squeeze=True):
         out = encode_image(sd, preprocess(frames_nhwc_u8))
         out = out.reshape(out.shape[0], -1)
         return (out.squeeze() if squeeze else out).numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# MAE ViT encoder (reference src/vision_models/mae.py:202-222 forward_encoder with mask_ratio=0; src/embeddings.py:
+# 81 Resize(256, interpolation=3 = bicubic) for 'mae' names, :137-140 mae_base, :377-379 CLS token output).
+# timm 0.5.4 (requirements.txt:20, not under /root/reference) Block restated: x += proj(MHA(qkv(norm1(x))));
+# x += fc2(GELU_erf(fc1(norm2(x)))), LayerNorm eps 1e-6 (mae.py:279).  random_masking(mask_ratio=0) only permutes the
+# patch tokens (mae.py:181-192); the CLS output is permutation invariant, so the shuffle is skipped.
+# PARITY PINNING: timm is not installable here -> "parity unpinned"; cross-checked against transformers.ViTModel.
+# ------------------------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def mae_preprocess_u8(frames_nhwc_u8, resize=256, crop=224):
+    """torchvision 0.10 tensor Resize(256, bicubic) (antialias off): float32 bicubic, clamp(0,255), round, uint8."""
+    x = _t(frames_nhwc_u8).transpose(1, 2).transpose(1, 3).contiguous()
+    n, c, h, w = x.shape
+    nh, nw = resize_size(h, w, resize)
+    if (nh, nw) != (h, w):
+        y = F.interpolate(x.float(), size=(nh, nw), mode='bicubic', align_corners=False)
+        x = y.clamp(0, 255).round().to(torch.uint8)
+    top, left = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+    return x[..., top:top + crop, left:left + crop]
+
+
+def mae_preprocess(frames_nhwc_u8):
+    x = mae_preprocess_u8(frames_nhwc_u8).float() / 255.0
+    m = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    return (x - m) / s
+
+
+def mae_encode(sd, x, heads=12, taps=None):
+    w1 = _t(sd['patch_embed.proj.weight'])
+    patch, width = w1.shape[-1], w1.shape[0]
+    x = F.conv2d(x, w1, _t(sd['patch_embed.proj.bias']), patch)
+    n = x.shape[0]
+    x = x.reshape(n, width, -1).permute(0, 2, 1)
+    pos = _t(sd['pos_embed'])
+    x = x + pos[:, 1:, :]
+    cls = (_t(sd['cls_token']) + pos[:, :1, :]).expand(n, -1, -1)
+    x = torch.cat([cls, x], dim=1)
+    T, hd = x.shape[1], width // heads
+    ln = lambda t, w, b: F.layer_norm(t, (width,), _t(w), _t(b), 1e-6)
+    i = 0
+    while ('blocks.%d.norm1.weight' % i) in sd:
+        p = 'blocks.%d.' % i
+        y = ln(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias'])
+        qkv = y @ _t(sd[p + 'attn.qkv.weight']).t() + _t(sd[p + 'attn.qkv.bias'])
+        q, k, v = qkv.split(width, dim=-1)
+        sh = lambda t: t.reshape(n, T, heads, hd).permute(0, 2, 1, 3)
+        a = torch.softmax((sh(q) @ sh(k).transpose(-1, -2)) * (hd ** -0.5), dim=-1) @ sh(v)
+        a = a.permute(0, 2, 1, 3).reshape(n, T, width)
+        x = x + a @ _t(sd[p + 'attn.proj.weight']).t() + _t(sd[p + 'attn.proj.bias'])
+        y = ln(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias'])
+        y = F.gelu(y @ _t(sd[p + 'mlp.fc1.weight']).t() + _t(sd[p + 'mlp.fc1.bias']))
+        x = x + y @ _t(sd[p + 'mlp.fc2.weight']).t() + _t(sd[p + 'mlp.fc2.bias'])
+        if taps is not None:
+            taps['block%d' % i] = x
+        i += 1
+    x = ln(x, sd['norm.weight'], sd['norm.bias'])
+    return x[:, 0, :]                                             # embeddings.py:379
+
+
+def mae_embed(sd, frames_nhwc_u8, squeeze=True):
+    with torch.no_grad():
+        out = mae_encode(sd, mae_preprocess(frames_nhwc_u8))
+        return (out.squeeze() if squeeze else out).numpy()

@@ -93,7 +93,8 @@ template <bool F16, int W>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ patch_emb,
                                                         const float *__restrict__ cls, const float *__restrict__ pos,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                        float *__restrict__ out_f32, u16 *__restrict__ out_h, int rows, int T) {
+                                                        float *__restrict__ out_f32, u16 *__restrict__ out_h, int rows, int T, float eps,
+                                                        int normalize) {
     constexpr int PER = W / 64;                   // 12 for 768
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -124,14 +125,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + eps);
 #pragma unroll
     for (int i = 0; i < PER / 4; ++i) {
         const int k = (i * 64 + lane) * 4;
-        const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + k), bt = *reinterpret_cast<const f32x4 *>(beta + k);
         f32x4 o;
+        if (normalize) {
+            const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + k), bt = *reinterpret_cast<const f32x4 *>(beta + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[i * 4 + e] - mean) * rstd * gm[e] + bt[e];
+            for (int e = 0; e < 4; ++e) o[e] = (v[i * 4 + e] - mean) * rstd * gm[e] + bt[e];
+        } else {                                                  // MAE: tokens + pos-emb enter the blocks un-normalised
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[i * 4 + e];
+        }
         if (out_f32) *reinterpret_cast<f32x4 *>(out_f32 + (size_t)row * W + k) = o;
         if (out_h) {
             ushort4 r;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
 template <int W>
 __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, const float *__restrict__ proj,
-                                                       float *__restrict__ out, int64_t out_stride, int T, int out_dim) {
+                                                       float *__restrict__ out, int64_t out_stride, int T, int out_dim, float eps) {
     __shared__ float y[W];
     __shared__ float red[8];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -276,13 +282,14 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__
     q = wave_sum(q);
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
     __syncthreads();
-    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + 1e-5f);
+    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)W + eps);
 #pragma unroll
     for (int i = 0; i < W / 256; ++i) y[tid + i * 256] = (v[i] - mean) * rstd * gamma[tid + i * 256] + beta[tid + i * 256];
     __syncthreads();
     for (int j = tid; j < out_dim; j += 256) {
         float acc = 0.f;
-        for (int k = 0; k < W; ++k) acc += y[k] * proj[(size_t)k * out_dim + j];
+        if (proj) for (int k = 0; k < W; ++k) acc += y[k] * proj[(size_t)k * out_dim + j];
+        else acc = y[j];                                          // MAE: the normalised CLS token is the embedding
         out[(size_t)b * out_stride + j] = acc;
     }
 }
@@ -302,6 +309,9 @@ struct VitBlock {
 
 struct pvr_vit {
     int patch = 32, width = 768, layers = 12, heads = 12, out_dim = 512, res = 224, grid = 7, T = 50, TK = 64;
+    bool mae = false;               // timm/MAE layout: patch bias, no ln_pre, LN eps 1e-6, erf GELU, CLS output without proj
+    float eps = 1e-5f;
+    int act = 2, resize_to = 224;
     std::vector<VitBlock> blocks;
     u16 *w_patch = nullptr;
     float *b_patch = nullptr, *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr,
@@ -348,8 +358,11 @@ static pvr_status up_linear(pvr_encoder *e, const std::string &wname, const std:
 
 pvr_status vit_create(pvr_encoder *e) {
     pvr_vit *v = new pvr_vit();
-    v->patch = e->desc.arch == PVR_ARCH_CLIP_VIT_B16 ? 16 : 32;
+    v->patch = e->desc.arch == PVR_ARCH_CLIP_VIT_B32 ? 32 : 16;
+    v->mae = e->desc.arch == PVR_ARCH_MAE_VIT_B16;
+    if (v->mae) { v->eps = 1e-6f; v->act = 3; v->out_dim = v->width; }
     v->res = e->desc.crop;
+    v->resize_to = e->desc.resize;
     v->grid = v->res / v->patch;
     v->T = v->grid * v->grid + 1;
     v->TK = (v->T + 31) / 32 * 32;
@@ -366,7 +379,9 @@ pvr_status vit_finalize(pvr_encoder *e) {
     // patch embedding: conv1 [W][3][P][P] (no bias) -> [W][(py,px,c)], Normalize + /255 folded:
     //   sum w*((x/255-mean)/std) = sum (w/(255 std)) (x-128) + sum w (128 - 255 mean)/(255 std)
     const HostTensor *w;
-    if ((s = enc_need(e, "visual.conv1.weight", &w, (size_t)W * K))) return s;
+    if ((s = enc_need(e, v->mae ? "patch_embed.proj.weight" : "visual.conv1.weight", &w, (size_t)W * K))) return s;
+    const HostTensor *pb = nullptr;                              // timm PatchEmbed has a bias, CLIP conv1 does not
+    if (v->mae && (s = enc_need(e, "patch_embed.proj.bias", &pb, (size_t)W))) return s;
     {
         std::vector<u16> hw((size_t)W * K);
         std::vector<float> hb(W, 0.f);
@@ -379,32 +394,38 @@ pvr_status vit_finalize(pvr_encoder *e) {
                         hw[(size_t)co * K + (py * P + px) * 3 + c] = f32_to_h((float)(wv / (255.0 * e->desc.std_[c])), dt);
                         bsum += wv * (128.0 - 255.0 * e->desc.mean[c]) / (255.0 * e->desc.std_[c]);   // x = xc + 128
                     }
-            hb[co] = (float)bsum;
+            hb[co] = (float)bsum + (pb ? pb->data[co] : 0.f);
         }
         if ((s = enc_upload(&v->w_patch, hw))) return s;
         v->owned.push_back(v->w_patch);
         if ((s = enc_upload(&v->b_patch, hb))) return s;
         v->owned.push_back(v->b_patch);
     }
-    if ((s = up_f32(e, "visual.class_embedding", W, &v->cls))) return s;
-    if ((s = up_f32(e, "visual.positional_embedding", (size_t)v->T * W, &v->pos))) return s;
-    if ((s = up_f32(e, "visual.ln_pre.weight", W, &v->lnpre_w))) return s;
-    if ((s = up_f32(e, "visual.ln_pre.bias", W, &v->lnpre_b))) return s;
-    if ((s = up_f32(e, "visual.ln_post.weight", W, &v->lnpost_w))) return s;
-    if ((s = up_f32(e, "visual.ln_post.bias", W, &v->lnpost_b))) return s;
-    if ((s = up_f32(e, "visual.proj", (size_t)W * v->out_dim, &v->proj))) return s;
+    // names: openai/CLIP VisionTransformer (visual.*) or timm/MAE (mae.py:85-95)
+    if ((s = up_f32(e, v->mae ? "cls_token" : "visual.class_embedding", W, &v->cls))) return s;
+    if ((s = up_f32(e, v->mae ? "pos_embed" : "visual.positional_embedding", (size_t)v->T * W, &v->pos))) return s;
+    if (!v->mae) {
+        if ((s = up_f32(e, "visual.ln_pre.weight", W, &v->lnpre_w))) return s;
+        if ((s = up_f32(e, "visual.ln_pre.bias", W, &v->lnpre_b))) return s;
+        if ((s = up_f32(e, "visual.proj", (size_t)W * v->out_dim, &v->proj))) return s;
+    }
+    if ((s = up_f32(e, v->mae ? "norm.weight" : "visual.ln_post.weight", W, &v->lnpost_w))) return s;
+    if ((s = up_f32(e, v->mae ? "norm.bias" : "visual.ln_post.bias", W, &v->lnpost_b))) return s;
     v->blocks.resize(v->layers);
     for (int i = 0; i < v->layers; ++i) {
         VitBlock &b = v->blocks[i];
-        const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
-        if ((s = up_linear(e, p + "attn.in_proj_weight", p + "attn.in_proj_bias", 3 * W, W, &b.w_qkv, &b.b_qkv))) return s;
-        if ((s = up_linear(e, p + "attn.out_proj.weight", p + "attn.out_proj.bias", W, W, &b.w_out, &b.b_out))) return s;
-        if ((s = up_linear(e, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", 4 * W, W, &b.w_fc, &b.b_fc))) return s;
-        if ((s = up_linear(e, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", W, 4 * W, &b.w_proj, &b.b_proj))) return s;
-        if ((s = up_f32(e, p + "ln_1.weight", W, &b.ln1_w))) return s;
-        if ((s = up_f32(e, p + "ln_1.bias", W, &b.ln1_b))) return s;
-        if ((s = up_f32(e, p + "ln_2.weight", W, &b.ln2_w))) return s;
-        if ((s = up_f32(e, p + "ln_2.bias", W, &b.ln2_b))) return s;
+        const std::string p = (v->mae ? "blocks." : "visual.transformer.resblocks.") + std::to_string(i) + ".";
+        const char *n_qkv = v->mae ? "attn.qkv." : "attn.in_proj_", *n_out = v->mae ? "attn.proj." : "attn.out_proj.";
+        const char *n_fc = v->mae ? "mlp.fc1." : "mlp.c_fc.", *n_pj = v->mae ? "mlp.fc2." : "mlp.c_proj.";
+        const char *n_l1 = v->mae ? "norm1." : "ln_1.", *n_l2 = v->mae ? "norm2." : "ln_2.";
+        if ((s = up_linear(e, p + n_qkv + "weight", p + n_qkv + "bias", 3 * W, W, &b.w_qkv, &b.b_qkv))) return s;
+        if ((s = up_linear(e, p + n_out + "weight", p + n_out + "bias", W, W, &b.w_out, &b.b_out))) return s;
+        if ((s = up_linear(e, p + n_fc + "weight", p + n_fc + "bias", 4 * W, W, &b.w_fc, &b.b_fc))) return s;
+        if ((s = up_linear(e, p + n_pj + "weight", p + n_pj + "bias", W, 4 * W, &b.w_proj, &b.b_proj))) return s;
+        if ((s = up_f32(e, p + n_l1 + "weight", W, &b.ln1_w))) return s;
+        if ((s = up_f32(e, p + n_l1 + "bias", W, &b.ln1_b))) return s;
+        if ((s = up_f32(e, p + n_l2 + "weight", W, &b.ln2_w))) return s;
+        if ((s = up_f32(e, p + n_l2 + "bias", W, &b.ln2_b))) return s;
     }
     const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid;
     auto alloc = [&](void **ptr, size_t bytes) -> pvr_status {
@@ -461,16 +482,50 @@ static void aa_tables(int in, int out, std::vector<int> &mn, std::vector<int> &s
     }
 }
 
+// ATen upsample_bicubic2d (no antialias, align_corners=False, A = -0.75) for one dimension, in window form: the 4 taps
+// ix-1..ix+2 are clamped to the image, so border duplicates merge into one weight (torchvision 0.10 Resize(256,
+// interpolation=3) on tensors, reference src/embeddings.py:81 for the 'mae' names)
+static void cubic_tables(int in, int out, std::vector<int> &mn, std::vector<int> &sz, std::vector<float> &wt, int &maxk) {
+    const float scale = (float)in / (float)out, A = -0.75f;
+    maxk = 4;
+    mn.assign(out, 0); sz.assign(out, 0); wt.assign((size_t)out * maxk, 0.f);
+    for (int i = 0; i < out; ++i) {
+        const float src = scale * ((float)i + 0.5f) - 0.5f;
+        const float fl = floorf(src);
+        const int ix = (int)fl;
+        const float t = src - fl;
+        float c[4];
+        float x = t + 1.f;  c[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+        x = t;              c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+        x = 1.f - t;        c[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+        x = 2.f - t;        c[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+        int lo = ix - 1 < 0 ? 0 : (ix - 1 > in - 1 ? in - 1 : ix - 1);
+        mn[i] = lo;
+        int last = 0;
+        for (int j = 0; j < 4; ++j) {
+            int idx = ix - 1 + j; idx = idx < 0 ? 0 : (idx > in - 1 ? in - 1 : idx);
+            wt[(size_t)i * maxk + (idx - lo)] += c[j];
+            last = idx - lo;
+        }
+        sz[i] = last + 1;
+    }
+}
+
 static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
     pvr_vit *v = e->vit;
     if (v->rs_h == h && v->rs_w == w) return PVR_OK;
     const int sh = w <= h ? w : h, lg = w <= h ? h : w;
-    const int ns = v->res, nl = (int)((double)v->res * (double)lg / (double)sh);     // torchvision resize(int size)
+    const int ns = v->resize_to, nl = (int)((double)v->resize_to * (double)lg / (double)sh);     // torchvision resize(int size)
     v->rs_rw = w <= h ? ns : nl; v->rs_rh = w <= h ? nl : ns;
     std::vector<int> xm, xs, ym, ys;
     std::vector<float> wx, wy;
-    aa_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
-    aa_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
+    if (v->mae) {
+        cubic_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
+        cubic_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
+    } else {
+        aa_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
+        aa_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
+    }
     void *old[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp, v->rs_u8};
     PVR_HIP_TRY(hipDeviceSynchronize());
     for (void *q : old) if (q) (void)hipFree(q);
@@ -491,7 +546,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
     PVR_REQUIRE(W == 768, "vit: width %d not built", W);
     // transforms (embeddings.py:309-314): Resize(res, BICUBIC, antialias) is the identity when the short side is res
     const int sh = w <= h ? w : h;
-    const bool resize = sh != v->res;
+    const bool resize = sh != v->resize_to;
     pvr_status s;
     if (resize && (s = aa_prepare(e, h, w))) return s;
     const int eh = resize ? v->rs_rh : h, ew = resize ? v->rs_rw : w;              // size after Resize
@@ -518,7 +573,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         if ((s = launch_conv(v->A, v->w_patch, v->b_patch, nullptr, v->pe, v->zero, prow, 1, 1, K, W, 1, 1, 1, 0, 0, 1, dt, st))) return s;
         // tokens + positional embedding + ln_pre -> residual stream x0 (fp32)
         hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *)nullptr, v->pe, v->cls,
-                           v->pos, v->lnpre_w, v->lnpre_b, v->x0, (u16 *)nullptr, rows, T);
+                           v->pos, v->lnpre_w, v->lnpre_b, v->x0, (u16 *)nullptr, rows, T, v->eps, v->mae ? 0 : 1);
         PVR_LAUNCH_CHECK();
         e->last_n = nb;
         const std::string &stop = e->stop_after;
@@ -528,7 +583,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         const size_t att_lds = (size_t)v->TK * 128 + (size_t)64 * (v->TK + 4) * 2;
         for (auto &b : v->blocks) {
             hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T);
+                               (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
             if ((s = launch_conv(v->y, b.w_qkv, b.b_qkv, nullptr, v->qkv, v->zero, rows, 1, 1, W, 3 * W, 1, 1, 1, 0, 0, 0, dt, st))) return s;
             if (bi == 0 && stop == "qkv0") return PVR_OK;
             hipLaunchKernelGGL(attention_kernel<F16>, dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
@@ -538,15 +593,15 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
             if ((s = launch_conv(v->att, b.w_out, b.b_out, x, xn, v->zero, rows, 1, 1, W, W, 1, 1, 1, 0, 0, 3, dt, st))) return s;
             if (bi == 0 && stop == "res0") return PVR_OK;
             hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, xn, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, b.ln2_w, b.ln2_b, (float *)nullptr, v->y, rows, T);
-            if ((s = launch_conv(v->y, b.w_fc, b.b_fc, nullptr, v->hid, v->zero, rows, 1, 1, W, 4 * W, 1, 1, 1, 0, 2, 0, dt, st))) return s;   // QuickGELU
+                               (const float *)nullptr, (const float *)nullptr, b.ln2_w, b.ln2_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
+            if ((s = launch_conv(v->y, b.w_fc, b.b_fc, nullptr, v->hid, v->zero, rows, 1, 1, W, 4 * W, 1, 1, 1, 0, v->act, 0, dt, st))) return s;   // QuickGELU / GELU
             if (bi == 0 && stop == "fc0") return PVR_OK;
             if ((s = launch_conv(v->hid, b.w_proj, b.b_proj, xn, x, v->zero, rows, 1, 1, 4 * W, W, 1, 1, 1, 0, 0, 3, dt, st))) return s;
             if (stop == "block" + std::to_string(bi)) return PVR_OK;
             ++bi;
         }
         hipLaunchKernelGGL((cls_head_kernel<768>), dim3(nb), dim3(256), 0, st, x, v->lnpost_w, v->lnpost_b, v->proj,
-                           out + (size_t)f0 * out_stride, out_stride, T, v->out_dim);
+                           out + (size_t)f0 * out_stride, out_stride, T, v->out_dim, v->eps);
         PVR_LAUNCH_CHECK();
         e->last_n = nb;
     }

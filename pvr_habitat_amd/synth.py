@@ -241,3 +241,48 @@ def clip_vit_state_dict(seed=1, patch=32, width=768, layers=12, out_dim=512, res
         sd[p + 'mlp.c_proj.weight'] = normal(seed, p + 'pjw', (width, 4 * width), std=float((4 * width) ** -0.5) * 0.5)
         sd[p + 'mlp.c_proj.bias'] = uniform(seed, p + 'pjb', (width,), -0.05, 0.05)
     return sd
+
+
+# ------------------------------------------------------------------------------------------
+# MAE ViT-B/16 encoder (reference src/vision_models/mae.py:74-130, 202-222; timm 0.5.4 Block / PatchEmbed keys)
+# ------------------------------------------------------------------------------------------
+def sincos_2d_pos_embed(embed_dim, grid_size, cls_token=True):
+    """Fixed 2-D sin-cos position embedding of MAE (mae.py:23-70): first half of the channels encodes the
+    w coordinate of np.meshgrid(w, h), second half the h coordinate; sin block then cos block per half."""
+    def one_d(dim, pos):
+        omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+        out = np.einsum('m,d->md', pos.reshape(-1).astype(np.float64), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid_size, grid_size)     # "here w goes first"
+    emb = np.concatenate([one_d(embed_dim // 2, grid[0]), one_d(embed_dim // 2, grid[1])], axis=1)
+    if cls_token:
+        emb = np.concatenate([np.zeros((1, embed_dim)), emb], axis=0)
+    return emb.astype(np.float32)
+
+
+def mae_vit_state_dict(seed=1, patch=16, width=768, layers=12, resolution=224):
+    sd = {}
+    grid = resolution // patch
+    s = width ** -0.5
+    sd['cls_token'] = normal(seed, 'mae.cls', (1, 1, width), std=0.02)
+    sd['pos_embed'] = sincos_2d_pos_embed(width, grid)[None]
+    sd['patch_embed.proj.weight'] = normal(seed, 'mae.pe.w', (width, 3, patch, patch), std=float(np.sqrt(1.0 / (3 * patch * patch))))
+    sd['patch_embed.proj.bias'] = uniform(seed, 'mae.pe.b', (width,), -0.05, 0.05)
+    for i in range(layers):
+        p = 'blocks.%d.' % i
+        for ln in ('norm1', 'norm2'):
+            sd[p + ln + '.weight'] = uniform(seed, p + ln + 'w', (width,), 0.8, 1.2)
+            sd[p + ln + '.bias'] = uniform(seed, p + ln + 'b', (width,), -0.1, 0.1)
+        sd[p + 'attn.qkv.weight'] = normal(seed, p + 'qkvw', (3 * width, width), std=s)
+        sd[p + 'attn.qkv.bias'] = uniform(seed, p + 'qkvb', (3 * width,), -0.05, 0.05)
+        sd[p + 'attn.proj.weight'] = normal(seed, p + 'projw', (width, width), std=s * 0.5)
+        sd[p + 'attn.proj.bias'] = uniform(seed, p + 'projb', (width,), -0.05, 0.05)
+        sd[p + 'mlp.fc1.weight'] = normal(seed, p + 'fc1w', (4 * width, width), std=s)
+        sd[p + 'mlp.fc1.bias'] = uniform(seed, p + 'fc1b', (4 * width,), -0.05, 0.05)
+        sd[p + 'mlp.fc2.weight'] = normal(seed, p + 'fc2w', (width, 4 * width), std=float((4 * width) ** -0.5) * 0.5)
+        sd[p + 'mlp.fc2.bias'] = uniform(seed, p + 'fc2b', (width,), -0.05, 0.05)
+    sd['norm.weight'] = uniform(seed, 'mae.norm.w', (width,), 0.8, 1.2)
+    sd['norm.bias'] = uniform(seed, 'mae.norm.b', (width,), -0.1, 0.1)
+    return sd

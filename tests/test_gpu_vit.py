@@ -60,3 +60,25 @@ def test_clip_antialiased_bicubic_resize(h, w):
     ref = vo.embed(sd, fr, squeeze=False)
     l2 = float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
     assert l2 < 1e-3, l2
+
+
+@pytest.mark.parametrize('h,w', [(224, 224), (64, 64), (300, 256)])
+def test_mae_vit_b16_matches_oracle(h, w):
+    """MAE ViT-B/16 encoder (mae.py:202-222), Resize(256, bicubic) + CenterCrop(224), CLS output 768."""
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.mae_vit_state_dict(1)
+    fr = synth.smooth_frames(47, 2, h, w)
+    ref = vo.mae_embed(sd, fr, squeeze=False)
+    m = HipResNet50(sd, 'mae_b16', compute_dtype='f16', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert out.shape == (2, 768)
+    if min(h, w) != 256:                                         # short side 256: Resize is the identity, nothing to tap
+        u8 = vo.mae_preprocess_u8(fr).permute(0, 2, 3, 1).numpy().astype(np.float32)
+        got = m.tap('resized', u8.size).cpu().numpy().reshape(u8.shape)
+        d = np.abs(got - u8)
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    l2, mx = _rel(out, ref)
+    print('\n[mae_b16 f16 %dx%d] rel-L2 %.2e max-norm %.2e' % (h, w, l2, mx))
+    assert l2 < 1e-3

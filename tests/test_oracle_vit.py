@@ -57,3 +57,42 @@ def test_vit_b16_tokens_and_transforms():
     assert vo.embed(sd, fr).shape == (512,)
     up = vo.preprocess_u8(synth.smooth_frames(3, 1, 64, 64))                # 64 -> 224 antialiased bicubic, clamped
     assert up.shape == (1, 3, 224, 224) and up.dtype == torch.uint8
+
+
+def test_mae_vit_b16_matches_independent_implementation():
+    """oracle mae_encode vs transformers.ViTModel (timm-layout ViT: qkv bias, exact GELU, LN eps 1e-6)."""
+    from transformers import ViTConfig, ViTModel
+    torch.set_num_threads(8)
+    sd = synth.mae_vit_state_dict(1)
+    cfg = ViTConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, hidden_act='gelu',
+                    layer_norm_eps=1e-6, image_size=224, patch_size=16, qkv_bias=True)
+    m = ViTModel(cfg, add_pooling_layer=False).eval()
+    t = lambda k: torch.from_numpy(np.array(sd[k]))
+    new = {'embeddings.cls_token': t('cls_token'), 'embeddings.position_embeddings': t('pos_embed'),
+           'embeddings.patch_embeddings.projection.weight': t('patch_embed.proj.weight'),
+           'embeddings.patch_embeddings.projection.bias': t('patch_embed.proj.bias'),
+           'layernorm.weight': t('norm.weight'), 'layernorm.bias': t('norm.bias')}
+    for i in range(12):
+        p, q = 'blocks.%d.' % i, 'layers.%d.' % i
+        w, b = t(p + 'attn.qkv.weight'), t(p + 'attn.qkv.bias')
+        for j, nm in enumerate(('q_proj', 'k_proj', 'v_proj')):
+            new[q + 'attention.%s.weight' % nm] = w[j * 768:(j + 1) * 768].clone()
+            new[q + 'attention.%s.bias' % nm] = b[j * 768:(j + 1) * 768].clone()
+        new[q + 'attention.o_proj.weight'] = t(p + 'attn.proj.weight'); new[q + 'attention.o_proj.bias'] = t(p + 'attn.proj.bias')
+        new[q + 'layernorm_before.weight'] = t(p + 'norm1.weight'); new[q + 'layernorm_before.bias'] = t(p + 'norm1.bias')
+        new[q + 'layernorm_after.weight'] = t(p + 'norm2.weight'); new[q + 'layernorm_after.bias'] = t(p + 'norm2.bias')
+        new[q + 'mlp.fc1.weight'] = t(p + 'mlp.fc1.weight'); new[q + 'mlp.fc1.bias'] = t(p + 'mlp.fc1.bias')
+        new[q + 'mlp.fc2.weight'] = t(p + 'mlp.fc2.weight'); new[q + 'mlp.fc2.bias'] = t(p + 'mlp.fc2.bias')
+    missing, unexpected = m.load_state_dict(new, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    fr = synth.smooth_frames(6, 2, 224, 224)
+    x = vo.mae_preprocess(fr)
+    with torch.no_grad():
+        ours = vo.mae_encode(sd, x).numpy()
+        hf = m(pixel_values=x).last_hidden_state[:, 0].numpy()
+    np.testing.assert_allclose(ours, hf, rtol=2e-4, atol=2e-5)
+    # fixed sin-cos table: position (h=0,w=0) is [0..0 | 1..1] per half, cls row is zero (mae.py:37-38)
+    pe = sd['pos_embed'][0]
+    assert np.all(pe[0] == 0) and np.allclose(pe[1, :192], 0) and np.allclose(pe[1, 192:384], 1)
+    up = vo.mae_preprocess_u8(synth.smooth_frames(3, 1, 64, 64))
+    assert up.shape == (1, 3, 224, 224)
