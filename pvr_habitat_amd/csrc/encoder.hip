@@ -164,7 +164,7 @@ extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
-    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_MAE_VIT_B16, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_RANDOM5, "unknown arch %d", desc->arch);
     PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16, "dtype must be PVR_BF16 or PVR_F16");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
     PVR_REQUIRE(desc->crop == 224, "crop must be 224 (reference embeddings.py:82; CLIP input_resolution 224)");
@@ -172,7 +172,9 @@ pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     pvr_encoder *e = new pvr_encoder();
     e->desc = *desc;
     if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
-    if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32) {
+    if (e->desc.arch == PVR_ARCH_RANDOM5) {
+        random5_create(e);
+    } else if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32) {
         pvr_status s = vit_create(e);
         if (s) { delete e; return s; }
     } else {
@@ -198,8 +200,8 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     PVR_REQUIRE(enc, "null encoder");
     PVR_REQUIRE(!enc->finalized, "encoder already finalized");
     pvr_status s;
-    if (enc->vit) {
-        if ((s = vit_finalize(enc))) return s;
+    if (enc->vit || enc->rnd) {
+        if ((s = enc->vit ? vit_finalize(enc) : random5_finalize(enc))) return s;
         PVR_HIP_TRY(hipDeviceSynchronize());
         enc->weights.clear();
         enc->finalized = true;
@@ -244,6 +246,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
     const int dt = enc->desc.dtype;
     pvr_status s;
     if (enc->vit) return vit_forward(enc, frames, n, h, w, out, out_stride, st);
+    if (enc->rnd) return random5_forward(enc, frames, n, h, w, out, out_stride, st);
     for (int f0 = 0; f0 < n; f0 += enc->desc.chunk) {
         const int nb = (n - f0 < enc->desc.chunk) ? n - f0 : enc->desc.chunk;
         const uint8_t *fr = frames + (size_t)f0 * h * w * 3;
@@ -370,6 +373,7 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
 void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
     if (enc->vit) vit_destroy(enc);
+    if (enc->rnd) random5_destroy(enc);
     for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_b) (void)hipFree(op.d_b); }
     for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
     if (enc->d_img) (void)hipFree(enc->d_img);

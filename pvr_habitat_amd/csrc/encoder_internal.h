@@ -53,7 +53,8 @@ struct pvr_encoder {
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap
     std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
-    struct pvr_vit *vit = nullptr;                                   // CLIP ViT plan (vit.hip) when arch >= PVR_ARCH_CLIP_VIT_B32
+    struct pvr_vit *vit = nullptr;
+    struct pvr_random5 *rnd = nullptr;                               // 'random' 5-conv PVR (random_pvr.hip)                                   // CLIP ViT plan (vit.hip) when arch >= PVR_ARCH_CLIP_VIT_B32
 };
 
 
@@ -66,6 +67,11 @@ pvr_status enc_upload(T **dptr, const std::vector<T> &h) {
     PVR_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return PVR_OK;
 }
+// random_pvr.hip
+pvr_status random5_create(pvr_encoder *e);
+pvr_status random5_finalize(pvr_encoder *e);
+pvr_status random5_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st);
+void random5_destroy(pvr_encoder *e);
 // vit.hip
 pvr_status vit_create(pvr_encoder *e);
 pvr_status vit_finalize(pvr_encoder *e);

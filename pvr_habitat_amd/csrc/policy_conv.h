@@ -10,7 +10,7 @@
 namespace pvr {
 
 struct ConvFP {
-    const void *in;          // CIN==3: uint8 obs (N,64,64,3*nf); else fp32 NHWC [F][Sin][Sin][32]
+    const void *in;          // CIN==3: uint8 obs (N,64,64,3*nf); CIN==4: fp32 NHWC [F][Sin][Sin][4] (RGB + zero pad); else fp32 NHWC [F][Sin][Sin][32]
     const float *W, *bias;   // [32][9][CINP] (CINP = 4 or 32), [32]
     float *out;              // [F][So][So][32] post-ELU
     int F, Sin, So, nf;      // F frames (= N*nf)
@@ -18,8 +18,8 @@ struct ConvFP {
 
 // forward: wave = 16 output pixels x 32 channels
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
-    constexpr int CP = CIN == 3 ? 4 : 32;
+static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
+    constexpr int CP = CIN <= 4 ? 4 : 32;
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long npix = (long long)p.F * p.So * p.So;
@@ -42,6 +42,11 @@ __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
                 const uint8_t *x = (const uint8_t *)p.in;
                 a = (float)x[(((size_t)n * p.Sin + ix) * p.Sin + iy) * (3 * p.nf) + 3 * fi + fq] / 255.0f;
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
+        } else if constexpr (CIN == 4) {
+            // 'random' PVR first layer: normalised fp32 image, k-slot fq = channel (slot 3 is the zero pad)
+            const float a = ok ? ((const float *)p.in)[(((size_t)f * p.Sin + iy) * p.Sin + ix) * 4 + fq] : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
         } else {
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
 }
 
 // d(pre-activation) = d(out) * (out > 0 ? 1 : out + 1)   in place  (elu'(x) = exp(x) = out + 1 for x <= 0)
-__global__ __launch_bounds__(256) void elu_bwd_kernel(float *__restrict__ d, const float *__restrict__ out, size_t n4) {
+static __global__ __launch_bounds__(256) void elu_bwd_kernel(float *__restrict__ d, const float *__restrict__ out, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 g = reinterpret_cast<f32x4 *>(d)[i];
         const f32x4 o = reinterpret_cast<const f32x4 *>(out)[i];
@@ -93,7 +98,7 @@ struct ConvWP {
 };
 
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
+static __global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
     constexpr int CP = CIN == 3 ? 4 : 32;
     constexpr int NT = CIN == 3 ? 3 : 18;                 // 16-column tiles over the 9*CP columns (36 / 288)
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
@@ -156,7 +161,7 @@ struct ConvDP {
     int F, Sin, So;
 };
 
-__global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
+static __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long npix = (long long)p.F * p.Sin * p.Sin;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
 }
 
 // W [32 co][9][32 ci] -> Wt [9][32 ci][32 co]
-__global__ __launch_bounds__(256) void conv_wt_kernel(const float *__restrict__ W, float *__restrict__ Wt) {
+static __global__ __launch_bounds__(256) void conv_wt_kernel(const float *__restrict__ W, float *__restrict__ Wt) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 9 * 32 * 32; i += gridDim.x * 256) {
         const int co = i % 32, ci = (i / 32) % 32, tap = i / 1024;
         Wt[i] = W[(co * 9 + tap) * 32 + ci];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_wt_kernel(const float *__restrict__ 
 
 // OIHW (32,CIN,3,3) <-> [32][9][CP] packing of the reference parameter (and back for gradients)
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ oihw, float *__restrict__ packed, int to_packed) {
+static __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ oihw, float *__restrict__ packed, int to_packed) {
     constexpr int CP = CIN == 3 ? 4 : 32;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 32 * 9 * CP; i += gridDim.x * 256) {
         const int ci = i % CP, tap = (i / CP) % 9, co = i / (9 * CP);
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
 }
 
 // features: feat[n][c*(4*nf) + a*(2*nf) + fi*2 + b] = act5[n*nf + fi][a][b][c]   (torch.cat(..., -1).view(T*B, -1))
-__global__ __launch_bounds__(256) void conv_feat_kernel(float *__restrict__ act5, float *__restrict__ feat, int N, int nf, int to_feat) {
+static __global__ __launch_bounds__(256) void conv_feat_kernel(float *__restrict__ act5, float *__restrict__ feat, int N, int nf, int to_feat) {
     const int per = 32 * 4 * nf;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N * per; i += gridDim.x * 256) {
         const int n = i / per, k = i % per;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_feat_kernel(float *__restrict__ act5
 }
 
 // partial[g][c] = sum over rows [g*per, min((g+1)*per, R)) of X[r][c], C = 32 (bias gradients of the conv stack)
-__global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float *__restrict__ X, float *__restrict__ partial, int R, int per) {
+static __global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float *__restrict__ X, float *__restrict__ partial, int R, int per) {
     __shared__ float s[8][33];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int beg = blockIdx.x * per, end = beg + per < R ? beg + per : R;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float *__res
 }
 
 // BatchNorm1d input gradient: dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N)
-__global__ __launch_bounds__(256) void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
+static __global__ __launch_bounds__(256) void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
                                                     const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                     const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                     float *__restrict__ dx, int N, int C) {

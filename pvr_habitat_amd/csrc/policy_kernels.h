@@ -29,7 +29,7 @@ struct GemmP {
 };
 
 template <bool ATR, bool BTR>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int LDN = 36;        // [rows][k] stride (floats) of a k-contiguous operand tile
     constexpr int LDT = 80;        // [k][rows] stride of a row-contiguous operand tile (== 16 mod 32: conflict-free)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 }
 
 // [R][C] -> [C][R]
-__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
+static __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
     __shared__ float t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -163,7 +163,7 @@ struct ColP {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
+static __global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
     __shared__ float s0[8][33], s1[8][33];
     const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
 }
 
 // y = (x - mean) * invstd * gamma + beta  (training: batch stats; eval: running stats, invstd computed here)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+static __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd_or_var, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, float *__restrict__ y, size_t total4,
                                                        int C, int is_var) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void notdone_kernel(const uint8_t *__restrict__ done, float *__restrict__ nd, int n) {
+static __global__ __launch_bounds__(256) void notdone_kernel(const uint8_t *__restrict__ done, float *__restrict__ nd, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) nd[i] = fabsf(1.0f - (done[i] ? 1.0f : 0.0f));      // models.py:66
 }
@@ -249,7 +249,7 @@ struct LstmFwdP {
     int B, H;
 };
 
-__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
+static __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
     __shared__ float part[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -327,7 +327,7 @@ struct LstmRecP {
     int B, H;
 };
 
-__global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) {
+static __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) {
     __shared__ float part[4][4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int H = p.H, K = 4 * p.H;
@@ -379,7 +379,7 @@ struct LstmCellBP {
     int B, H;
 };
 
-__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) {
+static __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int H = p.H;
     if (i >= p.B * H) return;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) {
 }
 
 // Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh
-__global__ __launch_bounds__(256) void hprev_kernel(const float *__restrict__ hs, const float *__restrict__ h_init,
+static __global__ __launch_bounds__(256) void hprev_kernel(const float *__restrict__ hs, const float *__restrict__ h_init,
                                                     const float *__restrict__ nd, float *__restrict__ out, int T, int B, int H) {
     const size_t total4 = (size_t)T * B * H / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
@@ -434,7 +434,7 @@ struct HeadP {
     int N, H, A;
 };
 
-__global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
+static __global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
 }
 
 // fixed-order sum of n values scaled by `scale` -> out[0]  (loss mean; 1 block)
-__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int n, float scale, float *__restrict__ out) {
+static __global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int n, float scale, float *__restrict__ out) {
     __shared__ float s[256];
     float a = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) a += x[i];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, i
 }
 
 // dout[n][k] = sum_a dlogits[n][a] * Wp[a][k]
-__global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dl, const float *__restrict__ Wp,
+static __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dl, const float *__restrict__ Wp,
                                                       float *__restrict__ dout, int N, int H, int A) {
     const size_t total = (size_t)N * H;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
 }
 
 // dWp[a][k] = sum_n dlogits[n][a] * out[n][k];  dbp[a] = sum_n dlogits[n][a]   (32 columns x 8 row groups / block)
-__global__ __launch_bounds__(256) void head_dw_kernel(const float *__restrict__ dl, const float *__restrict__ out,
+static __global__ __launch_bounds__(256) void head_dw_kernel(const float *__restrict__ dl, const float *__restrict__ out,
                                                       float *__restrict__ dWp, float *__restrict__ dbp, int N, int H, int A) {
     __shared__ float s[8][33];
     const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void head_dw_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // grad norm + clip + RMSprop (main_bc_2.py:220-227; torch.optim.RMSprop momentum=0, centered=False)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial) {
+static __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial) {
     __shared__ float s[256];
     const size_t per = (n + gridDim.x - 1) / gridDim.x;
     const size_t beg = (size_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restr
 }
 
 // stats[1] = ||g||, stats[2] = clip coefficient min(1, max_norm / (norm + 1e-6))
-__global__ __launch_bounds__(256) void norm_final_kernel(const float *__restrict__ partial, int n, float max_norm, float *__restrict__ stats) {
+static __global__ __launch_bounds__(256) void norm_final_kernel(const float *__restrict__ partial, int n, float max_norm, float *__restrict__ stats) {
     __shared__ float s[256];
     float a = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__ p, float *__restrict__ v, const float *__restrict__ g,
+static __global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__ p, float *__restrict__ v, const float *__restrict__ g,
                                                       const float *__restrict__ stats, size_t n4, float lr, float alpha, float eps) {
     const float coef = stats[2];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {

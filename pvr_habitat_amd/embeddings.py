@@ -25,9 +25,9 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768}
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'random5': 1568}
 _ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3,
-         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5}
+         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6}
 
 # ---------------------------------------------------------------------------------------------
 # name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
@@ -66,7 +66,7 @@ for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_cropo
     for _combo in ('345', '35', '34', '45'):
         _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
 # names the reference registers but whose model families are not built yet
-_NOT_BUILT = ('random', 'resnet18', 'resnet34', 'mae_large', 'mae_huge', 'maskrcnn_l3', 'clip_rn50')
+_NOT_BUILT = ('resnet18', 'resnet34', 'mae_large', 'mae_huge', 'maskrcnn_l3', 'clip_rn50')
 # CLIP visual towers: 'clip_vit' is the reference's name (ViT-B/32, embeddings.py:303-304); 'clip_vit_b16' is the
 # same block layout at patch 16 (BASELINE config 3), not a reference registry name
 _CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16)}
@@ -325,6 +325,14 @@ def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, trai
         else:
             raise FileNotFoundError(ckpt)
         model = HipResNet50(sd, variant, **hip_kw)
+    elif embedding_name == 'random':
+        # embeddings.py:90-106: orthogonal(gain=relu) weights, zero bias, same constructor order -> same weights per torch seed
+        init_ = lambda m: (nn.init.orthogonal_(m.weight.data, gain=nn.init.calculate_gain('relu')), nn.init.constant_(m.bias.data, 0), m)[2]
+        layers, cin = [], in_channels
+        for _ in range(5):
+            layers += [init_(nn.Conv2d(cin, 32, kernel_size=(3, 3), stride=2, padding=1)), nn.ELU()]
+            cin = 32
+        model = HipResNet50(nn.Sequential(*layers).state_dict(), 'random5', **hip_kw)
     elif embedding_name == 'mae_base':                # embeddings.py:137-140; encoder keys only (strict=False there)
         f = _find_checkpoint('mae_pretrain_vit_base.pth') if pretrained else None
         if f is not None:

@@ -238,3 +238,23 @@ def test_stream_embed_matches_batched_calls(monkeypatch):
     a = stream_embed(net, fr, batch=16)
     b = np.concatenate([net(torch.from_numpy(fr[i:i + 16])).reshape(-1, 2048) for i in range(0, 70, 16)])
     assert a.shape == (70, 2048) and np.array_equal(a, b)
+
+
+def test_random_pvr_matches_torch():
+    """EmbeddingNet('random') = default transforms + 5 x (conv3x3 s2 + ELU), fp32, C-major flatten."""
+    import torch.nn.functional as F
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import EmbeddingNet
+    torch.manual_seed(3)
+    net = EmbeddingNet('random', max_batch=4)
+    assert net.out_size == 1568 and list(net.state_dict())[:2] == ['embedding.0.weight', 'embedding.0.bias']
+    fr = synth.smooth_frames(51, 3, 64, 64)
+    out = net(torch.from_numpy(fr))
+    sd = net.state_dict()
+    with torch.no_grad():
+        x = eo.preprocess(fr)
+        for l in range(5):
+            x = F.elu(F.conv2d(x, sd['embedding.%d.weight' % (2 * l)], sd['embedding.%d.bias' % (2 * l)], 2, 1))
+        ref = x.reshape(3, -1).numpy()
+    assert out.shape == (3, 1568)
+    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
