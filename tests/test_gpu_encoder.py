@@ -258,3 +258,18 @@ def test_random_pvr_matches_torch():
         ref = x.reshape(3, -1).numpy()
     assert out.shape == (3, 1568)
     np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 65, 91), (5, 256, 341), (2, 480, 270)])
+def test_odd_frame_sizes_and_single_frame(n, h, w):
+    """Non-square, non-dyadic frames and N=1 (the PNG loader embeds one frame per call, save_embedded_obs.py:69-77)."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(4, 'conv5')
+    fr = synth.smooth_frames(61, n, h, w)
+    ref = eo.embed(sd, fr, 'conv5', squeeze=False)
+    m = HipResNet50(sd, 'conv5', compute_dtype='f16', max_batch=8)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    l2, mx = _relerr(out, ref)
+    assert out.shape == (n, 2048) and l2 < 1e-3, (l2, mx)        # <=1 LSB resize ties are far below the f16 noise

@@ -159,3 +159,85 @@ def test_policy_step_is_deterministic_and_single_step_eval():
         acts.append(int(out['action']))
     ref, _ = m(dict(obs=torch.from_numpy(obs[0][:5, :1]), done=torch.zeros(5, 1, dtype=torch.bool)), m.initial_state(1))
     assert acts == [int(a) for a in ref['action'].flatten()]
+
+
+@pytest.mark.parametrize('T,B', [(1, 1), (3, 5), (7, 17), (2, 33)])
+def test_policy_ragged_shapes_match_oracle(T, B):
+    """Batch sizes that are not multiples of the 16-row MFMA tile (padded rows must not leak), T=1, carried state."""
+    from oracle import policy_oracle as po
+    from pvr_habitat_amd.models import HipRMSprop
+    O, A = 64, 3
+    m, sd = _model(11, O, A, True, T, B)
+    obs, done, act = synth.bc_batches(11, T, B, O, A, 1)
+    done[0, 0, :] = False
+    p = po.to_params(sd)
+    h0 = torch.from_numpy(synth.normal(11, 'h0', (2, B, 1024), std=0.3)); c0 = torch.from_numpy(synth.normal(11, 'c0', (2, B, 1024), std=0.3))
+    m.eval()
+    out, st = m(dict(obs=torch.from_numpy(obs[0]), done=torch.from_numpy(done[0])), (h0, c0))
+    with torch.no_grad():
+        ref, rst = po.forward(p, torch.from_numpy(obs[0]), torch.from_numpy(done[0]), (h0, c0), True, training=False)
+    np.testing.assert_allclose(out['policy_logits'].cpu().numpy(), ref['policy_logits'].numpy(), rtol=1e-4, atol=5e-5)
+    assert np.array_equal(out['action'].cpu().numpy(), ref['action'].numpy())
+    np.testing.assert_allclose(st[1].cpu().numpy(), rst[1].numpy(), rtol=1e-4, atol=1e-4)
+    if T * B > 1:                                                # BatchNorm1d training needs more than one row
+        m.train()
+        opt = HipRMSprop(m, max_epochs=10)
+        o = po.RMSpropState(p, max_epochs=10)
+        opt.scheduler_step()
+        loss, gn = opt.step(torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(act[0]))
+        rl, rg, _ = po.bc_step(p, o, torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(act[0]), True)
+        assert float(loss) == pytest.approx(rl, rel=2e-5) and float(gn) == pytest.approx(rg, rel=3e-4)
+        for k in ('core.weight_hh_l0', 'fc.1.weight', 'policy.bias', 'fc.0.weight'):
+            np.testing.assert_allclose(m.state_dict()[k].cpu().numpy(), p[k].detach().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+_DP_GPU_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pvr_habitat_amd import synth
+from pvr_habitat_amd.models import PolicyNet, PolicyNetWithConv, HipRMSprop
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)       # two ranks share the single test GPU: gloo, not RCCL
+conv = sys.argv[2] == 'conv'
+T, B, O, A = 6, 8, 128, 3
+if conv:
+    m = PolicyNetWithConv((64, 64, 6), A, False, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(21, 256, A, False, conv=True)
+    obs, done, act = synth.bc_conv_batches(21, T, B, 2, A)
+else:
+    m = PolicyNet((O,), A, False, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(21, O, A, False)
+    obs, done, act = synth.bc_batches(21, T, B, O, A, 2)
+m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+m = m.to('cuda').train()
+opt = HipRMSprop(m, max_epochs=20)
+lo, hi = rank * B // world, (rank + 1) * B // world
+for s in range(2):
+    opt.scheduler_step()
+    loss, gn = opt.step_data_parallel(torch.from_numpy(obs[s][:, lo:hi]), torch.from_numpy(done[s][:, lo:hi]), torch.from_numpy(act[s][:, lo:hi]))
+if rank == 0:
+    np.savez(sys.argv[1], flat=m._flat.cpu().numpy(), loss=float(loss), gn=float(gn))
+dist.barrier()
+'''
+
+
+@pytest.mark.parametrize('kind', ['vec', 'conv'])
+def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
+    """Finetune DP (SURVEY 8e): 2 ranks x B/2 sequences + one all-reduce of the flat gradient == 1 rank x B
+    (BatchNorm off: its statistics are per rank, see DESIGN.md section 6).  Both ranks run on the one test GPU."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dp_gpu.py'
+    script.write_text(_DP_GPU_WORKER % dict(root=root))
+    res = {}
+    for world in (1, 2):
+        out = tmp_path / ('w%d.npz' % world)
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29751 + world))
+            procs.append(subprocess.Popen([sys.executable, str(script), str(out), kind], env=env))
+        assert all(p.wait(timeout=300) == 0 for p in procs)
+        res[world] = np.load(out)
+    assert float(res[2]['loss']) == pytest.approx(float(res[1]['loss']), rel=1e-5)
+    assert float(res[2]['gn']) == pytest.approx(float(res[1]['gn']), rel=1e-4)
+    np.testing.assert_allclose(res[2]['flat'], res[1]['flat'], rtol=1e-4, atol=1e-6)
