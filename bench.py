@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_FRAME = 8.174           # 2 x 4.0871 GMAC, 53 convs @ 224x224
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3           # f32-input MFMA (= the fp32 vector rate), reference-precision mode only
 
 
 def conv_algorithmic_bytes(n):
@@ -168,7 +169,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--frame', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
@@ -243,6 +244,9 @@ def main():
             tf = op_fl[i] / (op_ms[i] * 1e-3) / 1e12 if op_ms[i] > 0 else 0.0
             print('%-28s %8.3f ms %8.1f TFLOP/s' % (names[i] if i < len(names) else '?', op_ms[i], tf), file=sys.stderr)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_F32_TFLOPS if args.dtype == 'f32' else PEAK_BF16_TFLOPS
+    if args.dtype == 'f32':
+        traffic = None                                       # the PMC passes were taken on the bf16 kernel
     barrier()
 
     if rank == 0:
@@ -256,11 +260,11 @@ def main():
                        'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk,
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
             'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_note': 'avg HBM bytes per conv launch, rocprofv3 PMC passes (profiles/pmc_conv_traffic.json); algorithmic '
                                          'in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': 'conv_igemm_kernel (all %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'conv_igemm_kernel') + ' %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},
         }
@@ -269,7 +273,8 @@ def main():
         if world == 1 and not args.no_pcie:
             line['pcie_inclusive'] = pcie_bench(sd, args.batch, args.frame, args.dtype)
         if world == 1 and not args.no_vit:
-            line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, args.dtype), vit_bench('clip_b32', args.batch, 5, 2, args.dtype)]
+            vdt = 'f16' if args.dtype == 'f32' else args.dtype   # the fp32 mode covers the ResNet50 family only
+            line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, vdt), vit_bench('clip_b32', args.batch, 5, 2, vdt)]
         if world == 1 and not args.no_bc:
             line['bc'] = bc_bench(max(args.steps, 10), args.warmup, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)

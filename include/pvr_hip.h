@@ -32,7 +32,8 @@ typedef int pvr_status;
 #define PVR_ERR_STATE 4
 
 /* storage / MFMA input type of the encoder ("throughput" = bf16, "parity" = f16); accumulation
- * is always fp32 */
+ * is always fp32.  PVR_F32 (ResNet50 family only) stores and multiplies in fp32 on the f32-input MFMA: the
+ * reference's own arithmetic type, ~1e-6 from the fp32 oracle, at the f32 MFMA rate */
 #define PVR_BF16 0
 #define PVR_F16 1
 #define PVR_F32 2
@@ -59,7 +60,7 @@ typedef struct pvr_encoder pvr_encoder;
 
 typedef struct pvr_encoder_desc {
     int32_t arch;          /* PVR_ARCH_* */
-    int32_t dtype;         /* PVR_BF16 or PVR_F16 */
+    int32_t dtype;         /* PVR_BF16, PVR_F16, or PVR_F32 (ResNet50 family) */
     int32_t max_batch;     /* frames per forward call the workspace is sized for */
     int32_t chunk;         /* frames pushed through the layer stack at a time (0 = max_batch) */
     int32_t resize;        /* short-side target, 256 (embeddings.py:81) */

@@ -131,6 +131,16 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
                 }
     std::vector<float> hb(cout_pad, 0.f);
     for (int co = 0; co < cor; ++co) hb[co] = shift[co];
+    if (e->desc.dtype == PVR_F32) {               // reference-precision mode: same layout, fp32 values
+        std::vector<float> hf(cout_pad * K, 0.f);
+        for (int co = 0; co < cor; ++co)
+            for (int ci = 0; ci < cr; ++ci)
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < k; ++b)
+                        hf[co * K + ((size_t)a * k + b) * op.cin + ci] = w->data[(((size_t)co * cr + ci) * k + a) * k + b] * scale[co];
+        if ((s = enc_upload(&op.d_wf, hf))) return s;
+        return enc_upload(&op.d_b, hb);
+    }
     if ((s = enc_upload(&op.d_w, hw))) return s;
     return enc_upload(&op.d_b, hb);
 }
@@ -141,6 +151,14 @@ static pvr_status finalize_stem(pvr_encoder *e) {
     if ((s = enc_need(e, "conv1.weight", &w, 64 * 3 * 7 * 7))) return s;
     std::vector<float> scale, shift;
     if ((s = bn_fold(e, "bn1", 64, scale, shift))) return s;
+    if (e->desc.dtype == PVR_F32) {               // normalisation stays a separate fp32 kernel, exactly as torch applies it
+        std::vector<float> hf(64 * 49 * 4, 0.f);
+        for (int co = 0; co < 64; ++co)
+            for (int c = 0; c < 3; ++c)
+                for (int t = 0; t < 49; ++t) hf[((size_t)co * 49 + t) * 4 + c] = w->data[((size_t)co * 3 + c) * 49 + t] * scale[co];
+        if ((s = enc_upload(&e->d_stem_wf, hf))) return s;
+        return enc_upload(&e->d_stem_b, shift);
+    }
     std::vector<u16> hw(64 * 224, 0);
     for (int co = 0; co < 64; ++co)
         for (int a = 0; a < 7; ++a)
@@ -165,7 +183,8 @@ extern "C" {
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
     PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_RANDOM5, "unknown arch %d", desc->arch);
-    PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16, "dtype must be PVR_BF16 or PVR_F16");
+    PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16 || (desc->dtype == PVR_F32 && desc->arch <= PVR_ARCH_RESNET50_L3),
+                "dtype must be PVR_BF16 or PVR_F16 (PVR_F32 is built for the ResNet50 family only)");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
     PVR_REQUIRE(desc->crop == 224, "crop must be 224 (reference embeddings.py:82; CLIP input_resolution 224)");
     PVR_REQUIRE(desc->resize >= desc->crop, "resize must be >= crop");
@@ -211,15 +230,18 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     for (auto &op : enc->ops)
         if ((s = finalize_conv(enc, op))) return s;
     const int C = enc->desc.chunk, crop = enc->desc.crop;
+    const bool f32 = enc->desc.dtype == PVR_F32;
+    const size_t esz = f32 ? 4 : 2;                               // activation element size
     const size_t img = (size_t)C * (crop + 6) * (crop + 8) * 4;
     PVR_HIP_TRY(hipMalloc((void **)&enc->d_img, img * 2));
     PVR_HIP_TRY(hipMemset(enc->d_img, 0, img * 2));            // zero border = conv1 padding, written once
-    PVR_HIP_TRY(hipMalloc((void **)&enc->d_stem, (size_t)C * 112 * 112 * 64 * 2));
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_stem, (size_t)C * 112 * 112 * 64 * esz));
+    if (f32) PVR_HIP_TRY(hipMalloc((void **)&enc->d_imgf, (size_t)C * crop * crop * 4 * sizeof(float)));
     PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, 256));
     PVR_HIP_TRY(hipMemset(enc->d_zero, 0, 256));
     enc->buf_elems = (size_t)C * 56 * 56 * 256;                 // largest activation (layer1 output)
     for (int b = 0; b < B_COUNT; ++b) {
-        size_t bytes = enc->buf_elems * 2;
+        size_t bytes = enc->buf_elems * esz;
         if (b == B_F32) bytes = (size_t)C * enc->final_hw * enc->final_c * 4;
         PVR_HIP_TRY(hipMalloc(&enc->d_buf[b], bytes));
     }
@@ -260,6 +282,35 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             return PVR_OK;
         };
         if ((s = mark())) return s;
+        if (dt == PVR_F32) {
+            // reference-precision plan: integer transforms (exact, via the bf16 image) -> fp32 /255, Normalize ->
+            // fp32 conv1 -> fp32 maxpool -> fp32 implicit-GEMM convs (f32 MFMA) -> fp32 pool / flatten
+            const int crop = enc->desc.crop;
+            if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, crop, enc->d_img, PVR_BF16, st))) return s;
+            if ((s = launch_normalize_nhwc4(enc->d_img, enc->d_imgf, nb, crop, enc->desc.mean, enc->desc.std_, PVR_BF16, st))) return s;
+            if ((s = mark())) return s;
+            if ((s = launch_stem_f32(enc->d_imgf, enc->d_stem_wf, enc->d_stem_b, (float *)enc->d_stem, nb, crop, st))) return s;
+            if ((s = mark())) return s;
+            if ((s = launch_maxpool_f32((const float *)enc->d_stem, (float *)enc->d_buf[B_X0], nb, 112, 112, 64, st))) return s;
+            if ((s = mark())) return s;
+            enc->last_n = nb;
+            for (auto &op : enc->ops) {
+                const float *res = op.res_buf == B_NONE ? nullptr : (const float *)enc->d_buf[op.res_buf];
+                if ((s = launch_conv_f32((const float *)enc->d_buf[op.in_buf], op.d_wf, op.d_b, res, (float *)enc->d_buf[op.out_buf], nb,
+                                         op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st)))
+                    return s;
+                if ((s = mark())) return s;
+            }
+            float *o32 = out + (size_t)f0 * out_stride;
+            if (enc->desc.arch == PVR_ARCH_RESNET50)
+                s = launch_avgpool(enc->d_buf[B_F32], o32, out_stride, nb, enc->final_hw, enc->final_c, 1, dt, st);
+            else
+                s = launch_nhwc_to_chw((const float *)enc->d_buf[B_F32], o32, out_stride, nb, enc->final_hw, enc->final_c,
+                                       enc->final_creal, st);
+            if (s) return s;
+            if ((s = mark())) return s;
+            continue;
+        }
         if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st))) return s;
         if ((s = mark())) return s;
         enc->last_n = nb;
@@ -374,7 +425,9 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_b) (void)hipFree(op.d_b); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); }
+    if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
+    if (enc->d_imgf) (void)hipFree(enc->d_imgf);
     for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
     if (enc->d_img) (void)hipFree(enc->d_img);
     if (enc->d_stem) (void)hipFree(enc->d_stem);

@@ -30,6 +30,7 @@ struct ConvOp {
     int in_buf, out_buf, res_buf;
     int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
     u16 *d_w = nullptr;
+    float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
     std::string tap;               // non-empty: output of this op is the named tap
 };
@@ -47,7 +48,7 @@ struct pvr_encoder {
     int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation
     // device
     u16 *d_img = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_stem_w = nullptr, *d_zero = nullptr;
-    float *d_stem_b = nullptr;
+    float *d_stem_b = nullptr, *d_stem_wf = nullptr, *d_imgf = nullptr;   // fp32 mode: [64][49][4] stem weights, normalised NHWC4 image
     void *d_buf[B_COUNT] = {nullptr};
     size_t buf_elems = 0;
     int last_n = 0;
@@ -67,6 +68,11 @@ pvr_status enc_upload(T **dptr, const std::vector<T> &h) {
     PVR_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return PVR_OK;
 }
+// conv_f32.hip (PVR_F32 reference-precision mode) and the fp32 normaliser of random_pvr.hip
+pvr_status launch_conv_f32(const float *, const float *, const float *, const float *, float *, int, int, int, int, int, int, int, int, int, hipStream_t);
+pvr_status launch_stem_f32(const float *, const float *, const float *, float *, int, int, hipStream_t);
+pvr_status launch_maxpool_f32(const float *, float *, int, int, int, int, hipStream_t);
+pvr_status launch_normalize_nhwc4(const void *img_h, float *out, int n, int crop, const float *mean, const float *std_, int dtype, hipStream_t);
 // random_pvr.hip
 pvr_status random5_create(pvr_encoder *e);
 pvr_status random5_finalize(pvr_encoder *e);

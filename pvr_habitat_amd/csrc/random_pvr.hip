@@ -26,6 +26,16 @@ __global__ __launch_bounds__(256) void normalize_nhwc4_kernel(const u16 *__restr
 
 }  // namespace pvr
 
+namespace pvr {
+pvr_status launch_normalize_nhwc4(const void *img_h, float *out, int n, int crop, const float *mean, const float *std_, int dtype, hipStream_t st) {
+    const size_t tot = (size_t)n * crop * crop;
+    hipLaunchKernelGGL(normalize_nhwc4_kernel, dim3((unsigned)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, st,
+                       (const u16 *)img_h, out, n, crop, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], dtype == PVR_F16 ? 1 : 0);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+}  // namespace pvr
+
 using namespace pvr;
 
 struct pvr_random5 {

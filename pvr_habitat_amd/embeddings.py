@@ -78,7 +78,9 @@ def _dtype_from_env(compute_dtype=None):
         return _lib.PVR_BF16
     if d in ('f16', 'fp16', 'float16', 'half'):
         return _lib.PVR_F16
-    raise ValueError('compute dtype must be bf16 or f16, got %r' % d)
+    if d in ('f32', 'fp32', 'float32'):
+        return _lib.PVR_F32                     # reference-precision mode (ResNet50 family only): f32 MFMA, ~1/8 the speed
+    raise ValueError('compute dtype must be bf16, f16 or f32, got %r' % d)
 
 
 # ---------------------------------------------------------------------------------------------

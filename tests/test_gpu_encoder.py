@@ -273,3 +273,20 @@ def test_odd_frame_sizes_and_single_frame(n, h, w):
     out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
     l2, mx = _relerr(out, ref)
     assert out.shape == (n, 2048) and l2 < 1e-3, (l2, mx)        # <=1 LSB resize ties are far below the f16 noise
+
+
+@pytest.mark.parametrize('variant,frame', [('conv5', 256), ('conv3', 128), ('conv4', 64)])
+def test_fp32_reference_precision_mode(variant, frame):
+    """PVR_F32: fp32 storage + f32-input MFMA (the reference's arithmetic type): every ResNet50 variant within
+    1e-4 of the fp32 oracle (measured ~1e-6), i.e. an order of magnitude inside the north-star 1e-3 bound."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(6, variant)
+    fr = synth.smooth_frames(71, 3, frame, frame)
+    ref = eo.embed(sd, fr, variant, squeeze=False)
+    m = HipResNet50(sd, variant, compute_dtype='f32', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    l2, mx = _relerr(out, ref)
+    print('\n[%s f32] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
+    assert l2 < 1e-4 and mx < 1e-4
