@@ -175,6 +175,7 @@ def main():
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
+    ap.add_argument('--no-fuse', action='store_true', help='one launch per convolution (A/B against the fused bottleneck tails)')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
     args = ap.parse_args()
 
@@ -193,6 +194,8 @@ def main():
     from pvr_habitat_amd.embeddings import HipResNet50
     sd = synth.resnet50_state_dict(1, 'conv5')               # MoCo-v2 encoder_q layout == torchvision resnet50
     model = HipResNet50(sd, 'conv5', compute_dtype=args.dtype, max_batch=args.batch, chunk=args.chunk)
+    if args.no_fuse:
+        model.set_fusion(False)
     # each rank owns its own shard of the frame stream (different seed = different frames)
     frames_np = synth.frames(1 + rank, args.batch, args.frame, args.frame)
     frames = torch.from_numpy(frames_np).cuda()

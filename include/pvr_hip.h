@@ -90,6 +90,11 @@ pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames_dev, int3
  * NHWC, into out_dev. name: "pre","stem","pool","layer1".."layer4". Returns element count via *count. */
 pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out_dev, int64_t cap,
                            int64_t *count, void *hip_stream);
+/* debug / A-B: 0 runs one launch per convolution instead of the fused layer1-layer2 bottleneck tails
+ * (bottleneck_chain.hip).  Both plans give bit-identical outputs.  Default on; env PVR_FUSE=0 also disables. */
+pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on);
+/* name of launch `index` in the order pvr_encoder_profile reports; returns its length, 0 past the end */
+int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf, int32_t cap);
 /* debug: make pvr_encoder_forward return right after the named tap has been produced (NULL/"" = off) */
 pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap);
 /* Instrumented forward of one chunk (n <= chunk): HIP events between launches on the caller's stream;

@@ -27,6 +27,8 @@ _SIGS = {
     'pvr_encoder_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'pvr_encoder_tap': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     'pvr_encoder_debug_stop_after': (C.c_int, [C.c_void_p, C.c_char_p]),
+    'pvr_encoder_debug_set_fusion': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pvr_encoder_launch_name': (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     'pvr_encoder_destroy': (None, [C.c_void_p]),
     'pvr_encoder_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),

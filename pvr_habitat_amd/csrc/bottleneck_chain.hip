@@ -1,0 +1,420 @@
+// Fused tail of a torchvision Bottleneck (reference src/embeddings.py:118-120 -> torchvision resnet50; the
+// blocks of layer1 / layer2, whose 1x1 convolutions are HBM-bound as separate launches):
+//
+//     t2  = relu(conv2_3x3(t1) + b2)                       (Cm -> Cm, stride 1 or 2)   phase A
+//     y   = relu(conv3_1x1(t2) + b3 + residual)            (Cm -> 4Cm)                 phase B, per 64-cout group
+//     t1' = relu(conv1_1x1_of_the_NEXT_block(y) + b1')     (4Cm -> Cmn, optional)      phase B, accumulated over groups
+//
+// conv2 is the only spatial operator of the chain and it comes first, so one block of 128 output pixels carries
+// its tile through all three GEMMs with no halo recompute: t2 never leaves LDS, y is written once and never
+// re-read by the next block's conv1, and the residual is read once.  HBM bytes per pixel of a layer1 block drop
+// from 128 (t2 w) + 128 (t2 r) + 512 (res) + 512 (y w) + 512 (y r) + 128 (t1' w) to 512 + 512 + 128.
+//
+// Numerics are those of the unfused launches bit for bit: the same 16-bit rounding points (t2, y, t1'), the same
+// K order in every accumulation (conv1' walks y's channels in ascending 64-channel groups = conv_igemm's K slices).
+//
+// Layout tricks:
+//   * weights are the MFMA A operand (D rows = couts).  W3 and W1' are stored with their rows permuted inside every
+//     32-row block (row 16t+4a+c holds cout 8a+4t+c) so that a lane's accumulators of an MFMA tile PAIR are 8
+//     CONSECUTIVE output channels of one pixel: residual loads, y / t1' stores and the LDS write of y are all 16-byte
+//     lane accesses straight from the accumulator layout - no fp32 LDS staging pass.
+//   * LDS (<= 80 KB, two blocks per CU): the phase-A pipeline buffers are re-used in phase B for t2, the y group and
+//     the W3 group; only the W1' slice lives beside them.
+//   * phase-B weights and the next group's residual are prefetched into registers one group ahead; plain loads, so
+//     hipcc's counted vmcnt keeps them in flight across the barriers.
+#include "common.h"
+
+namespace pvr {
+
+struct ChainP {
+    const u16 *in, *w2, *w3, *w1n, *res;
+    const float *b2, *b3, *b1n;
+    u16 *y, *t1n;
+    int N, H, W, Ho, Wo, stride, M;
+    unsigned in_bytes, w2_bytes, w3_bytes, w1n_bytes, y_bytes, t1n_bytes;
+};
+
+template <int CM, int CMN, bool F16>
+__global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int BM = 128, BK = 64, BN = CM;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32, TM = 4, TN = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int C4 = 4 * CM, G = C4 / 64, KS3 = CM / 64;     // conv3: G groups of 64 couts over KS3 K-slices
+    constexpr int TN1 = CMN / 32;                              // conv1': 16-cout tiles per wave
+    constexpr int W3_CH = CM / 32, W1_CH = CMN / 32;           // 16-B staging chunks per thread
+    // phase-B LDS map (bytes); [rows][64] 16-bit tiles, 128-B rows, chunk ^= (row>>1)&7
+    constexpr int T2_OFF = 0;                                  // KS3 x [128][64]
+    constexpr int YG_OFF = KS3 * 16384;                        // [128][64]
+    constexpr int W3_OFF = YG_OFF + 16384;                     // KS3 x [64][64]
+    constexpr int W1_OFF = 2 * STAGE;                          // [CMN][64]
+    static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE, "phase-B tiles must fit the phase-A pipeline buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int srow = tid >> 3, pch = tid & 7;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
+    const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
+    const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1n), 0, p.w1n_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.y_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+
+    // ---- phase A staging (conv_igemm.hip's scheme: one byte offset per chunk + 9-bit tap masks) ----------------
+    int a_off[A_CH], a_mask[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int row = srow + 32 * i;
+        const int lch = pch ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
+        const int hi0 = ho * p.stride - 1, wi0 = wo * p.stride - 1;
+        a_off[i] = (((n * p.H + hi0) * p.W + wi0) * CM + lch * 8) * 2;
+        int hb = 0, wb = 0;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            hb |= (int)(ok && (unsigned)(hi0 + t3) < (unsigned)p.H) << t3;
+            wb |= (int)((unsigned)(wi0 + t3) < (unsigned)p.W) << t3;
+        }
+        int mask = 0;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * 3)) : 0;
+        a_mask[i] = mask;
+    }
+    int b_off[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int row = srow + 32 * i;
+        b_off[i] = (row * (9 * CM) + (pch ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const int lds_st = srow * 128 + pch * 16;
+    u32x4 ra[A_CH], rb[B_CH];
+    constexpr int cpt = CM / BK, nk = 9 * cpt;
+    int kh = 0, kw = 0, cs = 0, tap = 0;
+#define PVR_LOAD_SLICE(kt_)                                                                             \
+    {                                                                                                   \
+        const int tap_off = ((kh * p.W + kw) * CM + cs * BK) * 2;                                       \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                              \
+            const int vo = ((a_mask[i] >> tap) & 1) ? a_off[i] + tap_off : OOB;                         \
+            ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0));  \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, b_off[i], (kt_) * (BK * 2), 0)); \
+        if (++cs == cpt) { cs = 0; ++tap; if (++kw == 3) { kw = 0; ++kh; } }                            \
+    }
+#define PVR_STORE_SLICE(buf_)                                                                           \
+    {                                                                                                   \
+        char *base = smem + (buf_) * STAGE + lds_st;                                                    \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + i * 32 * 128) = ra[i];                                    \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + BM * 128 + i * 32 * 128) = rb[i];                         \
+    }
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    int x_rd[2][TM];                              // pixel-operand fragment offsets inside a [128][64] tile (phases A and B)
+    int b_rd[2][TN];                              // conv2 weight fragments
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int row = wm * 64 + j * 16 + fr;
+            x_rd[ks][j] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int row = wn * (BN / 2) + i * 16 + fr;
+            b_rd[ks][i] = BM * 128 + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+    }
+
+    // ---- phase-B addressing and the first group's prefetches (their latency hides under phase A) ----------------
+    // lane's 8 consecutive couts of a 64-cout group start at wn*32 + fq*8; pixel of tile j is wm*64 + 16j + fr
+    int y_off[TM];                                // byte offset of (pixel, group 0) in res / y
+    int t_off[TM];                                // byte offset of the pixel row in t1'
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        y_off[j] = m < p.M ? (m * C4 + wn * 32 + fq * 8) * 2 : OOB;
+        t_off[j] = m < p.M ? (m * CMN + wn * (CMN / 2) + fq * 8) * 2 : OOB;
+    }
+    int w3_g[W3_CH], w3_l[W3_CH];                 // W3 group staging: global byte offset (group 0), LDS byte offset
+#pragma unroll
+    for (int i = 0; i < W3_CH; ++i) {
+        const int q = tid + 256 * i, r = (q >> 3) & 63, s = q >> 9;
+        w3_g[i] = (r * CM + s * 64 + ((q & 7) ^ ((r >> 1) & 7)) * 8) * 2;
+        w3_l[i] = W3_OFF + s * 8192 + r * 128 + (q & 7) * 16;
+    }
+    int w1_g[CMN ? W1_CH : 1], w1_l[CMN ? W1_CH : 1];
+    if constexpr (CMN > 0) {
+#pragma unroll
+        for (int i = 0; i < W1_CH; ++i) {
+            const int q = tid + 256 * i, r = q >> 3;
+            w1_g[i] = (r * C4 + ((q & 7) ^ ((r >> 1) & 7)) * 8) * 2;
+            w1_l[i] = W1_OFF + r * 128 + (q & 7) * 16;
+        }
+    }
+    u32x4 rres[TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) rres[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], 0, 0));
+#pragma unroll
+    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));
+    if constexpr (CMN > 0) {
+#pragma unroll
+        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));
+    }
+
+    // ---- phase A: conv2 3x3 as implicit GEMM, 128 pixels x CM couts, K = 9*CM --------------------------------
+    f32x4 acc2[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    PVR_LOAD_SLICE(0);
+    PVR_STORE_SLICE(0);
+    __syncthreads();
+#define PVR_K_STEP(kt_, CUR_)                                                                           \
+    {                                                                                                   \
+        const bool more = (kt_) + 1 < nk;                                                               \
+        if (more) PVR_LOAD_SLICE((kt_) + 1);                                                            \
+        const char *sb = smem + (CUR_) * STAGE;                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+            V8 xa[TM], wb[TN];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(sb + x_rd[ks][j]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(sb + b_rd[ks][i]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                              \
+                _Pragma("unroll") for (int j = 0; j < TM; ++j) acc2[i][j] = mfma16<F16>(wb[i], xa[j], acc2[i][j]); \
+        }                                                                                               \
+        if (more) PVR_STORE_SLICE(1 - (CUR_));                                                          \
+        __syncthreads();                                                                                \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        PVR_K_STEP(kt, 0);
+        if (kt + 1 < nk) PVR_K_STEP(kt + 1, 1);
+    }
+#undef PVR_K_STEP
+#undef PVR_LOAD_SLICE
+#undef PVR_STORE_SLICE
+
+    // t2 = relu(acc2 + b2) -> 16-bit -> LDS [pixel][cout] (every wave is past the loop's last barrier)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int c = wn * (BN / 2) + i * 16 + fq * 4;           // D row 4*fq + reg = cout
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + c);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int row = wm * 64 + j * 16 + fr;
+            const f32x4 a = acc2[i][j];
+            const unsigned lo = (unsigned)to_h<F16>(fmaxf(a[0] + bv.x, 0.f)) | ((unsigned)to_h<F16>(fmaxf(a[1] + bv.y, 0.f)) << 16);
+            const unsigned hi = (unsigned)to_h<F16>(fmaxf(a[2] + bv.z, 0.f)) | ((unsigned)to_h<F16>(fmaxf(a[3] + bv.w, 0.f)) << 16);
+            const int cc = c & 63;
+            char *dst = smem + T2_OFF + (c >> 6) * 16384 + row * 128 + ((((cc >> 3) ^ ((row >> 1) & 7))) << 4) + (cc & 4) * 2;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+        }
+    }
+    // first W3 group / W1' slice -> LDS
+#pragma unroll
+    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+    if constexpr (CMN > 0) {
+#pragma unroll
+        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+    }
+    if (G > 1) {
+#pragma unroll
+        for (int i = 0; i < W3_CH; ++i)
+            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
+        if constexpr (CMN > 0) {
+#pragma unroll
+            for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B ---------------------------------------------------------------------------------------------
+    int w3_rd[2][2], w1_rd[2][CMN ? TN1 : 1], yg_wr[TM];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = wn * 32 + t * 16 + fr;
+            w3_rd[ks][t] = W3_OFF + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+        if constexpr (CMN > 0) {
+#pragma unroll
+            for (int i = 0; i < TN1; ++i) {
+                const int row = wn * (CMN / 2) + i * 16 + fr;
+                w1_rd[ks][i] = W1_OFF + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int row = wm * 64 + j * 16 + fr;
+        yg_wr[j] = YG_OFF + row * 128 + (((wn * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+    f32x4 acc1[CMN ? TN1 : 1][TM];
+    if constexpr (CMN > 0) {
+#pragma unroll
+        for (int i = 0; i < TN1; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        // conv3 group: 128 pixels x 64 couts, K = CM
+        f32x4 acc3[2][TM];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc3[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS3; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                V8 xa[TM], wb[2];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(smem + T2_OFF + s * 16384 + x_rd[ks][j]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wb[t] = *reinterpret_cast<const V8 *>(smem + s * 8192 + w3_rd[ks][t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wb[t], xa[j], acc3[t][j]);
+            }
+        // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane -> 16-B global store + 16-B LDS write
+        const int c0 = g * 64 + wn * 32 + fq * 8;
+        const float4 bA = *reinterpret_cast<const float4 *>(p.b3 + c0), bB = *reinterpret_cast<const float4 *>(p.b3 + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const f32x4 lo = acc3[0][j], hi = acc3[1][j];
+            float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
+            const u32x4 r = rres[j];
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
+                const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
+                o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, y_off[j], g * 128, 0);
+            if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
+        }
+        if (g + 1 < G) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                rres[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + 1) * 128, 0));
+        }
+        __syncthreads();                          // y group visible; every wave is done with this W3 group
+        if (g + 1 < G) {
+#pragma unroll
+            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+            if (g + 2 < G) {
+#pragma unroll
+                for (int i = 0; i < W3_CH; ++i)
+                    w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
+            }
+        }
+        if constexpr (CMN == 0) __syncthreads();  // next W3 group visible (the conv1' path has its own barrier below)
+        if constexpr (CMN > 0) {
+            // t1' += y_group x W1'[:, group]  (K = 64)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                V8 xa[TM], wb[TN1];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(smem + YG_OFF + x_rd[ks][j]);
+#pragma unroll
+                for (int i = 0; i < TN1; ++i) wb[i] = *reinterpret_cast<const V8 *>(smem + w1_rd[ks][i]);
+#pragma unroll
+                for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc1[i][j] = mfma16<F16>(wb[i], xa[j], acc1[i][j]);
+            }
+            __syncthreads();                      // every wave is done with the y group and this W1' slice
+            if (g + 1 < G) {
+#pragma unroll
+                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+                if (g + 2 < G) {
+#pragma unroll
+                    for (int i = 0; i < W1_CH; ++i)
+                        w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
+                }
+            }
+        }
+    }
+
+    if constexpr (CMN > 0) {
+        // t1' = relu(acc1 + b1'): tile pair (2q, 2q+1) = 8 consecutive couts per lane
+#pragma unroll
+        for (int q = 0; q < TN1 / 2; ++q) {
+            const int c0 = wn * (CMN / 2) + q * 32 + fq * 8;
+            const float4 bA = *reinterpret_cast<const float4 *>(p.b1n + c0), bB = *reinterpret_cast<const float4 *>(p.b1n + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const f32x4 lo = acc1[2 * q][j], hi = acc1[2 * q + 1][j];
+                const float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_t, t_off[j], q * 64, 0);
+            }
+        }
+    }
+}
+
+template <int CM, int CMN, bool F16>
+static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
+    const int grid = (p.M + 127) / 128;
+    const size_t lds = 2 * (128 + CM) * 128 + CMN * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16>), dim3(grid), dim3(256), lds, stream, p);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+template <bool F16>
+static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream) {
+    if (cm == 64 && cmn == 64) return launch_chain_inst<64, 64, F16>(p, stream);
+    if (cm == 64 && cmn == 128) return launch_chain_inst<64, 128, F16>(p, stream);
+    if (cm == 64 && cmn == 0) return launch_chain_inst<64, 0, F16>(p, stream);
+    if (cm == 128 && cmn == 128) return launch_chain_inst<128, 128, F16>(p, stream);
+    if (cm == 128 && cmn == 0) return launch_chain_inst<128, 0, F16>(p, stream);
+    set_error("bottleneck chain: no instance for Cm=%d, next Cm=%d", cm, cmn);
+    return PVR_ERR_INVALID;
+}
+
+bool chain_supported(int cm, int cmn) { return (cm == 64 && (cmn == 0 || cmn == 64 || cmn == 128)) || (cm == 128 && (cmn == 0 || cmn == 128)); }
+
+// row permutation of the chain's 1x1 weights: inside every 32-row block, row 16t + 4a + c holds cout 8a + 4t + c
+int chain_row_source(int row) { return (row & ~31) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3); }
+
+pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
+                                   void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
+                                   int stride, int dtype, hipStream_t stream) {
+    PVR_REQUIRE(chain_supported(cm, cmn), "bottleneck chain: unsupported widths Cm=%d next=%d", cm, cmn);
+    PVR_REQUIRE(t1 && w2 && b2 && w3p && b3 && res && y && (cmn == 0 || (w1np && b1n && t1n)), "bottleneck chain: null argument");
+    ChainP p;
+    p.in = (const u16 *)t1; p.w2 = (const u16 *)w2; p.w3 = (const u16 *)w3p; p.w1n = (const u16 *)w1np; p.res = (const u16 *)res;
+    p.b2 = b2; p.b3 = b3; p.b1n = b1n; p.y = (u16 *)y; p.t1n = (u16 *)t1n;
+    p.N = n; p.H = h; p.W = w; p.stride = stride;
+    p.Ho = (h + 2 - 3) / stride + 1; p.Wo = (w + 2 - 3) / stride + 1;
+    const int64_t M = (int64_t)n * p.Ho * p.Wo;
+    const int64_t inb = (int64_t)n * h * w * cm * 2, yb = M * 4 * cm * 2, tb = M * (cmn ? cmn : 1) * 2;
+    PVR_REQUIRE(inb < 0x7ffffff0ll && yb < 0x7ffffff0ll && tb < 0x7ffffff0ll, "bottleneck chain: operand larger than 2 GiB (use a smaller chunk)");
+    p.M = (int)M; p.in_bytes = (unsigned)inb; p.y_bytes = (unsigned)yb; p.t1n_bytes = (unsigned)tb;
+    p.w2_bytes = (unsigned)(cm * 9 * cm * 2); p.w3_bytes = (unsigned)(4 * cm * cm * 2); p.w1n_bytes = (unsigned)(cmn * 4 * cm * 2);
+    return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
+}
+
+}  // namespace pvr

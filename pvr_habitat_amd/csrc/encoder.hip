@@ -142,7 +142,69 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
         return enc_upload(&op.d_b, hb);
     }
     if ((s = enc_upload(&op.d_w, hw))) return s;
+    op.h_w = std::move(hw);
     return enc_upload(&op.d_b, hb);
+}
+
+static bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// Build both launch schedules.  Fused: every bottleneck of width 64 / 128 (layer1, layer2) runs as
+// [conv1 unless the previous chain already produced it] [downsample] [chain: conv2 -> conv3 (+res) -> next conv1].
+static pvr_status build_schedules(pvr_encoder *e) {
+    const int n = (int)e->ops.size();
+    for (int i = 0; i < n; ++i) { Launch l; l.conv2 = i; e->sched_plain.push_back(l); }
+    if (e->desc.dtype == PVR_F32) { e->sched_fused = e->sched_plain; return PVR_OK; }
+    int cur_t1 = B_T1;
+    bool conv1_done = false;
+    for (int i = 0; i < n;) {
+        ConvOp &op = e->ops[i];
+        if (ends_with(op.conv, ".conv1") && conv1_done) { conv1_done = false; ++i; continue; }
+        int c3 = -1;
+        if (ends_with(op.conv, ".conv2") && op.k == 3 && op.cin == op.cout && op.cin_real == op.cin && op.cout_real == op.cout) {
+            c3 = i + 1;
+            if (c3 < n && ends_with(e->ops[c3].conv, ".downsample.0")) ++c3;
+            if (!(c3 < n && ends_with(e->ops[c3].conv, ".conv3") && e->ops[c3].cout == 4 * op.cout && e->ops[c3].relu &&
+                  !e->ops[c3].out_f32 && e->ops[c3].res_buf != B_NONE && chain_supported(op.cout, 0)))
+                c3 = -1;
+        }
+        if (c3 < 0) {
+            Launch l; l.conv2 = i;
+            e->sched_fused.push_back(l);
+            if (ends_with(op.conv, ".conv1")) cur_t1 = B_T1;
+            ++i;
+            continue;
+        }
+        for (int d = i + 1; d < c3; ++d) { Launch l; l.conv2 = d; e->sched_fused.push_back(l); }   // the downsample runs first
+        Launch l;
+        l.conv2 = i; l.conv3 = c3; l.t1_in = cur_t1;
+        const int nx = c3 + 1;
+        if (nx < n && ends_with(e->ops[nx].conv, ".conv1") && e->ops[nx].k == 1 && e->ops[nx].stride == 1 && e->ops[nx].relu &&
+            e->ops[nx].cin == 4 * op.cout && e->ops[nx].in_buf == e->ops[c3].out_buf && e->ops[nx].cout_real == e->ops[nx].cout &&
+            chain_supported(op.cout, e->ops[nx].cout)) {
+            l.next1 = nx;
+            l.t1_out = cur_t1 == B_T1 ? B_T2 : B_T1;
+            cur_t1 = l.t1_out;
+            conv1_done = true;
+        }
+        e->sched_fused.push_back(l);
+        // row-permuted copies of the chain's 1x1 weights
+        for (int which = 0; which < 2; ++which) {
+            const int oi = which == 0 ? c3 : l.next1;
+            if (oi < 0) continue;
+            ConvOp &o = e->ops[oi];
+            if (o.d_wp) continue;
+            const size_t K = (size_t)o.cin;
+            std::vector<u16> hp((size_t)o.cout * K);
+            for (int r = 0; r < o.cout; ++r) memcpy(&hp[(size_t)r * K], &o.h_w[(size_t)chain_row_source(r) * K], K * 2);
+            pvr_status s = enc_upload(&o.d_wp, hp);
+            if (s) return s;
+        }
+        i = c3 + 1;
+    }
+    return PVR_OK;
 }
 
 static pvr_status finalize_stem(pvr_encoder *e) {
@@ -229,6 +291,9 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     if ((s = finalize_stem(enc))) return s;
     for (auto &op : enc->ops)
         if ((s = finalize_conv(enc, op))) return s;
+    if ((s = build_schedules(enc))) return s;
+    for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); }
+    if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
     const int C = enc->desc.chunk, crop = enc->desc.crop;
     const bool f32 = enc->desc.dtype == PVR_F32;
     const size_t esz = f32 ? 4 : 2;                               // activation element size
@@ -325,11 +390,20 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false;
-        for (auto &op : enc->ops) {
+        for (const Launch &l : (enc->fuse ? enc->sched_fused : enc->sched_plain)) {
+            const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
-            if ((s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h,
-                                 op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st)))
-                return s;
+            if (l.conv3 >= 0) {
+                const ConvOp &c2 = enc->ops[l.conv2];
+                const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
+                s = launch_bottleneck_chain(enc->d_buf[l.t1_in], c2.d_w, c2.d_b, op.d_wp, op.d_b, res, enc->d_buf[op.out_buf],
+                                            c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
+                                            c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st);
+            } else {
+                s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h, op.w,
+                                op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
+            }
+            if (s) return s;
             if ((s = mark())) return s;
             if (!enc->stop_after.empty() && op.tap == enc->stop_after) { stopped = true; break; }
         }
@@ -376,15 +450,47 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
         // stem: 118.0 MMAC/frame = 112*112*64*147
         if (nl > 1) op_flops[1] = 2.0 * n * 112.0 * 112.0 * 64.0 * 147.0;
         int i = 3;
-        for (auto &op : enc->ops) {
-            if (i >= nl) break;
+        auto flops = [&](int oi) {
+            if (oi < 0) return 0.0;
+            const ConvOp &op = enc->ops[oi];
             const double ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
-            op_flops[i++] = 2.0 * n * ho * ho * (double)op.cout_real * op.k * op.k * op.cin_real;
+            return 2.0 * n * ho * ho * (double)op.cout_real * op.k * op.k * op.cin_real;
+        };
+        const bool fused = enc->fuse && enc->desc.dtype != PVR_F32;
+        for (const Launch &l : (fused ? enc->sched_fused : enc->sched_plain)) {
+            if (i >= nl) break;
+            op_flops[i++] = flops(l.conv2) + flops(l.conv3) + flops(l.next1);
         }
         *n_ops = nl;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
     return s;
+}
+
+pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on) {
+    PVR_REQUIRE(enc, "null encoder");
+    enc->fuse = on != 0;
+    return PVR_OK;
+}
+
+// name of launch `index` of the current plan (the order pvr_encoder_profile reports); returns the name's length, 0 past the end
+int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf, int32_t cap) {
+    if (!enc || !buf || cap <= 0 || index < 0) return 0;
+    std::string nm;
+    static const char *head[3] = {"preprocess", "stem", "maxpool"};
+    if (index < 3) nm = head[index];
+    else {
+        const bool fused = enc->fuse && enc->desc.dtype != PVR_F32;
+        const std::vector<Launch> &sc = fused ? enc->sched_fused : enc->sched_plain;
+        const int i = index - 3;
+        if (i < (int)sc.size()) {
+            nm = enc->ops[sc[i].conv2].conv;
+            if (sc[i].conv3 >= 0) nm += "+" + enc->ops[sc[i].conv3].conv.substr(enc->ops[sc[i].conv3].conv.rfind('.') + 1);
+            if (sc[i].next1 >= 0) nm += "+" + enc->ops[sc[i].next1].conv;
+        } else if (i == (int)sc.size() && !enc->vit && !enc->rnd) nm = "pool/flatten";
+    }
+    snprintf(buf, (size_t)cap, "%s", nm.c_str());
+    return (int32_t)nm.size();
 }
 
 pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap) {
@@ -417,15 +523,19 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
     }
     PVR_REQUIRE((int64_t)elems <= cap, "tap %s needs %zu elements, cap %lld", name, elems, (long long)cap);
     *count = (int64_t)elems;
-    if (f32) { PVR_HIP_TRY(hipMemcpyAsync(out, src, elems * 4, hipMemcpyDeviceToDevice, st)); return PVR_OK; }
-    return launch_h_to_f32(src, out, elems, enc->desc.dtype, st);
+    const bool img16 = nm == "pre";                     // the transformed image stays 16-bit in every mode
+    if (f32 || (enc->desc.dtype == PVR_F32 && !img16)) {
+        PVR_HIP_TRY(hipMemcpyAsync(out, src, elems * 4, hipMemcpyDeviceToDevice, st));
+        return PVR_OK;
+    }
+    return launch_h_to_f32(src, out, elems, enc->desc.dtype == PVR_F32 ? PVR_BF16 : enc->desc.dtype, st);
 }
 
 void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     if (enc->d_imgf) (void)hipFree(enc->d_imgf);
     for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);

@@ -30,10 +30,25 @@ struct ConvOp {
     int in_buf, out_buf, res_buf;
     int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
     u16 *d_w = nullptr;
+    u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
+    std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
     std::string tap;               // non-empty: output of this op is the named tap
 };
+
+// one launch of the forward plan: a single convolution, or a fused bottleneck tail
+// (conv2 3x3 -> conv3 1x1 + residual -> the next block's conv1 1x1; bottleneck_chain.hip)
+struct Launch {
+    int conv2 = -1, conv3 = -1, next1 = -1;   // chain members (indices into ops); conv3 < 0: single launch of ops[conv2]
+    int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
+};
+
+bool chain_supported(int cm, int cmn);
+int chain_row_source(int row);
+pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
+                                   void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
+                                   int stride, int dtype, hipStream_t stream);
 
 }  // namespace pvr
 
@@ -43,6 +58,8 @@ struct pvr_encoder {
     pvr_encoder_desc desc;
     std::map<std::string, HostTensor> weights;
     std::vector<ConvOp> ops;
+    std::vector<Launch> sched_plain, sched_fused;   // one launch per op / with the layer1-layer2 bottleneck tails fused
+    bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
     bool finalized = false;
     int out_size = 0;
     int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation

@@ -247,16 +247,21 @@ class HipResNet50(_Node):
                                              C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
 
     def op_names(self):
-        """conv launch order of the HIP plan (mirrors build_resnet50 in csrc/encoder.hip)."""
-        names = []
-        stages = 3 if self.variant == 'conv3' else 4
-        for li in range(stages):
-            for bi in range((3, 4, 6, 3)[li]):
-                p = 'layer%d.%d' % (li + 1, bi)
-                names += [p + '.conv1', p + '.conv2'] + ([p + '.downsample'] if bi == 0 else []) + [p + '.conv3']
-        if self.variant != 'conv5':
-            names += ['head.conv1', 'head.downsample', 'head.conv2']
-        return names
+        """conv launches of the current HIP plan, in launch order (fused bottleneck tails read 'a.conv2+conv3+b.conv1')."""
+        if self._handle is None:
+            self._build()
+        names, buf, i = [], C.create_string_buffer(256), 3
+        while _lib.lib().pvr_encoder_launch_name(self._handle, i, buf, 256) > 0:
+            names.append(buf.value.decode())
+            i += 1
+        return [n for n in names if n != 'pool/flatten']
+
+    def set_fusion(self, on):
+        """A/B switch between the fused layer1/layer2 bottleneck-tail plan (default) and one launch per convolution;
+        both give bit-identical outputs."""
+        if self._handle is None:
+            self._build()
+        _lib.check(_lib.lib().pvr_encoder_debug_set_fusion(self._handle, 1 if on else 0))
 
     def tap(self, name, n_elems):
         """fp32 copy of an intermediate activation of the last forward (parity debugging)."""

@@ -290,3 +290,24 @@ def test_fp32_reference_precision_mode(variant, frame):
     l2, mx = _relerr(out, ref)
     print('\n[%s f32] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
     assert l2 < 1e-4 and mx < 1e-4
+
+
+@pytest.mark.parametrize('variant,dtype,n', [('conv5', 'bf16', 3), ('conv5', 'f16', 5), ('conv3', 'bf16', 2), ('conv4', 'f16', 1)])
+def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n):
+    """bottleneck_chain.hip (conv2 -> conv3 + residual -> next conv1 in one launch, layer1/layer2) keeps the unfused
+    plan's rounding points and K order, so the two plans must agree BIT FOR BIT (n chosen so that the 128-pixel tiles
+    have tails: n*56*56 is not a multiple of 128 for odd n)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(8, variant)
+    fr = torch.from_numpy(synth.smooth_frames(90 + n, n, 160, 200)).cuda()
+    m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
+    names = m.op_names()
+    assert any('+conv3+' in x for x in names), names          # the fused plan is the default
+    fused = m(fr).clone()
+    m.set_fusion(False)
+    assert not any('+' in x for x in m.op_names())
+    plain = m(fr).clone()
+    m.set_fusion(True)
+    again = m(fr)
+    assert torch.equal(fused, plain), float((fused - plain).abs().max())
+    assert torch.equal(fused, again)
