@@ -34,8 +34,19 @@ struct ChainP {
     unsigned in_bytes, w2_bytes, w3_bytes, w1n_bytes, y_bytes, t1n_bytes;
 };
 
-template <int CM, int CMN, bool F16>
-__global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
+// 16-byte buffer store with a compile-time byte offset.  The offset goes into the instruction's immediate field
+// (voffset + constant, soffset = 0), NEVER into soffset: with an SGPR soffset hipcc (ROCm 7.2) omits the wait states
+// between a buffer_store_dwordx4 and the next VALU write of its data registers (its hazard rule exempts that form),
+// and on gfx950 the store then reads overwritten data - measured here as ~6000 wrong y elements per batch-256 launch
+// in the fully unrolled group loop, where the next pixel tile's packing reuses the registers immediately
+// (scripts/debug_determinism.py; the data dword clobbered was exactly the first VALU destination after the store).
+__device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
+}
+
+// RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
+template <int CM, int CMN, bool F16, int RD, int OCC>
+__global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BM = 128, BK = 64, BN = CM;
     constexpr int A_CH = BM / 32, B_CH = BN / 32, TM = 4, TN = BN / 32;
@@ -47,8 +58,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
     constexpr int T2_OFF = 0;                                  // KS3 x [128][64]
     constexpr int YG_OFF = KS3 * 16384;                        // [128][64]
     constexpr int W3_OFF = YG_OFF + 16384;                     // KS3 x [64][64]
-    constexpr int W1_OFF = 2 * STAGE;                          // [CMN][64]
+    constexpr int W1_IN = W3_OFF + KS3 * 8192 + CMN * 128 <= 2 * STAGE;   // the W1' slice fits the pipeline buffers too
+    constexpr int W1_OFF = W1_IN ? W3_OFF + KS3 * 8192 : 2 * STAGE;        // [CMN][64]
     static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE, "phase-B tiles must fit the phase-A pipeline buffers");
+    static_assert(RD >= 1 && RD <= G, "residual prefetch depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
             w1_l[i] = W1_OFF + r * 128 + (q & 7) * 16;
         }
     }
-    u32x4 rres[TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
+    u32x4 rres[RD][TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) rres[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], 0, 0));
+    for (int d = 0; d < RD; ++d)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0));
 #pragma unroll
     for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));
     if constexpr (CMN > 0) {
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
             for (int j = 0; j < TM; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < G; ++g) {
         // conv3 group: 128 pixels x 64 couts, K = CM
         f32x4 acc3[2][TM];
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
         for (int j = 0; j < TM; ++j) {
             const f32x4 lo = acc3[0][j], hi = acc3[1][j];
             float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
-            const u32x4 r = rres[j];
+            const u32x4 r = rres[g % RD][j];
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -303,13 +318,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
                 const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
                 o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, y_off[j], g * 128, 0);
+            store_b128_imm(o, rs_y, y_off[j], g * 128);
             if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
-        if (g + 1 < G) {
+        if (g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                rres[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + 1) * 128, 0));
+                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + RD) * 128, 0));
         }
         __syncthreads();                          // y group visible; every wave is done with this W3 group
         if (g + 1 < G) {
@@ -363,33 +378,56 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_t, t_off[j], q * 64, 0);
+                store_b128_imm(o, rs_t, t_off[j], q * 64);
             }
         }
     }
 }
 
-template <int CM, int CMN, bool F16>
+template <int CM, int CMN, bool F16, int RD, int OCC>
 static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
     const int grid = (p.M + 127) / 128;
-    const size_t lds = 2 * (128 + CM) * 128 + CMN * 128;
+    const size_t pipe = 2 * (128 + CM) * 128, inpipe = (CM / 64) * 16384 + 16384 + (CM / 64) * 8192 + CMN * 128;
+    const size_t lds = inpipe <= pipe ? pipe : pipe + CMN * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
 
+// tuning knob for A/B runs: PVR_CHAIN_CFG = 10*RD + OCC for the Cm = 64 instances (default 12: measured best, profiles/experiments)
+static int chain_cfg() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_CHAIN_CFG"); v = e ? atoi(e) : 12; }
+    return v;
+}
+
 template <bool F16>
 static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream) {
-    if (cm == 64 && cmn == 64) return launch_chain_inst<64, 64, F16>(p, stream);
-    if (cm == 64 && cmn == 128) return launch_chain_inst<64, 128, F16>(p, stream);
-    if (cm == 64 && cmn == 0) return launch_chain_inst<64, 0, F16>(p, stream);
-    if (cm == 128 && cmn == 128) return launch_chain_inst<128, 128, F16>(p, stream);
-    if (cm == 128 && cmn == 0) return launch_chain_inst<128, 0, F16>(p, stream);
+    const int cfg = chain_cfg();
+#define PVR_CHAIN64(CMN_)                                                                 \
+    switch (cfg) {                                                                        \
+    case 12: return launch_chain_inst<64, CMN_, F16, 1, 2>(p, stream);                    \
+    case 13: return launch_chain_inst<64, CMN_, F16, 1, 3>(p, stream);                    \
+    case 22: return launch_chain_inst<64, CMN_, F16, 2, 2>(p, stream);                    \
+    case 23: return launch_chain_inst<64, CMN_, F16, 2, 3>(p, stream);                    \
+    default: return launch_chain_inst<64, CMN_, F16, 4, 2>(p, stream);                    \
+    }
+    if (cm == 64 && cmn == 64) PVR_CHAIN64(64)
+    if (cm == 64 && cmn == 128) {                 // 64 KB of LDS: two blocks per CU whatever the register cap
+        if (cfg / 10 == 1) return launch_chain_inst<64, 128, F16, 1, 2>(p, stream);
+        if (cfg / 10 == 2) return launch_chain_inst<64, 128, F16, 2, 2>(p, stream);
+        return launch_chain_inst<64, 128, F16, 4, 2>(p, stream);
+    }
+    if (cm == 64 && cmn == 0) PVR_CHAIN64(0)
+#undef PVR_CHAIN64
+    if (cm == 128 && cmn == 128) return launch_chain_inst<128, 128, F16, 1, 2>(p, stream);
+    if (cm == 128 && cmn == 0) return launch_chain_inst<128, 0, F16, 1, 2>(p, stream);
     set_error("bottleneck chain: no instance for Cm=%d, next Cm=%d", cm, cmn);
     return PVR_ERR_INVALID;
 }

@@ -390,6 +390,8 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false;
+        int launch_idx = 0;                          // debug: stop_after = "#k" ends the forward after conv launch k of the plan
+        const int stop_idx = enc->stop_after.size() > 1 && enc->stop_after[0] == '#' ? atoi(enc->stop_after.c_str() + 1) : -1;
         for (const Launch &l : (enc->fuse ? enc->sched_fused : enc->sched_plain)) {
             const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
@@ -406,6 +408,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if (s) return s;
             if ((s = mark())) return s;
             if (!enc->stop_after.empty() && op.tap == enc->stop_after) { stopped = true; break; }
+            if (launch_idx++ == stop_idx) { stopped = true; break; }
         }
         if (stopped) return PVR_OK;
         float *o = out + (size_t)f0 * out_stride;
@@ -512,7 +515,11 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
     if (nm == "pre") { src = enc->d_img; elems = (size_t)n * (crop + 6) * (crop + 8) * 4; }
     else if (nm == "stem") { src = enc->d_stem; elems = (size_t)n * 112 * 112 * 64; }
     else if (nm == "pool") { src = enc->d_buf[B_X0]; elems = (size_t)n * 56 * 56 * 64; }
-    else {
+    else if (nm.compare(0, 3, "buf") == 0 && nm.find(':') != std::string::npos) {   // debug: "buf<b>:<elems>" = raw workspace buffer b
+        const int b = atoi(nm.c_str() + 3);
+        PVR_REQUIRE(b >= 0 && b < B_F32, "tap %s: 16-bit workspace buffers are 0..%d", name, B_F32 - 1);
+        src = enc->d_buf[b]; elems = (size_t)atoll(nm.c_str() + nm.find(':') + 1);
+    } else {
         auto it = enc->taps.find(nm);
         PVR_REQUIRE(it != enc->taps.end(), "unknown tap %s", name);
         // taps alias ping-pong buffers: only the LAST layer's tap is guaranteed intact after a full forward
