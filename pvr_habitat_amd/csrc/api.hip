@@ -23,6 +23,8 @@ pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, in
 pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
                        int, int, int, int, int, int, int, int, hipStream_t);
 
+void set_conv_algo(int a);
+
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
     if (!g_zero) {
@@ -81,6 +83,12 @@ pvr_status pvr_op_conv2d(const void *in, const void *wgt, const float *bias, con
     if (s) return s;
     return launch_conv(in, wgt, bias, residual, out, z, n, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, dtype,
                        (hipStream_t)stream);
+}
+
+pvr_status pvr_debug_set_conv_algo(int32_t algo) {
+    PVR_REQUIRE(algo >= -1 && algo <= 1, "pvr_debug_set_conv_algo: algo must be -1 (auto), 0 (conv_igemm) or 1 (conv_pp256)");
+    set_conv_algo(algo);
+    return PVR_OK;
 }
 
 pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_t n, int32_t hw, int32_t c, int32_t in_f32,

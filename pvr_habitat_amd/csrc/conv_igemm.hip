@@ -19,6 +19,11 @@
 
 namespace pvr {
 
+// conv_pp256.hip
+bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
+pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, hipStream_t stream);
+
 struct ConvP {
     const u16 *in;
     const u16 *wgt;
@@ -319,12 +324,35 @@ static pvr_status launch_cfg(ConvP &p, int dtype, hipStream_t stream) {
     return single ? launch_inst<BM, BN, false, 1>(p, stream) : launch_inst<BM, BN, false, 2>(p, stream);
 }
 
+// kernel choice: -1 auto (measured crossover), 0 conv_igemm only, 1 conv_pp256 whenever it accepts the shape
+static int g_conv_algo = -2;
+int conv_algo() {
+    if (g_conv_algo == -2) { const char *e = getenv("PVR_CONV_ALGO"); g_conv_algo = e ? atoi(e) : -1; }
+    return g_conv_algo;
+}
+void set_conv_algo(int a) { g_conv_algo = a; }
+
 pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const void *res, void *out, const void *zero,
                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
                        int out_f32, int dtype, hipStream_t stream) {
     PVR_REQUIRE(cin % 64 == 0, "conv: cin %d not a multiple of 64", cin);
     PVR_REQUIRE(cout % 8 == 0, "conv: cout %d not a multiple of 8", cout);
     PVR_REQUIRE(zero != nullptr, "conv: zero page missing");
+    {
+        const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+        const int64_t M = (int64_t)n * ho * wo, K = (int64_t)kh * kw * cin;
+        const int of32 = out_f32 & 1, rf32 = (out_f32 >> 1) & 1;
+        const int algo = conv_algo();
+        const bool ok = pp256_supported(M, cin, cout, kh, kw, (int64_t)n * h * w * cin * 2, (int64_t)((cout + 63) / 64 * 64) * K * 2,
+                                        M * cout * (of32 ? 4 : 2), res ? M * cout * (rf32 ? 4 : 2) : 0);
+        // auto (measured per launch at batch 256, profiles/experiments/r01_pp256_vs_igemm_per_op.txt): the 256x256 kernel runs one
+        // block per CU, so its epilogue is not hidden behind another block's main loop and a grid of fewer tiles than ~2/3 of the
+        // CUs leaves the chip idle.  It wins for K >= 512, and for K = 256 when there is no residual to read in the epilogue.
+        const int64_t tiles = ((M + 255) / 256) * ((cout + 255) / 256);
+        const bool want = algo == 1 || (algo == -1 && cout >= 256 && tiles >= 160 && (K >= 512 || (K >= 256 && !res)));
+        if (ok && want)
+            return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, stream);
+    }
     ConvP p;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;
     p.zero = (const u16 *)zero;

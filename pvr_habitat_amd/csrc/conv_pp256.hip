@@ -1,0 +1,333 @@
+// Deep-K implicit-GEMM convolution / linear layer: 256 x 256 output tile, 8 waves in two groups that alternate
+// between "feed" (LDS fragment reads + LDS-DMA prefetch) and "math" (16 MFMAs) phases, so the matrix pipe of every SIMD
+// always has one wave issuing MFMAs while its partner wave loads.  Serves the 3x3 and K >= 512 1x1 convolutions of
+// layer3 / layer4 (torchvision Bottleneck reached from reference src/embeddings.py:118-120) and the transformer
+// linear layers of the CLIP / MAE encoders (reference src/embeddings.py:298-314, src/vision_models/mae.py:85-93).
+// Same GEMM view, operand layouts, K order and epilogue arithmetic as conv_igemm.hip, so results agree with it to the
+// last bit of the fp32 accumulation order per output (K slices ascending, 2 x 32-deep MFMA steps per slice).
+//
+//   out[m][co] = sum_k X[m][k] * W[co][k],  m = (n,ho,wo),  k = (kh,kw,c),  BK = 64 = one filter tap x 64 channels
+//
+// Structure (cdna_hip_programming.md "256^2 8-phase template", re-derived for NHWC implicit GEMM):
+//   * waves 2 (pixels) x 4 (couts): a wave owns 128 pixels x 64 couts = 8 x 4 MFMA tiles = 128 accumulator VGPRs.
+//   * LDS 128 KB = 2 buffers x {X-lo, X-hi, W-lo, W-hi} half tiles of [128 rows][64] 16-bit (16 KB each), rows of 128 B
+//     with the 16-byte chunk index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128 fragment reads).
+//   * staging is LDS-DMA only (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write.  A wave instruction writes
+//     1024 contiguous LDS bytes = 8 rows; the swizzle and the im2col gather live in the per-lane SOURCE offset.  Filter
+//     taps outside the image, pixel-tile tails and cout tails use an offset past num_records: the DMA writes zeros.
+//     The weight rows are permuted on the way in (LDS row 16t+4a+c of a 32-row block <- cout 8a+4t+c) so that a lane's
+//     accumulators of an MFMA tile pair are 8 consecutive output channels: 16-byte epilogue stores / residual loads
+//     straight from registers.
+//   * one K tile = 4 phases of [feed | barrier | 16 MFMA | barrier]:
+//         phase 0: read X0 (pixel tiles 0-3), W0 (cout tiles 0-1); DMA W-lo(t+1);   math W0 x X0
+//         phase 1: read X1 (pixel tiles 4-7);                      DMA W-hi(t+1);   math W0 x X1
+//         phase 2: read W1 (cout tiles 2-3);                       DMA X-lo(t+2);   math W1 x X1
+//         phase 3:                                                 DMA X-hi(t+2);   math W1 x X0
+//     The second wave group starts one barrier late, so its feed half-phase coincides with the first group's math
+//     half-phase and vice versa.
+//   * hazards (counted by hand; the compiler does not order LDS-DMA against ds_read):
+//       WAR  every wave waits lgkmcnt(0) BEFORE the barrier that ends its feed half-phase, so a half tile last read in
+//            phase p may be re-staged from phase p+1 on by either group.  X halves are last read in phase 1 -> re-staged in
+//            phases 2/3 (same buffer, tile t+2); W halves are last read in phase 2 of tile t-1 -> re-staged in phases 0/1 of
+//            tile t (other buffer, tile t+1).
+//       RAW  one counted wait per K tile, in phase 3 after that phase's DMA issue: vmcnt(4) leaves X-lo/X-hi(t+2) in flight
+//            and retires everything of tile t+1; every wave then passes at least one barrier before any wave reads tile t+1.
+#include "common.h"
+
+namespace pvr {
+
+struct ConvP;   // conv_igemm.hip
+struct PPP {
+    const u16 *in, *wgt, *res;
+    const float *bias;
+    void *out;
+    int H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad, M, K;
+    unsigned in_bytes, w_bytes, out_bytes, res_bytes;
+    int act, out_f32;
+    int n_tiles;
+};
+
+#define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
+
+template <bool F16, int RES>
+__global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int BUF = 65536, HALF = 16384, WOFF = 32768;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = swz % p.n_tiles, tm = swz / p.n_tiles;
+    const int m0 = tm * 256, co0 = tn * 256;
+
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
+
+    // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
+    int a_off[2][2], a_mask[2][2], b_off[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (i * 8 + wave) * 8 + (lane >> 3);
+            const int lch = (lane & 7) ^ ((r >> 1) & 7);                // logical chunk held by this physical slot
+            const int m = m0 + h * 128 + r;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            a_off[h][i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
+            int hb = 0, wb = 0;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                hb |= (int)(ok && t3 < p.KH && (unsigned)(hi0 + t3) < (unsigned)p.H) << t3;
+                wb |= (int)(t3 < p.KW && (unsigned)(wi0 + t3) < (unsigned)p.W) << t3;
+            }
+            int mask = 0;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
+            a_mask[h][i] = mask;
+            const int R = h * 128 + r;                                  // A-operand row inside the 256-cout tile
+            const int co = co0 + (R & ~31) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
+            b_off[h][i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
+        }
+    const int cpt = p.Cin >> 6;                   // K tiles per filter tap
+    const int nk = p.KH * p.KW * cpt;
+    int xs_tap = 0, xs_kh = 0, xs_kw = 0, xs_cs = 0;   // filter position of the next X tile to stage (wave-uniform)
+
+#define PP_STAGE_X(h_, buf_)                                                                                     \
+    {                                                                                                            \
+        const int tap_off = ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+            const int vo = ((a_mask[h_][i] >> xs_tap) & 1) ? a_off[h_][i] + tap_off : OOB;                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * HALF + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
+        }                                                                                                        \
+    }
+#define PP_ADVANCE_X()                                                                                           \
+    { if (++xs_cs == cpt) { xs_cs = 0; ++xs_tap; if (++xs_kw == p.KW) { xs_kw = 0; ++xs_kh; } } }
+#define PP_STAGE_W(h_, kt_, buf_)                                                                                \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, PP_LDS_PTR((buf_) * BUF + WOFF + (h_) * HALF + (i * 8 + wave) * 1024), 16, \
+                                                     b_off[h_][i], (kt_) * 128, 0, 0);                           \
+    }
+
+    // ---- fragment read bases (per buffer and 32-deep k-step); tile offsets are instruction immediates --------------
+    const int fr = lane & 15, fq = lane >> 4;
+    int xrd[2][2], wrd[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ((ks * 4 + fq) ^ ((fr >> 1) & 7)) << 4;
+            xrd[b][ks] = b * BUF + wr * HALF + fr * 128 + sw;
+            wrd[b][ks] = b * BUF + WOFF + (wc >> 1) * HALF + (wc & 1) * 8192 + fr * 128 + sw;
+        }
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: tile 0 entirely, X of tile 1 ----------------------------------------------------------------------
+    PP_STAGE_X(0, 0); PP_STAGE_X(1, 0); PP_ADVANCE_X();
+    PP_STAGE_W(0, 0, 0); PP_STAGE_W(1, 0, 0);
+    if (nk > 1) {
+        PP_STAGE_X(0, 1); PP_STAGE_X(1, 1); PP_ADVANCE_X();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave group runs one half-phase behind
+    __builtin_amdgcn_sched_barrier(0);
+
+#define PP_FEED_DONE()                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);
+#define PP_MATH_DONE()                                                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_READ_X(dst_, j0_, B_)                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+            dst_[j][ks] = *reinterpret_cast<const V8 *>(smem + xrd[B_][ks] + ((j0_) + j) * 2048);
+#define PP_READ_W(i0_, B_)                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            wf[i][ks] = *reinterpret_cast<const V8 *>(smem + wrd[B_][ks] + ((i0_) + i) * 2048);
+#define PP_MATH(i0_, x_, j0_)                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                acc[(i0_) + i][(j0_) + j] = mfma16<F16>(wf[i][ks], x_[j][ks], acc[(i0_) + i][(j0_) + j]);
+
+    // one K tile; B_ is a literal so that every LDS address is base register + immediate
+#define PP_TILE(kt_, B_)                                                                                         \
+    {                                                                                                            \
+        const bool next1 = (kt_) + 1 < nk, next2 = (kt_) + 2 < nk;                                               \
+        V8 x0[4][2], x1[4][2], wf[2][2];                                                                         \
+        PP_READ_X(x0, 0, B_); PP_READ_W(0, B_);                                                                  \
+        if (next1) PP_STAGE_W(0, (kt_) + 1, 1 - (B_));                                                           \
+        PP_FEED_DONE(); PP_MATH(0, x0, 0); PP_MATH_DONE();                                                       \
+        PP_READ_X(x1, 4, B_);                                                                                    \
+        if (next1) PP_STAGE_W(1, (kt_) + 1, 1 - (B_));                                                           \
+        PP_FEED_DONE(); PP_MATH(0, x1, 4); PP_MATH_DONE();                                                       \
+        PP_READ_W(2, B_);                                                                                        \
+        if (next2) PP_STAGE_X(0, B_);                                                                            \
+        PP_FEED_DONE(); PP_MATH(2, x1, 4); PP_MATH_DONE();                                                       \
+        if (next2) {                                                                                             \
+            PP_STAGE_X(1, B_); PP_ADVANCE_X();                                                                   \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                     \
+        } else {                                                                                                 \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        }                                                                                                        \
+        PP_FEED_DONE(); PP_MATH(2, x0, 0); PP_MATH_DONE();                                                       \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        PP_TILE(kt, 0);
+        if (kt + 1 < nk) PP_TILE(kt + 1, 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
+    __builtin_amdgcn_sched_barrier(0);
+#undef PP_TILE
+#undef PP_MATH
+#undef PP_READ_W
+#undef PP_READ_X
+#undef PP_MATH_DONE
+#undef PP_FEED_DONE
+#undef PP_STAGE_W
+#undef PP_ADVANCE_X
+#undef PP_STAGE_X
+
+    // ---- epilogue: straight from the accumulators -------------------------------------------------------------------
+    // D row 4*fq + reg of tile i is A-operand row 64*wc + 16*i + 4*fq + reg = cout co0 + 64*wc + 32*(i>>1) + 8*fq + 4*(i&1) + reg,
+    // D column fr of tile j is pixel m0 + 128*wr + 16*j + fr: tiles (2q, 2q+1) give a lane 8 consecutive couts of one pixel.
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, RES ? p.res_bytes : 0, 0x00020000);
+    float bs[2][8];
+    bool cok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = co0 + wc * 64 + q * 32 + fq * 8;
+        cok[q] = c < p.Cout;
+        const float4 lo = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 hi = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bs[q][0] = lo.x; bs[q][1] = lo.y; bs[q][2] = lo.z; bs[q][3] = lo.w;
+        bs[q][4] = hi.x; bs[q][5] = hi.y; bs[q][6] = hi.z; bs[q][7] = hi.w;
+    }
+    const int esz_o = p.out_f32 ? 4 : 2;
+    constexpr int esz_r = RES == 2 ? 4 : 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + wr * 128 + j * 16 + fr;
+        u32x4 rr[2][2];
+        if constexpr (RES != 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = co0 + wc * 64 + q * 32 + fq * 8;
+                const int ro = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_r : OOB;
+                rr[q][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0));
+                if constexpr (RES == 2) rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 16, 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = co0 + wc * 64 + q * 32 + fq * 8;
+            const f32x4 lo = acc[2 * q][j], hi = acc[2 * q + 1][j];
+            float v[8] = {lo[0] + bs[q][0], lo[1] + bs[q][1], lo[2] + bs[q][2], lo[3] + bs[q][3],
+                          hi[0] + bs[q][4], hi[1] + bs[q][5], hi[2] + bs[q][6], hi[3] + bs[q][7]};
+            if constexpr (RES == 1) {
+                const u32x4 r = rr[q][0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu));
+                    v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16));
+                }
+            } else if constexpr (RES == 2) {
+                const f32x4 r0 = __builtin_bit_cast(f32x4, rr[q][0]), r1 = __builtin_bit_cast(f32x4, rr[q][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+            } else if (p.act == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+            }
+            // byte offsets go into voffset (soffset stays 0): see store_b128_imm in bottleneck_chain.hip
+            const int oo = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_o : OOB;
+            if (p.out_f32) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_out, oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo + 16, 0, 0);
+            } else {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, oo, 0, 0);
+            }
+        }
+    }
+}
+
+template <bool F16, int RES>
+static pvr_status launch_pp_inst(PPP &p, int grid, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_pp256_kernel<F16, RES>), dim3(grid), dim3(512), 131072, stream, p);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// shapes the kernel accepts (the caller decides whether it is the faster choice)
+bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes) {
+    return cin % 64 == 0 && cout % 8 == 0 && kh <= 3 && kw <= 3 && M < (1ll << 31) && in_bytes < 0x7ffffff0ll && w_bytes < 0x7ffffff0ll &&
+           out_bytes < 0x7ffffff0ll && res_bytes < 0x7ffffff0ll;
+}
+
+pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype,
+                             hipStream_t stream) {
+    PPP p;
+    p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.res = (const u16 *)res; p.bias = bias; p.out = out;
+    p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
+    p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (h + 2 * pad - kh) / stride + 1;
+    p.Wo = (w + 2 * pad - kw) / stride + 1;
+    const int64_t M = (int64_t)n * p.Ho * p.Wo;
+    p.K = kh * kw * cin;
+    const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2, ob = M * cout * (out_f32 ? 4 : 2),
+                  rb = res ? M * cout * (res_f32 ? 4 : 2) : 0;
+    PVR_REQUIRE(pp256_supported(M, cin, cout, kh, kw, inb, wb, ob, rb), "conv_pp256: unsupported shape");
+    p.M = (int)M; p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
+    p.act = act; p.out_f32 = out_f32;
+    p.n_tiles = (cout + 255) / 256;
+    const int grid = ((p.M + 255) / 256) * p.n_tiles;
+    const int rmode = !res ? 0 : (res_f32 ? 2 : 1);
+    if (dtype == PVR_F16) {
+        if (rmode == 0) return launch_pp_inst<true, 0>(p, grid, stream);
+        return rmode == 1 ? launch_pp_inst<true, 1>(p, grid, stream) : launch_pp_inst<true, 2>(p, grid, stream);
+    }
+    if (rmode == 0) return launch_pp_inst<false, 0>(p, grid, stream);
+    return rmode == 1 ? launch_pp_inst<false, 1>(p, grid, stream) : launch_pp_inst<false, 2>(p, grid, stream);
+}
+
+}  // namespace pvr

@@ -71,9 +71,20 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture
+def conv_algo():
+    """select the implicit-GEMM kernel for one test (0 = conv_igemm 128x128, 1 = conv_pp256 256x256 ping-pong); restores 'auto'"""
+    def _set(a):
+        _lib.check(_lib.lib().pvr_debug_set_conv_algo(a))
+    yield _set
+    _lib.check(_lib.lib().pvr_debug_set_conv_algo(-1))
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
-def test_conv2d_matches_torch(case, dt):
+@pytest.mark.parametrize('algo', [0, 1])
+def test_conv2d_matches_torch(case, dt, algo, conv_algo):
+    conv_algo(algo)
     n, h, w, cin, cout, k, stride, relu, res, out_f32 = case
     tdt, cdt = DT[dt]
     pad = k // 2
@@ -103,6 +114,60 @@ def test_conv2d_matches_torch(case, dt):
     l2, mx = _relerr(o.numpy(), ref.numpy())
     tol = 2e-5 if out_f32 else (6e-3 if dt == 'bf16' else 8e-4)      # output rounding only (inputs pre-rounded)
     assert l2 < tol and mx < 2 * tol + 1e-3 * (not out_f32), (l2, mx)
+
+
+def _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res_f32, cdt, tdt):
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.full((n, ho, wo, cout), float('nan'), dtype=torch.float32 if out_f32 else tdt, device='cuda')
+    _lib.check(_lib.lib().pvr_op_conv2d(C.c_void_p(x.data_ptr()), C.c_void_p(wk.data_ptr()), C.c_void_p(b.data_ptr()),
+                                        C.c_void_p(r.data_ptr()) if r is not None else None, C.c_void_p(out.data_ptr()),
+                                        n, h, w, cin, cout, k, k, stride, pad, act, (1 if out_f32 else 0) | (2 if res_f32 else 0),
+                                        cdt, _lib.stream_ptr()))
+    return out
+
+
+PP_CASES = [
+    # n, h, w, cin, cout, k, stride, act, res(0 none, 1 16-bit, 2 fp32), out_f32     -- shapes of the deep-K launches
+    (64, 14, 14, 256, 256, 3, 1, 1, 0, 0),       # layer3 conv2: K = 2304
+    (64, 14, 14, 1024, 256, 1, 1, 1, 0, 0),      # layer3 conv1
+    (64, 28, 28, 512, 1024, 1, 2, 0, 0, 0),      # layer3 downsample (strided 1x1)
+    (64, 7, 7, 512, 2048, 1, 1, 1, 1, 1),        # layer4 conv3 + residual, fp32 out
+    (64, 14, 14, 256, 256, 3, 2, 1, 0, 0),       # strided 3x3
+    (4, 197, 1, 768, 2304, 1, 1, 0, 0, 0),       # ViT QKV (ragged M = 788)
+    (4, 197, 1, 768, 3072, 1, 1, 2, 0, 0),       # ViT FC + QuickGELU
+    (4, 197, 1, 3072, 768, 1, 1, 0, 2, 1),       # ViT proj + fp32 residual stream
+    (3, 50, 1, 768, 3072, 1, 1, 3, 0, 0),        # MAE FC + erf-GELU, M = 150 (< one tile)
+    (2, 9, 11, 128, 72, 3, 1, 1, 1, 0),          # cout tail (72 of a 256 tile), ragged M
+]
+
+
+@pytest.mark.parametrize('case', PP_CASES)
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
+    """Both implicit-GEMM kernels accumulate every output in the same K order: outputs must agree bit for bit, and the
+    ping-pong kernel (hand-counted LDS-DMA hazards) must give the same bits on every repeat."""
+    n, h, w, cin, cout, k, stride, act, res, out_f32 = case
+    tdt, cdt = DT[dt]
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x = torch.from_numpy(synth.normal(7, 'px%s' % (case,), (n, h, w, cin))).to(tdt).cuda()
+    cout_pad = (cout + 63) // 64 * 64
+    wk = torch.zeros((cout_pad, k * k * cin), dtype=tdt)
+    wk[:cout] = torch.from_numpy(synth.normal(7, 'pw%s' % (case,), (cout, k * k * cin), std=float(np.sqrt(2.0 / (cin * k * k))))).to(tdt)
+    wk = wk.cuda()
+    b = torch.zeros(cout_pad); b[:cout] = torch.from_numpy(synth.uniform(7, 'pb%s' % (case,), (cout,), -0.5, 0.5)); b = b.cuda()
+    r = None
+    if res:
+        r = torch.from_numpy(synth.normal(7, 'pr%s' % (case,), (n, ho, wo, cout))).to(torch.float32 if res == 2 else tdt).cuda()
+    conv_algo(0)
+    ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
+    conv_algo(1)
+    for rep in range(4):
+        out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(out, ref), (rep, int((out != ref).sum()))
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
