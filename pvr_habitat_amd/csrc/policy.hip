@@ -38,6 +38,25 @@ struct pvr_policy {
     float *act[5] = {nullptr}, *dact[5] = {nullptr}, *wp[5] = {nullptr}, *wt[5] = {nullptr}, *feat = nullptr, *dfeat = nullptr;
     float *cpartial = nullptr, *cgpacked = nullptr, *bpartial = nullptr;
     std::vector<void *> conv_owned;
+    // Optional hipGraph replay of the whole training iteration (pvr_policy_step, PVR_POLICY_GRAPH=1): the ~430 launches of
+    // one T=100 iteration are 5-7 us kernels with ~3.8 us between them (rocprofv3 kernel trace).  Inputs are copied into
+    // library-owned staging buffers and lr into stats[3] so that the captured graph has fixed addresses; it is re-captured
+    // when any other argument changes.  Measured on ROCm 7.2 / MI355X (scripts/bc_graph_ab.py, 50 steps): replay 174.5-174.8
+    // steps/s vs eager 173.2-174.2 - the gap is per-dispatch cost in the command processor, which a graph of kernel nodes
+    // pays as well - so the default stays eager; fewer, larger launches are what removes it.
+    void *in_obs = nullptr; uint8_t *in_done = nullptr; long long *in_act = nullptr;
+    struct StepKey {
+        const void *params = nullptr, *sq = nullptr, *bn_rm = nullptr, *bn_rv = nullptr, *bn_nbt = nullptr, *stream = nullptr;
+        int T = 0, B = 0; float alpha = 0, eps = 0, mgn = 0;
+        bool operator==(const StepKey &o) const {
+            return params == o.params && sq == o.sq && bn_rm == o.bn_rm && bn_rv == o.bn_rv && bn_nbt == o.bn_nbt && stream == o.stream &&
+                   T == o.T && B == o.B && alpha == o.alpha && eps == o.eps && mgn == o.mgn;
+        }
+    } graph_key, eager_key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;       // capture happens on a private stream (the caller's may be the legacy stream, which cannot capture)
+    int use_graph = 0;
 };
 
 namespace {
@@ -274,14 +293,36 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     return PVR_OK;
 }
 
-static pvr_status apply_core(pvr_policy *pol, float *params, float *square_avg, const float *Gd, float lr, float alpha, float eps,
+// lr is read from pol->stats[3] (set_lr)
+static pvr_status apply_core(pvr_policy *pol, float *params, float *square_avg, const float *Gd, float alpha, float eps,
                              float max_grad_norm, hipStream_t st) {
     const size_t nt = (size_t)pol->n_train;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, st, Gd, nt, pol->partial);
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, pol->partial, 1024, max_grad_norm, pol->stats);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, square_avg, Gd, pol->stats, nt / 4, lr, alpha, eps);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, square_avg, Gd, pol->stats, nt / 4, alpha, eps);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
+}
+
+static pvr_status set_lr(pvr_policy *pol, float lr, hipStream_t st) {
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, pol->stats + 3, lr);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// forward (training mode, zero initial state: main_bc_2.py:207-209) + loss + backward into `grads`
+static pvr_status loss_backward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs, const uint8_t *done,
+                                const long long *actions, int T, int B, float *grads, hipStream_t st) {
+    const int N = T * B;
+    TRY(forward_core(pol, params, bn, obs, done, pol->zeros, pol->zeros, T, B, 1, actions, st));
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, pol->loss_row, N, 1.0f / (float)N, pol->stats);
+    return backward_core(pol, params, obs, T, B, grads, st);
+}
+
+static void drop_graph(pvr_policy *pol) {
+    if (pol->graph_exec) (void)hipGraphExecDestroy(pol->graph_exec);
+    if (pol->graph) (void)hipGraphDestroy(pol->graph);
+    pol->graph_exec = nullptr; pol->graph = nullptr;
 }
 
 extern "C" {
@@ -337,6 +378,13 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
         }
         A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)256 * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, 256 * 32);
     }
+    if (!s) {
+        const size_t ob = desc->conv_frames > 0 ? N * 64 * 64 * 3 * desc->conv_frames : N * O * 4;
+        uint8_t *raw = nullptr;
+        s = dalloc(&raw, ob); p->in_obs = raw;
+    }
+    A_(in_done, N); A_(in_act, N);
+    if (const char *e = getenv("PVR_POLICY_GRAPH")) p->use_graph = atoi(e) != 0;
 #undef A_
     if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("policy: device sync failed"); s = PVR_ERR_HIP; }
     if (s) { pvr_policy_destroy(p); return s; }
@@ -349,7 +397,9 @@ void pvr_policy_destroy(pvr_policy *p) {
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
                     p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
-                    p->cpartial, p->cgpacked, p->bpartial};
+                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act};
+    drop_graph(p);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (int l = 0; l < 5; ++l) { void *c[] = {p->act[l], p->dact[l], p->wp[l], p->wt[l]}; for (void *q : c) if (q) (void)hipFree(q); }
     delete p;
@@ -392,11 +442,8 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;
-    // forward (training mode, zero initial state: main_bc_2.py:207-209) + loss
-    TRY(forward_core(pol, params, bn, obs, done, pol->zeros, pol->zeros, T, B, 1, (const long long *)actions, st));
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, pol->loss_row, N, 1.0f / (float)N, pol->stats);
+    TRY(loss_backward(pol, params, bn, obs, done, (const long long *)actions, T, B, grads, st));
     if (logits_out) PVR_HIP_TRY(hipMemcpyAsync(logits_out, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
-    TRY(backward_core(pol, params, obs, T, B, grads, st));
     if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out, pol->stats, sizeof(float), hipMemcpyDeviceToDevice, st));
     return PVR_OK;
 }
@@ -405,7 +452,8 @@ pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, c
                             float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && grads, "pvr_policy_apply: null argument");
     hipStream_t st = (hipStream_t)hip_stream;
-    TRY(apply_core(pol, params, square_avg, grads, lr, alpha, eps, max_grad_norm, st));
+    TRY(set_lr(pol, lr, st));
+    TRY(apply_core(pol, params, square_avg, grads, alpha, eps, max_grad_norm, st));
     if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out + 1, pol->stats + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     return PVR_OK;
 }
@@ -414,9 +462,49 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
                            const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
                            float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
-    TRY(pvr_policy_backward(pol, params, bn, obs, done, actions, T, B, pol->grads, nullptr, logits_out, hip_stream));
-    TRY(apply_core(pol, params, square_avg, pol->grads, lr, alpha, eps, max_grad_norm, st));
+    const int N = T * B, A = pol->d.num_actions;
+    TRY(set_lr(pol, lr, st));
+    if (!pol->use_graph) {
+        TRY(loss_backward(pol, params, bn, obs, done, (const long long *)actions, T, B, pol->grads, st));
+        TRY(apply_core(pol, params, square_avg, pol->grads, alpha, eps, max_grad_norm, st));
+    } else {
+        // fixed addresses for the captured launches
+        const size_t obs_bytes = pol->d.conv_frames > 0 ? (size_t)N * 64 * 64 * 3 * pol->d.conv_frames : (size_t)N * pol->d.obs_size * 4;
+        PVR_HIP_TRY(hipMemcpyAsync(pol->in_obs, obs, obs_bytes, hipMemcpyDeviceToDevice, st));
+        PVR_HIP_TRY(hipMemcpyAsync(pol->in_done, done, (size_t)N, hipMemcpyDeviceToDevice, st));
+        PVR_HIP_TRY(hipMemcpyAsync(pol->in_act, actions, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
+        pvr_policy::StepKey key;
+        key.params = params; key.sq = square_avg;
+        if (bn) { key.bn_rm = bn->running_mean; key.bn_rv = bn->running_var; key.bn_nbt = bn->num_batches_tracked; }
+        key.T = T; key.B = B; key.alpha = alpha; key.eps = eps; key.mgn = max_grad_norm;
+        if (pol->graph_exec && key == pol->graph_key) {
+            PVR_HIP_TRY(hipGraphLaunch(pol->graph_exec, st));
+        } else if (key == pol->eager_key) {
+            // second iteration with these arguments (the first ran eagerly, so every lazy initialisation is done): capture
+            drop_graph(pol);
+            if (!pol->cap_stream) PVR_HIP_TRY(hipStreamCreateWithFlags(&pol->cap_stream, hipStreamNonBlocking));
+            hipStream_t cs = pol->cap_stream;
+            PVR_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            pvr_status s = loss_backward(pol, params, bn, pol->in_obs, pol->in_done, pol->in_act, T, B, pol->grads, cs);
+            if (!s) s = apply_core(pol, params, square_avg, pol->grads, alpha, eps, max_grad_norm, cs);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(cs, &g);
+            if (s) { if (g) (void)hipGraphDestroy(g); return s; }
+            if (e != hipSuccess || !g) { set_error("pvr_policy_step: stream capture failed: %s", hipGetErrorString(e)); return PVR_ERR_HIP; }
+            pol->graph = g;
+            PVR_HIP_TRY(hipGraphInstantiate(&pol->graph_exec, g, nullptr, nullptr, 0));
+            pol->graph_key = key;
+            PVR_HIP_TRY(hipGraphLaunch(pol->graph_exec, st));
+        } else {
+            TRY(loss_backward(pol, params, bn, pol->in_obs, pol->in_done, pol->in_act, T, B, pol->grads, st));
+            TRY(apply_core(pol, params, square_avg, pol->grads, alpha, eps, max_grad_norm, st));
+            pol->eager_key = key;
+        }
+    }
+    pol->have_grads = true;
+    if (logits_out) PVR_HIP_TRY(hipMemcpyAsync(logits_out, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
     if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out, pol->stats, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return PVR_OK;
 }

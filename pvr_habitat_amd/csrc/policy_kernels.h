@@ -556,8 +556,8 @@ static __global__ __launch_bounds__(256) void norm_final_kernel(const float *__r
 }
 
 static __global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__ p, float *__restrict__ v, const float *__restrict__ g,
-                                                      const float *__restrict__ stats, size_t n4, float lr, float alpha, float eps) {
-    const float coef = stats[2];
+                                                      const float *__restrict__ stats, size_t n4, float alpha, float eps) {
+    const float coef = stats[2], lr = stats[3];   // lr lives in device memory so that a captured graph can be replayed with a new value
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
         f32x4 vv = reinterpret_cast<f32x4 *>(v)[i];
@@ -572,5 +572,7 @@ static __global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__
         reinterpret_cast<f32x4 *>(p)[i] = pv;
     }
 }
+
+static __global__ void set_scalar_kernel(float *dst, float v) { *dst = v; }
 
 }  // namespace pvr

@@ -161,6 +161,35 @@ def test_policy_step_is_deterministic_and_single_step_eval():
     assert acts == [int(a) for a in ref['action'].flatten()]
 
 
+@pytest.mark.parametrize('conv', [False, True])
+def test_policy_step_graph_replay_equals_eager_launches(monkeypatch, conv):
+    """pvr_policy_step replays a captured hipGraph from the third iteration on (eager, capture, replay...): parameters,
+    optimizer state, BN buffers and per-step statistics must be bit-identical to eager launches (PVR_POLICY_GRAPH=0),
+    also when the shape changes in between (re-capture) and when lr changes every step (device-side scalar)."""
+    from pvr_habitat_amd.models import HipRMSprop
+    T, B, O, A, S = 12, 8, 256, 3, 6
+    obs, done, act = synth.bc_conv_batches(5, T, B, S, A) if conv else synth.bc_batches(5, T, B, O, A, S)
+    results = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv('PVR_POLICY_GRAPH', graph)
+        m, _ = _model(5, O, A, True, T, B, conv)
+        opt = HipRMSprop(m, max_epochs=50)
+        m.train()
+        stats = []
+        for s in range(S):
+            opt.scheduler_step()
+            if s == 4:                                          # another (T,B): falls back to eager, then re-captures
+                l, g = opt.step(torch.from_numpy(obs[s][:5, :3]), torch.from_numpy(done[s][:5, :3]), torch.from_numpy(act[s][:5, :3]))
+            else:
+                l, g = opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+            stats.append((float(l), float(g)))
+        results.append((m._flat.clone(), opt.square_avg.clone(), {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'tracked' in k}, stats))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    assert results[0][3] == results[1][3]
+    for k, v in results[0][2].items():
+        assert torch.equal(v, results[1][2][k]), k
+
+
 @pytest.mark.parametrize('T,B', [(1, 1), (3, 5), (7, 17), (2, 33)])
 def test_policy_ragged_shapes_match_oracle(T, B):
     """Batch sizes that are not multiples of the 16-row MFMA tile (padded rows must not leak), T=1, carried state."""
