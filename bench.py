@@ -28,20 +28,43 @@ PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH
 PEAK_F32_TFLOPS = 157.3           # f32-input MFMA (= the fp32 vector rate), reference-precision mode only
 
 
-def conv_algorithmic_bytes(n):
-    """Sum over the 52 bottleneck convs of input + output (+ residual) activation bytes at 16-bit for n frames."""
-    tot, hw, inpl = 0, 56, 64
-    for li, nb in enumerate((3, 4, 6, 3)):
-        planes = 64 << li
-        for bi in range(nb):
-            s = 2 if (bi == 0 and li > 0) else 1
-            o = hw // s
-            tot += hw * hw * inpl + hw * hw * planes                     # conv1
-            tot += hw * hw * planes + o * o * planes                     # conv2
-            if bi == 0:
-                tot += hw * hw * inpl + o * o * planes * 4               # downsample
-            tot += o * o * planes + 2 * o * o * planes * 4               # conv3 (+ residual)
-            hw, inpl = o, planes * 4
+def conv_algorithmic_bytes(n, names=None):
+    """Activation bytes (16-bit) the conv launches of one n-frame chunk must move: input + output (+ residual) of every
+    launch of the plan `names` (HipResNet50.op_names(); a fused bottleneck tail 'a.conv2+conv3+b.conv1' reads t1 and the
+    residual and writes y and the next block's t1, nothing else).  names=None: one launch per convolution."""
+    def geom(layer, block):
+        planes = 64 << (layer - 1)
+        hw_out = 56 >> (layer - 1)
+        hw_in = hw_out * 2 if (block == 0 and layer > 1) else hw_out
+        inpl = (64 if layer == 1 else planes * 2) if block == 0 else planes * 4
+        return planes, hw_in, hw_out, inpl
+    if names is None:
+        names = []
+        for li, nb in enumerate((3, 4, 6, 3)):
+            for bi in range(nb):
+                names += ['layer%d.%d.conv1' % (li + 1, bi), 'layer%d.%d.conv2' % (li + 1, bi)]
+                if bi == 0:
+                    names.append('layer%d.%d.downsample.0' % (li + 1, bi))
+                names.append('layer%d.%d.conv3' % (li + 1, bi))
+    tot = 0
+    for nm in names:
+        parts = nm.split('+')
+        head = parts[0].split('.')
+        layer, block, kind = int(head[0][5:]), int(head[1]), head[2]
+        planes, hi, ho, inpl = geom(layer, block)
+        if len(parts) > 1:                                   # conv2 -> conv3 (+ residual) [-> next conv1]
+            tot += hi * hi * planes + 2 * ho * ho * planes * 4
+            if len(parts) > 2:
+                nh = parts[2].split('.')
+                tot += ho * ho * geom(int(nh[0][5:]), int(nh[1]))[0]
+        elif kind == 'conv1':
+            tot += hi * hi * inpl + hi * hi * planes
+        elif kind == 'conv2':
+            tot += hi * hi * planes + ho * ho * planes
+        elif kind == 'downsample':
+            tot += hi * hi * inpl + ho * ho * planes * 4
+        elif kind == 'conv3':
+            tot += ho * ho * planes + 2 * ho * ho * planes * 4
     return tot * 2 * n
 
 
@@ -225,7 +248,7 @@ def main():
     cap = 128
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
     conv_ms, conv_fl, other_ms = 0.0, 0.0, 0.0
-    algo_bytes = conv_algorithmic_bytes(chunk)
+    algo_bytes = conv_algorithmic_bytes(chunk, [nm for nm in model.op_names()] if args.dtype != 'f32' else None)
     reps = 3
     for _ in range(reps):
         _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(frames.data_ptr()), chunk, args.frame, args.frame,
@@ -267,7 +290,7 @@ def main():
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_note': 'avg HBM bytes per conv launch, rocprofv3 PMC passes (profiles/pmc_conv_traffic.json); algorithmic '
                                          'in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'conv_igemm_kernel') + ' %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel') + ' %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},
         }
