@@ -129,8 +129,8 @@ pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *b
                          int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                          int32_t relu, int32_t out_f32, int32_t dtype, void *hip_stream);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
- * (default), 0 = conv_igemm (128x128 tiles) only, 1 = conv_pp256 (256x256 ping-pong tiles) whenever it accepts the shape.
- * Both kernels accumulate every output in the same K order and give bit-identical results. Process-global. */
+ * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 tiles) whenever it
+ * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */
 pvr_status pvr_debug_set_conv_algo(int32_t algo);
 /* global average pool of NHWC (16-bit or fp32) -> fp32 rows at out + i*out_stride */
 pvr_status pvr_op_avgpool(const void *in_dev, float *out_dev, int64_t out_stride, int32_t n, int32_t hw,

@@ -22,7 +22,7 @@ namespace pvr {
 // conv_pp256.hip
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, hipStream_t stream);
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream);
 
 struct ConvP {
     const u16 *in;
@@ -324,7 +324,8 @@ static pvr_status launch_cfg(ConvP &p, int dtype, hipStream_t stream) {
     return single ? launch_inst<BM, BN, false, 1>(p, stream) : launch_inst<BM, BN, false, 2>(p, stream);
 }
 
-// kernel choice: -1 auto (measured crossover), 0 conv_igemm only, 1 conv_pp256 whenever it accepts the shape
+// kernel choice: -1 auto (measured crossover), 0 conv_igemm only, 1 / 2 conv_pp256 with 256- / 128-pixel tiles
+// whenever it accepts the shape
 static int g_conv_algo = -2;
 int conv_algo() {
     if (g_conv_algo == -2) { const char *e = getenv("PVR_CONV_ALGO"); g_conv_algo = e ? atoi(e) : -1; }
@@ -348,10 +349,12 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         // auto (measured per launch at batch 256, profiles/experiments/r01_pp256_vs_igemm_per_op.txt): the 256x256 kernel runs one
         // block per CU, so its epilogue is not hidden behind another block's main loop and a grid of fewer tiles than ~2/3 of the
         // CUs leaves the chip idle.  It wins for K >= 512, and for K = 256 when there is no residual to read in the epilogue.
-        const int64_t tiles = ((M + 255) / 256) * ((cout + 255) / 256);
-        const bool want = algo == 1 || (algo == -1 && cout >= 256 && tiles >= 160 && (K >= 512 || (K >= 256 && !res)));
-        if (ok && want)
-            return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, stream);
+        const int64_t nt = (cout + 255) / 256, tiles = ((M + 255) / 256) * nt, tiles128 = ((M + 127) / 128) * nt;
+        const bool deep = cout >= 256 && (K >= 512 || (K >= 256 && !res));
+        // algo 1 / 2: force the 256- / 128-pixel tile; auto: 256 when that grid fills ~2/3 of the CUs, else 128 when that one does
+        const int bm = algo == 1 ? 256 : algo == 2 ? 128 : (algo == -1 && deep) ? (tiles >= 160 ? 256 : (tiles128 >= 160 ? 128 : 0)) : 0;
+        if (ok && bm)
+            return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, bm, stream);
     }
     ConvP p;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;

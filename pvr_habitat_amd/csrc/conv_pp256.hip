@@ -49,10 +49,18 @@ struct PPP {
 
 #define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
-template <bool F16, int RES>
+// BM = 256: the structure above.  BM = 128 (launches whose 256-pixel tiles would not fill the chip, e.g. layer4 at batch 256):
+// a wave owns 64 pixels x 64 couts, X half tiles are 64 rows (one DMA instruction each), a K tile is two phases:
+//         phase 0: read X (pixel tiles 0-3), W0;  DMA W-lo(t+1), W-hi(t+1);           math W0 x X
+//         phase 1: read W1;                       DMA X-lo(t+2), X-hi(t+2), vmcnt(2); math W1 x X
+template <int BM, bool F16, int RES>
 __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     typedef typename HT<F16>::V8 V8;
-    constexpr int BUF = 65536, HALF = 16384, WOFF = 32768;
+    constexpr int TMW = BM / 32;                   // 16-pixel MFMA tiles per wave
+    constexpr int XH = BM / 2, XHB = XH * 128;     // rows / bytes of an X half tile
+    constexpr int XI = XH / 64;                    // DMA instructions per X half tile (8 waves x 8 rows each)
+    constexpr int HALF = 16384;                    // W half tile: 128 couts
+    constexpr int WOFF = 2 * XHB, BUF = WOFF + 2 * HALF;
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -61,35 +69,37 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = swz % p.n_tiles, tm = swz / p.n_tiles;
-    const int m0 = tm * 256, co0 = tn * 256;
+    const int m0 = tm * BM, co0 = tn * 256;
 
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
 
     // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
-    int a_off[2][2], a_mask[2][2], b_off[2][2];
+    int a_off[2][XI], a_mask[2][XI], b_off[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (i * 8 + wave) * 8 + (lane >> 3);
             const int lch = (lane & 7) ^ ((r >> 1) & 7);                // logical chunk held by this physical slot
-            const int m = m0 + h * 128 + r;
-            const bool ok = m < p.M;
-            const int mm = ok ? m : 0;
-            const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
-            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            a_off[h][i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
-            int hb = 0, wb = 0;
+            if (i < XI) {
+                const int m = m0 + h * XH + r;
+                const bool ok = m < p.M;
+                const int mm = ok ? m : 0;
+                const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                a_off[h][i < XI ? i : 0] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
+                int hb = 0, wb = 0;
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                hb |= (int)(ok && t3 < p.KH && (unsigned)(hi0 + t3) < (unsigned)p.H) << t3;
-                wb |= (int)(t3 < p.KW && (unsigned)(wi0 + t3) < (unsigned)p.W) << t3;
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    hb |= (int)(ok && t3 < p.KH && (unsigned)(hi0 + t3) < (unsigned)p.H) << t3;
+                    wb |= (int)(t3 < p.KW && (unsigned)(wi0 + t3) < (unsigned)p.W) << t3;
+                }
+                int mask = 0;
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
+                a_mask[h][i < XI ? i : 0] = mask;
             }
-            int mask = 0;
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
-            a_mask[h][i] = mask;
             const int R = h * 128 + r;                                  // A-operand row inside the 256-cout tile
             const int co = co0 + (R & ~31) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
             b_off[h][i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
@@ -101,9 +111,9 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #define PP_STAGE_X(h_, buf_)                                                                                     \
     {                                                                                                            \
         const int tap_off = ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                         \
             const int vo = ((a_mask[h_][i] >> xs_tap) & 1) ? a_off[h_][i] + tap_off : OOB;                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * HALF + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * XHB + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
         }                                                                                                        \
     }
 #define PP_ADVANCE_X()                                                                                           \
@@ -123,22 +133,23 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int sw = ((ks * 4 + fq) ^ ((fr >> 1) & 7)) << 4;
-            xrd[b][ks] = b * BUF + wr * HALF + fr * 128 + sw;
+            xrd[b][ks] = b * BUF + wr * XHB + fr * 128 + sw;
             wrd[b][ks] = b * BUF + WOFF + (wc >> 1) * HALF + (wc & 1) * 8192 + fr * 128 + sw;
         }
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][TMW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: tile 0 entirely, X of tile 1 ----------------------------------------------------------------------
     PP_STAGE_X(0, 0); PP_STAGE_X(1, 0); PP_ADVANCE_X();
     PP_STAGE_W(0, 0, 0); PP_STAGE_W(1, 0, 0);
     if (nk > 1) {
         PP_STAGE_X(0, 1); PP_STAGE_X(1, 1); PP_ADVANCE_X();
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (XI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -195,10 +206,35 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         }                                                                                                        \
         PP_FEED_DONE(); PP_MATH(2, x0, 0); PP_MATH_DONE();                                                       \
     }
-    for (int kt = 0; kt < nk; kt += 2) {
-        PP_TILE(kt, 0);
-        if (kt + 1 < nk) PP_TILE(kt + 1, 1);
+    // BM = 128: two phases per K tile
+#define PP_TILE128(kt_, B_)                                                                                      \
+    {                                                                                                            \
+        const bool next1 = (kt_) + 1 < nk, next2 = (kt_) + 2 < nk;                                               \
+        V8 x0[4][2], wf[2][2];                                                                                   \
+        PP_READ_X(x0, 0, B_); PP_READ_W(0, B_);                                                                  \
+        if (next1) { PP_STAGE_W(0, (kt_) + 1, 1 - (B_)); PP_STAGE_W(1, (kt_) + 1, 1 - (B_)); }                   \
+        PP_FEED_DONE(); PP_MATH(0, x0, 0); PP_MATH_DONE();                                                       \
+        PP_READ_W(2, B_);                                                                                        \
+        if (next2) {                                                                                             \
+            PP_STAGE_X(0, B_); PP_STAGE_X(1, B_); PP_ADVANCE_X();                                                \
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                     \
+        } else {                                                                                                 \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        }                                                                                                        \
+        PP_FEED_DONE(); PP_MATH(2, x0, 0); PP_MATH_DONE();                                                       \
     }
+    if constexpr (BM == 256) {
+        for (int kt = 0; kt < nk; kt += 2) {
+            PP_TILE(kt, 0);
+            if (kt + 1 < nk) PP_TILE(kt + 1, 1);
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt += 2) {
+            PP_TILE128(kt, 0);
+            if (kt + 1 < nk) PP_TILE128(kt + 1, 1);
+        }
+    }
+#undef PP_TILE128
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
     __builtin_amdgcn_sched_barrier(0);
 #undef PP_TILE
@@ -230,8 +266,8 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     const int esz_o = p.out_f32 ? 4 : 2;
     constexpr int esz_r = RES == 2 ? 4 : 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int m = m0 + wr * 128 + j * 16 + fr;
+    for (int j = 0; j < TMW; ++j) {
+        const int m = m0 + wr * XH + j * 16 + fr;
         u32x4 rr[2][2];
         if constexpr (RES != 0) {
 #pragma unroll
@@ -285,16 +321,28 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     }
 }
 
-template <bool F16, int RES>
-static pvr_status launch_pp_inst(PPP &p, int grid, hipStream_t stream) {
+template <int BM, bool F16, int RES>
+static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
+    constexpr int lds = 2 * (BM * 128 + 32768);
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_pp256_kernel<F16, RES>), dim3(grid), dim3(512), 131072, stream, p);
+    const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
+    hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, RES>), dim3(grid), dim3(512), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
+}
+
+template <int BM>
+static pvr_status launch_pp_bm(PPP &p, int rmode, int dtype, hipStream_t stream) {
+    if (dtype == PVR_F16) {
+        if (rmode == 0) return launch_pp_inst<BM, true, 0>(p, stream);
+        return rmode == 1 ? launch_pp_inst<BM, true, 1>(p, stream) : launch_pp_inst<BM, true, 2>(p, stream);
+    }
+    if (rmode == 0) return launch_pp_inst<BM, false, 0>(p, stream);
+    return rmode == 1 ? launch_pp_inst<BM, false, 1>(p, stream) : launch_pp_inst<BM, false, 2>(p, stream);
 }
 
 // shapes the kernel accepts (the caller decides whether it is the faster choice)
@@ -304,7 +352,7 @@ bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_by
 }
 
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype,
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm,
                              hipStream_t stream) {
     PPP p;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.res = (const u16 *)res; p.bias = bias; p.out = out;
@@ -317,17 +365,12 @@ pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias,
     const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2, ob = M * cout * (out_f32 ? 4 : 2),
                   rb = res ? M * cout * (res_f32 ? 4 : 2) : 0;
     PVR_REQUIRE(pp256_supported(M, cin, cout, kh, kw, inb, wb, ob, rb), "conv_pp256: unsupported shape");
+    PVR_REQUIRE(bm == 256 || bm == 128, "conv_pp256: pixel tile must be 256 or 128");
     p.M = (int)M; p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
     p.act = act; p.out_f32 = out_f32;
     p.n_tiles = (cout + 255) / 256;
-    const int grid = ((p.M + 255) / 256) * p.n_tiles;
     const int rmode = !res ? 0 : (res_f32 ? 2 : 1);
-    if (dtype == PVR_F16) {
-        if (rmode == 0) return launch_pp_inst<true, 0>(p, grid, stream);
-        return rmode == 1 ? launch_pp_inst<true, 1>(p, grid, stream) : launch_pp_inst<true, 2>(p, grid, stream);
-    }
-    if (rmode == 0) return launch_pp_inst<false, 0>(p, grid, stream);
-    return rmode == 1 ? launch_pp_inst<false, 1>(p, grid, stream) : launch_pp_inst<false, 2>(p, grid, stream);
+    return bm == 256 ? launch_pp_bm<256>(p, rmode, dtype, stream) : launch_pp_bm<128>(p, rmode, dtype, stream);
 }
 
 }  // namespace pvr

@@ -21,7 +21,7 @@ pvr_status launch_conv(const void *, const void *, const float *, const void *, 
 // conv_pp256.hip: 256x256-tile ping-pong kernel for deep-K convolutions / linear layers
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, hipStream_t stream);
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream);
 int conv_algo();
 void set_conv_algo(int a);
 

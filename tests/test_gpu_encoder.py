@@ -73,7 +73,8 @@ CONV_CASES = [
 
 @pytest.fixture
 def conv_algo():
-    """select the implicit-GEMM kernel for one test (0 = conv_igemm 128x128, 1 = conv_pp256 256x256 ping-pong); restores 'auto'"""
+    """select the implicit-GEMM kernel for one test (0 = conv_igemm 128x128, 1 / 2 = conv_pp256 ping-pong with 256- / 128-pixel
+    tiles); restores 'auto'"""
     def _set(a):
         _lib.check(_lib.lib().pvr_debug_set_conv_algo(a))
     yield _set
@@ -82,7 +83,7 @@ def conv_algo():
 
 @pytest.mark.parametrize('case', CONV_CASES)
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
-@pytest.mark.parametrize('algo', [0, 1])
+@pytest.mark.parametrize('algo', [0, 1, 2])
 def test_conv2d_matches_torch(case, dt, algo, conv_algo):
     conv_algo(algo)
     n, h, w, cin, cout, k, stride, relu, res, out_f32 = case
@@ -162,12 +163,13 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
         r = torch.from_numpy(synth.normal(7, 'pr%s' % (case,), (n, ho, wo, cout))).to(torch.float32 if res == 2 else tdt).cuda()
     conv_algo(0)
     ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
-    conv_algo(1)
-    for rep in range(4):
-        out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
-        torch.cuda.synchronize()
-        assert torch.isfinite(out.float()).all()
-        assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+    for algo in (1, 2):                                            # 256- and 128-pixel tiles
+        conv_algo(algo)
+        for rep in range(4):
+            out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()
+            assert torch.equal(out, ref), (algo, rep, int((out != ref).sum()))
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
