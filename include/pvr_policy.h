@@ -52,6 +52,17 @@ typedef struct pvr_policy_bn {
     int64_t *num_batches_tracked;
 } pvr_policy_bn;
 
+/* SyncBN for the data-parallel finetune (BASELINE config 4; the reference itself is single-GPU, src/models.py:132-136 is a plain
+ * BatchNorm1d): with a callback installed and world_size > 1, training-mode BatchNorm uses the statistics of the GLOBAL batch
+ * (world_size x T x B rows, equal rows per rank), which makes N ranks x B/N sequences equal to one rank x B.  The library writes
+ * per-rank column sums into sync_buf (device, 2 * obs_size floats, caller-owned) and calls fn(offset, count, user) from inside
+ * pvr_policy_backward / _step / _forward(training); fn must enqueue, on the stream of that call, an in-place SUM all-reduce of
+ * sync_buf[offset, offset+count) over the ranks (torch.distributed.all_reduce on the current stream: RCCL over xGMI).  Three
+ * calls per iteration: mean (obs_size floats), centred second moment (obs_size), backward sums (2 * obs_size).  fn = NULL
+ * restores per-rank statistics. */
+typedef void (*pvr_policy_sync_fn)(int64_t offset, int64_t count, void *user);
+pvr_status pvr_policy_set_bn_sync(pvr_policy *pol, float *sync_buf, int32_t world_size, pvr_policy_sync_fn fn, void *user);
+
 /* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32 (uint8 (T,B,64,64,3n) when conv_frames = n > 0), done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
  * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82), h_out/c_out
  * (2,B,hidden) are device outputs.  training != 0 uses batch statistics and updates the BN buffers (:31-34). */

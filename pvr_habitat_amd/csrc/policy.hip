@@ -53,6 +53,11 @@ struct pvr_policy {
                    T == o.T && B == o.B && alpha == o.alpha && eps == o.eps && mgn == o.mgn;
         }
     } graph_key, eager_key;
+    // SyncBN for the data-parallel finetune (pvr_policy_set_bn_sync): BatchNorm statistics over the global batch
+    float *sync_buf = nullptr;              // caller-owned device buffer of 2 * obs_size floats, all-reduced (SUM) by the callback
+    pvr_policy_sync_fn sync_cb = nullptr;
+    void *sync_user = nullptr;
+    int sync_world = 1;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;       // capture happens on a private stream (the caller's may be the legacy stream, which cannot capture)
@@ -140,10 +145,28 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         PVR_REQUIRE(bn && bn->running_mean && bn->running_var, "policy: batch_norm=1 needs the BN buffers");
         if (training) {
             PVR_REQUIRE(N > 1, "BatchNorm1d training needs more than one row");
-            ColP c = {};
-            c.X = obs; c.out0 = pol->bn_mean; c.out1 = pol->bn_invstd; c.running_mean = bn->running_mean;
-            c.running_var = bn->running_var; c.nbt = (long long *)bn->num_batches_tracked; c.R = N; c.C = O;
-            hipLaunchKernelGGL(colreduce_kernel<1>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+            if (pol->sync_cb && pol->sync_world > 1) {
+                // global mean, then global centred second moment: two all-reduces of obs_size floats
+                const float ng = (float)N * (float)pol->sync_world;
+                ColP c = {};
+                c.X = obs; c.out0 = pol->sync_buf; c.R = N; c.C = O;
+                hipLaunchKernelGGL(colreduce_kernel<0>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+                PVR_LAUNCH_CHECK();
+                pol->sync_cb(0, O, pol->sync_user);
+                hipLaunchKernelGGL(scale_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->bn_mean, pol->sync_buf, 1.0f / ng, O);
+                ColP c2 = {};
+                c2.X = obs; c2.mean_in = pol->bn_mean; c2.out0 = pol->sync_buf + O; c2.R = N; c2.C = O;
+                hipLaunchKernelGGL(colreduce_kernel<3>, dim3((O + 31) / 32), dim3(256), 0, st, c2);
+                PVR_LAUNCH_CHECK();
+                pol->sync_cb(O, O, pol->sync_user);
+                hipLaunchKernelGGL(bn_sync_final_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->sync_buf + O, pol->bn_mean, ng,
+                                   pol->bn_invstd, bn->running_mean, bn->running_var, (long long *)bn->num_batches_tracked, O);
+            } else {
+                ColP c = {};
+                c.X = obs; c.out0 = pol->bn_mean; c.out1 = pol->bn_invstd; c.running_mean = bn->running_mean;
+                c.running_var = bn->running_var; c.nbt = (long long *)bn->num_batches_tracked; c.R = N; c.C = O;
+                hipLaunchKernelGGL(colreduce_kernel<1>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+            }
             hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)N * O / 4)), dim3(256), 0, st, obs, pol->bn_mean, pol->bn_invstd,
                                P + pol->o_bnw, P + pol->o_bnb, pol->a0, (size_t)N * O / 4, O, 0);
         } else {
@@ -245,8 +268,17 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         c.out0 = Gd + pol->o_bnw; c.out1 = Gd + pol->o_bnb; c.R = N; c.C = O;
         hipLaunchKernelGGL(colreduce_kernel<2>, dim3((O + 31) / 32), dim3(256), 0, st, c);
         if (need_dobs) {
+            const float *dg = Gd + pol->o_bnw, *db = Gd + pol->o_bnb;
+            int n_bn = N;
+            if (pol->sync_cb && pol->sync_world > 1) {
+                // dx needs the sums over the GLOBAL batch; the gradient buffer keeps the local ones (they are averaged with the rest)
+                PVR_HIP_TRY(hipMemcpyAsync(pol->sync_buf, dg, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
+                PVR_HIP_TRY(hipMemcpyAsync(pol->sync_buf + O, db, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
+                pol->sync_cb(0, 2 * O, pol->sync_user);
+                dg = pol->sync_buf; db = pol->sync_buf + O; n_bn = N * pol->sync_world;
+            }
             hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks_for((size_t)N * O)), dim3(256), 0, st, obs, pol->da0, pol->bn_mean, pol->bn_invstd,
-                               P + pol->o_bnw, Gd + pol->o_bnw, Gd + pol->o_bnb, pol->dfeat, N, O);
+                               P + pol->o_bnw, dg, db, pol->dfeat, N, O, n_bn);
             dfeat = pol->dfeat;
         }
         PVR_LAUNCH_CHECK();
@@ -405,6 +437,13 @@ void pvr_policy_destroy(pvr_policy *p) {
     delete p;
 }
 
+pvr_status pvr_policy_set_bn_sync(pvr_policy *pol, float *sync_buf, int32_t world_size, pvr_policy_sync_fn fn, void *user) {
+    PVR_REQUIRE(pol, "pvr_policy_set_bn_sync: null policy");
+    PVR_REQUIRE(!fn || (sync_buf && world_size >= 1), "pvr_policy_set_bn_sync: callback needs a buffer of 2*obs_size floats and the world size");
+    pol->sync_buf = fn ? sync_buf : nullptr; pol->sync_cb = fn; pol->sync_user = user; pol->sync_world = fn ? world_size : 1;
+    return PVR_OK;
+}
+
 int64_t pvr_policy_param_count(const pvr_policy *p) { return p ? p->n_total : 0; }
 int64_t pvr_policy_trainable_count(const pvr_policy *p) { return p ? p->n_train : 0; }
 
@@ -466,7 +505,7 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;
     TRY(set_lr(pol, lr, st));
-    if (!pol->use_graph) {
+    if (!pol->use_graph || pol->sync_cb) {      // (a host callback cannot run inside a stream capture)
         TRY(loss_backward(pol, params, bn, obs, done, (const long long *)actions, T, B, pol->grads, st));
         TRY(apply_core(pol, params, square_avg, pol->grads, alpha, eps, max_grad_norm, st));
     } else {

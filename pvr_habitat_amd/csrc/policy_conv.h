@@ -250,9 +250,9 @@ static __global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float
 static __global__ __launch_bounds__(256) void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
                                                     const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                     const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-                                                    float *__restrict__ dx, int N, int C) {
+                                                    float *__restrict__ dx, int N, int C, int n_stat) {
     const size_t total = (size_t)N * C;
-    const float inv_n = 1.0f / (float)N;
+    const float inv_n = 1.0f / (float)n_stat;      // rows the statistics were taken over (N, or the global batch under SyncBN)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const float xh = (x[i] - mean[c]) * invstd[c];

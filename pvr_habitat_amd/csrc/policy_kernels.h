@@ -173,6 +173,11 @@ static __global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
         if (ok) for (int r = g; r < p.R; r += 8) a0 += p.X[(size_t)r * p.C + c];
     } else if (MODE == 1) {
         if (ok) for (int r = g; r < p.R; r += 8) a0 += p.X[(size_t)r * p.C + c];
+    } else if (MODE == 3) {          // centred sum of squares around a given mean (SyncBN second pass)
+        if (ok) {
+            const float mu = p.mean_in[c];
+            for (int r = g; r < p.R; r += 8) { const float d = p.X[(size_t)r * p.C + c] - mu; a0 += d * d; }
+        }
     } else {
         if (ok) {
             const float mu = p.mean_in[c], is = p.invstd_in[c];
@@ -188,7 +193,7 @@ static __global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { t0 += s0[i][cx]; t1 += s1[i][cx]; }
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         if (ok && g == 0) { p.out0[c] = t0; if (p.out1) p.out1[c] = t0; }
     } else if (MODE == 2) {
         if (ok && g == 0) { p.out0[c] = t0; p.out1[c] = t1; }
@@ -574,5 +579,22 @@ static __global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__
 }
 
 static __global__ void set_scalar_kernel(float *dst, float v) { *dst = v; }
+
+// SyncBN (data-parallel finetune): statistics over the GLOBAL batch of n_global rows, from all-reduced column sums
+static __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ out, const float *__restrict__ in, float s, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+static __global__ __launch_bounds__(256) void bn_sync_final_kernel(const float *__restrict__ sumsq, const float *__restrict__ mean,
+                                                            float n_global, float *__restrict__ invstd, float *__restrict__ running_mean,
+                                                            float *__restrict__ running_var, long long *nbt, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float var_b = sumsq[c] / n_global;
+    invstd[c] = 1.0f / sqrtf(var_b + 1e-5f);
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean[c];
+    running_var[c] = 0.9f * running_var[c] + 0.1f * (var_b * n_global / (n_global - 1.f));
+    if (c == 0 && nbt) *nbt += 1;
+}
 
 }  // namespace pvr

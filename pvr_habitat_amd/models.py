@@ -31,6 +31,9 @@ class PolicyDesc(C.Structure):
                 ('max_t', C.c_int32), ('max_b', C.c_int32), ('conv_frames', C.c_int32)]
 
 
+SYNC_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)     # pvr_policy_sync_fn (include/pvr_policy.h)
+
+
 def _plib():
     L = _lib.lib()
     if not getattr(L, '_policy_bound', False):
@@ -53,6 +56,8 @@ def _plib():
         L.pvr_policy_backward.argtypes = [vp, vp, C.POINTER(PolicyBN), vp, vp, vp, i32, i32, vp, vp, vp, vp]
         L.pvr_policy_apply.restype = C.c_int
         L.pvr_policy_apply.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, vp, vp]
+        L.pvr_policy_set_bn_sync.restype = C.c_int
+        L.pvr_policy_set_bn_sync.argtypes = [vp, vp, i32, SYNC_FN, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
         L.pvr_op_gemm_f32.restype = C.c_int
@@ -301,6 +306,7 @@ class HipRMSprop(object):
         self.steps = 0
         self._stats = None
         self._grads = None            # caller-owned flat gradient (data-parallel path)
+        self._sync_buf = self._sync_cb = self._sync_group = None   # SyncBN plumbing (data-parallel path)
 
     def scheduler_step(self):
         self.last_epoch += 1
@@ -331,16 +337,37 @@ class HipRMSprop(object):
         self.steps += 1
         return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
 
-    def step_data_parallel(self, obs, done, actions, group=None):
+    def _install_bn_sync(self, group, world):
+        """SyncBN: BatchNorm statistics over the global batch.  The library calls back between its statistic
+        kernels; the callback all-reduces a slice of a small device buffer on the current stream (pvr_policy.h)."""
+        import torch.distributed as dist
+        m = self.model
+        if self._sync_buf is None or self._sync_buf.device != m.device:
+            self._sync_buf = torch.zeros(2 * m.obs_size, dtype=torch.float32, device=m.device)
+
+            def _cb(offset, count, user, _buf=self._sync_buf):
+                dist.all_reduce(_buf[offset:offset + count], op=dist.ReduceOp.SUM, group=self._sync_group)
+            self._sync_cb = SYNC_FN(_cb)                      # keep the ctypes thunk alive
+        self._sync_group = group
+        _lib.check(_plib().pvr_policy_set_bn_sync(m._handle, C.c_void_p(self._sync_buf.data_ptr()), world, self._sync_cb, None))
+
+    def step_data_parallel(self, obs, done, actions, group=None, sync_bn=True):
         """Finetune configuration: every rank runs forward/backward on its slice of the batch, the flat
         gradient is summed over ranks with ONE all-reduce (RCCL over xGMI under backend 'nccl') and divided by the
         world size (loss is a mean over the global batch), then every rank applies the identical clipped RMSprop
-        update.  BatchNorm statistics are per-rank (torch DDP default); see DESIGN.md."""
+        update.  With sync_bn (default) BatchNorm uses global-batch statistics (three more all-reduces of <= 2*obs_size
+        floats), so N ranks x B/N sequences reproduce one rank x B; sync_bn=False keeps per-rank statistics (torch DDP
+        default)."""
         import torch.distributed as dist
         m = self.model
         T, B = obs.shape[0], obs.shape[1]
         m._ensure(T, B)
         dev = m.device
+        world0 = dist.get_world_size(group) if dist.is_initialized() else 1
+        if m.batch_norm and sync_bn and world0 > 1:
+            self._install_bn_sync(group, world0)
+        elif self._sync_cb is not None:
+            _lib.check(_plib().pvr_policy_set_bn_sync(m._handle, None, 1, SYNC_FN(), None))
         if self.square_avg.device != dev:
             self.square_avg = self.square_avg.to(dev)
         if self._grads is None or self._grads.device != dev:

@@ -227,15 +227,16 @@ from pvr_habitat_amd import synth
 from pvr_habitat_amd.models import PolicyNet, PolicyNetWithConv, HipRMSprop
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo', rank=rank, world_size=world)       # two ranks share the single test GPU: gloo, not RCCL
-conv = sys.argv[2] == 'conv'
+conv = sys.argv[2].startswith('conv')
+bn = sys.argv[2].endswith('_bn')                                    # SyncBN: global-batch statistics through the callback
 T, B, O, A = 6, 8, 128, 3
 if conv:
-    m = PolicyNetWithConv((64, 64, 6), A, False, max_unroll=T, max_batch=B)
-    sd = synth.policy_state_dict(21, 256, A, False, conv=True)
+    m = PolicyNetWithConv((64, 64, 6), A, bn, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(21, 256, A, bn, conv=True)
     obs, done, act = synth.bc_conv_batches(21, T, B, 2, A)
 else:
-    m = PolicyNet((O,), A, False, max_unroll=T, max_batch=B)
-    sd = synth.policy_state_dict(21, O, A, False)
+    m = PolicyNet((O,), A, bn, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(21, O, A, bn)
     obs, done, act = synth.bc_batches(21, T, B, O, A, 2)
 m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
 m = m.to('cuda').train()
@@ -245,15 +246,17 @@ for s in range(2):
     opt.scheduler_step()
     loss, gn = opt.step_data_parallel(torch.from_numpy(obs[s][:, lo:hi]), torch.from_numpy(done[s][:, lo:hi]), torch.from_numpy(act[s][:, lo:hi]))
 if rank == 0:
-    np.savez(sys.argv[1], flat=m._flat.cpu().numpy(), loss=float(loss), gn=float(gn))
+    extra = {k.replace('.', '_'): v.cpu().numpy() for k, v in m.state_dict().items() if 'running' in k}
+    np.savez(sys.argv[1], flat=m._flat.cpu().numpy(), loss=float(loss), gn=float(gn), **extra)
 dist.barrier()
 '''
 
 
-@pytest.mark.parametrize('kind', ['vec', 'conv'])
+@pytest.mark.parametrize('kind', ['vec', 'conv', 'vec_bn', 'conv_bn'])
 def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
-    """Finetune DP (SURVEY 8e): 2 ranks x B/2 sequences + one all-reduce of the flat gradient == 1 rank x B
-    (BatchNorm off: its statistics are per rank, see DESIGN.md section 6).  Both ranks run on the one test GPU."""
+    """Finetune DP (SURVEY 8e): 2 ranks x B/2 sequences + one all-reduce of the flat gradient == 1 rank x B, with BatchNorm
+    too (SyncBN: global-batch statistics through pvr_policy_set_bn_sync, incl. the running buffers and, for the conv
+    variant, the BN input gradient).  Both ranks run on the one test GPU."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'dp_gpu.py'
@@ -270,3 +273,6 @@ def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
     assert float(res[2]['loss']) == pytest.approx(float(res[1]['loss']), rel=1e-5)
     assert float(res[2]['gn']) == pytest.approx(float(res[1]['gn']), rel=1e-4)
     np.testing.assert_allclose(res[2]['flat'], res[1]['flat'], rtol=1e-4, atol=1e-6)
+    for k in res[1].files:
+        if 'running' in k:
+            np.testing.assert_allclose(res[2][k], res[1][k], rtol=1e-5, atol=1e-7, err_msg=k)
