@@ -162,7 +162,8 @@ def mae_encode(sd, x, heads=12, taps=None):
     return x[:, 0, :]                                             # embeddings.py:379
 
 
-def mae_embed(sd, frames_nhwc_u8, squeeze=True):
+def mae_embed(sd, frames_nhwc_u8, squeeze=True, heads=12):
+    """heads: 12 for mae_base (mae.py:277), 16 for mae_large (mae.py:285)"""
     with torch.no_grad():
-        out = mae_encode(sd, mae_preprocess(frames_nhwc_u8))
+        out = mae_encode(sd, mae_preprocess(frames_nhwc_u8), heads=heads)
         return (out.squeeze() if squeeze else out).numpy()

@@ -359,7 +359,8 @@ static pvr_status up_linear(pvr_encoder *e, const std::string &wname, const std:
 pvr_status vit_create(pvr_encoder *e) {
     pvr_vit *v = new pvr_vit();
     v->patch = e->desc.arch == PVR_ARCH_CLIP_VIT_B32 ? 32 : 16;
-    v->mae = e->desc.arch == PVR_ARCH_MAE_VIT_B16;
+    v->mae = e->desc.arch == PVR_ARCH_MAE_VIT_B16 || e->desc.arch == PVR_ARCH_MAE_VIT_L16;
+    if (e->desc.arch == PVR_ARCH_MAE_VIT_L16) { v->width = 1024; v->layers = 24; v->heads = 16; }   // mae.py:283-288
     if (v->mae) { v->eps = 1e-6f; v->act = 3; v->out_dim = v->width; }
     v->res = e->desc.crop;
     v->resize_to = e->desc.resize;
@@ -539,11 +540,11 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
     return PVR_OK;
 }
 
-template <bool F16>
+template <bool F16, int WD>
 static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
     pvr_vit *v = e->vit;
     const int W = v->width, P = v->patch, K = P * P * 3, T = v->T, g2 = v->grid * v->grid, dt = e->desc.dtype;
-    PVR_REQUIRE(W == 768, "vit: width %d not built", W);
+    PVR_REQUIRE(W == WD, "vit: width %d does not match the instantiated plan", W);
     // transforms (embeddings.py:309-314): Resize(res, BICUBIC, antialias) is the identity when the short side is res
     const int sh = w <= h ? w : h;
     const bool resize = sh != v->resize_to;
@@ -572,7 +573,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         // patch embedding GEMM -> fp32 [prow][W]
         if ((s = launch_conv(v->A, v->w_patch, v->b_patch, nullptr, v->pe, v->zero, prow, 1, 1, K, W, 1, 1, 1, 0, 0, 1, dt, st))) return s;
         // tokens + positional embedding + ln_pre -> residual stream x0 (fp32)
-        hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *)nullptr, v->pe, v->cls,
+        hipLaunchKernelGGL((layernorm_kernel<F16, WD>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *)nullptr, v->pe, v->cls,
                            v->pos, v->lnpre_w, v->lnpre_b, v->x0, (u16 *)nullptr, rows, T, v->eps, v->mae ? 0 : 1);
         PVR_LAUNCH_CHECK();
         e->last_n = nb;
@@ -582,7 +583,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         int bi = 0;
         const size_t att_lds = (size_t)v->TK * 128 + (size_t)64 * (v->TK + 4) * 2;
         for (auto &b : v->blocks) {
-            hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
+            hipLaunchKernelGGL((layernorm_kernel<F16, WD>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
                                (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
             if ((s = launch_conv(v->y, b.w_qkv, b.b_qkv, nullptr, v->qkv, v->zero, rows, 1, 1, W, 3 * W, 1, 1, 1, 0, 0, 0, dt, st))) return s;
             if (bi == 0 && stop == "qkv0") return PVR_OK;
@@ -592,7 +593,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
             // x' = x + out_proj(att): fp32 residual in (bit1), fp32 out (bit0)
             if ((s = launch_conv(v->att, b.w_out, b.b_out, x, xn, v->zero, rows, 1, 1, W, W, 1, 1, 1, 0, 0, 3, dt, st))) return s;
             if (bi == 0 && stop == "res0") return PVR_OK;
-            hipLaunchKernelGGL((layernorm_kernel<F16, 768>), dim3((rows + 3) / 4), dim3(256), 0, st, xn, (const float *)nullptr,
+            hipLaunchKernelGGL((layernorm_kernel<F16, WD>), dim3((rows + 3) / 4), dim3(256), 0, st, xn, (const float *)nullptr,
                                (const float *)nullptr, (const float *)nullptr, b.ln2_w, b.ln2_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
             if ((s = launch_conv(v->y, b.w_fc, b.b_fc, nullptr, v->hid, v->zero, rows, 1, 1, W, 4 * W, 1, 1, 1, 0, v->act, 0, dt, st))) return s;   // QuickGELU / GELU
             if (bi == 0 && stop == "fc0") return PVR_OK;
@@ -600,7 +601,7 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
             if (stop == "block" + std::to_string(bi)) return PVR_OK;
             ++bi;
         }
-        hipLaunchKernelGGL((cls_head_kernel<768>), dim3(nb), dim3(256), 0, st, x, v->lnpost_w, v->lnpost_b, v->proj,
+        hipLaunchKernelGGL((cls_head_kernel<WD>), dim3(nb), dim3(256), 0, st, x, v->lnpost_w, v->lnpost_b, v->proj,
                            out + (size_t)f0 * out_stride, out_stride, T, v->out_dim, v->eps);
         PVR_LAUNCH_CHECK();
         e->last_n = nb;
@@ -652,8 +653,11 @@ pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int 
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_done = true;
     }
-    return e->desc.dtype == PVR_F16 ? vit_forward_t<true>(e, frames, n, h, w, out, out_stride, st)
-                                    : vit_forward_t<false>(e, frames, n, h, w, out, out_stride, st);
+    if (e->vit->width == 1024)
+        return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 1024>(e, frames, n, h, w, out, out_stride, st)
+                                        : vit_forward_t<false, 1024>(e, frames, n, h, w, out, out_stride, st);
+    return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 768>(e, frames, n, h, w, out, out_stride, st)
+                                    : vit_forward_t<false, 768>(e, frames, n, h, w, out, out_stride, st);
 }
 
 }  // namespace pvr

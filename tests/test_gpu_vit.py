@@ -82,3 +82,19 @@ def test_mae_vit_b16_matches_oracle(h, w):
     l2, mx = _rel(out, ref)
     print('\n[mae_b16 f16 %dx%d] rel-L2 %.2e max-norm %.2e' % (h, w, l2, mx))
     assert l2 < 1e-3
+
+
+def test_mae_vit_l16_matches_oracle():
+    """MAE ViT-L/16 encoder ('mae_large': width 1024, 24 blocks, 16 heads; mae.py:283-288)."""
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.mae_vit_state_dict(2, width=1024, layers=24)
+    fr = synth.smooth_frames(48, 2, 128, 128)
+    ref = vo.mae_embed(sd, fr, squeeze=False, heads=16)
+    m = HipResNet50(sd, 'mae_l16', compute_dtype='f16', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert out.shape == (2, 1024)
+    l2, mx = _rel(out, ref)
+    print('\n[mae_l16 f16] rel-L2 %.2e max-norm %.2e' % (l2, mx))
+    assert l2 < 1.5e-3
