@@ -29,6 +29,12 @@ struct pvr_policy {
     float *a0 = nullptr, *bn_mean = nullptr, *bn_invstd = nullptr, *a1 = nullptr, *a2 = nullptr;
     float *G[2] = {nullptr, nullptr}, *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};
     float *hprev = nullptr, *nd = nullptr, *zeros = nullptr, *dc_carry = nullptr, *rec_partial = nullptr;
+    float *hprev1 = nullptr, *dc_carry1 = nullptr, *rec_partial1 = nullptr;   // layer-1 copies: the two layers run concurrently
+    // layer pipeline: the recurrences of the two LSTM layers are chains of ~6 us launches; layer 1 of time chunk c only needs
+    // layer 0 of chunk c (forward; mirrored in BPTT), so the two chains run on two streams, a quarter of the sequence apart
+    hipStream_t lane_a = nullptr, lane_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join_a = nullptr, ev_join_b = nullptr, ev_chunk[8] = {nullptr};
+    int pipeline = 1;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
@@ -178,11 +184,9 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
     }
     TRY(gemm(x0, P + pol->o_fc1w, P + pol->o_fc1b, nullptr, pol->a1, N, H, O, false, false, 1, st));
     TRY(gemm(pol->a1, P + pol->o_fc2w, P + pol->o_fc2b, nullptr, pol->a2, N, H, H, false, false, 1, st));
-    const float *xin = pol->a2;
-    for (int l = 0; l < 2; ++l) {
-        // hoisted input projection of all T steps: Gx = x W_ih^T + b_ih (b_hh is added in the recurrent step)
-        TRY(gemm(xin, P + pol->o_wih[l], P + pol->o_bih[l], nullptr, pol->G[l], N, 4 * H, H, false, false, 0, st));
-        for (int t = 0; t < T; ++t) {
+    // LSTM, two layers.  Input projections are hoisted out of the recurrence (one GEMM over all steps of a chunk).
+    auto fwd_steps = [&](int l, int t0, int t1, hipStream_t s_) {
+        for (int t = t0; t < t1; ++t) {
             LstmFwdP f;
             f.G = pol->G[l] + (size_t)t * B * 4 * H;
             f.h_prev = t == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t - 1) * B * H;
@@ -193,10 +197,38 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
             f.h_out = pol->Hs[l] + (size_t)t * B * H;
             f.c_out = pol->Cs[l] + (size_t)t * B * H;
             f.B = B; f.H = H;
-            hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, st, f);
+            hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, s_, f);
+        }
+    };
+    TRY(gemm(pol->a2, P + pol->o_wih[0], P + pol->o_bih[0], nullptr, pol->G[0], N, 4 * H, H, false, false, 0, st));
+    const int NCH = pol->pipeline && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
+    if (NCH == 1) {
+        fwd_steps(0, 0, T, st);
+        TRY(gemm(pol->Hs[0], P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1], N, 4 * H, H, false, false, 0, st));
+        fwd_steps(1, 0, T, st);
+        PVR_LAUNCH_CHECK();
+    } else {
+        // lane A: layer 0; lane B: per chunk the input projection of layer 1, then its steps
+        hipStream_t sa = pol->lane_a, sb = pol->lane_b;
+        PVR_HIP_TRY(hipEventRecord(pol->ev_fork, st));
+        PVR_HIP_TRY(hipStreamWaitEvent(sa, pol->ev_fork, 0));
+        PVR_HIP_TRY(hipStreamWaitEvent(sb, pol->ev_fork, 0));
+        for (int c = 0; c < NCH; ++c) {
+            const int t0 = c * CH, t1 = (c + 1) * CH < T ? (c + 1) * CH : T;
+            if (t0 >= t1) break;
+            fwd_steps(0, t0, t1, sa);
+            PVR_HIP_TRY(hipEventRecord(pol->ev_chunk[c], sa));
+            PVR_HIP_TRY(hipStreamWaitEvent(sb, pol->ev_chunk[c], 0));
+            const size_t r0 = (size_t)t0 * B;
+            TRY(gemm(pol->Hs[0] + r0 * H, P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1] + r0 * 4 * H, (t1 - t0) * B, 4 * H, H,
+                     false, false, 0, sb));
+            fwd_steps(1, t0, t1, sb);
         }
         PVR_LAUNCH_CHECK();
-        xin = pol->Hs[l];
+        PVR_HIP_TRY(hipEventRecord(pol->ev_join_a, sa));
+        PVR_HIP_TRY(hipEventRecord(pol->ev_join_b, sb));
+        PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_a, 0));
+        PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_b, 0));
     }
     HeadP hp;
     hp.out = pol->Hs[1]; hp.Wp = P + pol->o_pw; hp.bp = P + pol->o_pb; hp.Wb = P + pol->o_bw; hp.bb = P + pol->o_bb;
@@ -219,38 +251,73 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     hipLaunchKernelGGL(head_dx_kernel, dim3(blocks_for((size_t)N * H)), dim3(256), 0, st, pol->dlogits, P + pol->o_pw, pol->dA, N, H, A);
     PVR_LAUNCH_CHECK();
     // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
-    float *dh_ext = pol->dA, *dx = pol->dB;
-    for (int l = 1; l >= 0; --l) {
-        for (int t = T - 1; t >= 0; --t) {
+    float *scr_dc[2] = {pol->dc_carry, pol->dc_carry1}, *scr_rec[2] = {pol->rec_partial, pol->rec_partial1}, *scr_hp[2] = {pol->hprev, pol->hprev1};
+    auto bwd_steps = [&](int l, int t_hi, int t_lo, const float *dh_ext_, hipStream_t s_) {          // t = t_hi-1 ... t_lo
+        for (int t = t_hi - 1; t >= t_lo; --t) {
             const bool has_next = t < T - 1;
             if (has_next) {
                 LstmRecP r;
-                r.dG_next = pol->G[l] + (size_t)(t + 1) * B * 4 * H; r.W = P + pol->o_whh[l]; r.partial = pol->rec_partial; r.B = B; r.H = H;
-                hipLaunchKernelGGL(lstm_bwd_rec_kernel, dim3(256), dim3(256), 0, st, r);
+                r.dG_next = pol->G[l] + (size_t)(t + 1) * B * 4 * H; r.W = P + pol->o_whh[l]; r.partial = scr_rec[l]; r.B = B; r.H = H;
+                hipLaunchKernelGGL(lstm_bwd_rec_kernel, dim3(256), dim3(256), 0, s_, r);
             }
             LstmCellBP c;
-            c.partial = has_next ? pol->rec_partial : nullptr;
+            c.partial = has_next ? scr_rec[l] : nullptr;
             c.nd_next = has_next ? pol->nd + (size_t)(t + 1) * B : nullptr;
-            c.dh_ext = dh_ext + (size_t)t * B * H;
-            c.dc_carry = pol->dc_carry;
+            c.dh_ext = dh_ext_ + (size_t)t * B * H;
+            c.dc_carry = scr_dc[l];
             c.G = pol->G[l] + (size_t)t * B * 4 * H;
             c.c_t = pol->Cs[l] + (size_t)t * B * H;
             c.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
             c.nd = pol->nd + (size_t)t * B;
             c.B = B; c.H = H;
-            hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, c);
+            hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((B * H + 255) / 256), dim3(256), 0, s_, c);
+        }
+    };
+    // dW_hh = dG^T (nd * h_prev), dW_ih = dG^T x_in, db_ih = db_hh = colsum(dG)
+    auto weight_grads = [&](int l, hipStream_t s_) -> pvr_status {
+        const float *xin = l == 0 ? pol->a2 : pol->Hs[0];
+        hipLaunchKernelGGL(hprev_kernel, dim3(blocks_for((size_t)N * H / 4)), dim3(256), 0, s_, pol->Hs[l], pol->zeros, pol->nd, scr_hp[l], T, B, H);
+        TRY(gemm(pol->G[l], scr_hp[l], nullptr, nullptr, Gd + pol->o_whh[l], 4 * H, H, N, true, true, 0, s_));
+        TRY(gemm(pol->G[l], xin, nullptr, nullptr, Gd + pol->o_wih[l], 4 * H, H, N, true, true, 0, s_));
+        return colsum(pol->G[l], Gd + pol->o_bih[l], Gd + pol->o_bhh[l], N, 4 * H, s_);
+    };
+    float *dh1 = pol->dA, *dh0 = pol->dB;          // d(loss)/d(h) arriving from above: layer 1 <- heads, layer 0 <- layer 1's dx
+    const int NCH = pol->pipeline && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
+    if (NCH == 1) {
+        bwd_steps(1, T, 0, dh1, st);
+        PVR_LAUNCH_CHECK();
+        TRY(weight_grads(1, st));
+        TRY(gemm(pol->G[1], P + pol->o_wih[1], nullptr, nullptr, dh0, N, H, 4 * H, false, true, 0, st));
+        bwd_steps(0, T, 0, dh0, st);
+        PVR_LAUNCH_CHECK();
+    } else {
+        // lane A: layer 1 BPTT chunk by chunk (t descending), then its weight gradients; lane B: per chunk the dx GEMM of layer 1
+        // (= dh of layer 0) and layer 0's BPTT steps of that chunk
+        hipStream_t sa = pol->lane_a, sb = pol->lane_b;
+        PVR_HIP_TRY(hipEventRecord(pol->ev_fork, st));
+        PVR_HIP_TRY(hipStreamWaitEvent(sa, pol->ev_fork, 0));
+        PVR_HIP_TRY(hipStreamWaitEvent(sb, pol->ev_fork, 0));
+        for (int c = NCH - 1; c >= 0; --c) {
+            const int t0 = c * CH, t1 = (c + 1) * CH < T ? (c + 1) * CH : T;
+            if (t0 >= t1) continue;
+            bwd_steps(1, t1, t0, dh1, sa);
+            PVR_HIP_TRY(hipEventRecord(pol->ev_chunk[c], sa));
+            PVR_HIP_TRY(hipStreamWaitEvent(sb, pol->ev_chunk[c], 0));
+            const size_t r0 = (size_t)t0 * B;
+            TRY(gemm(pol->G[1] + r0 * 4 * H, P + pol->o_wih[1], nullptr, nullptr, dh0 + r0 * H, (t1 - t0) * B, H, 4 * H, false, true, 0, sb));
+            bwd_steps(0, t1, t0, dh0, sb);
         }
         PVR_LAUNCH_CHECK();
-        const float *xin = l == 0 ? pol->a2 : pol->Hs[0];
-        // dW_hh = dG^T (nd * h_prev), dW_ih = dG^T x_in, db_ih = db_hh = colsum(dG)
-        hipLaunchKernelGGL(hprev_kernel, dim3(blocks_for((size_t)N * H / 4)), dim3(256), 0, st, pol->Hs[l], pol->zeros, pol->nd, pol->hprev, T, B, H);
-        TRY(gemm(pol->G[l], pol->hprev, nullptr, nullptr, Gd + pol->o_whh[l], 4 * H, H, N, true, true, 0, st));
-        TRY(gemm(pol->G[l], xin, nullptr, nullptr, Gd + pol->o_wih[l], 4 * H, H, N, true, true, 0, st));
-        TRY(colsum(pol->G[l], Gd + pol->o_bih[l], Gd + pol->o_bhh[l], N, 4 * H, st));
-        // dx_in = dG W_ih; for layer 0 the ReLU of fc2 is applied as a mask (a2 > 0)
-        TRY(gemm(pol->G[l], P + pol->o_wih[l], nullptr, l == 0 ? pol->a2 : nullptr, dx, N, H, 4 * H, false, true, 0, st));
-        float *tmp = dh_ext; dh_ext = dx; dx = tmp;
+        TRY(weight_grads(1, sa));
+        PVR_HIP_TRY(hipEventRecord(pol->ev_join_a, sa));
+        PVR_HIP_TRY(hipEventRecord(pol->ev_join_b, sb));
+        PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_a, 0));
+        PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_b, 0));
     }
+    TRY(weight_grads(0, st));
+    // dx_in of layer 0 = dG W_ih with the ReLU of fc2 applied as a mask (a2 > 0); dh1's buffer is free again
+    TRY(gemm(pol->G[0], P + pol->o_wih[0], nullptr, pol->a2, dh1, N, H, 4 * H, false, true, 0, st));
+    float *dh_ext = dh1, *dx = dh0;
     // dh_ext now holds dz2 = d(fc2 pre-activation) [N][H]
     float *dz2 = dh_ext, *dz1 = dx;
     const float *x0 = d.batch_norm ? pol->a0 : obs;
@@ -400,6 +467,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     A_(a0, N * O); A_(bn_mean, O); A_(bn_invstd, O); A_(a1, N * H); A_(a2, N * H);
     for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); }
     A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H); A_(rec_partial, 16 * B * H);
+    A_(hprev1, N * H); A_(dc_carry1, B * H); A_(rec_partial1, 16 * B * H);
     A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
     A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
     if (desc->conv_frames > 0) {
@@ -417,6 +485,15 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     }
     A_(in_done, N); A_(in_act, N);
     if (const char *e = getenv("PVR_POLICY_GRAPH")) p->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
+    if (!s && p->pipeline) {
+        hipError_t he = hipStreamCreateWithFlags(&p->lane_a, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->lane_b, hipStreamNonBlocking);
+        hipEvent_t *evs[3] = {&p->ev_fork, &p->ev_join_a, &p->ev_join_b};
+        for (auto ev : evs) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        for (int i = 0; i < 8; ++i) if (he == hipSuccess) he = hipEventCreateWithFlags(&p->ev_chunk[i], hipEventDisableTiming);
+        if (he != hipSuccess) { set_error("policy: stream/event creation failed: %s", hipGetErrorString(he)); s = PVR_ERR_HIP; }
+    }
 #undef A_
     if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("policy: device sync failed"); s = PVR_ERR_HIP; }
     if (s) { pvr_policy_destroy(p); return s; }
@@ -429,7 +506,11 @@ void pvr_policy_destroy(pvr_policy *p) {
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
                     p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
-                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act};
+                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act, p->hprev1, p->dc_carry1, p->rec_partial1};
+    if (p->lane_a) (void)hipStreamDestroy(p->lane_a);
+    if (p->lane_b) (void)hipStreamDestroy(p->lane_b);
+    for (hipEvent_t ev : {p->ev_fork, p->ev_join_a, p->ev_join_b}) if (ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 8; ++i) if (p->ev_chunk[i]) (void)hipEventDestroy(p->ev_chunk[i]);
     drop_graph(p);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (void *q : ptrs) if (q) (void)hipFree(q);

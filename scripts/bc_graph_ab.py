@@ -1,8 +1,10 @@
-"""A/B of eager launches vs hipGraph replay for the BC iteration (PVR_POLICY_GRAPH), 5 warm-up + 50 timed steps."""
+"""A/B of the BC iteration launch strategies: PVR_POLICY_PIPELINE (two-lane layer pipeline of the LSTM recurrences) x
+PVR_POLICY_GRAPH (hipGraph replay).  5 warm-up + 50 timed steps each, one process."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-for g in ('0', '1', '0', '1'):
+for pipe, g in (('0', '0'), ('1', '0'), ('0', '1'), ('1', '1'), ('0', '0'), ('1', '0')):
+    os.environ['PVR_POLICY_PIPELINE'] = pipe
     os.environ['PVR_POLICY_GRAPH'] = g
     r = bench.bc_bench(50, 5, False)
-    print('PVR_POLICY_GRAPH=%s  %.1f steps/s  %.3f ms/step' % (g, r['value'], r['ms_per_step']), flush=True)
+    print('PIPELINE=%s GRAPH=%s  %.1f steps/s  %.3f ms/step  loss %.5f' % (pipe, g, r['value'], r['ms_per_step'], r['final_loss']), flush=True)
