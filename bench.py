@@ -194,6 +194,7 @@ def main():
     ap.add_argument('--frame', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--lanes', type=int, default=2, help='batches in flight per GPU (1 = strictly one forward at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
@@ -207,11 +208,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    # PVR_BENCH_ONE_GPU=1 (test aid for 1-GPU boxes): every rank on cuda:0 with the gloo backend, to exercise the N > 1 path
+    one_gpu = os.environ.get('PVR_BENCH_ONE_GPU', '0') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from pvr_habitat_amd import synth, _lib
     from pvr_habitat_amd.embeddings import HipResNet50
@@ -223,24 +231,39 @@ def main():
     frames_np = synth.frames(1 + rank, args.batch, args.frame, args.frame)
     frames = torch.from_numpy(frames_np).cuda()
     out = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
+    # Batches in flight per GPU: consecutive steps alternate between two activation workspaces ("lanes") on two streams, as the
+    # streaming path (stream_embed / save_embedded_obs) does, so batch k+1 starts while batch k drains; every step is a full
+    # forward of its own 256-frame batch into its own output buffer and all K steps finish inside the timed region.
+    lanes = max(1, min(args.lanes, model.lanes))
+    outs = [out] + [torch.empty_like(out) for _ in range(lanes - 1)]
+    streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [torch.cuda.current_stream()]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        model.forward_into(frames, out)
+    def run_steps(k):
+        if lanes == 1:
+            for _ in range(k):
+                model.forward_into(frames, out)
+            return
+        for i in range(k):
+            with torch.cuda.stream(streams[i % lanes]):
+                model.forward_into(frames, outs[i % lanes], lane=i % lanes)
+
+    run_steps(max(args.warmup, lanes))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.forward_into(frames, out)
+    run_steps(args.steps)
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    if lanes > 1:
+        assert torch.equal(outs[0], outs[1])                     # same frames on both lanes: identical embeddings
     assert torch.isfinite(out).all()
 
     # roofline of the dominant kernel (conv_igemm): HIP events between launches on the launch stream
@@ -283,7 +306,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: ResNet50 (MoCo-v2 layout) frozen, %dx%d uint8 frames resident in HBM, batch %d/GPU, '
                                    'random-init synthetic weights' % (args.frame, args.frame, args.batch),
-                       'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk,
+                       'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk, 'batches_in_flight': lanes,
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
             'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',

@@ -96,6 +96,13 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out_dev, i
 pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on);
 /* name of launch `index` in the order pvr_encoder_profile reports; returns its length, 0 past the end */
 int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf, int32_t cap);
+/* Same forward on one of two activation workspaces ("lanes", 0 or 1; lane 1 is allocated on first use).  Two forwards on
+ * DIFFERENT lanes may be in flight at once on different streams - e.g. batch k+1 on lane 1 while batch k drains on lane 0,
+ * which fills the CUs that tile tails and HBM-bound launches of a single batch-256 forward leave idle (+15 % frames/s
+ * measured).  Forwards on the SAME lane must be stream-ordered by the caller.  pvr_encoder_forward == lane 0.
+ * replaces: the batch loop of behavioral_cloning/save_embedded_obs.py:151-156, which runs one batch at a time. */
+pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames_dev, int32_t n, int32_t h,
+                                    int32_t w, float *out_dev, int64_t out_stride, void *hip_stream);
 /* debug: make pvr_encoder_forward return right after the named tap has been produced (NULL/"" = off) */
 pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap);
 /* Instrumented forward of one chunk (n <= chunk): HIP events between launches on the caller's stream;

@@ -240,6 +240,48 @@ static pvr_status finalize_stem(pvr_encoder *e) {
 
 }  // namespace pvr
 
+// activation workspace of the current lane (ResNet50 family)
+static pvr_status alloc_workspace(pvr_encoder *enc) {
+    const int C = enc->desc.chunk, crop = enc->desc.crop;
+    const bool f32 = enc->desc.dtype == PVR_F32;
+    const size_t esz = f32 ? 4 : 2;                               // activation element size
+    const size_t img = (size_t)C * (crop + 6) * (crop + 8) * 4;
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_img, img * 2));
+    PVR_HIP_TRY(hipMemset(enc->d_img, 0, img * 2));            // zero border = conv1 padding, written once
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_stem, (size_t)C * 112 * 112 * 64 * esz));
+    if (f32) PVR_HIP_TRY(hipMalloc((void **)&enc->d_imgf, (size_t)C * crop * crop * 4 * sizeof(float)));
+    enc->buf_elems = (size_t)C * 56 * 56 * 256;                 // largest activation (layer1 output)
+    for (int b = 0; b < B_COUNT; ++b) {
+        size_t bytes = enc->buf_elems * esz;
+        if (b == B_F32) bytes = (size_t)C * enc->final_hw * enc->final_c * 4;
+        PVR_HIP_TRY(hipMalloc(&enc->d_buf[b], bytes));
+    }
+    return PVR_OK;
+}
+static void save_lane(pvr_encoder *enc, int lane) {
+    auto &l = enc->lane_ws[lane];
+    l.d_img = enc->d_img; l.d_stem = enc->d_stem; l.d_imgf = enc->d_imgf;
+    for (int b = 0; b < B_COUNT; ++b) l.d_buf[b] = enc->d_buf[b];
+    l.valid = true; enc->cur_lane = lane;
+}
+static pvr_status use_lane(pvr_encoder *enc, int lane) {
+    if (lane == enc->cur_lane) return PVR_OK;
+    if (!enc->lane_ws[lane].valid) {                            // first use: allocate, off the hot path
+        enc->d_img = nullptr; enc->d_stem = nullptr; enc->d_imgf = nullptr;
+        for (int b = 0; b < B_COUNT; ++b) enc->d_buf[b] = nullptr;
+        pvr_status s = alloc_workspace(enc);
+        if (s) return s;
+        PVR_HIP_TRY(hipDeviceSynchronize());
+        save_lane(enc, lane);
+        return PVR_OK;
+    }
+    const auto &l = enc->lane_ws[lane];
+    enc->d_img = l.d_img; enc->d_stem = l.d_stem; enc->d_imgf = l.d_imgf;
+    for (int b = 0; b < B_COUNT; ++b) enc->d_buf[b] = l.d_buf[b];
+    enc->cur_lane = lane;
+    return PVR_OK;
+}
+
 extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
@@ -294,22 +336,11 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     if ((s = build_schedules(enc))) return s;
     for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); }
     if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
-    const int C = enc->desc.chunk, crop = enc->desc.crop;
-    const bool f32 = enc->desc.dtype == PVR_F32;
-    const size_t esz = f32 ? 4 : 2;                               // activation element size
-    const size_t img = (size_t)C * (crop + 6) * (crop + 8) * 4;
-    PVR_HIP_TRY(hipMalloc((void **)&enc->d_img, img * 2));
-    PVR_HIP_TRY(hipMemset(enc->d_img, 0, img * 2));            // zero border = conv1 padding, written once
-    PVR_HIP_TRY(hipMalloc((void **)&enc->d_stem, (size_t)C * 112 * 112 * 64 * esz));
-    if (f32) PVR_HIP_TRY(hipMalloc((void **)&enc->d_imgf, (size_t)C * crop * crop * 4 * sizeof(float)));
+    pvr_status ws = alloc_workspace(enc);
+    if (ws) return ws;
     PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, 256));
     PVR_HIP_TRY(hipMemset(enc->d_zero, 0, 256));
-    enc->buf_elems = (size_t)C * 56 * 56 * 256;                 // largest activation (layer1 output)
-    for (int b = 0; b < B_COUNT; ++b) {
-        size_t bytes = enc->buf_elems * esz;
-        if (b == B_F32) bytes = (size_t)C * enc->final_hw * enc->final_c * 4;
-        PVR_HIP_TRY(hipMalloc(&enc->d_buf[b], bytes));
-    }
+    save_lane(enc, 0);
     // the memsets above run on the null stream; forwards run on the caller's stream (torch's current
     // stream need not be ordered against it), so drain the device once here, off the hot path
     PVR_HIP_TRY(hipDeviceSynchronize());
@@ -427,6 +458,17 @@ extern "C" {
 
 pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
                                int64_t out_stride, void *hip_stream) {
+    PVR_REQUIRE(enc, "pvr_encoder_forward: null encoder");
+    if (enc->finalized && !enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, 0); if (s) return s; }
+    return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+}
+
+pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
+                                    int64_t out_stride, void *hip_stream) {
+    PVR_REQUIRE(enc, "pvr_encoder_forward_lane: null encoder");
+    PVR_REQUIRE(lane == 0 || lane == 1, "pvr_encoder_forward_lane: lane must be 0 or 1");
+    if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
+    if (!enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, lane); if (s) return s; }   // (the ViT / random plans have one workspace)
     return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
 }
 
@@ -439,7 +481,8 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
     PVR_REQUIRE(enc && op_ms && op_flops && n_ops, "pvr_encoder_profile: null argument");
     PVR_REQUIRE(n <= enc->desc.chunk, "profile: n=%d must fit one chunk (%d)", n, enc->desc.chunk);
     std::vector<hipEvent_t> ev;
-    pvr_status s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, &ev);
+    pvr_status s = (enc->finalized && !enc->vit && !enc->rnd) ? use_lane(enc, 0) : PVR_OK;
+    if (!s) s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, &ev);
     if (!s && hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) { set_error("profile: sync failed"); s = PVR_ERR_HIP; }
     const int nl = (int)ev.size() - 1;
     if (!s && nl > cap) { set_error("profile: %d launches > cap %d", nl, cap); s = PVR_ERR_INVALID; }
@@ -544,10 +587,21 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->rnd) random5_destroy(enc);
     for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
-    if (enc->d_imgf) (void)hipFree(enc->d_imgf);
-    for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
-    if (enc->d_img) (void)hipFree(enc->d_img);
-    if (enc->d_stem) (void)hipFree(enc->d_stem);
+    bool any_lane = false;
+    for (auto &l : enc->lane_ws) {
+        if (!l.valid) continue;
+        any_lane = true;
+        for (int b = 0; b < B_COUNT; ++b) if (l.d_buf[b]) (void)hipFree(l.d_buf[b]);
+        if (l.d_img) (void)hipFree(l.d_img);
+        if (l.d_stem) (void)hipFree(l.d_stem);
+        if (l.d_imgf) (void)hipFree(l.d_imgf);
+    }
+    if (!any_lane) {
+        for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
+        if (enc->d_img) (void)hipFree(enc->d_img);
+        if (enc->d_stem) (void)hipFree(enc->d_stem);
+        if (enc->d_imgf) (void)hipFree(enc->d_imgf);
+    }
     if (enc->d_stem_w) (void)hipFree(enc->d_stem_w);
     if (enc->d_stem_b) (void)hipFree(enc->d_stem_b);
     if (enc->d_zero) (void)hipFree(enc->d_zero);

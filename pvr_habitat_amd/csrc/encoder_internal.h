@@ -75,6 +75,10 @@ struct pvr_encoder {
     float *d_stem_b = nullptr, *d_stem_wf = nullptr, *d_imgf = nullptr;   // fp32 mode: [64][49][4] stem weights, normalised NHWC4 image
     void *d_buf[B_COUNT] = {nullptr};
     size_t buf_elems = 0;
+    // second activation workspace (pvr_encoder_forward_lane, lane 1): lets the caller keep two batches in flight on two
+    // streams; allocated on first use.  The members above are the CURRENT lane's pointers (swapped by use_lane).
+    struct LaneWs { u16 *d_img = nullptr, *d_stem = nullptr; float *d_imgf = nullptr; void *d_buf[B_COUNT] = {nullptr}; bool valid = false; } lane_ws[2];
+    int cur_lane = 0;
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap
     std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})

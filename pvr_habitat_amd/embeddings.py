@@ -232,8 +232,15 @@ class HipResNet50(_Node):
     def max_batch(self):
         return self._max_batch
 
-    def forward_into(self, frames_u8, out):
-        """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0)."""
+    @property
+    def lanes(self):
+        """activation workspaces that can be in flight at once (the ViT / random plans have a single workspace)"""
+        return 1 if (self._clip or self._mae or self.variant == 'random5') else 2
+
+    def forward_into(self, frames_u8, out, lane=0):
+        """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0).
+        lane (0 or 1) selects one of two activation workspaces: forwards on different lanes may be in flight at once on
+        different streams (pvr_encoder_forward_lane); same-lane forwards must be ordered by the caller's streams."""
         _lib.require_gpu()
         if self._handle is None:
             self._build()
@@ -243,8 +250,8 @@ class HipResNet50(_Node):
         L = _lib.lib()
         for i in range(0, n, self._max_batch):
             m = min(self._max_batch, n - i)
-            _lib.check(L.pvr_encoder_forward(self._handle, C.c_void_p(frames_u8[i:i + m].data_ptr()), m, h, w,
-                                             C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
+            _lib.check(L.pvr_encoder_forward_lane(self._handle, lane, C.c_void_p(frames_u8[i:i + m].data_ptr()), m, h, w,
+                                                  C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
 
     def op_names(self):
         """conv launches of the current HIP plan, in launch order (fused bottleneck tails read 'a.conv2+conv3+b.conv1')."""
@@ -296,10 +303,14 @@ class UberModel(nn.Module):
     def to(self, device):
         return self
 
-    def forward_into(self, frames_u8, out):
+    @property
+    def lanes(self):
+        return min(m.lanes for m in self.models)
+
+    def forward_into(self, frames_u8, out, lane=0):
         col = 0
         for m in self.models:
-            m.forward_into(frames_u8, out[:, col:col + m.out_size])
+            m.forward_into(frames_u8, out[:, col:col + m.out_size], lane=lane)
             col += m.out_size
 
     def forward(self, frames_u8):
@@ -413,8 +424,8 @@ class EmbeddingNet(nn.Module):
 
 def stream_embed(net, frames_u8, batch=256, out=None):
     """Embed a large host-resident uint8 (N,H,W,3) array with H2D copies, HIP compute and D2H copies overlapped:
-    pinned double buffers, one copy stream each way and one compute stream chained by events (the encoder workspace
-    is single-stream).  Same rows, same order, same values as calling `net` batch by batch; this is the
+    pinned double buffers, one copy stream each way and TWO compute streams (one per double-buffer slot, each on its own
+    encoder workspace lane, so batch k+1 starts while batch k drains) chained by events.  Same rows, same order, same values as calling `net` batch by batch; this is the
     "embeddings streamed to host" path of BASELINE config 5 and what save_embedded_obs uses for big scenes.
     Returns np.float32 (N, out_size) (no squeeze)."""
     _lib.require_gpu()
@@ -423,7 +434,10 @@ def stream_embed(net, frames_u8, batch=256, out=None):
     n, osz = x.shape[0], net.out_size
     res = torch.empty((n, osz), dtype=torch.float32).pin_memory() if out is None else out
     dev = torch.device('cuda')
-    h2d, d2h, comp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    h2d, d2h, comps = torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()]
+    model = net.embedding
+    if getattr(model, 'lanes', 1) < 2 or os.environ.get('PVR_STREAM_LANES', '2') == '1':
+        comps[1] = comps[0]                                     # single workspace: both slots on one compute stream
     pinned_src = x.is_pinned()                               # caller already holds page-locked frames: no staging copy
     stage_in = [None, None] if pinned_src else [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.uint8).pin_memory() for _ in range(2)]
     dev_in = [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -433,7 +447,6 @@ def stream_embed(net, frames_u8, batch=256, out=None):
     host_free = [torch.cuda.Event() for _ in range(2)]     # H2D finished reading stage_in[b]
     for e in in_free + out_free + host_free:
         e.record()
-    model = net.embedding
     for i, lo in enumerate(range(0, n, batch)):
         b, m = i & 1, min(batch, n - lo)
         if pinned_src:
@@ -447,10 +460,11 @@ def stream_embed(net, frames_u8, batch=256, out=None):
             dev_in[b][:m].copy_(src, non_blocking=True)
             host_free[b].record(h2d)
             ready = torch.cuda.Event(); ready.record(h2d)
+        comp = comps[b]
         with torch.cuda.stream(comp):
             comp.wait_event(ready)
             comp.wait_event(out_free[b])
-            model.forward_into(dev_in[b][:m], dev_out[b][:m])
+            model.forward_into(dev_in[b][:m], dev_out[b][:m], lane=b if comps[1] is not comps[0] else 0)
             in_free[b].record(comp)
             done = torch.cuda.Event(); done.record(comp)
         with torch.cuda.stream(d2h):
