@@ -460,6 +460,7 @@ pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                int64_t out_stride, void *hip_stream) {
     PVR_REQUIRE(enc, "pvr_encoder_forward: null encoder");
     if (enc->finalized && !enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, 0); if (s) return s; }
+    if (enc->finalized && enc->vit) { pvr_status s = vit_use_lane(enc, 0); if (s) return s; }
     return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
 }
 
@@ -468,7 +469,9 @@ pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_
     PVR_REQUIRE(enc, "pvr_encoder_forward_lane: null encoder");
     PVR_REQUIRE(lane == 0 || lane == 1, "pvr_encoder_forward_lane: lane must be 0 or 1");
     if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
-    if (!enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, lane); if (s) return s; }   // (the ViT / random plans have one workspace)
+    if (enc->vit) { pvr_status s = vit_use_lane(enc, lane); if (s) return s; }
+    else if (!enc->rnd) { pvr_status s = use_lane(enc, lane); if (s) return s; }            // (the 'random' plan has one workspace)
+    else PVR_REQUIRE(lane == 0, "pvr_encoder_forward_lane: the 'random' PVR plan has a single workspace");
     return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
 }
 

@@ -109,6 +109,7 @@ void random5_destroy(pvr_encoder *e);
 // vit.hip
 pvr_status vit_create(pvr_encoder *e);
 pvr_status vit_finalize(pvr_encoder *e);
+pvr_status vit_use_lane(pvr_encoder *e, int lane);
 pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st);
 void vit_destroy(pvr_encoder *e);
 pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, int64_t *count, hipStream_t st);

@@ -324,6 +324,11 @@ struct pvr_vit {
     int *rs_xmin = nullptr, *rs_xsize = nullptr, *rs_ymin = nullptr, *rs_ysize = nullptr;
     float *rs_wx = nullptr, *rs_wy = nullptr, *rs_tmp = nullptr;
     uint8_t *rs_u8 = nullptr;
+    // second workspace lane (pvr_encoder_forward_lane): the members above are the CURRENT lane's pointers
+    struct Ws { u16 *A = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr; float *pe = nullptr, *x0 = nullptr, *x1 = nullptr; bool valid = false; } ws[2];
+    float *rs_tmp_l[2] = {nullptr, nullptr};
+    uint8_t *rs_u8_l[2] = {nullptr, nullptr};
+    int cur = 0;
     std::vector<void *> owned;
 };
 
@@ -371,6 +376,25 @@ pvr_status vit_create(pvr_encoder *e) {
     e->vit = v;
     e->out_size = v->out_dim;
     return PVR_OK;
+}
+
+static pvr_status vit_alloc_ws(pvr_encoder *e) {
+    pvr_vit *v = e->vit;
+    const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid, W = v->width, K = (size_t)v->patch * v->patch * 3;
+    auto alloc = [&](void **ptr, size_t bytes) -> pvr_status {
+        PVR_HIP_TRY(hipMalloc(ptr, bytes));
+        v->owned.push_back(*ptr);
+        return PVR_OK;
+    };
+    pvr_status s;
+    if ((s = alloc((void **)&v->A, prow * K * 2))) return s;
+    if ((s = alloc((void **)&v->pe, prow * W * 4))) return s;
+    if ((s = alloc((void **)&v->x0, rows * W * 4))) return s;
+    if ((s = alloc((void **)&v->x1, rows * W * 4))) return s;
+    if ((s = alloc((void **)&v->y, rows * W * 2))) return s;
+    if ((s = alloc((void **)&v->qkv, rows * 3 * W * 2))) return s;
+    if ((s = alloc((void **)&v->att, rows * W * 2))) return s;
+    return alloc((void **)&v->hid, rows * 4 * W * 2);
 }
 
 pvr_status vit_finalize(pvr_encoder *e) {
@@ -428,22 +452,27 @@ pvr_status vit_finalize(pvr_encoder *e) {
         if ((s = up_f32(e, p + n_l2 + "weight", W, &b.ln2_w))) return s;
         if ((s = up_f32(e, p + n_l2 + "bias", W, &b.ln2_b))) return s;
     }
-    const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid;
-    auto alloc = [&](void **ptr, size_t bytes) -> pvr_status {
-        PVR_HIP_TRY(hipMalloc(ptr, bytes));
-        v->owned.push_back(*ptr);
-        return PVR_OK;
-    };
-    if ((s = alloc((void **)&v->A, prow * K * 2))) return s;
-    if ((s = alloc((void **)&v->pe, prow * W * 4))) return s;
-    if ((s = alloc((void **)&v->x0, rows * W * 4))) return s;
-    if ((s = alloc((void **)&v->x1, rows * W * 4))) return s;
-    if ((s = alloc((void **)&v->y, rows * W * 2))) return s;
-    if ((s = alloc((void **)&v->qkv, rows * 3 * W * 2))) return s;
-    if ((s = alloc((void **)&v->att, rows * W * 2))) return s;
-    if ((s = alloc((void **)&v->hid, rows * 4 * W * 2))) return s;
-    if ((s = alloc((void **)&v->zero, 256))) return s;
+    if ((s = vit_alloc_ws(e))) return s;
+    v->ws[0] = {v->A, v->y, v->qkv, v->att, v->hid, v->pe, v->x0, v->x1, true};
+    PVR_HIP_TRY(hipMalloc((void **)&v->zero, 256));
+    v->owned.push_back(v->zero);
     PVR_HIP_TRY(hipMemset(v->zero, 0, 256));
+    return PVR_OK;
+}
+
+pvr_status vit_use_lane(pvr_encoder *e, int lane) {
+    pvr_vit *v = e->vit;
+    if (lane == v->cur) return PVR_OK;
+    if (!v->ws[lane].valid) {
+        pvr_status s = vit_alloc_ws(e);
+        if (s) return s;
+        PVR_HIP_TRY(hipDeviceSynchronize());
+        v->ws[lane] = {v->A, v->y, v->qkv, v->att, v->hid, v->pe, v->x0, v->x1, true};
+    }
+    const auto &w = v->ws[lane];
+    v->A = w.A; v->y = w.y; v->qkv = w.qkv; v->att = w.att; v->hid = w.hid; v->pe = w.pe; v->x0 = w.x0; v->x1 = w.x1;
+    v->rs_tmp = v->rs_tmp_l[lane]; v->rs_u8 = v->rs_u8_l[lane];
+    v->cur = lane;
     return PVR_OK;
 }
 
@@ -451,7 +480,7 @@ void vit_destroy(pvr_encoder *e) {
     if (!e->vit) return;
     for (void *p : e->vit->owned) (void)hipFree(p);
     pvr_vit *v = e->vit;
-    void *rs[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp, v->rs_u8};
+    void *rs[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp_l[0], v->rs_u8_l[0], v->rs_tmp_l[1], v->rs_u8_l[1]};
     for (void *q : rs) if (q) (void)hipFree(q);
     delete e->vit;
     e->vit = nullptr;
@@ -527,14 +556,17 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
         aa_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
         aa_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
     }
-    void *old[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp, v->rs_u8};
+    void *old[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp_l[0], v->rs_u8_l[0], v->rs_tmp_l[1], v->rs_u8_l[1]};
     PVR_HIP_TRY(hipDeviceSynchronize());
     for (void *q : old) if (q) (void)hipFree(q);
     pvr_status s;
     if ((s = enc_upload(&v->rs_xmin, xm)) || (s = enc_upload(&v->rs_xsize, xs)) || (s = enc_upload(&v->rs_ymin, ym)) ||
         (s = enc_upload(&v->rs_ysize, ys)) || (s = enc_upload(&v->rs_wx, wx)) || (s = enc_upload(&v->rs_wy, wy))) return s;
-    PVR_HIP_TRY(hipMalloc((void **)&v->rs_tmp, (size_t)e->desc.chunk * h * v->res * 3 * sizeof(float)));
-    PVR_HIP_TRY(hipMalloc((void **)&v->rs_u8, (size_t)e->desc.chunk * v->res * v->res * 3));
+    for (int l = 0; l < 2; ++l) {
+        PVR_HIP_TRY(hipMalloc((void **)&v->rs_tmp_l[l], (size_t)e->desc.chunk * h * v->res * 3 * sizeof(float)));
+        PVR_HIP_TRY(hipMalloc((void **)&v->rs_u8_l[l], (size_t)e->desc.chunk * v->res * v->res * 3));
+    }
+    v->rs_tmp = v->rs_tmp_l[v->cur]; v->rs_u8 = v->rs_u8_l[v->cur];
     PVR_HIP_TRY(hipDeviceSynchronize());
     v->rs_h = h; v->rs_w = w;
     return PVR_OK;

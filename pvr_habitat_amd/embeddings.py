@@ -234,8 +234,8 @@ class HipResNet50(_Node):
 
     @property
     def lanes(self):
-        """activation workspaces that can be in flight at once (the ViT / random plans have a single workspace)"""
-        return 1 if (self._clip or self._mae or self.variant == 'random5') else 2
+        """activation workspaces that can be in flight at once (the 'random' plan has a single workspace)"""
+        return 1 if self.variant == 'random5' else 2
 
     def forward_into(self, frames_u8, out, lane=0):
         """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0).

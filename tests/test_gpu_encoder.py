@@ -296,6 +296,32 @@ def test_full_batch_properties():
     assert torch.isfinite(a).all() and float(a.std()) > 0
 
 
+@pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
+def test_two_lanes_in_flight_match_sequential_forwards(variant):
+    """pvr_encoder_forward_lane: forwards on the two workspaces, interleaved on two streams, give bit for bit what
+    sequential single-stream calls give (different inputs per lane, several rounds, ragged batch on one lane)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    if variant == 'conv5':
+        sd, hw, osz = synth.resnet50_state_dict(1, 'conv5'), 256, 2048
+    else:
+        sd, hw, osz = synth.clip_vit_state_dict(1, patch=16), 224, 512
+    m = HipResNet50(sd, variant, compute_dtype='bf16', max_batch=64)
+    fa = torch.from_numpy(synth.frames(11, 64, hw, hw)).cuda()
+    fb = torch.from_numpy(synth.frames(12, 40, hw, hw)).cuda()
+    ref_a, ref_b = m(fa).clone(), m(fb).clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    oa, ob = torch.zeros_like(ref_a), torch.zeros_like(ref_b)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            m.forward_into(fa, oa, lane=0)
+        with torch.cuda.stream(sb):
+            m.forward_into(fb, ob, lane=1)
+    torch.cuda.synchronize()
+    assert oa.shape == (64, osz) and torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+    assert torch.equal(m(fb), ref_b)                                   # the default entry point still works afterwards (lane 0)
+
+
 def test_stream_embed_matches_batched_calls(monkeypatch):
     """Overlapped H2D / compute / D2H path returns the same rows in the same order, bit for bit."""
     from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed
