@@ -49,6 +49,22 @@ struct PPP {
 
 #define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
+// Diagnostic build only (scripts/pp256_stamps.hip defines PP_STAMP): s_memtime stamps of one steady-state K tile, one wave of
+// each group of block 0, written to a buffer nothing else reads.  Compiles to nothing in the library.
+#ifdef PP_STAMP
+// PP_STAMP = K tile to sample, PP_PHASE = which phase's six stamps are compiled in (one build per phase keeps the SGPR cost
+// at 12 + 6).  The stamps are inline asm (no compiler-inserted lgkmcnt wait: s_memtime returns through lgkmcnt like the LDS
+// reads) and are only copied out after the tile's last barrier.
+#define PP_STAMP_DECL(kt_) const bool stamp_on = (kt_) == PP_STAMP; int sti = 0; (void)sti; unsigned long long tt_[6] = {0, 0, 0, 0, 0, 0}
+__device__ unsigned long long pp_stamps[2][8];
+#define PP_T(k_) { const int kk_ = (k_); if (kk_ / 6 == PP_PHASE) asm volatile("s_memtime %0" : "=s"(tt_[kk_ % 6]) :: "memory"); }
+#define PP_STAMP_LATCH() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (stamp_on) { _Pragma("unroll") for (int k = 0; k < 6; ++k) st_[k] = tt_[k]; } }
+#else
+#define PP_STAMP_DECL(kt_)
+#define PP_T(k_)
+#define PP_STAMP_LATCH()
+#endif
+
 // BM = 256: the structure above.  BM = 128 (launches whose 256-pixel tiles would not fill the chip, e.g. layer4 at batch 256):
 // a wave owns 64 pixels x 64 couts, X half tiles are 64 rows (one DMA instruction each), a K tile is two phases:
 //         phase 0: read X (pixel tiles 0-3), W0;  DMA W-lo(t+1), W-hi(t+1);           math W0 x X
@@ -143,6 +159,11 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #pragma unroll
         for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef PP_STAMP
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long clk0_, rt0_, clk1_, rt1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_) :: "memory");
+#endif
     // ---- prologue: tile 0 entirely, X of tile 1 ----------------------------------------------------------------------
     PP_STAGE_X(0, 0); PP_STAGE_X(1, 0); PP_ADVANCE_X();
     PP_STAGE_W(0, 0, 0); PP_STAGE_W(1, 0, 0);
@@ -160,16 +181,23 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     __builtin_amdgcn_sched_barrier(0);
 
 #define PP_FEED_DONE()                                                                                           \
+    PP_T(sti++);                                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    PP_T(sti++);                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
+    PP_T(sti++);                                                                                                 \
+    PP_T(sti++);                                                                                                 \
     __builtin_amdgcn_s_setprio(1);
 #define PP_MATH_DONE()                                                                                           \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
+    PP_T(sti++);                                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    PP_T(sti++);                                                                                                 \
+    PP_T(sti++);
 #define PP_READ_X(dst_, j0_, B_)                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
@@ -188,7 +216,9 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #define PP_TILE(kt_, B_)                                                                                         \
     {                                                                                                            \
         const bool next1 = (kt_) + 1 < nk, next2 = (kt_) + 2 < nk;                                               \
+        PP_STAMP_DECL(kt_);                                                                                      \
         V8 x0[4][2], x1[4][2], wf[2][2];                                                                         \
+        PP_T(sti++);                                                                                             \
         PP_READ_X(x0, 0, B_); PP_READ_W(0, B_);                                                                  \
         if (next1) PP_STAGE_W(0, (kt_) + 1, 1 - (B_));                                                           \
         PP_FEED_DONE(); PP_MATH(0, x0, 0); PP_MATH_DONE();                                                       \
@@ -205,11 +235,13 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
         }                                                                                                        \
         PP_FEED_DONE(); PP_MATH(2, x0, 0); PP_MATH_DONE();                                                       \
+        PP_STAMP_LATCH();                                                                                        \
     }
     // BM = 128: two phases per K tile
 #define PP_TILE128(kt_, B_)                                                                                      \
     {                                                                                                            \
         const bool next1 = (kt_) + 1 < nk, next2 = (kt_) + 2 < nk;                                               \
+        PP_STAMP_DECL(kt_);                                                                                      \
         V8 x0[4][2], wf[2][2];                                                                                   \
         PP_READ_X(x0, 0, B_); PP_READ_W(0, B_);                                                                  \
         if (next1) { PP_STAGE_W(0, (kt_) + 1, 1 - (B_)); PP_STAGE_W(1, (kt_) + 1, 1 - (B_)); }                   \
@@ -237,6 +269,14 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #undef PP_TILE128
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
     __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_STAMP
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_) :: "memory");
+    if (blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pp_stamps[wr][k] = st_[k];
+        pp_stamps[wr][6] = clk1_ - clk0_; pp_stamps[wr][7] = rt1_ - rt0_;
+    }
+#endif
 #undef PP_TILE
 #undef PP_MATH
 #undef PP_READ_W
