@@ -96,6 +96,11 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out_dev, i
 pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on);
 /* name of launch `index` in the order pvr_encoder_profile reports; returns its length, 0 past the end */
 int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf, int32_t cap);
+/* Which 224x224 window of the resized frame the following forwards embed: 0 = centre (torchvision CenterCrop, the reference's
+ * transform, embeddings.py:82; default), 1..4 = top-left, top-right, bottom-left, bottom-right (the corner crops of
+ * torchvision FiveCrop).  Build-defined extension for BASELINE config 5 ("5-crop"); the reference has only the centre crop.
+ * ResNet50 family only. */
+pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos);
 /* Same forward on one of two activation workspaces ("lanes", 0 or 1; lane 1 is allocated on first use).  Two forwards on
  * DIFFERENT lanes may be in flight at once on different streams - e.g. batch k+1 on lane 1 while batch k drains on lane 0,
  * which fills the CUs that tile tails and HBM-bound launches of a single batch-256 forward leave idle (+15 % frames/s

@@ -68,15 +68,23 @@ def center_crop(x, size=224):
     return x[..., top:top + size, left:left + size]
 
 
-def preprocess_u8(frames_nhwc_u8, resize=256, crop=224):
-    """uint8 (N,H,W,3) -> uint8 (N,3,crop,crop): the integer part of the transforms."""
+def preprocess_u8(frames_nhwc_u8, resize=256, crop=224, crop_pos=0):
+    """uint8 (N,H,W,3) -> uint8 (N,3,crop,crop): the integer part of the transforms.
+    crop_pos 0 = CenterCrop (the reference, embeddings.py:82); 1..4 = tl, tr, bl, br corner windows of the resized frame
+    (torchvision FiveCrop order; build-defined 5-crop extension)."""
     x = _t(frames_nhwc_u8)
     x = x.transpose(1, 2).transpose(1, 3).contiguous()        # embeddings.py:392
-    return center_crop(resize_u8(x, resize), crop)
+    r = resize_u8(x, resize)
+    if crop_pos == 0:
+        return center_crop(r, crop)
+    h, w = r.shape[-2:]
+    top = h - crop if crop_pos in (3, 4) else 0
+    left = w - crop if crop_pos in (2, 4) else 0
+    return r[..., top:top + crop, left:left + crop].contiguous()
 
 
-def preprocess(frames_nhwc_u8, resize=256, crop=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
-    x = preprocess_u8(frames_nhwc_u8, resize, crop).float() / 255.0
+def preprocess(frames_nhwc_u8, resize=256, crop=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, crop_pos=0):
+    x = preprocess_u8(frames_nhwc_u8, resize, crop, crop_pos).float() / 255.0
     m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
     s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
     return (x - m) / s
@@ -157,10 +165,10 @@ def resnet50_features(sd, x, variant='conv5', q=None, taps=None):
 OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156}
 
 
-def embed(sd, frames_nhwc_u8, variant='conv5', q=None, squeeze=True):
+def embed(sd, frames_nhwc_u8, variant='conv5', q=None, squeeze=True, crop_pos=0):
     """EmbeddingNet.forward (embeddings.py:386-402) for one ResNet50-family model."""
     with torch.no_grad():
-        x = preprocess(frames_nhwc_u8)
+        x = preprocess(frames_nhwc_u8, crop_pos=crop_pos)
         if q is not None:
             # HIP path feeds the stem exact uint8 values with normalisation folded into the
             # weights; emulate only weight/activation storage rounding here.

@@ -22,6 +22,8 @@ def make_parser():
     parser.add_argument('--train_embedding', action='store_true')
     parser.add_argument('--disable_pretrained_embedding', action='store_false', dest='pretrained_embedding')
     parser.add_argument('--batch_norm', action='store_true')
+    # not in the reference (src/arguments.py): 5 = corner + centre windows per frame (BASELINE config 5 extension), 1 = CenterCrop
+    parser.add_argument('--crops', type=int, default=1, choices=[1, 5])
     # Environment Settings.
     parser.add_argument('--env', type=str, default='HabitatImageNav-apartment_0')
     parser.add_argument('--num_input_frames', type=int, default=1)

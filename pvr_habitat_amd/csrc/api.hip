@@ -16,7 +16,7 @@ void set_error(const char *fmt, ...) {
 }
 const std::string &last_error() { return g_err; }
 
-pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
+pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t, int crop_pos = 0);
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);

@@ -382,7 +382,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             // reference-precision plan: integer transforms (exact, via the bf16 image) -> fp32 /255, Normalize ->
             // fp32 conv1 -> fp32 maxpool -> fp32 implicit-GEMM convs (f32 MFMA) -> fp32 pool / flatten
             const int crop = enc->desc.crop;
-            if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, crop, enc->d_img, PVR_BF16, st))) return s;
+            if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, crop, enc->d_img, PVR_BF16, st, enc->crop_pos))) return s;
             if ((s = launch_normalize_nhwc4(enc->d_img, enc->d_imgf, nb, crop, enc->desc.mean, enc->desc.std_, PVR_BF16, st))) return s;
             if ((s = mark())) return s;
             if ((s = launch_stem_f32(enc->d_imgf, enc->d_stem_wf, enc->d_stem_b, (float *)enc->d_stem, nb, crop, st))) return s;
@@ -407,7 +407,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if ((s = mark())) return s;
             continue;
         }
-        if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st))) return s;
+        if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st, enc->crop_pos))) return s;
         if ((s = mark())) return s;
         enc->last_n = nb;
         if (enc->stop_after == "pre") return PVR_OK;
@@ -514,6 +514,14 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
     }
     for (auto e : ev) (void)hipEventDestroy(e);
     return s;
+}
+
+pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos) {
+    PVR_REQUIRE(enc, "null encoder");
+    PVR_REQUIRE(pos >= 0 && pos <= 4, "crop position %d outside 0..4", pos);
+    PVR_REQUIRE(pos == 0 || (!enc->vit && !enc->rnd), "corner crops are built for the ResNet50 family only");
+    enc->crop_pos = pos;
+    return PVR_OK;
 }
 
 pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on) {

@@ -8,7 +8,7 @@
 
 namespace pvr {
 
-pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t);
+pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t, int crop_pos = 0);
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
 pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
@@ -79,6 +79,7 @@ struct pvr_encoder {
     // streams; allocated on first use.  The members above are the CURRENT lane's pointers (swapped by use_lane).
     struct LaneWs { u16 *d_img = nullptr, *d_stem = nullptr; float *d_imgf = nullptr; void *d_buf[B_COUNT] = {nullptr}; bool valid = false; } lane_ws[2];
     int cur_lane = 0;
+    int crop_pos = 0;                                // 0 centre (reference), 1..4 corner crops (pvr_encoder_set_crop_position)
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap
     std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})

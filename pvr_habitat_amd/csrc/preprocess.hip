@@ -74,8 +74,10 @@ void resized_size(int h, int w, int size, int *rh, int *rw) {
     if (w <= h) { *rw = ns; *rh = nl; } else { *rh = ns; *rw = nl; }
 }
 
+// crop_pos: 0 centre (the reference's CenterCrop), 1 top-left, 2 top-right, 3 bottom-left, 4 bottom-right of the resized frame
+// (the four corner crops of torchvision FiveCrop; build-defined 5-crop extension of BASELINE config 5)
 pvr_status launch_preprocess(const uint8_t *frames, int n, int h, int w, int resize, int crop, void *out,
-                             int dtype, hipStream_t stream) {
+                             int dtype, hipStream_t stream, int crop_pos) {
     PVR_REQUIRE(n > 0 && h > 0 && w > 0, "preprocess: bad shape n=%d h=%d w=%d", n, h, w);
     PreP p;
     p.src = frames; p.dst = (u16 *)out; p.n = n; p.h = h; p.w = w; p.crop = crop;
@@ -85,6 +87,11 @@ pvr_status launch_preprocess(const uint8_t *frames, int n, int h, int w, int res
     // CenterCrop: int(round((H - crop) / 2.0)) with Python's round-half-even
     p.top = (int)nearbyint((p.rh - crop) / 2.0);
     p.left = (int)nearbyint((p.rw - crop) / 2.0);
+    PVR_REQUIRE(crop_pos >= 0 && crop_pos <= 4, "preprocess: crop position %d outside 0..4", crop_pos);
+    if (crop_pos > 0) {
+        p.top = (crop_pos == 3 || crop_pos == 4) ? p.rh - crop : 0;
+        p.left = (crop_pos == 2 || crop_pos == 4) ? p.rw - crop : 0;
+    }
     p.scale_h = (float)h / (float)p.rh;
     p.scale_w = (float)w / (float)p.rw;
     dim3 grid((crop + 63) / 64, (crop + 3) / 4, n);

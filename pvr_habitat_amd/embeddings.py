@@ -263,6 +263,12 @@ class HipResNet50(_Node):
             i += 1
         return [n for n in names if n != 'pool/flatten']
 
+    def set_crop(self, pos):
+        """0 = centre crop (reference), 1..4 = tl / tr / bl / br corner windows (pvr_encoder_set_crop_position)"""
+        if self._handle is None:
+            self._build()
+        _lib.check(_lib.lib().pvr_encoder_set_crop_position(self._handle, int(pos)))
+
     def set_fusion(self, on):
         """A/B switch between the fused layer1/layer2 bottleneck-tail plan (default) and one launch per convolution;
         both give bit-identical outputs."""
@@ -307,11 +313,50 @@ class UberModel(nn.Module):
     def lanes(self):
         return min(m.lanes for m in self.models)
 
+    def set_crop(self, pos):
+        for m in self.models:
+            m.set_crop(pos)
+
     def forward_into(self, frames_u8, out, lane=0):
         col = 0
         for m in self.models:
             m.forward_into(frames_u8, out[:, col:col + m.out_size], lane=lane)
             col += m.out_size
+
+    def forward(self, frames_u8):
+        out = torch.empty((frames_u8.shape[0], self.out_size), dtype=torch.float32, device=frames_u8.device)
+        self.forward_into(frames_u8, out)
+        return out
+
+
+class FiveCrop(nn.Module):
+    """Build-defined 5-crop extension (BASELINE config 5; the reference itself only has CenterCrop,
+    embeddings.py:82): the wrapped model embeds the four corner windows and the centre window of the Resize(256) frame
+    (torchvision FiveCrop order tl, tr, bl, br, centre) and the five embeddings are concatenated along the feature axis:
+    (N, 5*O), the last O columns being exactly the reference's centre-crop embedding."""
+    ORDER = (1, 2, 3, 4, 0)
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = [model]                                   # plain list: not a sub-module (as UberModel.models)
+        self.training = model.training
+        self.out_size = 5 * model.out_size
+
+    def to(self, device):
+        return self
+
+    @property
+    def lanes(self):
+        return self.model[0].lanes
+
+    def forward_into(self, frames_u8, out, lane=0):
+        m, o = self.model[0], self.model[0].out_size
+        try:
+            for k, pos in enumerate(self.ORDER):
+                m.set_crop(pos)
+                m.forward_into(frames_u8, out[:, k * o:(k + 1) * o], lane=lane)
+        finally:
+            m.set_crop(0)
 
     def forward(self, frames_u8):
         out = torch.empty((frames_u8.shape[0], self.out_size), dtype=torch.float32, device=frames_u8.device)
@@ -388,7 +433,7 @@ class EmbeddingNet(nn.Module):
     """
 
     def __init__(self, embedding_name, in_channels=3, pretrained=True, train=False, disable_cuda=False,
-                 compute_dtype=None, max_batch=None, chunk=None):
+                 compute_dtype=None, max_batch=None, chunk=None, crops=1):
         super(EmbeddingNet, self).__init__()
         self.embedding_name = embedding_name
         if self.embedding_name == 'true_state':
@@ -396,6 +441,9 @@ class EmbeddingNet(nn.Module):
         self.in_channels = in_channels
         self.embedding, self.transforms = _get_embedding(embedding_name, in_channels, pretrained, train,
                                                          compute_dtype=compute_dtype, max_batch=max_batch, chunk=chunk)
+        assert crops in (1, 5), 'crops: 1 (the reference CenterCrop) or 5 (corner + centre windows, FiveCrop order)'
+        if crops == 5:
+            self.embedding = FiveCrop(self.embedding)
         # the reference discovers these with a dummy CPU forward (embeddings.py:359-363)
         self.in_shape = torch.Size((in_channels, 224, 224))
         self.out_size = int(self.embedding.out_size)

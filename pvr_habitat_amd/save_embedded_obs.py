@@ -125,7 +125,7 @@ def run(flags):
     embedding_model = EmbeddingNet(flags.embedding_name, in_channels=3, pretrained=flags.pretrained_embedding,
                                    train=flags.train_embedding, disable_cuda=flags.disable_cuda,
                                    compute_dtype=getattr(flags, 'compute_dtype', None),
-                                   max_batch=getattr(flags, 'embed_batch', 256))
+                                   max_batch=getattr(flags, 'embed_batch', 256), crops=getattr(flags, 'crops', 1))
     if rank == 0:
         emb_path = os.path.join(flags.data_path, flags.embedding_name)
         if flags.embedding_name == 'random':

@@ -279,6 +279,31 @@ def test_embeddingnet_surface_and_uber(monkeypatch):
         EmbeddingNet('not_a_model')
 
 
+def test_five_crop_extension_matches_oracle(monkeypatch):
+    """BASELINE config 5 ("5-crop multi-layer PVR"): corner + centre windows of the Resize(256) frame, FiveCrop order, for the
+    uber_345 concat; every window against the fp32 oracle, the centre block bit-identical to the 1-crop embedding."""
+    from pvr_habitat_amd.embeddings import EmbeddingNet
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    torch.set_num_threads(16)
+    fr = synth.smooth_frames(23, 2, 96, 128)                           # non-square: resized to 256 x 341, corners differ
+    one = EmbeddingNet('resnet50', pretrained=False, compute_dtype='f16')
+    five = EmbeddingNet('resnet50', pretrained=False, compute_dtype='f16', crops=5)
+    assert five.out_size == 5 * 2048
+    o1 = one(torch.from_numpy(fr)).reshape(2, 2048)
+    o5 = five(torch.from_numpy(fr)).reshape(2, 5, 2048)
+    np.testing.assert_array_equal(o5[:, 4], o1)                        # centre window == reference CenterCrop path
+    from pvr_habitat_amd.embeddings import _load_named_state_dict
+    from oracle import encoder_oracle as eo
+    sd, variant = _load_named_state_dict('resnet50', False)
+    for k, pos in enumerate((1, 2, 3, 4, 0)):
+        ref = eo.embed(sd, fr, variant, squeeze=False, crop_pos=pos)
+        l2, mx = _relerr(o5[:, k], ref)
+        assert l2 < 1e-3, (pos, l2, mx)
+    assert not np.array_equal(o5[:, 0], o5[:, 1])                      # the windows really differ
+    ub = EmbeddingNet('moco_aug_uber_345', pretrained=False, compute_dtype='f16', crops=5)
+    assert ub.out_size == 5 * 6262 and ub(torch.from_numpy(fr)).shape == (2, 5 * 6262)
+
+
 def test_full_batch_properties():
     """BASELINE config-2 sizes (batch 256 @ 256x256): determinism and batch-composition invariance."""
     from pvr_habitat_amd.embeddings import HipResNet50
