@@ -35,6 +35,12 @@ struct pvr_policy {
     hipStream_t lane_a = nullptr, lane_b = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join_a = nullptr, ev_join_b = nullptr, ev_chunk[8] = {nullptr};
     int pipeline = 1;
+    // persistent recurrence (lstm_fwd_seq_kernel, PVR_POLICY_PERSIST=1): one launch per (layer, chunk) instead of one per step.
+    // Bit-identical, but measured SLOWER than per-step launches on MI355X / ROCm 7.2 (scripts/bc_graph_ab.py: 154-164 vs 178
+    // steps/s): the per-step grid hand-off (sc1 stores + drain, agent-scope counter, poll, 64 KB of sc1 loads of h per block)
+    // costs ~13 us against ~11 us for a launch, so it stays off until the hand-off is cheaper.
+    unsigned *seq_counters = nullptr;       // 16 slots of 16 bytes, zeroed before each launch that uses one
+    int persist = 0;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
@@ -186,6 +192,19 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
     TRY(gemm(pol->a1, P + pol->o_fc2w, P + pol->o_fc2b, nullptr, pol->a2, N, H, H, false, false, 1, st));
     // LSTM, two layers.  Input projections are hoisted out of the recurrence (one GEMM over all steps of a chunk).
     auto fwd_steps = [&](int l, int t0, int t1, hipStream_t s_) {
+        if (pol->persist && H == 1024 && B <= 64 && t1 - t0 > 1) {
+            // one persistent launch for the whole step range (grid-wide hand-off per step inside the kernel)
+            unsigned *ctr = pol->seq_counters + 4 * ((l * 4 + (t0 * 4 / (T > 0 ? T : 1))) & 15);
+            (void)hipMemsetAsync(ctr, 0, 16, s_);
+            LstmSeqP q;
+            q.G = pol->G[l];
+            q.h_init = t0 == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t0 - 1) * B * H;
+            q.c_init = t0 == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t0 - 1) * B * H;
+            q.nd = pol->nd; q.W = P + pol->o_whh[l]; q.bhh = P + pol->o_bhh[l];
+            q.Hs = pol->Hs[l]; q.Cs = pol->Cs[l]; q.counter = ctr; q.t0 = t0; q.t1 = t1; q.B = B; q.H = H;
+            hipLaunchKernelGGL(lstm_fwd_seq_kernel, dim3(H / 4), dim3(256), 0, s_, q);
+            return;
+        }
         for (int t = t0; t < t1; ++t) {
             LstmFwdP f;
             f.G = pol->G[l] + (size_t)t * B * 4 * H;
@@ -486,6 +505,8 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     A_(in_done, N); A_(in_act, N);
     if (const char *e = getenv("PVR_POLICY_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
+    if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e) != 0;
+    A_(seq_counters, 64);
     if (!s && p->pipeline) {
         hipError_t he = hipStreamCreateWithFlags(&p->lane_a, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->lane_b, hipStreamNonBlocking);
@@ -506,7 +527,7 @@ void pvr_policy_destroy(pvr_policy *p) {
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
                     p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
-                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act, p->hprev1, p->dc_carry1, p->rec_partial1};
+                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act, p->hprev1, p->dc_carry1, p->rec_partial1, p->seq_counters};
     if (p->lane_a) (void)hipStreamDestroy(p->lane_a);
     if (p->lane_b) (void)hipStreamDestroy(p->lane_b);
     for (hipEvent_t ev : {p->ev_fork, p->ev_join_a, p->ev_join_b}) if (ev) (void)hipEventDestroy(ev);

@@ -318,6 +318,126 @@ static __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Persistent forward recurrence: ONE launch runs steps [t0, t1) of one layer.  Same block <-> hidden-unit map, same MFMA
+// chain and same reduction order as lstm_fwd_step_kernel (bit-identical results); what changes is what a step costs:
+//   * the block's 16 W_hh rows (4 gates x 4 units, 64 KB) stay in registers for the whole sequence;
+//   * the cell state of the block's units stays in registers;
+//   * a step ends with a grid-wide hand-off instead of a kernel boundary (~11 us of launch + ramp per step before): h_t is
+//     stored write-through (sc1), every storing wave drains its stores, one lane adds to an agent-scope counter; consumers
+//     poll that counter (relaxed, one lane) and read h_t with sc1 loads only (cdna_hip_programming.md section 6 G16,
+//     publish/consume recipe R1 with the all-sc1-loads form, so no acquire fence is needed).
+// The grid (H/4 blocks) must be co-resident: 256 blocks of 256 threads on 256 CUs, <= 2 per CU when both layers' lanes run.
+// Spins are bounded: on a timeout the block poisons its outputs with NaN (the loss shows it) instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------------------
+struct LstmSeqP {
+    float *G;                          // layer base [T][B][4H]: in = input projection (+ b_ih), out = activated gates
+    const float *h_init, *c_init;      // [B][H]: state before step t0
+    const float *nd, *W, *bhh;         // [T][B], [4H][H], [4H]
+    float *Hs, *Cs;                    // layer bases [T][B][H]
+    unsigned *counter;                 // zeroed before the launch
+    int t0, t1, B, H;
+};
+
+static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
+    __shared__ float part[4][16][17];
+    __shared__ __attribute__((aligned(16))) float hstage[16][4];
+    __shared__ int dead_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int u0 = blockIdx.x * 4, H = p.H, B = p.B;
+    if (tid == 0) dead_s = 0;
+    __syncthreads();
+    const float *wrow = p.W + (size_t)((fr >> 2) * H + u0 + (fr & 3)) * H;
+    const int kbeg = wave * (H / 4);
+    // weights of this lane for the whole sequence (H = 1024: 16 x float4)
+    f32x4 wv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) wv[c] = *reinterpret_cast<const f32x4 *>(wrow + kbeg + c * 16 + fq * 4);
+    const int tb = tid >> 2, tj = tid & 3;
+    float bh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bh[g] = p.bhh[g * H + u0 + tj];
+    }
+    float creg[4] = {0.f, 0.f, 0.f, 0.f};           // cell state of (batch row b0 + tb, unit u0 + tj) per 16-row batch group
+    const unsigned nblk = gridDim.x;
+    const size_t hbytes = (size_t)B * H * 4;
+    for (int t = p.t0; t < p.t1; ++t) {
+        const int s = t - p.t0;
+        if (s > 0) {
+            if (tid == 0 && !dead_s) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk * (unsigned)s) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { dead_s = 1; break; }     // bounded: never hang the GPU on a lost block
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the sc1 loads below the poll)
+        }
+        const float *hprev = s == 0 ? p.h_init : p.Hs + (size_t)(t - 1) * B * H;
+        const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hprev), 0, (unsigned)hbytes, 0x00020000);
+        float *Gt = p.G + (size_t)t * B * 4 * H;
+        int grp = 0;
+        for (int b0 = 0; b0 < B; b0 += 16, ++grp) {
+            const int b = b0 + fr;
+            const bool bok = b < B;
+            const float ndb = bok ? p.nd[(size_t)t * B + b] : 0.f;
+            const int hoff = ((bok ? b : 0) * H + kbeg + fq * 4) * 4;
+            const int tbi = b0 + tb;
+            const bool tok = tid < 64 && tbi < B;
+            float gx[4] = {0.f, 0.f, 0.f, 0.f}, ndt = 0.f;
+            if (tok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gx[g] = Gt[(size_t)tbi * 4 * H + g * H + u0 + tj] + bh[g];
+                ndt = p.nd[(size_t)t * B + tbi];
+                if (s == 0) creg[grp & 3] = p.c_init[(size_t)tbi * H + u0 + tj];
+            }
+            f32x4 hv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)                                  // sc1 loads: h_{t-1} was published by other CUs in this launch
+                hv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff, c * 64, 16));
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                hv[c] *= ndb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32(hv[c][e], wv[c][e], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
+            __syncthreads();
+            if (tok) {
+                float sg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    sg[g] = ((part[0][tb][g * 4 + tj] + part[1][tb][g * 4 + tj]) + (part[2][tb][g * 4 + tj] + part[3][tb][g * 4 + tj])) + gx[g];
+                const float ig = sigmoidf_(sg[0]), fg = sigmoidf_(sg[1]), gg = tanhf(sg[2]), og = sigmoidf_(sg[3]);
+                const float cm = ndt * creg[grp & 3];
+                const float c = fg * cm + ig * gg;
+                const float h = og * tanhf(c);
+                creg[grp & 3] = c;
+                float *g = Gt + (size_t)tbi * 4 * H + u0 + tj;
+                g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+                p.Cs[((size_t)t * B + tbi) * H + u0 + tj] = c;
+                hstage[tb][tj] = dead_s ? __builtin_nanf("") : h;
+            }
+            __syncthreads();
+            if (tid < 16 && b0 + tid < B) {                              // one 16-byte write-through store per batch row
+                const f32x4 hv4 = *reinterpret_cast<const f32x4 *>(&hstage[tid][0]);
+                const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.Hs + (size_t)t * B * H, 0, (unsigned)hbytes, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), rs_o, ((b0 + tid) * H + u0) * 4, 0, 16);
+            }
+        }
+        // publish h_t: the storing wave drains its write-through stores, then one lane signals
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) (void)__hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LSTM backward (BPTT), two launches per (layer, timestep), t descending, 2-D partition of the recurrent product:
 //   phase A  lstm_bwd_rec_kernel : partial[kg][b][u] = sum_{k in group kg} dG[t+1][b][k] * W_hh[k][u]
 //            grid 16 k-groups x 16 u-groups = 256 blocks; a block reads a 256 x 64 slab of the ORIGINAL [4H][H]

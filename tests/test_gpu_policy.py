@@ -161,6 +161,28 @@ def test_policy_step_is_deterministic_and_single_step_eval():
     assert acts == [int(a) for a in ref['action'].flatten()]
 
 
+def test_persistent_forward_recurrence_is_bit_identical(monkeypatch):
+    """PVR_POLICY_PERSIST=1: one launch per (layer, chunk) with a grid-wide hand-off of h_t per step (write-through stores,
+    agent-scope counter, sc1 loads) instead of one launch per step; same arithmetic order, so parameters after three updates
+    must be bit-identical, with and without the two-lane layer pipeline, and B > 16 (two batch groups per block)."""
+    from pvr_habitat_amd.models import HipRMSprop
+    T, B, O, A, S = 24, 20, 256, 3, 3
+    obs, done, act = synth.bc_batches(6, T, B, O, A, S)
+    finals = {}
+    for persist, pipe in (('0', '1'), ('1', '1'), ('1', '0')):
+        monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
+        monkeypatch.setenv('PVR_POLICY_PIPELINE', pipe)
+        m, _ = _model(6, O, A, True, T, B)
+        opt = HipRMSprop(m, max_epochs=50)
+        m.train()
+        for s in range(S):
+            opt.scheduler_step()
+            opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+        finals[(persist, pipe)] = m._flat.clone()
+        assert torch.isfinite(finals[(persist, pipe)]).all()
+    assert torch.equal(finals[('0', '1')], finals[('1', '1')]) and torch.equal(finals[('0', '1')], finals[('1', '0')])
+
+
 @pytest.mark.parametrize('conv', [False, True])
 def test_policy_step_graph_replay_equals_eager_launches(monkeypatch, conv):
     """pvr_policy_step replays a captured hipGraph from the third iteration on (eager, capture, replay...): parameters,
