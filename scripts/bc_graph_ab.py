@@ -1,12 +1,14 @@
-"""A/B of the BC iteration launch strategies: PVR_POLICY_PERSIST (persistent forward recurrence) x PVR_POLICY_PIPELINE (two-lane
-layer pipeline) x PVR_POLICY_GRAPH (hipGraph replay).  5 warm-up + 50 timed steps each, one process."""
+"""A/B of the BC iteration launch strategies.  Each arm is a comma list of KEY=VALUE with KEY in WAVEFRONT, PIPELINE, PERSIST, GRAPH
+(PVR_POLICY_<KEY>).  5 warm-up + 50 timed steps each, one process."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-arms = [a.split(',') for a in (sys.argv[1:] or ['0,1,0', '1,1,0', '1,0,0', '0,1,0', '1,1,0'])]
-for persist, pipe, g in arms:
-    os.environ['PVR_POLICY_PERSIST'] = persist
-    os.environ['PVR_POLICY_PIPELINE'] = pipe
-    os.environ['PVR_POLICY_GRAPH'] = g
+arms = sys.argv[1:] or ['WAVEFRONT=0', 'WAVEFRONT=1', 'WAVEFRONT=0', 'WAVEFRONT=1']
+for arm in arms:
+    for k in ('WAVEFRONT', 'PIPELINE', 'PERSIST', 'GRAPH'):
+        os.environ.pop('PVR_POLICY_' + k, None)
+    for kv in arm.split(','):
+        k, v = kv.split('=')
+        os.environ['PVR_POLICY_' + k] = v
     r = bench.bc_bench(50, 5, False)
-    print('PERSIST=%s PIPELINE=%s GRAPH=%s  %.1f steps/s  %.3f ms/step  loss %.5f' % (persist, pipe, g, r['value'], r['ms_per_step'], r['final_loss']), flush=True)
+    print('%-28s %.1f steps/s  %.3f ms/step  loss %.5f' % (arm, r['value'], r['ms_per_step'], r['final_loss']), flush=True)
