@@ -101,7 +101,7 @@ int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf
  * torchvision FiveCrop).  Build-defined extension for BASELINE config 5 ("5-crop"); the reference has only the centre crop.
  * ResNet50 family only. */
 pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos);
-/* Same forward on one of two activation workspaces ("lanes", 0 or 1; lane 1 is allocated on first use).  Two forwards on
+/* Same forward on one of up to four activation workspaces ("lanes" 0..3; lanes > 0 are allocated on first use).  Forwards on
  * DIFFERENT lanes may be in flight at once on different streams - e.g. batch k+1 on lane 1 while batch k drains on lane 0,
  * which fills the CUs that tile tails and HBM-bound launches of a single batch-256 forward leave idle (+15 % frames/s
  * measured).  Forwards on the SAME lane must be stream-ordered by the caller.  pvr_encoder_forward == lane 0.

@@ -30,6 +30,7 @@ struct HostTensor {
     std::vector<float> data;
 };
 
+constexpr int PVR_MAX_LANES = 4;
 enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT };
 
 struct ConvOp {
@@ -77,7 +78,7 @@ struct pvr_encoder {
     size_t buf_elems = 0;
     // second activation workspace (pvr_encoder_forward_lane, lane 1): lets the caller keep two batches in flight on two
     // streams; allocated on first use.  The members above are the CURRENT lane's pointers (swapped by use_lane).
-    struct LaneWs { u16 *d_img = nullptr, *d_stem = nullptr; float *d_imgf = nullptr; void *d_buf[B_COUNT] = {nullptr}; bool valid = false; } lane_ws[2];
+    struct LaneWs { u16 *d_img = nullptr, *d_stem = nullptr; float *d_imgf = nullptr; void *d_buf[B_COUNT] = {nullptr}; bool valid = false; } lane_ws[PVR_MAX_LANES];
     int cur_lane = 0;
     int crop_pos = 0;                                // 0 centre (reference), 1..4 corner crops (pvr_encoder_set_crop_position)
     int last_n = 0;

@@ -325,9 +325,9 @@ struct pvr_vit {
     float *rs_wx = nullptr, *rs_wy = nullptr, *rs_tmp = nullptr;
     uint8_t *rs_u8 = nullptr;
     // second workspace lane (pvr_encoder_forward_lane): the members above are the CURRENT lane's pointers
-    struct Ws { u16 *A = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr; float *pe = nullptr, *x0 = nullptr, *x1 = nullptr; bool valid = false; } ws[2];
-    float *rs_tmp_l[2] = {nullptr, nullptr};
-    uint8_t *rs_u8_l[2] = {nullptr, nullptr};
+    struct Ws { u16 *A = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr; float *pe = nullptr, *x0 = nullptr, *x1 = nullptr; bool valid = false; } ws[PVR_MAX_LANES];
+    float *rs_tmp_l[PVR_MAX_LANES] = {nullptr};
+    uint8_t *rs_u8_l[PVR_MAX_LANES] = {nullptr};
     int cur = 0;
     std::vector<void *> owned;
 };
@@ -469,6 +469,11 @@ pvr_status vit_use_lane(pvr_encoder *e, int lane) {
         PVR_HIP_TRY(hipDeviceSynchronize());
         v->ws[lane] = {v->A, v->y, v->qkv, v->att, v->hid, v->pe, v->x0, v->x1, true};
     }
+    if (v->rs_h != 0 && !v->rs_tmp_l[lane]) {                  // resize tables exist already: this lane's temporaries do not yet
+        PVR_HIP_TRY(hipMalloc((void **)&v->rs_tmp_l[lane], (size_t)e->desc.chunk * v->rs_h * v->res * 3 * sizeof(float)));
+        PVR_HIP_TRY(hipMalloc((void **)&v->rs_u8_l[lane], (size_t)e->desc.chunk * v->res * v->res * 3));
+        PVR_HIP_TRY(hipDeviceSynchronize());
+    }
     const auto &w = v->ws[lane];
     v->A = w.A; v->y = w.y; v->qkv = w.qkv; v->att = w.att; v->hid = w.hid; v->pe = w.pe; v->x0 = w.x0; v->x1 = w.x1;
     v->rs_tmp = v->rs_tmp_l[lane]; v->rs_u8 = v->rs_u8_l[lane];
@@ -480,7 +485,8 @@ void vit_destroy(pvr_encoder *e) {
     if (!e->vit) return;
     for (void *p : e->vit->owned) (void)hipFree(p);
     pvr_vit *v = e->vit;
-    void *rs[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp_l[0], v->rs_u8_l[0], v->rs_tmp_l[1], v->rs_u8_l[1]};
+    std::vector<void *> rs = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy};
+    for (int l = 0; l < PVR_MAX_LANES; ++l) { rs.push_back(v->rs_tmp_l[l]); rs.push_back(v->rs_u8_l[l]); }
     for (void *q : rs) if (q) (void)hipFree(q);
     delete e->vit;
     e->vit = nullptr;
@@ -556,13 +562,15 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
         aa_tables(w, v->rs_rw, xm, xs, wx, v->rs_maxk_w);
         aa_tables(h, v->rs_rh, ym, ys, wy, v->rs_maxk_h);
     }
-    void *old[] = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy, v->rs_tmp_l[0], v->rs_u8_l[0], v->rs_tmp_l[1], v->rs_u8_l[1]};
+    std::vector<void *> old = {v->rs_xmin, v->rs_xsize, v->rs_ymin, v->rs_ysize, v->rs_wx, v->rs_wy};
+    for (int l = 0; l < PVR_MAX_LANES; ++l) { old.push_back(v->rs_tmp_l[l]); old.push_back(v->rs_u8_l[l]); }
     PVR_HIP_TRY(hipDeviceSynchronize());
     for (void *q : old) if (q) (void)hipFree(q);
     pvr_status s;
     if ((s = enc_upload(&v->rs_xmin, xm)) || (s = enc_upload(&v->rs_xsize, xs)) || (s = enc_upload(&v->rs_ymin, ym)) ||
         (s = enc_upload(&v->rs_ysize, ys)) || (s = enc_upload(&v->rs_wx, wx)) || (s = enc_upload(&v->rs_wy, wy))) return s;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < PVR_MAX_LANES; ++l) {
+        if (l > 0 && !v->ws[l].valid) { v->rs_tmp_l[l] = nullptr; v->rs_u8_l[l] = nullptr; continue; }   // lanes never used need no buffers
         PVR_HIP_TRY(hipMalloc((void **)&v->rs_tmp_l[l], (size_t)e->desc.chunk * h * v->res * 3 * sizeof(float)));
         PVR_HIP_TRY(hipMalloc((void **)&v->rs_u8_l[l], (size_t)e->desc.chunk * v->res * v->res * 3));
     }

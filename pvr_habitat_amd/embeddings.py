@@ -235,7 +235,7 @@ class HipResNet50(_Node):
     @property
     def lanes(self):
         """activation workspaces that can be in flight at once (the 'random' plan has a single workspace)"""
-        return 1 if self.variant == 'random5' else 2
+        return 1 if self.variant == 'random5' else 4
 
     def forward_into(self, frames_u8, out, lane=0):
         """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0).
