@@ -286,7 +286,7 @@ extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
-    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_MAE_VIT_L16, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_MAE_VIT_H14, "unknown arch %d", desc->arch);
     PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16 || (desc->dtype == PVR_F32 && desc->arch <= PVR_ARCH_RESNET50_L3),
                 "dtype must be PVR_BF16 or PVR_F16 (PVR_F32 is built for the ResNet50 family only)");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");

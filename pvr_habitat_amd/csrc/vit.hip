@@ -23,7 +23,7 @@ namespace pvr {
 template <bool F16>
 __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t *__restrict__ frames, u16 *__restrict__ A, int n, int h,
                                                        int w, int top, int left, int res, int P) {
-    const int g = res / P, K = P * P * 3;
+    const int g = res / P, Kr = P * P * 3, K = (Kr + 63) / 64 * 64;   // rows padded to a multiple of 64 with zeros (patch 14: 588 -> 640)
     const size_t total = (size_t)n * g * g * (K / 8);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int k8 = (int)(i % (K / 8)) * 8;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t *__restrict
         for (int e = 0; e < 8; ++e) {
             const int k = k8 + e, c = k % 3, px = (k / 3) % P, py = k / (3 * P);
             const int y = top + gy * P + py, x = left + gx * P + px;
-            oe[e] = to_h<F16>((float)frames[(((size_t)b * h + y) * w + x) * 3 + c] - 128.f);     // centred, exact
+            oe[e] = k < Kr ? to_h<F16>((float)frames[(((size_t)b * h + y) * w + x) * 3 + c] - 128.f) : (u16)0;     // centred, exact
         }
         *reinterpret_cast<u32x4 *>(A + row * K + k8) = o;
     }
@@ -147,65 +147,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     }
 }
 
-// Multi-head attention, head dim 64.  qkv: [N*T][3W] 16-bit (q | k | v, head h at columns h*64..), out: [N*T][W].
-// grid (heads, N), 4 waves.  Keys are padded to TK (multiple of 32): padded scores are -inf, padded V rows zero.
-template <bool F16>
+// Multi-head attention, head dim HD (64: CLIP / MAE-B / MAE-L; 80: MAE-H).  qkv: [N*T][3W] 16-bit (q | k | v, head h at columns
+// h*HD..), out: [N*T][W].  grid (heads, N), 4 waves.  Keys are padded to TK (multiple of 32, <= 16*MAXNT): padded scores are -inf,
+// padded V rows zero.  The contraction dim of QK^T is padded to KP = 32*ceil(HD/32) with zero chunks.
+template <bool F16, int HD, int MAXNT>
 __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ qkv, u16 *__restrict__ out, int T, int TK, int W) {
     typedef typename HT<F16>::V8 V8;
+    constexpr int KP = (HD + 31) / 32 * 32, KCH = KP / 8, KSTEPS = KP / 32, MT = HD / 16;
+    constexpr int KS = HD == 64 ? 128 : KP * 2 + 16;              // K row stride (bytes); 64: chunk-swizzled 128-B rows, else padded rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VS = TK + 4;                                        // V^T row stride (elements)
-    char *Ks = smem;                                              // [TK][64] 16-bit, 128-B rows, chunk-swizzled
-    u16 *Vt = reinterpret_cast<u16 *>(smem + (size_t)TK * 128);   // [64][VS]
+    char *Ks = smem;                                              // [TK][KP] 16-bit
+    u16 *Vt = reinterpret_cast<u16 *>(smem + (size_t)TK * KS);    // [HD][VS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int hd = blockIdx.x, b = blockIdx.y;
     const size_t rs = (size_t)3 * W;
-    const u16 *base = qkv + (size_t)b * T * rs + hd * 64;
-    for (int idx = tid; idx < TK * 8; idx += 256) {
-        const int row = idx >> 3, ch = idx & 7;
+    const u16 *base = qkv + (size_t)b * T * rs + hd * HD;
+    auto kaddr = [&](int row, int ch) { return HD == 64 ? row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) : row * KS + (ch << 4); };
+    for (int idx = tid; idx < TK * KCH; idx += 256) {
+        const int row = idx / KCH, ch = idx % KCH;
         u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-        if (row < T) {
+        const bool real = ch * 8 < HD;
+        if (row < T && real) {
             kv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + W + ch * 8);
             vv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + 2 * W + ch * 8);
         }
-        *reinterpret_cast<u32x4 *>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
-        const u16 *ve = reinterpret_cast<const u16 *>(&vv);
+        *reinterpret_cast<u32x4 *>(Ks + kaddr(row, ch)) = kv;
+        if (real) {
+            const u16 *ve = reinterpret_cast<const u16 *>(&vv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+        }
     }
     __syncthreads();
-    const int NT = TK / 16;                                       // key tiles (<= 14)
+    const int NT = TK / 16;                                       // key tiles (<= MAXNT)
+    const float scale = HD == 64 ? 0.125f : 1.0f / sqrtf((float)HD);
     for (int qt = wave; qt * 16 < T; qt += 4) {
         const int query = qt * 16 + fr;
         const bool qok = query < T;
         // B operand of S^T = K Q^T : Q[query = fr][d = ks*32 + 8*fq + j]
-        V8 qf[2];
+        V8 qf[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 t = u32x4{0u, 0u, 0u, 0u};
-            if (qok) t = *reinterpret_cast<const u32x4 *>(base + (size_t)query * rs + ks * 32 + fq * 8);
+            if (qok && ks * 32 + fq * 8 < HD) t = *reinterpret_cast<const u32x4 *>(base + (size_t)query * rs + ks * 32 + fq * 8);
             qf[ks] = __builtin_bit_cast(V8, t);
         }
-        f32x4 s[14];
+        f32x4 s[MAXNT];
 #pragma unroll
-        for (int nt = 0; nt < 14; ++nt) {
+        for (int nt = 0; nt < MAXNT; ++nt) {
             s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (nt < NT) {
                 const int krow = nt * 16 + fr;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const V8 kf = *reinterpret_cast<const V8 *>(Ks + krow * 128 + (((ks * 4 + fq) ^ ((krow >> 1) & 7)) << 4));
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const V8 kf = *reinterpret_cast<const V8 *>(Ks + kaddr(krow, ks * 4 + fq));
                     s[nt] = mfma16<F16>(kf, qf[ks], s[nt]);
                 }
             }
         }
-        // s[nt][r] = S^T[key = nt*16 + 4*fq + r][query = fr]; softmax over keys (scores / sqrt(64))
+        // s[nt][r] = S^T[key = nt*16 + 4*fq + r][query = fr]; softmax over keys (scores / sqrt(HD))
         float mx = -INFINITY;
 #pragma unroll
-        for (int nt = 0; nt < 14; ++nt)
+        for (int nt = 0; nt < MAXNT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = nt * 16 + fq * 4 + r;
-                const float v = (nt < NT && key < T) ? s[nt][r] * 0.125f : -INFINITY;
+                const float v = (nt < NT && key < T) ? s[nt][r] * scale : -INFINITY;
                 s[nt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 14; ++nt)
+        for (int nt = 0; nt < MAXNT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __expf(s[nt][r] - mx);            // exp(-inf) = 0 for padded keys
@@ -224,11 +232,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         // O^T = V^T P^T : k-slot (fq, j) <-> key 32*ks + 16*(j>>2) + 4*fq + (j&3), identical for both operands
-        f32x4 o[4];
+        f32x4 o[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
+        for (int ks = 0; ks < MAXNT / 2; ++ks) {
             if (ks * 32 < TK) {
                 u16 pe[8];
 #pragma unroll
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
                 for (int e = 0; e < 4; ++e) pw[e] = (unsigned)pe[2 * e] | ((unsigned)pe[2 * e + 1] << 16);
                 const V8 pf = __builtin_bit_cast(V8, pw);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const u16 *vr = Vt + (size_t)(mt * 16 + fr) * VS + ks * 32 + fq * 4;
                     const uint2 lo = *reinterpret_cast<const uint2 *>(vr), hi = *reinterpret_cast<const uint2 *>(vr + 16);
                     const u32x4 vw = u32x4{lo.x, lo.y, hi.x, hi.y};
@@ -247,9 +255,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
             }
         }
         if (qok) {
-            u16 *orow = out + ((size_t)b * T + query) * W + hd * 64 + fq * 4;
+            u16 *orow = out + ((size_t)b * T + query) * W + hd * HD + fq * 4;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 ushort4 r;
                 r.x = to_h<F16>(o[mt][0] * inv); r.y = to_h<F16>(o[mt][1] * inv);
                 r.z = to_h<F16>(o[mt][2] * inv); r.w = to_h<F16>(o[mt][3] * inv);
@@ -364,15 +372,18 @@ static pvr_status up_linear(pvr_encoder *e, const std::string &wname, const std:
 pvr_status vit_create(pvr_encoder *e) {
     pvr_vit *v = new pvr_vit();
     v->patch = e->desc.arch == PVR_ARCH_CLIP_VIT_B32 ? 32 : 16;
-    v->mae = e->desc.arch == PVR_ARCH_MAE_VIT_B16 || e->desc.arch == PVR_ARCH_MAE_VIT_L16;
+    v->mae = e->desc.arch == PVR_ARCH_MAE_VIT_B16 || e->desc.arch == PVR_ARCH_MAE_VIT_L16 || e->desc.arch == PVR_ARCH_MAE_VIT_H14;
     if (e->desc.arch == PVR_ARCH_MAE_VIT_L16) { v->width = 1024; v->layers = 24; v->heads = 16; }   // mae.py:283-288
+    if (e->desc.arch == PVR_ARCH_MAE_VIT_H14) { v->width = 1280; v->layers = 32; v->heads = 16; v->patch = 14; }   // mae.py:291-296
     if (v->mae) { v->eps = 1e-6f; v->act = 3; v->out_dim = v->width; }
     v->res = e->desc.crop;
     v->resize_to = e->desc.resize;
     v->grid = v->res / v->patch;
     v->T = v->grid * v->grid + 1;
     v->TK = (v->T + 31) / 32 * 32;
-    if (v->TK > 224) { delete v; set_error("vit: more than 224 tokens not supported"); return PVR_ERR_INVALID; }
+    if (v->TK > 288 || v->width % v->heads || (v->width / v->heads != 64 && v->width / v->heads != 80)) {
+        delete v; set_error("vit: more than 288 tokens or a head dim other than 64 / 80 is not built"); return PVR_ERR_INVALID;
+    }
     e->vit = v;
     e->out_size = v->out_dim;
     return PVR_OK;
@@ -380,7 +391,7 @@ pvr_status vit_create(pvr_encoder *e) {
 
 static pvr_status vit_alloc_ws(pvr_encoder *e) {
     pvr_vit *v = e->vit;
-    const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid, W = v->width, K = (size_t)v->patch * v->patch * 3;
+    const size_t C = e->desc.chunk, rows = C * v->T, prow = C * v->grid * v->grid, W = v->width, K = ((size_t)v->patch * v->patch * 3 + 63) / 64 * 64;
     auto alloc = [&](void **ptr, size_t bytes) -> pvr_status {
         PVR_HIP_TRY(hipMalloc(ptr, bytes));
         v->owned.push_back(*ptr);
@@ -399,16 +410,16 @@ static pvr_status vit_alloc_ws(pvr_encoder *e) {
 
 pvr_status vit_finalize(pvr_encoder *e) {
     pvr_vit *v = e->vit;
-    const int W = v->width, P = v->patch, K = P * P * 3, dt = e->desc.dtype;
+    const int W = v->width, P = v->patch, Kr = P * P * 3, K = (Kr + 63) / 64 * 64, dt = e->desc.dtype;   // K: zero-padded row length
     pvr_status s;
     // patch embedding: conv1 [W][3][P][P] (no bias) -> [W][(py,px,c)], Normalize + /255 folded:
     //   sum w*((x/255-mean)/std) = sum (w/(255 std)) (x-128) + sum w (128 - 255 mean)/(255 std)
     const HostTensor *w;
-    if ((s = enc_need(e, v->mae ? "patch_embed.proj.weight" : "visual.conv1.weight", &w, (size_t)W * K))) return s;
+    if ((s = enc_need(e, v->mae ? "patch_embed.proj.weight" : "visual.conv1.weight", &w, (size_t)W * Kr))) return s;
     const HostTensor *pb = nullptr;                              // timm PatchEmbed has a bias, CLIP conv1 does not
     if (v->mae && (s = enc_need(e, "patch_embed.proj.bias", &pb, (size_t)W))) return s;
     {
-        std::vector<u16> hw((size_t)W * K);
+        std::vector<u16> hw((size_t)W * K, 0);
         std::vector<float> hb(W, 0.f);
         for (int co = 0; co < W; ++co) {
             double bsum = 0.0;
@@ -583,7 +594,7 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
 template <bool F16, int WD>
 static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
     pvr_vit *v = e->vit;
-    const int W = v->width, P = v->patch, K = P * P * 3, T = v->T, g2 = v->grid * v->grid, dt = e->desc.dtype;
+    const int W = v->width, P = v->patch, K = (P * P * 3 + 63) / 64 * 64, T = v->T, g2 = v->grid * v->grid, dt = e->desc.dtype;
     PVR_REQUIRE(W == WD, "vit: width %d does not match the instantiated plan", W);
     // transforms (embeddings.py:309-314): Resize(res, BICUBIC, antialias) is the identity when the short side is res
     const int sh = w <= h ? w : h;
@@ -621,13 +632,19 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         if (stop == "pe" || stop == "ln_pre") return PVR_OK;
         float *x = v->x0, *xn = v->x1;
         int bi = 0;
-        const size_t att_lds = (size_t)v->TK * 128 + (size_t)64 * (v->TK + 4) * 2;
+        const int HDm = W / v->heads;
+        const size_t att_lds = (size_t)v->TK * (HDm == 64 ? 128 : 208) + (size_t)HDm * (v->TK + 4) * 2;
         for (auto &b : v->blocks) {
             hipLaunchKernelGGL((layernorm_kernel<F16, WD>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
                                (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
             if ((s = launch_conv(v->y, b.w_qkv, b.b_qkv, nullptr, v->qkv, v->zero, rows, 1, 1, W, 3 * W, 1, 1, 1, 0, 0, 0, dt, st))) return s;
             if (bi == 0 && stop == "qkv0") return PVR_OK;
-            hipLaunchKernelGGL(attention_kernel<F16>, dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
+            if (HDm == 64 && v->TK <= 224)
+                hipLaunchKernelGGL((attention_kernel<F16, 64, 14>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
+            else if (HDm == 64)
+                hipLaunchKernelGGL((attention_kernel<F16, 64, 18>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
+            else
+                hipLaunchKernelGGL((attention_kernel<F16, 80, 18>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
             PVR_LAUNCH_CHECK();
             if (bi == 0 && stop == "att0") return PVR_OK;
             // x' = x + out_proj(att): fp32 residual in (bit1), fp32 out (bit0)
@@ -689,13 +706,20 @@ pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, in
 pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 64, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 64, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         attr_done = true;
     }
     if (e->vit->width == 1024)
         return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 1024>(e, frames, n, h, w, out, out_stride, st)
                                         : vit_forward_t<false, 1024>(e, frames, n, h, w, out, out_stride, st);
+    if (e->vit->width == 1280)
+        return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 1280>(e, frames, n, h, w, out, out_stride, st)
+                                        : vit_forward_t<false, 1280>(e, frames, n, h, w, out, out_stride, st);
     return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 768>(e, frames, n, h, w, out, out_stride, st)
                                     : vit_forward_t<false, 768>(e, frames, n, h, w, out, out_stride, st);
 }

@@ -25,9 +25,9 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'random5': 1568}
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'mae_h14': 1280, 'random5': 1568}
 _ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3,
-         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7}
+         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7, 'mae_h14': 8}
 
 # ---------------------------------------------------------------------------------------------
 # name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
@@ -66,7 +66,7 @@ for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_cropo
     for _combo in ('345', '35', '34', '45'):
         _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
 # names the reference registers but whose model families are not built yet
-_NOT_BUILT = ('resnet18', 'resnet34', 'mae_huge', 'maskrcnn_l3', 'clip_rn50')
+_NOT_BUILT = ('resnet18', 'resnet34', 'maskrcnn_l3', 'clip_rn50')
 # CLIP visual towers: 'clip_vit' is the reference's name (ViT-B/32, embeddings.py:303-304); 'clip_vit_b16' is the
 # same block layout at patch 16 (BASELINE config 3), not a reference registry name
 _CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16)}
@@ -396,20 +396,21 @@ def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, trai
             layers += [init_(nn.Conv2d(cin, 32, kernel_size=(3, 3), stride=2, padding=1)), nn.ELU()]
             cin = 32
         model = HipResNet50(nn.Sequential(*layers).state_dict(), 'random5', **hip_kw)
-    elif embedding_name in ('mae_base', 'mae_large'):   # embeddings.py:137-144; encoder keys only (strict=False there)
-        large = embedding_name == 'mae_large'
-        ckpt = 'mae_pretrain_vit_large.pth' if large else 'mae_pretrain_vit_base.pth'
-        width, layers = (1024, 24) if large else (768, 12)                           # mae.py:275-288
+    elif embedding_name in ('mae_base', 'mae_large', 'mae_huge'):   # embeddings.py:137-148; encoder keys only (strict=False there)
+        ckpt, variant, patch, width, layers = {                                       # mae.py:275-296
+            'mae_base': ('mae_pretrain_vit_base.pth', 'mae_b16', 16, 768, 12),
+            'mae_large': ('mae_pretrain_vit_large.pth', 'mae_l16', 16, 1024, 24),
+            'mae_huge': ('mae_pretrain_vit_huge.pth', 'mae_h14', 14, 1280, 32)}[embedding_name]
         f = _find_checkpoint(ckpt) if pretrained else None
         if f is not None:
             ck = torch.load(f, map_location='cpu')['model']
             sd = {k: v.float() for k, v in ck.items() if not k.startswith(('decoder', 'mask_token'))}
-            sd.setdefault('pos_embed', torch.from_numpy(synth.sincos_2d_pos_embed(width, 14)[None]))     # fixed buffer
+            sd.setdefault('pos_embed', torch.from_numpy(synth.sincos_2d_pos_embed(width, 224 // patch)[None]))     # fixed buffer
         elif os.environ.get('PVR_SYNTHETIC_WEIGHTS', '0') == '1' or not pretrained:
-            sd = synth.mae_vit_state_dict(zlib.crc32(embedding_name.encode()) & 0x7fffffff, width=width, layers=layers)
+            sd = synth.mae_vit_state_dict(zlib.crc32(embedding_name.encode()) & 0x7fffffff, patch=patch, width=width, layers=layers)
         else:
             raise FileNotFoundError(ckpt)
-        model = HipResNet50(sd, 'mae_l16' if large else 'mae_b16', **hip_kw)
+        model = HipResNet50(sd, variant, **hip_kw)
     elif embedding_name in _UBER:
         model = UberModel([_get_embedding(n, in_channels, pretrained, train, **hip_kw)[0] for n in _UBER[embedding_name]])
     elif embedding_name in _NOT_BUILT:

@@ -98,3 +98,20 @@ def test_mae_vit_l16_matches_oracle():
     l2, mx = _rel(out, ref)
     print('\n[mae_l16 f16] rel-L2 %.2e max-norm %.2e' % (l2, mx))
     assert l2 < 1.5e-3
+
+
+def test_mae_vit_h14_matches_oracle():
+    """SURVEY 8f N1: MAE ViT-H/14 encoder ('mae_huge': width 1280, 32 blocks, 16 heads of dim 80, patch 14 -> 257 tokens;
+    mae.py:291-296): second attention instantiation (head dim 80 padded to 96 in QK^T, 18 key tiles) and zero-padded patch rows."""
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.mae_vit_state_dict(3, patch=14, width=1280, layers=32)
+    fr = synth.smooth_frames(49, 2, 96, 96)
+    ref = vo.mae_embed(sd, fr, squeeze=False, heads=16)
+    m = HipResNet50(sd, 'mae_h14', compute_dtype='f16', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert out.shape == (2, 1280)
+    l2, mx = _rel(out, ref)
+    print('\n[mae_h14 f16] rel-L2 %.2e max-norm %.2e' % (l2, mx))
+    assert l2 < 1.5e-3
