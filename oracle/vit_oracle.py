@@ -167,3 +167,70 @@ def mae_embed(sd, frames_nhwc_u8, squeeze=True, heads=12):
     with torch.no_grad():
         out = mae_encode(sd, mae_preprocess(frames_nhwc_u8), heads=heads)
         return (out.squeeze() if squeeze else out).numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CLIP RN50 visual tower (reference src/embeddings.py:305-306 clip.load("RN50"), :309-314 transforms, :375-376
+# encode_image).  openai/CLIP `ModifiedResNet` restated from its published model.py (not under /root/reference, unpinned
+# git HEAD; transformers ships no CLIP-ResNet, so this restatement has NO independent cross-check: parity unpinned):
+#   stem: conv1 3x3/2 (3->32) bn relu, conv2 3x3 (32->32) bn relu, conv3 3x3 (32->64) bn relu, AvgPool2d(2)
+#   Bottleneck(inplanes, planes, stride): conv1 1x1 bn relu -> conv2 3x3 (stride 1!) bn relu -> AvgPool2d(stride) ->
+#       conv3 1x1 bn ; downsample (stride > 1 or inplanes != 4*planes) = AvgPool2d(stride) -> conv 1x1 -> bn ; relu(out + id)
+#   layers (3, 4, 6, 3), widths 64/128/256/512 (x4), strides 1/2/2/2 -> (N, 2048, 7, 7)
+#   AttentionPool2d(7, 2048, heads 32, out 1024): tokens = [mean ; x_hw] + positional_embedding(50, 2048);
+#       multi_head_attention_forward(query = tokens[:1], key = value = tokens) with separate q/k/v projections (+bias),
+#       out = c_proj(attn)  -> (N, 1024).  BatchNorm eps 1e-5 (eval).
+# ------------------------------------------------------------------------------------------------------------------
+def _bn_eval(sd, p, x):
+    return F.batch_norm(x, _t(sd[p + '.running_mean']), _t(sd[p + '.running_var']), _t(sd[p + '.weight']), _t(sd[p + '.bias']), False, 0.0, 1e-5)
+
+
+def clip_rn50_features(sd, x, taps=None):
+    v = 'visual.'
+    x = F.relu(_bn_eval(sd, v + 'bn1', F.conv2d(x, _t(sd[v + 'conv1.weight']), None, 2, 1)))
+    x = F.relu(_bn_eval(sd, v + 'bn2', F.conv2d(x, _t(sd[v + 'conv2.weight']), None, 1, 1)))
+    x = F.relu(_bn_eval(sd, v + 'bn3', F.conv2d(x, _t(sd[v + 'conv3.weight']), None, 1, 1)))
+    x = F.avg_pool2d(x, 2)
+    if taps is not None:
+        taps['stem'] = x
+    inpl = 64
+    for li, nb in enumerate((3, 4, 6, 3)):
+        planes = 64 << li
+        for bi in range(nb):
+            p = v + 'layer%d.%d.' % (li + 1, bi)
+            stride = 2 if (bi == 0 and li > 0) else 1
+            o = F.relu(_bn_eval(sd, p + 'bn1', F.conv2d(x, _t(sd[p + 'conv1.weight']))))
+            o = F.relu(_bn_eval(sd, p + 'bn2', F.conv2d(o, _t(sd[p + 'conv2.weight']), None, 1, 1)))
+            if stride > 1:
+                o = F.avg_pool2d(o, stride)
+            o = _bn_eval(sd, p + 'bn3', F.conv2d(o, _t(sd[p + 'conv3.weight'])))
+            idn = x
+            if (p + 'downsample.0.weight') in sd:              # Sequential(OrderedDict('-1' AvgPool2d, '0' conv, '1' bn))
+                idn = F.avg_pool2d(x, stride) if stride > 1 else x
+                idn = _bn_eval(sd, p + 'downsample.1', F.conv2d(idn, _t(sd[p + 'downsample.0.weight'])))
+            x = F.relu(o + idn)
+            inpl = planes * 4
+        if taps is not None:
+            taps['layer%d' % (li + 1)] = x
+    return x
+
+
+def clip_rn50_attnpool(sd, x, heads=32):
+    a = 'visual.attnpool.'
+    n, c, h, w = x.shape
+    t = x.reshape(n, c, h * w).permute(0, 2, 1)                        # (N, HW, C)
+    t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1) + _t(sd[a + 'positional_embedding'])[None]
+    q = t[:, :1] @ _t(sd[a + 'q_proj.weight']).t() + _t(sd[a + 'q_proj.bias'])
+    k = t @ _t(sd[a + 'k_proj.weight']).t() + _t(sd[a + 'k_proj.bias'])
+    vv = t @ _t(sd[a + 'v_proj.weight']).t() + _t(sd[a + 'v_proj.bias'])
+    hd = c // heads
+    sh = lambda z: z.reshape(n, -1, heads, hd).permute(0, 2, 1, 3)
+    att = torch.softmax((sh(q) @ sh(k).transpose(-1, -2)) * (hd ** -0.5), dim=-1) @ sh(vv)      # (N, heads, 1, hd)
+    att = att.permute(0, 2, 1, 3).reshape(n, c)
+    return att @ _t(sd[a + 'c_proj.weight']).t() + _t(sd[a + 'c_proj.bias'])
+
+
+def clip_rn50_embed(sd, frames_nhwc_u8, squeeze=True, taps=None):
+    with torch.no_grad():
+        out = clip_rn50_attnpool(sd, clip_rn50_features(sd, preprocess(frames_nhwc_u8), taps=taps))
+        return (out.squeeze() if squeeze else out).numpy()

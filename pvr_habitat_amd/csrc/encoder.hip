@@ -75,6 +75,57 @@ static void build_resnet50(pvr_encoder *e) {
     e->out_size = c * hw * hw; e->final_hw = hw * hw; e->final_c = 64; e->final_creal = c;
 }
 
+// openai/CLIP ModifiedResNet-50 (reference embeddings.py:305-306): stem conv1 (3x3/2, run by the stem kernel as a 7x7 with only
+// its centre taps set) is not in the list; conv2 / conv3 of the stem, AvgPool2d(2), then Bottlenecks whose convolutions all have
+// stride 1 - the stride is an AvgPool2d after conv2 and in front of the downsample convolution.  Channels 32 are padded to 64.
+static void add_pool(pvr_encoder *e, int in_buf, int out_buf, int h, int c) {
+    ConvOp op;
+    op.kind = 1; op.conv = "avgpool2"; op.in_buf = in_buf; op.out_buf = out_buf; op.res_buf = B_NONE;
+    op.h = h; op.w = h; op.cin = op.cin_real = op.cout = op.cout_real = c; op.k = 2; op.stride = 2; op.pad = 0; op.relu = 0; op.out_f32 = 0;
+    e->ops.push_back(op);
+}
+
+static void build_clip_rn50(pvr_encoder *e) {
+    const std::string v = "visual.";
+    add_conv(e, v + "conv2", v + "bn2", B_STEM, B_X0, B_NONE, 112, 112, 64, 32, 64, 32, 3, 1, 1);
+    add_conv(e, v + "conv3", v + "bn3", B_X0, B_X1, B_NONE, 112, 112, 64, 32, 64, 64, 3, 1, 1);
+    add_pool(e, B_X1, B_X0, 112, 64);
+    e->ops.back().tap = "stem3";
+    e->taps["stem3"] = {B_X0, {56, 56, 64, 0}};
+    const int nblk[4] = {3, 4, 6, 3};
+    int hw = 56, inpl = 64, x = B_X0;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        for (int bi = 0; bi < nblk[li]; ++bi) {
+            char pfx[64];
+            snprintf(pfx, sizeof pfx, "visual.layer%d.%d", li + 1, bi);
+            const std::string p = pfx;
+            const int stride = (bi == 0 && li > 0) ? 2 : 1;
+            const int ohw = hw / stride;
+            const int y = x == B_X0 ? B_X1 : B_X0;
+            const bool last = (li == 3 && bi == nblk[li] - 1);
+            add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
+            add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_T2, B_NONE, hw, hw, planes, planes, planes, planes, 3, 1, 1);
+            int c3_in = B_T2, res = x;
+            if (stride > 1) { add_pool(e, B_T2, B_T1, hw, planes); c3_in = B_T1; }
+            if (stride > 1 || inpl != planes * 4) {
+                int ds_in = x;
+                if (stride > 1) { add_pool(e, x, B_T2, hw, inpl); ds_in = B_T2; }
+                add_conv(e, p + ".downsample.0", p + ".downsample.1", ds_in, B_DS, B_NONE, ohw, ohw, inpl, inpl, planes * 4, planes * 4, 1, 1, 0);
+                res = B_DS;
+            }
+            add_conv(e, p + ".conv3", p + ".bn3", c3_in, last ? B_F32 : y, res, ohw, ohw, planes, planes, planes * 4, planes * 4, 1, 1, 1, last ? 1 : 0);
+            if (bi == nblk[li] - 1) {
+                char tn[16]; snprintf(tn, sizeof tn, "layer%d", li + 1);
+                e->ops.back().tap = tn;
+                e->taps[tn] = {last ? B_F32 : y, {ohw, ohw, planes * 4, last ? 1 : 0}};
+            }
+            x = y; hw = ohw; inpl = planes * 4;
+        }
+    }
+    e->out_size = 1024; e->final_hw = 49; e->final_c = 2048; e->final_creal = 2048;
+}
+
 const HostTensor *enc_find(pvr_encoder *e, const std::string &name) {
     auto it = e->weights.find(name);
     return it == e->weights.end() ? nullptr : &it->second;
@@ -156,7 +207,7 @@ static bool ends_with(const std::string &s, const char *suf) {
 static pvr_status build_schedules(pvr_encoder *e) {
     const int n = (int)e->ops.size();
     for (int i = 0; i < n; ++i) { Launch l; l.conv2 = i; e->sched_plain.push_back(l); }
-    if (e->desc.dtype == PVR_F32) { e->sched_fused = e->sched_plain; return PVR_OK; }
+    if (e->desc.dtype == PVR_F32 || e->desc.arch == PVR_ARCH_CLIP_RN50) { e->sched_fused = e->sched_plain; return PVR_OK; }   // (CLIP: pools between the convolutions)
     int cur_t1 = B_T1;
     bool conv1_done = false;
     for (int i = 0; i < n;) {
@@ -207,17 +258,26 @@ static pvr_status build_schedules(pvr_encoder *e) {
     return PVR_OK;
 }
 
-static pvr_status finalize_stem(pvr_encoder *e) {
+// conv_name (cout_real, 3, ks, ks) with ks = 7 (torchvision) or 3 (CLIP: stride 2, pad 1 == the centre 3x3 taps of a 7x7 / pad 3)
+static pvr_status finalize_stem(pvr_encoder *e, const std::string &conv_name = "conv1.weight", const std::string &bn_name = "bn1",
+                                int cout_real = 64, int ks = 7) {
     const HostTensor *w;
     pvr_status s;
-    if ((s = enc_need(e, "conv1.weight", &w, 64 * 3 * 7 * 7))) return s;
+    if ((s = enc_need(e, conv_name, &w, (size_t)cout_real * 3 * ks * ks))) return s;
     std::vector<float> scale, shift;
-    if ((s = bn_fold(e, "bn1", 64, scale, shift))) return s;
+    if ((s = bn_fold(e, bn_name, cout_real, scale, shift))) return s;
+    scale.resize(64, 0.f); shift.resize(64, 0.f);
+    const int t0 = (7 - ks) / 2;
+    auto wat = [&](int co, int c, int a, int b) -> double {       // 7x7 view of the (possibly smaller) filter
+        const int aa = a - t0, bb = b - t0;
+        if (co >= cout_real || aa < 0 || aa >= ks || bb < 0 || bb >= ks) return 0.0;
+        return (double)w->data[(((size_t)co * 3 + c) * ks + aa) * ks + bb];
+    };
     if (e->desc.dtype == PVR_F32) {               // normalisation stays a separate fp32 kernel, exactly as torch applies it
         std::vector<float> hf(64 * 49 * 4, 0.f);
         for (int co = 0; co < 64; ++co)
             for (int c = 0; c < 3; ++c)
-                for (int t = 0; t < 49; ++t) hf[((size_t)co * 49 + t) * 4 + c] = w->data[((size_t)co * 3 + c) * 49 + t] * scale[co];
+                for (int t = 0; t < 49; ++t) hf[((size_t)co * 49 + t) * 4 + c] = (float)wat(co, c, t / 7, t % 7) * scale[co];
         if ((s = enc_upload(&e->d_stem_wf, hf))) return s;
         return enc_upload(&e->d_stem_b, shift);
     }
@@ -227,7 +287,7 @@ static pvr_status finalize_stem(pvr_encoder *e) {
             for (int b = 0; b < 7; ++b) {
                 double vsum = 0.0;
                 for (int c = 0; c < 3; ++c) {
-                    const double wv = (double)w->data[(((size_t)co * 3 + c) * 7 + a) * 7 + b] * scale[co];
+                    const double wv = wat(co, c, a, b) * scale[co];
                     // (x/255 - mean)/std with x = xc + 128:  xc/(255 std) + (128 - 255 mean)/(255 std)
                     hw[co * 224 + (a * 8 + b) * 4 + c] = f32_to_h((float)(wv / (255.0 * e->desc.std_[c])), e->desc.dtype);
                     vsum += wv * (128.0 - 255.0 * e->desc.mean[c]) / (255.0 * e->desc.std_[c]);
@@ -236,6 +296,33 @@ static pvr_status finalize_stem(pvr_encoder *e) {
             }
     if ((s = enc_upload(&e->d_stem_w, hw))) return s;
     return enc_upload(&e->d_stem_b, shift);
+}
+
+// CLIP AttentionPool2d parameters: q/k/v projections concatenated row-wise (one GEMM), c_proj, positional embedding
+static pvr_status finalize_attnpool(pvr_encoder *e) {
+    const int C = 2048, O = 1024, dt = e->desc.dtype;
+    const std::string a = "visual.attnpool.";
+    pvr_status s;
+    std::vector<u16> wq((size_t)3 * C * C);
+    std::vector<float> bq((size_t)3 * C);
+    const char *nm[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int i = 0; i < 3; ++i) {
+        const HostTensor *w, *b;
+        if ((s = enc_need(e, a + nm[i] + ".weight", &w, (size_t)C * C))) return s;
+        if ((s = enc_need(e, a + nm[i] + ".bias", &b, (size_t)C))) return s;
+        for (size_t k = 0; k < (size_t)C * C; ++k) wq[(size_t)i * C * C + k] = f32_to_h(w->data[k], dt);
+        for (int k = 0; k < C; ++k) bq[(size_t)i * C + k] = b->data[k];
+    }
+    const HostTensor *wc, *bc, *pos;
+    if ((s = enc_need(e, a + "c_proj.weight", &wc, (size_t)O * C))) return s;
+    if ((s = enc_need(e, a + "c_proj.bias", &bc, (size_t)O))) return s;
+    if ((s = enc_need(e, a + "positional_embedding", &pos, (size_t)50 * C))) return s;
+    std::vector<u16> wch((size_t)O * C);
+    for (size_t k = 0; k < wch.size(); ++k) wch[k] = f32_to_h(wc->data[k], dt);
+    if ((s = enc_upload(&e->ap_wqkv, wq)) || (s = enc_upload(&e->ap_bqkv, bq)) || (s = enc_upload(&e->ap_wc, wch)) ||
+        (s = enc_upload(&e->ap_bc, bc->data)) || (s = enc_upload(&e->ap_pos, pos->data))) return s;
+    PVR_HIP_TRY(hipMalloc((void **)&e->ap_out, (size_t)e->desc.chunk * O * sizeof(float) * PVR_MAX_LANES));
+    return PVR_OK;
 }
 
 }  // namespace pvr
@@ -286,7 +373,7 @@ extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
-    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_MAE_VIT_H14, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_CLIP_RN50, "unknown arch %d", desc->arch);
     PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16 || (desc->dtype == PVR_F32 && desc->arch <= PVR_ARCH_RESNET50_L3),
                 "dtype must be PVR_BF16 or PVR_F16 (PVR_F32 is built for the ResNet50 family only)");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
@@ -297,6 +384,9 @@ pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
     if (e->desc.arch == PVR_ARCH_RANDOM5) {
         random5_create(e);
+    } else if (e->desc.arch == PVR_ARCH_CLIP_RN50) {
+        build_clip_rn50(e);
+        resizer_create(e);
     } else if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32) {
         pvr_status s = vit_create(e);
         if (s) { delete e; return s; }
@@ -330,9 +420,11 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
         enc->finalized = true;
         return PVR_OK;
     }
-    if ((s = finalize_stem(enc))) return s;
+    const bool rn50c = enc->desc.arch == PVR_ARCH_CLIP_RN50;
+    if ((s = rn50c ? finalize_stem(enc, "visual.conv1.weight", "visual.bn1", 32, 3) : finalize_stem(enc))) return s;
+    if (rn50c && (s = finalize_attnpool(enc))) return s;
     for (auto &op : enc->ops)
-        if ((s = finalize_conv(enc, op))) return s;
+        if (op.kind == 0 && (s = finalize_conv(enc, op))) return s;
     if ((s = build_schedules(enc))) return s;
     for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); }
     if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
@@ -352,6 +444,39 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
 int32_t pvr_encoder_out_size(const pvr_encoder *enc) { return enc ? enc->out_size : 0; }
 
 }  // extern "C"
+
+// One chunk of the CLIP RN50 tower: Resize(224, bicubic, antialias) + CenterCrop -> stem image -> conv1 (stem kernel) -> plan
+// (convolutions and 2x2 average pools) -> attention pool (tokens, fused q/k/v GEMM, attention core, c_proj of token 0).
+static void *bufp(pvr_encoder *enc, int id) { return id == B_STEM ? (void *)enc->d_stem : enc->d_buf[id]; }
+
+static pvr_status clip_rn50_chunk(pvr_encoder *enc, const uint8_t *fr, int nb, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
+    const int dt = enc->desc.dtype, crop = enc->desc.crop;
+    pvr_status s;
+    const uint8_t *u8; int oh, ow;
+    if ((s = resizer_run(enc, enc->cur_lane, fr, nb, h, w, st, &u8, &oh, &ow))) return s;
+    // short side == crop here, so this only centre-crops and converts to the stem's centred 4-channel image
+    if ((s = launch_preprocess(u8, nb, oh, ow, enc->desc.resize, crop, enc->d_img, dt, st))) return s;
+    enc->last_n = nb;
+    if (enc->stop_after == "pre") return PVR_OK;
+    if ((s = launch_stem(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_stem, nb, crop, dt, st))) return s;
+    for (const ConvOp &op : enc->ops) {
+        if (op.kind == 1) s = launch_avgpool2(bufp(enc, op.in_buf), bufp(enc, op.out_buf), nb, op.h, op.w, op.cin, dt, st);
+        else s = launch_conv(bufp(enc, op.in_buf), op.d_w, op.d_b, op.res_buf == B_NONE ? nullptr : bufp(enc, op.res_buf), bufp(enc, op.out_buf),
+                             enc->d_zero, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
+        if (s) return s;
+        if (!enc->stop_after.empty() && op.tap == enc->stop_after) return PVR_OK;
+    }
+    // AttentionPool2d(7, 2048, 32 heads, 1024)
+    const int C = 2048, T = 50;
+    if ((s = launch_attnpool_tokens((const float *)enc->d_buf[B_F32], enc->ap_pos, enc->d_buf[B_T1], nb, 49, C, dt, st))) return s;
+    if ((s = launch_conv(enc->d_buf[B_T1], enc->ap_wqkv, enc->ap_bqkv, nullptr, enc->d_buf[B_X0], enc->d_zero, nb * T, 1, 1, C, 3 * C, 1, 1, 1, 0, 0, 0, dt, st))) return s;
+    if ((s = launch_attention(enc->d_buf[B_X0], enc->d_buf[B_T2], T, C, 32, nb, dt, st))) return s;
+    // c_proj of token 0 only: a 1x1 "convolution" over (n, T, 1) with stride T picks row 0 of every image; fp32 out
+    float *dense = enc->ap_out + (size_t)enc->cur_lane * enc->desc.chunk * 1024;
+    if ((s = launch_conv(enc->d_buf[B_T2], enc->ap_wc, enc->ap_bc, nullptr, dense, enc->d_zero, nb, T, 1, C, 1024, 1, 1, T, 0, 0, 1, dt, st))) return s;
+    PVR_HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride * 4, dense, 1024 * 4, 1024 * 4, nb, hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
 
 // ev != nullptr: record one event before the first launch and one after every launch of the FIRST chunk
 static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
@@ -405,6 +530,10 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                        enc->final_creal, st);
             if (s) return s;
             if ((s = mark())) return s;
+            continue;
+        }
+        if (enc->desc.arch == PVR_ARCH_CLIP_RN50) {
+            if ((s = clip_rn50_chunk(enc, fr, nb, h, w, out + (size_t)f0 * out_stride, out_stride, st))) return s;
             continue;
         }
         if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st, enc->crop_pos))) return s;
@@ -519,7 +648,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
 pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos) {
     PVR_REQUIRE(enc, "null encoder");
     PVR_REQUIRE(pos >= 0 && pos <= 4, "crop position %d outside 0..4", pos);
-    PVR_REQUIRE(pos == 0 || (!enc->vit && !enc->rnd), "corner crops are built for the ResNet50 family only");
+    PVR_REQUIRE(pos == 0 || (!enc->vit && !enc->rnd && enc->desc.arch != PVR_ARCH_CLIP_RN50), "corner crops are built for the ResNet50 family only");
     enc->crop_pos = pos;
     return PVR_OK;
 }
@@ -616,6 +745,8 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->d_stem_w) (void)hipFree(enc->d_stem_w);
     if (enc->d_stem_b) (void)hipFree(enc->d_stem_b);
     if (enc->d_zero) (void)hipFree(enc->d_zero);
+    resizer_destroy(enc);
+    for (void *q : {(void *)enc->ap_wqkv, (void *)enc->ap_wc, (void *)enc->ap_bqkv, (void *)enc->ap_bc, (void *)enc->ap_pos, (void *)enc->ap_out}) if (q) (void)hipFree(q);
     delete enc;
 }
 

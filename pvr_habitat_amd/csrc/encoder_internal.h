@@ -31,12 +31,13 @@ struct HostTensor {
 };
 
 constexpr int PVR_MAX_LANES = 4;
-enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT };
+enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT, B_STEM = B_COUNT };   // B_STEM: d_stem (112x112x64), not in d_buf
 
 struct ConvOp {
     std::string conv, bn;          // state_dict prefixes
     int in_buf, out_buf, res_buf;
     int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
+    int kind = 0;                  // 0 convolution, 1 AvgPool2d(2) on NHWC 16-bit (CLIP ModifiedResNet; cin = channels)
     u16 *d_w = nullptr;
     u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
@@ -84,6 +85,10 @@ struct pvr_encoder {
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap
     std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
+    // CLIP RN50 (clip_rn50.hip): antialiased-bicubic resizer (a weight-less pvr_vit), attention-pool parameters
+    struct pvr_vit *resizer = nullptr;
+    u16 *ap_wqkv = nullptr, *ap_wc = nullptr;
+    float *ap_bqkv = nullptr, *ap_bc = nullptr, *ap_pos = nullptr, *ap_out = nullptr;
     struct pvr_vit *vit = nullptr;
     struct pvr_random5 *rnd = nullptr;                               // 'random' 5-conv PVR (random_pvr.hip)                                   // CLIP ViT plan (vit.hip) when arch >= PVR_ARCH_CLIP_VIT_B32
 };
@@ -112,6 +117,15 @@ void random5_destroy(pvr_encoder *e);
 pvr_status vit_create(pvr_encoder *e);
 pvr_status vit_finalize(pvr_encoder *e);
 pvr_status vit_use_lane(pvr_encoder *e, int lane);
+// vit.hip pieces shared with the CLIP RN50 plan: Resize(224, bicubic, antialias) + CenterCrop into a (res,res,3) uint8 image, attention core
+pvr_status resizer_create(pvr_encoder *e);
+pvr_status resizer_run(pvr_encoder *e, int lane, const uint8_t *frames, int nb, int h, int w, hipStream_t st, const uint8_t **u8, int *oh, int *ow);
+void resizer_destroy(pvr_encoder *e);
+pvr_status launch_attention(const void *qkv, void *out, int T, int W, int heads, int nb, int dtype, hipStream_t st);
+// clip_rn50.hip
+pvr_status launch_avgpool2(const void *in, void *out, int n, int h, int w, int c, int dtype, hipStream_t st);
+pvr_status launch_attnpool_tokens(const float *x, const float *pos, void *tokens, int n, int hw, int c, int dtype, hipStream_t st);
+pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st);
 void vit_destroy(pvr_encoder *e);
 pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, int64_t *count, hipStream_t st);

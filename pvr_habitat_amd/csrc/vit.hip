@@ -703,7 +703,7 @@ pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, in
     return launch_h_to_f32(src, out, elems, e->desc.dtype, st);
 }
 
-pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
+static pvr_status attention_attrs() {
     static bool attr_done = false;
     if (!attr_done) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 64, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -713,6 +713,66 @@ pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int 
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         attr_done = true;
+    }
+    return PVR_OK;
+}
+
+// attention core for callers outside the ViT plan (CLIP RN50 attention pool): head dim 64, <= 224 keys
+pvr_status launch_attention(const void *qkv, void *out, int T, int W, int heads, int nb, int dtype, hipStream_t st) {
+    PVR_REQUIRE(W == heads * 64 && T <= 224, "launch_attention: head dim must be 64 and T <= 224");
+    pvr_status s = attention_attrs();
+    if (s) return s;
+    const int TK = (T + 31) / 32 * 32;
+    const size_t lds = (size_t)TK * 128 + (size_t)64 * (TK + 4) * 2;
+    if (dtype == PVR_F16) hipLaunchKernelGGL((attention_kernel<true, 64, 14>), dim3(heads, nb), dim3(256), lds, st, (const u16 *)qkv, (u16 *)out, T, TK, W);
+    else hipLaunchKernelGGL((attention_kernel<false, 64, 14>), dim3(heads, nb), dim3(256), lds, st, (const u16 *)qkv, (u16 *)out, T, TK, W);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// Resize(res, BICUBIC, antialias=True) + CenterCrop(res) as a stand-alone service (CLIP RN50 plan): a weight-less pvr_vit that
+// only owns the resampling tables and per-lane temporaries
+pvr_status resizer_create(pvr_encoder *e) {
+    pvr_vit *v = new pvr_vit();
+    v->res = e->desc.crop; v->resize_to = e->desc.resize; v->mae = false;
+    for (auto &w : v->ws) w.valid = true;                       // every lane gets its resize temporaries
+    e->resizer = v;
+    return PVR_OK;
+}
+
+pvr_status resizer_run(pvr_encoder *e, int lane, const uint8_t *frames, int nb, int h, int w, hipStream_t st, const uint8_t **u8, int *oh, int *ow) {
+    pvr_vit *v = e->resizer;
+    const int sh = w <= h ? w : h;
+    if (sh == v->resize_to) { *u8 = frames; *oh = h; *ow = w; return PVR_OK; }      // Resize is the identity: the caller centre-crops
+    pvr_vit *saved = e->vit;
+    e->vit = v;
+    pvr_status s = aa_prepare(e, h, w);
+    e->vit = saved;
+    if (s) return s;
+    const int top = (int)nearbyint((v->rs_rh - v->res) / 2.0), left = (int)nearbyint((v->rs_rw - v->res) / 2.0);
+    const size_t t1 = (size_t)nb * h * v->res * 3, t2 = (size_t)nb * v->res * v->res * 3;
+    hipLaunchKernelGGL(aa_resize_h_kernel, dim3((int)((t1 + 255) / 256 > 8192 ? 8192 : (t1 + 255) / 256)), dim3(256), 0, st, frames,
+                       v->rs_tmp_l[lane], v->rs_xmin, v->rs_xsize, v->rs_wx, v->rs_maxk_w, nb, h, w, left, v->res);
+    hipLaunchKernelGGL(aa_resize_v_kernel, dim3((int)((t2 + 255) / 256 > 8192 ? 8192 : (t2 + 255) / 256)), dim3(256), 0, st,
+                       v->rs_tmp_l[lane], v->rs_u8_l[lane], v->rs_ymin, v->rs_ysize, v->rs_wy, v->rs_maxk_h, nb, h, top, v->res);
+    PVR_LAUNCH_CHECK();
+    *u8 = v->rs_u8_l[lane]; *oh = v->res; *ow = v->res;
+    return PVR_OK;
+}
+
+void resizer_destroy(pvr_encoder *e) {
+    if (!e->resizer) return;
+    pvr_vit *saved = e->vit;
+    e->vit = e->resizer;
+    vit_destroy(e);
+    e->vit = saved;
+    e->resizer = nullptr;
+}
+
+pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
+    {
+        pvr_status sa = attention_attrs();
+        if (sa) return sa;
     }
     if (e->vit->width == 1024)
         return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 1024>(e, frames, n, h, w, out, out_stride, st)

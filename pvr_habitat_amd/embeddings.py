@@ -25,9 +25,9 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'mae_h14': 1280, 'random5': 1568}
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'mae_h14': 1280, 'clip_rn50': 1024, 'random5': 1568}
 _ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3,
-         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7, 'mae_h14': 8}
+         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7, 'mae_h14': 8, 'clip_rn50': 9}
 
 # ---------------------------------------------------------------------------------------------
 # name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
@@ -66,10 +66,11 @@ for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_cropo
     for _combo in ('345', '35', '34', '45'):
         _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
 # names the reference registers but whose model families are not built yet
-_NOT_BUILT = ('resnet18', 'resnet34', 'maskrcnn_l3', 'clip_rn50')
+_NOT_BUILT = ('resnet18', 'resnet34', 'maskrcnn_l3')
 # CLIP visual towers: 'clip_vit' is the reference's name (ViT-B/32, embeddings.py:303-304); 'clip_vit_b16' is the
 # same block layout at patch 16 (BASELINE config 3), not a reference registry name
-_CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16)}
+_CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16),
+         'clip_rn50': ('clip_rn50', 'RN50.pt', 0)}            # embeddings.py:305-306 (ModifiedResNet-50 + attention pool)
 
 
 def _dtype_from_env(compute_dtype=None):
@@ -384,7 +385,8 @@ def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, trai
             full = torch.jit.load(f, map_location='cpu').state_dict()
             sd = {k: v.float() for k, v in full.items() if k.startswith('visual.')}
         elif os.environ.get('PVR_SYNTHETIC_WEIGHTS', '0') == '1' or not pretrained:
-            sd = synth.clip_vit_state_dict(zlib.crc32(embedding_name.encode()) & 0x7fffffff, patch=patch)
+            seed = zlib.crc32(embedding_name.encode()) & 0x7fffffff
+            sd = synth.clip_rn50_state_dict(seed) if variant == 'clip_rn50' else synth.clip_vit_state_dict(seed, patch=patch)
         else:
             raise FileNotFoundError(ckpt)
         model = HipResNet50(sd, variant, **hip_kw)

@@ -286,3 +286,53 @@ def mae_vit_state_dict(seed=1, patch=16, width=768, layers=12, resolution=224):
     sd['norm.weight'] = uniform(seed, 'mae.norm.w', (width,), 0.8, 1.2)
     sd['norm.bias'] = uniform(seed, 'mae.norm.b', (width,), -0.1, 0.1)
     return sd
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP RN50 visual tower (openai/CLIP ModifiedResNet + AttentionPool2d; reference src/embeddings.py:305-306)
+# ------------------------------------------------------------------------------------------
+def clip_rn50_state_dict(seed=1, width=64, out_dim=1024, keys_only=False):
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + '.weight'] = None if keys_only else normal(seed, name, (cout, cin, k, k), std=float(np.sqrt(2.0 / (cin * k * k))))
+
+    def bn(name, c, gamma=(0.8, 1.2)):
+        if keys_only:
+            for f in ('weight', 'bias', 'running_mean', 'running_var'):
+                sd[name + '.' + f] = None
+            return
+        sd[name + '.weight'] = uniform(seed, name + '.w', (c,), *gamma)
+        sd[name + '.bias'] = uniform(seed, name + '.b', (c,), -0.1, 0.1)
+        sd[name + '.running_mean'] = uniform(seed, name + '.m', (c,), -0.2, 0.2)
+        sd[name + '.running_var'] = uniform(seed, name + '.v', (c,), 0.5, 1.5)
+
+    v = 'visual.'
+    conv(v + 'conv1', width // 2, 3, 3); bn(v + 'bn1', width // 2)
+    conv(v + 'conv2', width // 2, width // 2, 3); bn(v + 'bn2', width // 2)
+    conv(v + 'conv3', width, width // 2, 3); bn(v + 'bn3', width)
+    inpl = width
+    for li, nb in enumerate((3, 4, 6, 3)):
+        planes = width << li
+        for bi in range(nb):
+            p = v + 'layer%d.%d.' % (li + 1, bi)
+            stride = 2 if (bi == 0 and li > 0) else 1
+            conv(p + 'conv1', planes, inpl, 1); bn(p + 'bn1', planes)
+            conv(p + 'conv2', planes, planes, 3); bn(p + 'bn2', planes)
+            conv(p + 'conv3', planes * 4, planes, 1); bn(p + 'bn3', planes * 4, gamma=(0.2, 0.4))
+            if stride > 1 or inpl != planes * 4:
+                conv(p + 'downsample.0', planes * 4, inpl, 1); bn(p + 'downsample.1', planes * 4, gamma=(0.6, 0.9))
+            inpl = planes * 4
+    a, c = v + 'attnpool.', width * 32
+    if keys_only:
+        for k in ('positional_embedding', 'q_proj.weight', 'q_proj.bias', 'k_proj.weight', 'k_proj.bias', 'v_proj.weight', 'v_proj.bias',
+                  'c_proj.weight', 'c_proj.bias'):
+            sd[a + k] = None
+        return sd
+    sd[a + 'positional_embedding'] = normal(seed, a + 'pos', (50, c), std=float(c ** -0.5))
+    for nm in ('q', 'k', 'v'):
+        sd[a + nm + '_proj.weight'] = normal(seed, a + nm + 'w', (c, c), std=float(c ** -0.5))
+        sd[a + nm + '_proj.bias'] = uniform(seed, a + nm + 'b', (c,), -0.05, 0.05)
+    sd[a + 'c_proj.weight'] = normal(seed, a + 'cw', (out_dim, c), std=float(c ** -0.5))
+    sd[a + 'c_proj.bias'] = uniform(seed, a + 'cb', (out_dim,), -0.05, 0.05)
+    return sd

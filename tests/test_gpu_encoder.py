@@ -321,13 +321,15 @@ def test_full_batch_properties():
     assert torch.isfinite(a).all() and float(a.std()) > 0
 
 
-@pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
+@pytest.mark.parametrize('variant', ['conv5', 'clip_b16', 'clip_rn50'])
 def test_two_lanes_in_flight_match_sequential_forwards(variant):
     """pvr_encoder_forward_lane: forwards on the two workspaces, interleaved on two streams, give bit for bit what
     sequential single-stream calls give (different inputs per lane, several rounds, ragged batch on one lane)."""
     from pvr_habitat_amd.embeddings import HipResNet50
     if variant == 'conv5':
         sd, hw, osz = synth.resnet50_state_dict(1, 'conv5'), 256, 2048
+    elif variant == 'clip_rn50':
+        sd, hw, osz = synth.clip_rn50_state_dict(1), 160, 1024          # 160 != 224: the antialiased resizer runs on both lanes
     else:
         sd, hw, osz = synth.clip_vit_state_dict(1, patch=16), 224, 512
     m = HipResNet50(sd, variant, compute_dtype='bf16', max_batch=64)

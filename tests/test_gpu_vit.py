@@ -115,3 +115,29 @@ def test_mae_vit_h14_matches_oracle():
     l2, mx = _rel(out, ref)
     print('\n[mae_h14 f16] rel-L2 %.2e max-norm %.2e' % (l2, mx))
     assert l2 < 1.5e-3
+
+
+@pytest.mark.parametrize('h,w', [(224, 224), (64, 64), (96, 128)])
+def test_clip_rn50_matches_oracle(h, w):
+    """CLIP RN50 visual tower (embeddings.py:305-306): 3-conv stem, AvgPool2d strides, attention pool -> 1024."""
+    from oracle import vit_oracle as vo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(16)
+    sd = synth.clip_rn50_state_dict(4)
+    fr = synth.smooth_frames(50, 3, h, w)
+    taps = {}
+    ref = vo.clip_rn50_embed(sd, fr, squeeze=False, taps=taps)
+    m = HipResNet50(sd, 'clip_rn50', compute_dtype='f16', max_batch=4)
+    d = torch.from_numpy(fr).cuda()
+    errs = {}
+    for name in ('stem3', 'layer1', 'layer2', 'layer3', 'layer4'):
+        m.debug_stop_after(name); m(d)
+        r = taps['stem' if name == 'stem3' else name].permute(0, 2, 3, 1).contiguous().numpy()
+        g = m.tap(name, r.size).cpu().numpy().reshape(r.shape)
+        errs[name] = _rel(g, r)[0]
+    m.debug_stop_after('')
+    out = m(d).cpu().numpy()
+    assert out.shape == (3, 1024)
+    l2, mx = _rel(out, ref)
+    print('\n[clip_rn50 f16 %dx%d] stages %s embedding rel-L2 %.2e max-norm %.2e' % (h, w, {k: '%.1e' % v for k, v in errs.items()}, l2, mx))
+    assert l2 < 2e-3 and max(errs.values()) < 3e-3
