@@ -48,6 +48,8 @@ typedef int pvr_status;
 #define PVR_ARCH_MAE_VIT_L16 7   /* MAE/timm ViT-L/16 encoder (width 1024, 24 blocks, 16 heads) -> 1024 (mae.py:283-288, embeddings.py:141-144) */
 #define PVR_ARCH_MAE_VIT_H14 8   /* MAE/timm ViT-H/14 encoder (width 1280, 32 blocks, 16 heads of 80, 257 tokens) -> 1280 (mae.py:291-296, embeddings.py:145-148) */
 #define PVR_ARCH_CLIP_RN50 9     /* openai/CLIP visual ModifiedResNet-50 + attention pool -> 1024 (embeddings.py:305-306, 375-376) */
+#define PVR_ARCH_RESNET18 10     /* torchvision resnet18, fc=Identity -> 512 (embeddings.py:112-114) */
+#define PVR_ARCH_RESNET34 11     /* torchvision resnet34, fc=Identity -> 512 (embeddings.py:115-117; in the reference's sweeps, slurm_eo.py:100) */
 #define PVR_ARCH_MAE_VIT_B16 5   /* MAE/timm ViT-B/16 encoder, CLS token  -> 768 (mae.py:202-222, embeddings.py:137-140,377-379) */
 
 const char *pvr_version(void);

@@ -138,6 +138,16 @@ def basic_block(sd, p, x, q=None):
     return F.relu(out + idn)
 
 
+def plain_basic_block(sd, p, x, stride, q=None):
+    """torchvision BasicBlock of resnet18 / resnet34: stride on conv1, identity or 1x1(stride)+BN downsample."""
+    out = _q(F.relu(_conv_bn(sd, p + '.conv1', p + '.bn1', x, stride, 1, q=q)), q)
+    out = _conv_bn(sd, p + '.conv2', p + '.bn2', out, 1, 1, q=q)
+    idn = x
+    if (p + '.downsample.0.weight') in sd:
+        idn = _q(_conv_bn(sd, p + '.downsample.0', p + '.downsample.1', x, stride, 0, q=q), q)
+    return F.relu(out + idn)
+
+
 def resnet50_features(sd, x, variant='conv5', q=None, taps=None):
     """x: fp32 (N,3,224,224) normalised.  Returns the model output before flatten."""
     stem = F.relu(_conv_bn(sd, 'conv1', 'bn1', x, 2, 3, q=None if q is None else q))
@@ -145,6 +155,16 @@ def resnet50_features(sd, x, variant='conv5', q=None, taps=None):
     if taps is not None:
         taps['conv1'] = stem
         taps['stem'] = x
+    if variant in ('r18', 'r34'):                    # embeddings.py:112-117: torchvision resnet18 / resnet34, fc = Identity
+        layers = (2, 2, 2, 2) if variant == 'r18' else (3, 4, 6, 3)
+        for li in range(4):
+            for bi in range(layers[li]):
+                x = plain_basic_block(sd, 'layer%d.%d' % (li + 1, bi), x, 2 if (bi == 0 and li > 0) else 1, q=q)
+                if not (li == 3 and bi == layers[li] - 1):
+                    x = _q(x, q)
+            if taps is not None:
+                taps['layer%d' % (li + 1)] = x
+        return F.adaptive_avg_pool2d(x, 1)
     stages = 4 if variant in ('conv5', 'conv4') else 3
     for li in range(stages):
         nested = (variant == 'conv4' and li == 3) or (variant == 'conv3' and li == 2)
@@ -162,7 +182,7 @@ def resnet50_features(sd, x, variant='conv5', q=None, taps=None):
     return basic_block(sd, p, x, q=q)               # avgpool/fc (and layer4) are empty Sequentials
 
 
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156}
+OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'r18': 512, 'r34': 512}
 
 
 def embed(sd, frames_nhwc_u8, variant='conv5', q=None, squeeze=True, crop_pos=0):

@@ -75,6 +75,40 @@ static void build_resnet50(pvr_encoder *e) {
     e->out_size = c * hw * hw; e->final_hw = hw * hw; e->final_c = 64; e->final_creal = c;
 }
 
+// torchvision resnet18 / resnet34 (reference embeddings.py:112-117): BasicBlock = conv3x3(stride) bn relu, conv3x3 bn, (+ identity
+// or 1x1(stride)+bn downsample), relu; layers [2,2,2,2] / [3,4,6,3], widths 64..512, global average pool -> 512
+static void build_basic_resnet(pvr_encoder *e) {
+    const int nb18[4] = {2, 2, 2, 2}, nb34[4] = {3, 4, 6, 3};
+    const int *nblk = e->desc.arch == PVR_ARCH_RESNET18 ? nb18 : nb34;
+    int hw = 56, inpl = 64, x = B_X0;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        for (int bi = 0; bi < nblk[li]; ++bi) {
+            char pfx[64];
+            snprintf(pfx, sizeof pfx, "layer%d.%d", li + 1, bi);
+            const std::string p = pfx;
+            const int stride = (bi == 0 && li > 0) ? 2 : 1;
+            const int ohw = hw / stride;
+            const int y = x == B_X0 ? B_X1 : B_X0;
+            const bool last = (li == 3 && bi == nblk[li] - 1);
+            add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 3, stride, 1);
+            int res = x;
+            if (stride > 1 || inpl != planes) {
+                add_conv(e, p + ".downsample.0", p + ".downsample.1", x, B_DS, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, stride, 0);
+                res = B_DS;
+            }
+            add_conv(e, p + ".conv2", p + ".bn2", B_T1, last ? B_F32 : y, res, ohw, ohw, planes, planes, planes, planes, 3, 1, 1, last ? 1 : 0);
+            if (bi == nblk[li] - 1) {
+                char tn[16]; snprintf(tn, sizeof tn, "layer%d", li + 1);
+                e->ops.back().tap = tn;
+                e->taps[tn] = {last ? B_F32 : y, {ohw, ohw, planes, last ? 1 : 0}};
+            }
+            x = y; hw = ohw; inpl = planes;
+        }
+    }
+    e->out_size = 512; e->final_hw = 49; e->final_c = 512; e->final_creal = 512;
+}
+
 // openai/CLIP ModifiedResNet-50 (reference embeddings.py:305-306): stem conv1 (3x3/2, run by the stem kernel as a 7x7 with only
 // its centre taps set) is not in the list; conv2 / conv3 of the stem, AvgPool2d(2), then Bottlenecks whose convolutions all have
 // stride 1 - the stride is an AvgPool2d after conv2 and in front of the downsample convolution.  Channels 32 are padded to 64.
@@ -373,8 +407,8 @@ extern "C" {
 
 pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc && out, "pvr_encoder_create: null argument");
-    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_CLIP_RN50, "unknown arch %d", desc->arch);
-    PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16 || (desc->dtype == PVR_F32 && desc->arch <= PVR_ARCH_RESNET50_L3),
+    PVR_REQUIRE(desc->arch >= PVR_ARCH_RESNET50 && desc->arch <= PVR_ARCH_RESNET34, "unknown arch %d", desc->arch);
+    PVR_REQUIRE(desc->dtype == PVR_BF16 || desc->dtype == PVR_F16 || (desc->dtype == PVR_F32 && (desc->arch <= PVR_ARCH_RESNET50_L3 || desc->arch == PVR_ARCH_RESNET18 || desc->arch == PVR_ARCH_RESNET34)),
                 "dtype must be PVR_BF16 or PVR_F16 (PVR_F32 is built for the ResNet50 family only)");
     PVR_REQUIRE(desc->max_batch > 0, "max_batch must be positive");
     PVR_REQUIRE(desc->crop == 224, "crop must be 224 (reference embeddings.py:82; CLIP input_resolution 224)");
@@ -384,10 +418,12 @@ pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
     if (e->desc.arch == PVR_ARCH_RANDOM5) {
         random5_create(e);
+    } else if (e->desc.arch == PVR_ARCH_RESNET18 || e->desc.arch == PVR_ARCH_RESNET34) {
+        build_basic_resnet(e);
     } else if (e->desc.arch == PVR_ARCH_CLIP_RN50) {
         build_clip_rn50(e);
         resizer_create(e);
-    } else if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32) {
+    } else if (e->desc.arch >= PVR_ARCH_CLIP_VIT_B32 && e->desc.arch <= PVR_ARCH_MAE_VIT_H14) {
         pvr_status s = vit_create(e);
         if (s) { delete e; return s; }
     } else {
@@ -447,6 +483,10 @@ int32_t pvr_encoder_out_size(const pvr_encoder *enc) { return enc ? enc->out_siz
 
 // One chunk of the CLIP RN50 tower: Resize(224, bicubic, antialias) + CenterCrop -> stem image -> conv1 (stem kernel) -> plan
 // (convolutions and 2x2 average pools) -> attention pool (tokens, fused q/k/v GEMM, attention core, c_proj of token 0).
+static bool pooled_head(const pvr_encoder *enc) {   // global average pool of the fp32 last activation (vs C-major flatten of the compression heads)
+    return enc->desc.arch == PVR_ARCH_RESNET50 || enc->desc.arch == PVR_ARCH_RESNET18 || enc->desc.arch == PVR_ARCH_RESNET34;
+}
+
 static void *bufp(pvr_encoder *enc, int id) { return id == B_STEM ? (void *)enc->d_stem : enc->d_buf[id]; }
 
 static pvr_status clip_rn50_chunk(pvr_encoder *enc, const uint8_t *fr, int nb, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
@@ -523,7 +563,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 if ((s = mark())) return s;
             }
             float *o32 = out + (size_t)f0 * out_stride;
-            if (enc->desc.arch == PVR_ARCH_RESNET50)
+            if (pooled_head(enc))
                 s = launch_avgpool(enc->d_buf[B_F32], o32, out_stride, nb, enc->final_hw, enc->final_c, 1, dt, st);
             else
                 s = launch_nhwc_to_chw((const float *)enc->d_buf[B_F32], o32, out_stride, nb, enc->final_hw, enc->final_c,
@@ -572,7 +612,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         }
         if (stopped) return PVR_OK;
         float *o = out + (size_t)f0 * out_stride;
-        if (enc->desc.arch == PVR_ARCH_RESNET50)
+        if (pooled_head(enc))
             s = launch_avgpool(enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c, 1, dt, st);
         else
             s = launch_nhwc_to_chw((const float *)enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c,

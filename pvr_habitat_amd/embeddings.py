@@ -25,14 +25,16 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
-OUT_SIZE = {'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'mae_h14': 1280, 'clip_rn50': 1024, 'random5': 1568}
+OUT_SIZE = {'r18': 512, 'r34': 512, 'conv5': 2048, 'conv4': 2058, 'conv3': 2156, 'clip_b32': 512, 'clip_b16': 512, 'mae_b16': 768, 'mae_l16': 1024, 'mae_h14': 1280, 'clip_rn50': 1024, 'random5': 1568}
 _ARCH = {'conv5': _lib.ARCH_RESNET50, 'conv4': _lib.ARCH_RESNET50_L4, 'conv3': _lib.ARCH_RESNET50_L3,
-         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7, 'mae_h14': 8, 'clip_rn50': 9}
+         'clip_b32': 3, 'clip_b16': 4, 'mae_b16': 5, 'random5': 6, 'mae_l16': 7, 'mae_h14': 8, 'clip_rn50': 9, 'r18': 10, 'r34': 11}
 
 # ---------------------------------------------------------------------------------------------
 # name registry (reference src/embeddings.py:113-280): name -> (loader family, variant, checkpoint)
 # ---------------------------------------------------------------------------------------------
 _SINGLE = {
+    'resnet18': ('torchvision', 'r18', None),        # embeddings.py:112-117
+    'resnet34': ('torchvision', 'r34', None),
     'resnet50': ('torchvision', 'conv5', None),
     'resnet50_places': ('resnet', 'conv5', 'resnet50_places.pth.tar'),
     'resnet50_l4': ('resnet', 'conv4', 'resnet50_l4.pth.tar'),
@@ -66,7 +68,7 @@ for _base in ('moco_aug_places', 'moco_aug', 'moco_croponly_places', 'moco_cropo
     for _combo in ('345', '35', '34', '45'):
         _UBER['%s_uber_%s' % (_base, _combo)] = [_m[c] for c in _combo]      # embeddings.py:195-280
 # names the reference registers but whose model families are not built yet
-_NOT_BUILT = ('resnet18', 'resnet34', 'maskrcnn_l3')
+_NOT_BUILT = ('maskrcnn_l3',)
 # CLIP visual towers: 'clip_vit' is the reference's name (ViT-B/32, embeddings.py:303-304); 'clip_vit_b16' is the
 # same block layout at patch 16 (BASELINE config 3), not a reference registry name
 _CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16', 'ViT-B-16.pt', 16),
@@ -131,12 +133,12 @@ def _load_named_state_dict(name, pretrained):
     seed = zlib.crc32(name.encode()) & 0x7fffffff
     if family == 'torchvision':
         # torchvision hub weights cannot be downloaded here; a local torchvision-format file is used if present
-        f = _find_checkpoint('resnet50.pth') if pretrained else None
+        f = _find_checkpoint(name + '.pth') if pretrained else None
         if f is not None:
             sd = torch.load(f, map_location='cpu')
             return {k: v for k, v in sd.items() if not k.startswith('fc.')}, variant
         if pretrained and not synthetic_ok:
-            raise FileNotFoundError("pretrained torchvision resnet50 weights: put 'resnet50.pth' in . or "
+            raise FileNotFoundError("pretrained torchvision weights: put '" + name + ".pth' in . or "
                                     "$PVR_CHECKPOINT_DIR (no network), or set PVR_SYNTHETIC_WEIGHTS=1")
         return synth.resnet50_state_dict(seed, variant), variant
     f = _find_checkpoint(ckpt)

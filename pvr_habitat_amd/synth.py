@@ -125,7 +125,30 @@ def resnet50_state_dict(seed=1, variant='conv5', keys_only=False):
         _KEYS_ONLY = False
 
 
+def _resnet_basic_state_dict(seed, layers):
+    """torchvision resnet18 / resnet34 keys (BasicBlock trunks, reference embeddings.py:112-117)"""
+    sd = {}
+    _conv(sd, seed, 'conv1', 64, 3, 7)
+    _bn(sd, seed, 'bn1', 64)
+    inplanes = 64
+    for li in range(4):
+        planes = 64 << li
+        for bi in range(layers[li]):
+            p = 'layer%d.%d' % (li + 1, bi)
+            _conv(sd, seed, p + '.conv1', planes, inplanes, 3)
+            _bn(sd, seed, p + '.bn1', planes)
+            _conv(sd, seed, p + '.conv2', planes, planes, 3)
+            _bn(sd, seed, p + '.bn2', planes, gamma=(0.25, 0.45))
+            if bi == 0 and li > 0:
+                _conv(sd, seed, p + '.downsample.0', planes, inplanes, 1, gain=1.0)
+                _bn(sd, seed, p + '.downsample.1', planes)
+            inplanes = planes
+    return sd
+
+
 def _resnet50_state_dict(seed, variant):
+    if variant in ('r18', 'r34'):
+        return _resnet_basic_state_dict(seed, (2, 2, 2, 2) if variant == 'r18' else (3, 4, 6, 3))
     sd = {}
     _conv(sd, seed, 'conv1', 64, 3, 7)
     _bn(sd, seed, 'bn1', 64)

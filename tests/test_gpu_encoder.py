@@ -279,6 +279,37 @@ def test_embeddingnet_surface_and_uber(monkeypatch):
         EmbeddingNet('not_a_model')
 
 
+@pytest.mark.parametrize('name,variant', [('resnet18', 'r18'), ('resnet34', 'r34')])
+def test_resnet18_34_match_oracle(monkeypatch, name, variant):
+    """torchvision resnet18 / resnet34 (BasicBlock trunks, embeddings.py:112-117; resnet34 is in the reference's sweeps):
+    stage taps and the 512-d embedding against the fp32 oracle in f16 storage and in the fp32 reference-precision mode."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import EmbeddingNet, HipResNet50
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    torch.set_num_threads(16)
+    sd = synth.resnet50_state_dict(31, variant)
+    fr = synth.smooth_frames(31, 3, 128, 128)
+    taps = {}
+    with torch.no_grad():
+        ref = eo.resnet50_features(sd, eo.preprocess(fr), variant, taps=taps).reshape(3, 512).numpy()
+    m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
+    d = torch.from_numpy(fr).cuda()
+    for tname in ('layer1', 'layer2', 'layer3', 'layer4'):
+        m.debug_stop_after(tname); m(d)
+        r = taps[tname].permute(0, 2, 3, 1).contiguous().numpy()
+        g = m.tap(tname, r.size).cpu().numpy().reshape(r.shape)
+        assert _relerr(g, r)[0] < 2e-3, tname
+    m.debug_stop_after('')
+    out = m(d).cpu().numpy()
+    l2, mx = _relerr(out, ref)
+    assert out.shape == (3, 512) and l2 < 1e-3, (l2, mx)
+    m32 = HipResNet50(sd, variant, compute_dtype='f32', max_batch=4)
+    l2f, _ = _relerr(m32(d).cpu().numpy(), ref)
+    assert l2f < 2e-5, l2f
+    net = EmbeddingNet(name, pretrained=False, compute_dtype='f16')
+    assert net.out_size == 512 and net(torch.from_numpy(fr)).shape == (3, 512)
+
+
 def test_five_crop_extension_matches_oracle(monkeypatch):
     """BASELINE config 5 ("5-crop multi-layer PVR"): corner + centre windows of the Resize(256) frame, FiveCrop order, for the
     uber_345 concat; every window against the fp32 oracle, the centre block bit-identical to the 1-crop embedding."""
