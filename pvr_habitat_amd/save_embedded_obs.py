@@ -68,42 +68,59 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256):
-    """PNG layout of save_opt_trajectories_png.py:44-58.  The reference embeds one frame per forward (:69-77);
-    here a trajectory's frames are decoded on the host and embedded together (same rows, same order)."""
+def _load_png_trajectory(data_path, t, pool):
+    """Decode trajectory t: (goal, meta dict, frames (L,H,W,3) uint8, file names) or None past the last trajectory.
+    Frames are decoded by the thread pool (PIL / cv2 release the GIL while decoding)."""
+    meta_path = os.path.join(data_path, '%d.pickle' % t)
+    goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
+    if goal is None:
+        return None
+    with open(meta_path, 'rb') as f:
+        tmp = pickle.load(f)
+    names = []
+    for s in range(500):                                       # max steps per trajectory (habitat_config/nav_task.yaml:4)
+        p = os.path.join(data_path, '%d_%d.png' % (t, s))
+        if not os.path.isfile(p):
+            break
+        names.append(p)
+    frames = list(pool.map(_imread, names)) if names else []
+    return goal, tmp, (np.stack(frames) if frames else None), names
+
+
+def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None):
+    """PNG layout of save_opt_trajectories_png.py:44-58.  The reference decodes and embeds one frame per forward (:69-77);
+    here a trajectory's frames are decoded by a host thread pool and embedded together (same rows, same order), and
+    trajectory t+1 is decoded while trajectory t is on the GPU (keeping the GPU fed from the PNG source)."""
+    from concurrent.futures import ThreadPoolExecutor
     print('loading %s ...' % data_path)
     data = dict(obs=[], action=[], reward=[], done=[], true_state=[], png=[])
     if n_trajectories == -1:
         n_trajectories = 100000
+    workers = decode_workers or min(16, os.cpu_count() or 1)
     t = 0
-    for t in range(n_trajectories):
-        meta_path = os.path.join(data_path, '%d.pickle' % t)
-        goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
-        if goal is None:
-            break
-        with open(meta_path, 'rb') as f:
-            tmp = pickle.load(f)
-        for k in data.keys():
-            if k in tmp:
-                data[k].append(tmp[k])
-        frames, names = [], []
-        for s in range(500):                                   # max steps per trajectory (habitat_config/nav_task.yaml:4)
-            p = os.path.join(data_path, '%d_%d.png' % (t, s))
-            f = _imread(p) if os.path.isfile(p) else None
-            if f is None:
+    with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
+        nxt = ahead.submit(_load_png_trajectory, data_path, 0, pool) if n_trajectories > 0 else None
+        for t in range(n_trajectories):
+            cur = nxt.result()
+            if cur is None:
                 break
-            frames.append(f); names.append(p)
-        if not frames:
-            continue
-        frames = np.stack(frames)
-        if model is not None:
-            g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
-            e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
-                                for i in range(0, len(frames), batch)])
-            data['obs'].extend(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, pool) if t + 1 < n_trajectories else None
+            goal, tmp, frames, names = cur
+            for k in data.keys():
+                if k in tmp:
+                    data[k].append(tmp[k])
+            if frames is None:
+                continue
+            if model is not None:
+                g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
+                e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
+                                    for i in range(0, len(frames), batch)])
+                data['obs'].extend(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+            else:
+                data['obs'].extend(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
+            data['png'] += names
         else:
-            data['obs'].extend(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
-        data['png'] += names
+            t = n_trajectories
     n_trajectories = t
     data['obs'] = np.stack(data['obs'])
     for k in ('action', 'reward', 'done', 'true_state'):

@@ -59,6 +59,38 @@ def test_embed_rows_order_and_shapes():
     np.testing.assert_array_equal(out[:, 3:], obs[..., 3:].reshape(5, -1)[:, :3])
 
 
+def test_png_source_reader_rows_and_order(tmp_path):
+    """PNG layout of the reference (save_opt_trajectories_png.py:44-58: <t>_<s>.png, <t>_goal.png, <t>.pickle, written with
+    cv2.imwrite of RGB arrays and read back with cv2.imread): the threaded / prefetching reader returns the rows a serial reader
+    would, in order - each observation = frame channels then goal channels, ragged trajectory lengths, stops at the first gap."""
+    import pickle
+    from PIL import Image
+    from pvr_habitat_amd import save_embedded_obs as seo
+    rng = np.random.RandomState(0)
+    lens, frames, goals = [5, 1, 7], [], []
+    for t, L in enumerate(lens):
+        g = rng.randint(0, 256, (16, 16, 3), dtype=np.uint8)
+        fr = rng.randint(0, 256, (L, 16, 16, 3), dtype=np.uint8)
+        # cv2.imwrite(array) stores array[..., ::-1] as the file's RGB; cv2.imread returns the array again
+        Image.fromarray(np.ascontiguousarray(g[..., ::-1])).save(tmp_path / ('%d_goal.png' % t))
+        for s_ in range(L):
+            Image.fromarray(np.ascontiguousarray(fr[s_][..., ::-1])).save(tmp_path / ('%d_%d.png' % (t, s_)))
+        with open(tmp_path / ('%d.pickle' % t), 'wb') as f:
+            pickle.dump(dict(action=np.arange(L), reward=np.ones(L), done=np.arange(L) == L - 1, true_state=np.zeros((L, 12))), f)
+        frames.append(fr); goals.append(g)
+    Image.fromarray(goals[0]).save(tmp_path / '4_goal.png')                      # trajectory 3 is missing: 4 must not be read
+    for workers in (1, 4):
+        d = seo.read_habitat_data_from_png(str(tmp_path), None, -1, decode_workers=workers)
+        assert d['obs'].shape == (sum(lens), 16, 16, 6) and len(d['action']) == sum(lens) and len(d['png']) == sum(lens)
+        row = 0
+        for t, L in enumerate(lens):
+            np.testing.assert_array_equal(d['obs'][row:row + L, ..., :3], frames[t])
+            np.testing.assert_array_equal(d['obs'][row:row + L, ..., 3:], np.broadcast_to(goals[t], frames[t].shape))
+            row += L
+    d2 = seo.read_habitat_data_from_png(str(tmp_path), None, 2)
+    assert d2['obs'].shape[0] == lens[0] + lens[1]
+
+
 def test_shard_bounds_cover_rows_in_order():
     for n in (0, 1, 7, 100000):
         for w in (1, 2, 3, 8):
