@@ -39,6 +39,10 @@ struct pvr_policy {
     // Bit-identical, but measured SLOWER than per-step launches on MI355X / ROCm 7.2 (scripts/bc_graph_ab.py: 154-164 vs 178
     // steps/s): the per-step grid hand-off (sc1 stores + drain, agent-scope counter, poll, 64 KB of sc1 loads of h per block)
     // costs ~13 us against ~11 us for a launch, so it stays off until the hand-off is cheaper.
+    // chunked layer wavefront (default): the two recurrences share launches - layer 0 at step t and layer 1 one chunk (T/4 steps)
+    // behind run as the two blockIdx.y jobs of one launch, forward and BPTT, with the hoisted projections done per chunk.  Same
+    // per-(layer, step) arithmetic as every other mode (bit-identical); (NCH+1)/(2 NCH) of the dependent launches.
+    int chunkwave = 1;
     unsigned *seq_counters = nullptr;       // 16 slots of 16 bytes, zeroed before each launch that uses one
     int persist = 0;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
@@ -220,8 +224,43 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         }
     };
     TRY(gemm(pol->a2, P + pol->o_wih[0], P + pol->o_bih[0], nullptr, pol->G[0], N, 4 * H, H, false, false, 0, st));
-    const int NCH = pol->pipeline && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
-    if (NCH == 1) {
+    const int NCH = (pol->pipeline || pol->chunkwave) && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
+    auto fwd_job = [&](int l, int t) {
+        LstmFwdP f;
+        f.G = pol->G[l] + (size_t)t * B * 4 * H;
+        f.h_prev = t == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t - 1) * B * H;
+        f.c_prev = t == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t - 1) * B * H;
+        f.nd = pol->nd + (size_t)t * B;
+        f.W = P + pol->o_whh[l];
+        f.bhh = P + pol->o_bhh[l];
+        f.h_out = pol->Hs[l] + (size_t)t * B * H;
+        f.c_out = pol->Cs[l] + (size_t)t * B * H;
+        f.B = B; f.H = H;
+        return f;
+    };
+    if (pol->chunkwave && !pol->persist && NCH > 1) {
+        for (int c = 0; c <= NCH; ++c) {
+            if (c >= 1) {                                       // input projection of layer 1 for the chunk layer 0 has just finished
+                const int t0 = (c - 1) * CH, t1 = c * CH < T ? c * CH : T;
+                if (t1 > t0) {
+                    const size_t r0 = (size_t)t0 * B;
+                    TRY(gemm(pol->Hs[0] + r0 * H, P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1] + r0 * 4 * H, (t1 - t0) * B, 4 * H, H,
+                             false, false, 0, st));
+                }
+            }
+            for (int s_ = 0; s_ < CH; ++s_) {
+                const int ta = c * CH + s_, tb = (c - 1) * CH + s_;
+                LstmFwd2P w = {};
+                w.active[0] = c < NCH && ta < T && ta < (c + 1) * CH;
+                w.active[1] = c >= 1 && tb < T && tb < c * CH;
+                if (!w.active[0] && !w.active[1]) continue;
+                if (w.active[0]) w.j[0] = fwd_job(0, ta);
+                if (w.active[1]) w.j[1] = fwd_job(1, tb);
+                hipLaunchKernelGGL(lstm_fwd_step2_kernel, dim3(H / 4, 2), dim3(256), 0, st, w);
+            }
+        }
+        PVR_LAUNCH_CHECK();
+    } else if (NCH == 1 || !pol->pipeline) {
         fwd_steps(0, 0, T, st);
         TRY(gemm(pol->Hs[0], P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1], N, 4 * H, H, false, false, 0, st));
         fwd_steps(1, 0, T, st);
@@ -301,8 +340,56 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         return colsum(pol->G[l], Gd + pol->o_bih[l], Gd + pol->o_bhh[l], N, 4 * H, s_);
     };
     float *dh1 = pol->dA, *dh0 = pol->dB;          // d(loss)/d(h) arriving from above: layer 1 <- heads, layer 0 <- layer 1's dx
-    const int NCH = pol->pipeline && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
-    if (NCH == 1) {
+    const int NCH = (pol->pipeline || pol->chunkwave) && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
+    auto rec_job = [&](int l, int t) {
+        LstmRecP r;
+        r.dG_next = pol->G[l] + (size_t)(t + 1) * B * 4 * H; r.W = P + pol->o_whh[l]; r.partial = scr_rec[l]; r.B = B; r.H = H;
+        return r;
+    };
+    auto cell_job = [&](int l, int t, const float *dh_ext_) {
+        const bool has_next = t < T - 1;
+        LstmCellBP c;
+        c.partial = has_next ? scr_rec[l] : nullptr;
+        c.nd_next = has_next ? pol->nd + (size_t)(t + 1) * B : nullptr;
+        c.dh_ext = dh_ext_ + (size_t)t * B * H;
+        c.dc_carry = scr_dc[l];
+        c.G = pol->G[l] + (size_t)t * B * 4 * H;
+        c.c_t = pol->Cs[l] + (size_t)t * B * H;
+        c.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
+        c.nd = pol->nd + (size_t)t * B;
+        c.B = B; c.H = H;
+        return c;
+    };
+    if (pol->chunkwave && NCH > 1) {
+        // chunk index c descending; launch pair s: layer 1 at the s-th step (from the top) of chunk c, layer 0 at the s-th of chunk c+1
+        for (int c = NCH - 1; c >= -1; --c) {
+            for (int s_ = 0; s_ < CH; ++s_) {
+                const int hi1 = (c + 1) * CH < T ? (c + 1) * CH : T, hi0 = (c + 2) * CH < T ? (c + 2) * CH : T;
+                const int ta = hi1 - 1 - s_, tb = hi0 - 1 - s_;          // layer 1 step, layer 0 step
+                const bool a1 = c >= 0 && ta >= c * CH && ta >= 0, a0 = c + 1 < NCH && tb >= (c + 1) * CH && tb >= 0;
+                if (!a1 && !a0) continue;
+                LstmRec2P r = {};
+                r.active[0] = a0 && tb < T - 1; r.active[1] = a1 && ta < T - 1;
+                if (r.active[0]) r.j[0] = rec_job(0, tb);
+                if (r.active[1]) r.j[1] = rec_job(1, ta);
+                if (r.active[0] || r.active[1]) hipLaunchKernelGGL(lstm_bwd_rec2_kernel, dim3(256, 2), dim3(256), 0, st, r);
+                LstmCellB2P q = {};
+                q.active[0] = a0; q.active[1] = a1;
+                if (a0) q.j[0] = cell_job(0, tb, dh0);
+                if (a1) q.j[1] = cell_job(1, ta, dh1);
+                hipLaunchKernelGGL(lstm_bwd_cell2_kernel, dim3((B * H + 255) / 256, 2), dim3(256), 0, st, q);
+            }
+            PVR_LAUNCH_CHECK();
+            if (c >= 0) {                                       // dh of layer 0 for the chunk layer 1 has just finished
+                const int t0 = c * CH, t1 = (c + 1) * CH < T ? (c + 1) * CH : T;
+                if (t1 > t0) {
+                    const size_t r0 = (size_t)t0 * B;
+                    TRY(gemm(pol->G[1] + r0 * 4 * H, P + pol->o_wih[1], nullptr, nullptr, dh0 + r0 * H, (t1 - t0) * B, H, 4 * H, false, true, 0, st));
+                }
+            }
+        }
+        TRY(weight_grads(1, st));
+    } else if (NCH == 1 || !pol->pipeline) {
         bwd_steps(1, T, 0, dh1, st);
         PVR_LAUNCH_CHECK();
         TRY(weight_grads(1, st));
@@ -506,6 +593,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     if (const char *e = getenv("PVR_POLICY_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e) != 0;
+    if (const char *e = getenv("PVR_POLICY_CHUNKWAVE")) p->chunkwave = atoi(e) != 0;
     A_(seq_counters, 64);
     if (!s && p->pipeline) {
         hipError_t he = hipStreamCreateWithFlags(&p->lane_a, hipStreamNonBlocking);

@@ -254,7 +254,7 @@ struct LstmFwdP {
     int B, H;
 };
 
-static __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
+static __device__ __forceinline__ void lstm_fwd_step_body(const LstmFwdP &p) {
     __shared__ float part[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -315,6 +315,16 @@ static __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) {
         }
         __syncthreads();
     }
+}
+
+static __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdP p) { lstm_fwd_step_body(p); }
+
+// Chunked layer wavefront: blockIdx.y selects one of two independent (layer, step) jobs - layer 0 at step t and layer 1 one chunk
+// behind - so the two recurrences share launches instead of alternating them (same per-job arithmetic, bit-identical).
+struct LstmFwd2P { LstmFwdP j[2]; int active[2]; };
+static __global__ __launch_bounds__(256) void lstm_fwd_step2_kernel(LstmFwd2P pp) {
+    if (!pp.active[blockIdx.y]) return;
+    lstm_fwd_step_body(pp.j[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -452,7 +462,7 @@ struct LstmRecP {
     int B, H;
 };
 
-static __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) {
+static __device__ __forceinline__ void lstm_bwd_rec_body(const LstmRecP &p) {
     __shared__ float part[4][4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int H = p.H, K = 4 * p.H;
@@ -497,6 +507,13 @@ static __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) {
     }
 }
 
+static __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(LstmRecP p) { lstm_bwd_rec_body(p); }
+struct LstmRec2P { LstmRecP j[2]; int active[2]; };
+static __global__ __launch_bounds__(256) void lstm_bwd_rec2_kernel(LstmRec2P pp) {      // chunked layer wavefront (blockIdx.y = job)
+    if (!pp.active[blockIdx.y]) return;
+    lstm_bwd_rec_body(pp.j[blockIdx.y]);
+}
+
 struct LstmCellBP {
     const float *partial, *nd_next, *dh_ext;      // [16][B][H] (nullptr at t = T-1), [B], [B][H]
     float *dc_carry, *G;                          // [B][H] in/out, [B][4H] gates in / dG out
@@ -504,7 +521,7 @@ struct LstmCellBP {
     int B, H;
 };
 
-static __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) {
+static __device__ __forceinline__ void lstm_bwd_cell_body(const LstmCellBP &p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int H = p.H;
     if (i >= p.B * H) return;
@@ -528,6 +545,13 @@ static __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p)
     g[2 * H] = dc * ig * (1.f - gg * gg);
     g[3 * H] = dog;
     p.dc_carry[i] = p.nd[bi] * dc * fg;
+}
+
+static __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) { lstm_bwd_cell_body(p); }
+struct LstmCellB2P { LstmCellBP j[2]; int active[2]; };
+static __global__ __launch_bounds__(256) void lstm_bwd_cell2_kernel(LstmCellB2P pp) {
+    if (!pp.active[blockIdx.y]) return;
+    lstm_bwd_cell_body(pp.j[blockIdx.y]);
 }
 
 // Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh
