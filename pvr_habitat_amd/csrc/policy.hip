@@ -112,9 +112,40 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
     return PVR_OK;
 }
 
+#define TRY(x) do { pvr_status _s = (x); if (_s) return _s; } while (0)
+#define TRY_(x) TRY(x)
+
+// scratch of the two-stage column reductions: [2 * row groups][C] floats, grown on demand (first, eager, iteration)
+static float *g_col_scratch = nullptr;
+static size_t g_col_scratch_elems = 0;
+static pvr_status col_scratch(size_t elems, float **out) {
+    if (elems > g_col_scratch_elems) {
+        if (g_col_scratch) { PVR_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_col_scratch); }
+        PVR_HIP_TRY(hipMalloc((void **)&g_col_scratch, elems * sizeof(float)));
+        g_col_scratch_elems = elems;
+    }
+    *out = g_col_scratch;
+    return PVR_OK;
+}
+
+// column reduction of a [R][C] fp32 matrix: MODE 0 sum, 3 centred sum of squares (c.mean_in), 2 BatchNorm backward sums
+template <int MODE>
+static pvr_status colreduce2(ColP c, hipStream_t st) {
+    constexpr int RPG = 64;
+    const int G = (c.R + RPG - 1) / RPG;
+    float *part;
+    TRY_(col_scratch((size_t)2 * G * c.C, &part));
+    hipLaunchKernelGGL(colpart_kernel<MODE>, dim3((c.C / 4 + 31) / 32, G), dim3(256), 0, st, c, part, RPG);
+    if (MODE == 2) hipLaunchKernelGGL(colfinal_kernel<1>, dim3((c.C + 255) / 256), dim3(256), 0, st, part, c.out0, c.out1, G, c.C);
+    else hipLaunchKernelGGL(colfinal_kernel<0>, dim3((c.C + 255) / 256), dim3(256), 0, st, part, c.out0, c.out1, G, c.C);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
 pvr_status colsum(const float *X, float *out0, float *out1, int R, int C, hipStream_t st) {
     ColP c = {};
     c.X = X; c.out0 = out0; c.out1 = out1; c.R = R; c.C = C;
+    if (R >= 512 && C % 4 == 0) return colreduce2<0>(c, st);
     hipLaunchKernelGGL(colreduce_kernel<0>, dim3((C + 31) / 32), dim3(256), 0, st, c);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
@@ -125,7 +156,6 @@ inline int blocks_for(size_t n, int cap = 4096) {
     return (int)(b > (size_t)cap ? cap : (b ? b : 1));
 }
 
-#define TRY(x) do { pvr_status _s = (x); if (_s) return _s; } while (0)
 
 // forward through the workspace; logits/baseline/action land in pol->logits etc.  `target` non-null also
 // produces dlogits and per-row losses.
@@ -161,27 +191,24 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         PVR_REQUIRE(bn && bn->running_mean && bn->running_var, "policy: batch_norm=1 needs the BN buffers");
         if (training) {
             PVR_REQUIRE(N > 1, "BatchNorm1d training needs more than one row");
-            if (pol->sync_cb && pol->sync_world > 1) {
-                // global mean, then global centred second moment: two all-reduces of obs_size floats
-                const float ng = (float)N * (float)pol->sync_world;
-                ColP c = {};
-                c.X = obs; c.out0 = pol->sync_buf; c.R = N; c.C = O;
-                hipLaunchKernelGGL(colreduce_kernel<0>, dim3((O + 31) / 32), dim3(256), 0, st, c);
-                PVR_LAUNCH_CHECK();
-                pol->sync_cb(0, O, pol->sync_user);
-                hipLaunchKernelGGL(scale_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->bn_mean, pol->sync_buf, 1.0f / ng, O);
+            {
+                // mean, then centred second moment (two passes, as torch): per-rank, or over the global batch under SyncBN with an
+                // all-reduce of obs_size floats after each pass
+                const bool sync = pol->sync_cb && pol->sync_world > 1;
+                const float ng = (float)N * (float)(sync ? pol->sync_world : 1);
+                float *sums = sync ? pol->sync_buf : pol->bn_invstd;                // (bn_invstd doubles as scratch until the final kernel)
+                float *sq = sync ? pol->sync_buf + O : pol->da0;                    // (da0 is free during the forward pass)
+                TRY(colsum(obs, sums, nullptr, N, O, st));
+                if (sync) pol->sync_cb(0, O, pol->sync_user);
+                hipLaunchKernelGGL(scale_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->bn_mean, sums, 1.0f / ng, O);
                 ColP c2 = {};
-                c2.X = obs; c2.mean_in = pol->bn_mean; c2.out0 = pol->sync_buf + O; c2.R = N; c2.C = O;
-                hipLaunchKernelGGL(colreduce_kernel<3>, dim3((O + 31) / 32), dim3(256), 0, st, c2);
+                c2.X = obs; c2.mean_in = pol->bn_mean; c2.out0 = sq; c2.R = N; c2.C = O;
+                if (N >= 512 && O % 4 == 0) TRY(colreduce2<3>(c2, st));
+                else hipLaunchKernelGGL(colreduce_kernel<3>, dim3((O + 31) / 32), dim3(256), 0, st, c2);
                 PVR_LAUNCH_CHECK();
-                pol->sync_cb(O, O, pol->sync_user);
-                hipLaunchKernelGGL(bn_sync_final_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->sync_buf + O, pol->bn_mean, ng,
+                if (sync) pol->sync_cb(O, O, pol->sync_user);
+                hipLaunchKernelGGL(bn_sync_final_kernel, dim3((O + 255) / 256), dim3(256), 0, st, sq, pol->bn_mean, ng,
                                    pol->bn_invstd, bn->running_mean, bn->running_var, (long long *)bn->num_batches_tracked, O);
-            } else {
-                ColP c = {};
-                c.X = obs; c.out0 = pol->bn_mean; c.out1 = pol->bn_invstd; c.running_mean = bn->running_mean;
-                c.running_var = bn->running_var; c.nbt = (long long *)bn->num_batches_tracked; c.R = N; c.C = O;
-                hipLaunchKernelGGL(colreduce_kernel<1>, dim3((O + 31) / 32), dim3(256), 0, st, c);
             }
             hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)N * O / 4)), dim3(256), 0, st, obs, pol->bn_mean, pol->bn_invstd,
                                P + pol->o_bnw, P + pol->o_bnb, pol->a0, (size_t)N * O / 4, O, 0);
@@ -305,7 +332,16 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     const int N = T * B, H = d.hidden, O = d.obs_size, A = d.num_actions;
     const float *obs = d.conv_frames > 0 ? pol->feat : (const float *)obs_in;
     // ---- heads backward --------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(head_dw_kernel, dim3((H + 1 + 31) / 32), dim3(256), 0, st, pol->dlogits, pol->Hs[1], Gd + pol->o_pw, Gd + pol->o_pb, N, H, A);
+    if (N >= 512 && H % 4 == 0) {
+        constexpr int RPG = 64;
+        const int G = (N + RPG - 1) / RPG;
+        float *part;
+        TRY(col_scratch((size_t)G * A * (H + 4), &part));
+        hipLaunchKernelGGL(head_dw_part_kernel, dim3((H / 4 + 31) / 32, G), dim3(256), 0, st, pol->dlogits, pol->Hs[1], part, N, H, A, RPG);
+        hipLaunchKernelGGL(head_dw_final_kernel, dim3((A * (H + 1) + 255) / 256), dim3(256), 0, st, part, Gd + pol->o_pw, Gd + pol->o_pb, G, H, A);
+    } else {
+        hipLaunchKernelGGL(head_dw_kernel, dim3((H + 1 + 31) / 32), dim3(256), 0, st, pol->dlogits, pol->Hs[1], Gd + pol->o_pw, Gd + pol->o_pb, N, H, A);
+    }
     hipLaunchKernelGGL(head_dx_kernel, dim3(blocks_for((size_t)N * H)), dim3(256), 0, st, pol->dlogits, P + pol->o_pw, pol->dA, N, H, A);
     PVR_LAUNCH_CHECK();
     // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
@@ -439,7 +475,8 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         ColP c = {};
         c.X = obs; c.dY = pol->da0; c.mean_in = pol->bn_mean; c.invstd_in = pol->bn_invstd;
         c.out0 = Gd + pol->o_bnw; c.out1 = Gd + pol->o_bnb; c.R = N; c.C = O;
-        hipLaunchKernelGGL(colreduce_kernel<2>, dim3((O + 31) / 32), dim3(256), 0, st, c);
+        if (N >= 512 && O % 4 == 0) TRY(colreduce2<2>(c, st));
+        else hipLaunchKernelGGL(colreduce_kernel<2>, dim3((O + 31) / 32), dim3(256), 0, st, c);
         if (need_dobs) {
             const float *dg = Gd + pol->o_bnw, *db = Gd + pol->o_bnb;
             int n_bn = N;

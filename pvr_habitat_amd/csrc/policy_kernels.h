@@ -219,6 +219,50 @@ static __global__ __launch_bounds__(256) void colreduce_kernel(ColP p) {
     }
 }
 
+// Two-stage column reductions for tall matrices (R >= 512): colreduce_kernel has only C/32 blocks, each walking all R rows with
+// 128-byte row segments (55-100 us for 1600 x 4096 fp32, rocprofv3) - here a (column block, row group) grid reads 16 bytes per lane
+// and a second launch adds the row-group partials in ascending order (fixed order: deterministic).
+//   MODE 0: sum x     MODE 3: sum (x - mean[c])^2     MODE 2: out0 = sum dy * (x - mean[c]) * invstd[c], out1 = sum dy
+template <int MODE>
+static __global__ __launch_bounds__(256) void colpart_kernel(ColP p, float *__restrict__ part, int rpg) {
+    __shared__ f32x4 s0[8][33], s1[8][33];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cq) * 4, g = blockIdx.y;
+    const bool ok = c < p.C;
+    const int r0 = g * rpg, r1 = r0 + rpg < p.R ? r0 + rpg : p.R;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, is = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (MODE != 0) mu = *reinterpret_cast<const f32x4 *>(p.mean_in + c);
+        if (MODE == 2) is = *reinterpret_cast<const f32x4 *>(p.invstd_in + c);
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(p.X + (size_t)r * p.C + c);
+            if (MODE == 0) a0 += x;
+            else if (MODE == 3) { const f32x4 d = x - mu; a0 += d * d; }
+            else { const f32x4 dy = *reinterpret_cast<const f32x4 *>(p.dY + (size_t)r * p.C + c); a0 += dy * ((x - mu) * is); a1 += dy; }
+        }
+    }
+    s0[rl][cq] = a0; if (MODE == 2) s1[rl][cq] = a1;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0 += s0[i][cq]; if (MODE == 2) t1 += s1[i][cq]; }
+        *reinterpret_cast<f32x4 *>(part + (size_t)g * p.C + c) = t0;
+        if (MODE == 2) *reinterpret_cast<f32x4 *>(part + (size_t)(gridDim.y + g) * p.C + c) = t1;
+    }
+}
+// out0[c] (= out1[c] when TWO == 0 and out1 given) = sum_g part[g][c];  TWO: out1[c] = sum_g part[G + g][c]
+template <int TWO>
+static __global__ __launch_bounds__(256) void colfinal_kernel(const float *__restrict__ part, float *__restrict__ out0, float *__restrict__ out1, int G, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int g = 0; g < G; ++g) { t0 += part[(size_t)g * C + c]; if (TWO) t1 += part[(size_t)(G + g) * C + c]; }
+    out0[c] = t0;
+    if (TWO) out1[c] = t1; else if (out1) out1[c] = t0;
+}
+
 // y = (x - mean) * invstd * gamma + beta  (training: batch stats; eval: running stats, invstd computed here)
 static __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd_or_var, const float *__restrict__ gamma,
@@ -665,6 +709,55 @@ static __global__ __launch_bounds__(256) void head_dw_kernel(const float *__rest
         }
         __syncthreads();
     }
+}
+
+// two-stage version of head_dw_kernel for tall batches (33 blocks x all N rows took 107 us at N = 1600): (column block, row group)
+// partials, then a fixed-order sum over the row groups.  part layout: [G][A][H + 4] (column H = bias sum)
+static __global__ __launch_bounds__(256) void head_dw_part_kernel(const float *__restrict__ dl, const float *__restrict__ out,
+                                                           float *__restrict__ part, int N, int H, int A, int rpg) {
+    __shared__ f32x4 s[8][33];
+    __shared__ float sb[8];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int k = (blockIdx.x * 32 + cq) * 4, g = blockIdx.y;
+    const int r0 = g * rpg, r1 = r0 + rpg < N ? r0 + rpg : N;
+    const bool ok = k < H;
+    for (int a = 0; a < A; ++a) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        float accb = 0.f;
+        for (int n = r0 + rl; n < r1; n += 8) {
+            const float d = dl[(size_t)n * 16 + a];
+            if (ok) acc += d * *reinterpret_cast<const f32x4 *>(out + (size_t)n * H + k);
+            accb += d;
+        }
+        s[rl][cq] = acc;
+        if (cq == 0) sb[rl] = accb;
+        __syncthreads();
+        if (rl == 0) {
+            float *prow = part + ((size_t)g * A + a) * (H + 4);
+            if (ok) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t += s[i][cq];
+                *reinterpret_cast<f32x4 *>(prow + k) = t;
+            }
+            if (cq == 0 && blockIdx.x == 0) {
+                float tb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tb += sb[i];
+                prow[H] = tb;
+            }
+        }
+        __syncthreads();
+    }
+}
+static __global__ __launch_bounds__(256) void head_dw_final_kernel(const float *__restrict__ part, float *__restrict__ dWp, float *__restrict__ dbp,
+                                                            int G, int H, int A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;            // over A * (H + 1)
+    if (i >= A * (H + 1)) return;
+    const int a = i / (H + 1), k = i % (H + 1);
+    float t = 0.f;
+    for (int g = 0; g < G; ++g) t += part[((size_t)g * A + a) * (H + 4) + k];
+    if (k < H) dWp[(size_t)a * H + k] = t; else dbp[a] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------
