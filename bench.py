@@ -320,6 +320,12 @@ def main():
                                          'in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
                          'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel') + ' %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
+                         # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
+                         # (with two batches in flight the step is shorter than the sum of its launches)
+                         'hbm_step': None if traffic is None else {
+                             'achieved': round(traffic * n_conv / (el / args.steps) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': round(traffic * n_conv / (el / args.steps) / 8e12, 4),
+                             'note': 'conv-launch HBM bytes per batch (PMC) / step time; layer1-2 launches alone run at 3.2-4.0 TB/s'},
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
