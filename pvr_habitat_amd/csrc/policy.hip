@@ -96,18 +96,44 @@ pvr_status dalloc(T **ptr, size_t n) {
     return PVR_OK;
 }
 
+static float *g_splitk_scratch = nullptr;
+static size_t g_splitk_elems = 0;
+
 pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
                 bool a_km, bool b_kn, int relu, hipStream_t st) {
     GemmP g;
     g.A = A; g.B = B; g.bias = bias; g.mask = mask; g.C = C; g.M = M; g.N = N; g.K = K;
     g.lda = a_km ? M : K; g.ldb = b_kn ? N : K; g.ldc = N; g.relu = relu;
+    g.a_kstride = 0; g.b_kstride = 0; g.c_stride = 0;
     PVR_REQUIRE(((a_km && b_kn) || K % 4 == 0) && (!a_km || M % 4 == 0) && (!b_kn || N % 4 == 0),
                 "gemm_f32: contiguous dims must be multiples of 4 (M=%d N=%d K=%d)", M, N, K);
     const int grid = ((M + 63) / 64) * ((N + 63) / 64);
-    if (!a_km && !b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(grid), dim3(256), 0, st, g);
-    else if (!a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(grid), dim3(256), 0, st, g);
+    // too few output tiles for the chip and a long K: split K over blockIdx.y into fp32 partial products, summed in slice order
+    int S = 1;
+    if (grid < 192 && K >= 2048 && K % 128 == 0) S = 4;
+    if (S > 1) {
+        const size_t need = (size_t)S * M * N;
+        if (need > g_splitk_elems) {
+            if (g_splitk_scratch) { PVR_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_splitk_scratch); }
+            PVR_HIP_TRY(hipMalloc((void **)&g_splitk_scratch, need * sizeof(float)));
+            g_splitk_elems = need;
+        }
+        g.K = K / S;
+        g.a_kstride = a_km ? (long long)g.K * g.lda : g.K;
+        g.b_kstride = b_kn ? (long long)g.K * g.ldb : g.K;
+        g.c_stride = (long long)M * N;
+        g.C = g_splitk_scratch; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
+    }
+    const dim3 gd(grid, S);
+    if (!a_km && !b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), gd, dim3(256), 0, st, g);
+    else if (!a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), gd, dim3(256), 0, st, g);
+    else if (a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), gd, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), gd, dim3(256), 0, st, g);
+    if (S > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st,
+                           g_splitk_scratch, C, bias, mask, S, n, N, relu);
+    }
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }

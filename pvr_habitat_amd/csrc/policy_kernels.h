@@ -26,6 +26,9 @@ struct GemmP {
     const float *A, *B, *bias, *mask;
     float *C;
     int M, N, K, lda, ldb, ldc, relu;
+    // split-K (blockIdx.y = slice): slice s multiplies k in [s*K, (s+1)*K) of the full problem into C + s*c_stride (K is the slice length);
+    // used when M*N alone gives too few blocks (BPTT chunk GEMMs: M = 400, K = 4096); the slices are summed in a fixed order afterwards
+    long long a_kstride, b_kstride, c_stride;
 };
 
 template <bool ATR, bool BTR>
@@ -40,6 +43,7 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (swz / n_tiles) * BM, n0 = (swz % n_tiles) * BN;
     const int nk = (p.K + BK - 1) / BK;
+    p.A += (long long)blockIdx.y * p.a_kstride; p.B += (long long)blockIdx.y * p.b_kstride; p.C += (long long)blockIdx.y * p.c_stride;
 
     f32x4 ra[2], rb[2];
 #define PVR_G_LOAD(kt_)                                                                                   \
@@ -133,6 +137,19 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 if (p.mask && p.mask[(size_t)m * p.ldc + n] <= 0.f) v = 0.f;
                 p.C[(size_t)m * p.ldc + n] = v;
             }
+    }
+}
+
+// out = sum over the split-K slices (ascending), then the epilogue the GEMM kernel would have applied
+static __global__ __launch_bounds__(256) void splitk_sum_kernel(const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ bias,
+                                                         const float *__restrict__ mask, int S, size_t n, int N, int relu) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) v += part[(size_t)s_ * n + i];
+        if (bias) v += bias[i % N];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask && mask[i] <= 0.f) v = 0.f;
+        out[i] = v;
     }
 }
 

@@ -15,7 +15,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(),
 
 
 @pytest.mark.parametrize('M,N,K,a_km,b_kn', [(1600, 1024, 4096, 0, 0), (100, 64, 32, 0, 0), (1600, 1024, 4096, 0, 1),
-                                             (4096, 1024, 1600, 1, 1), (1024, 64, 100, 1, 1), (37, 1024, 1024, 0, 0), (1, 1024, 64, 0, 0)])
+                                             (4096, 1024, 1600, 1, 1), (1024, 64, 100, 1, 1), (37, 1024, 1024, 0, 0), (1, 1024, 64, 0, 0),
+                                             (400, 1024, 4096, 0, 1), (100, 256, 2048, 0, 0), (64, 64, 4096, 1, 1)])     # split-K (few tiles, long K)
 def test_gemm_f32(M, N, K, a_km, b_kn):
     from pvr_habitat_amd.models import _plib
     if a_km and M % 4:
