@@ -50,6 +50,40 @@ def test_resnet50_matches_independent_implementation():
     assert n_conv == 23454912          # 23.455 M conv weights
 
 
+def test_resnet34_matches_independent_implementation():
+    """BasicBlock trunks ('resnet18' / 'resnet34', embeddings.py:112-117) against transformers.ResNetModel(layer_type='basic')."""
+    from transformers import ResNetConfig, ResNetModel
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(2, 'r34')
+    cfg = ResNetConfig(layer_type='basic', hidden_sizes=[64, 128, 256, 512], depths=[3, 4, 6, 3], embedding_size=64)
+    m = ResNetModel(cfg).eval()
+    new = {}
+
+    def bn(dst, src):
+        for a in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+            new[dst + '.' + a] = torch.from_numpy(np.array(sd[src + '.' + a]))
+
+    new['embedder.embedder.convolution.weight'] = torch.from_numpy(sd['conv1.weight'])
+    bn('embedder.embedder.normalization', 'bn1')
+    for li, nb in enumerate((3, 4, 6, 3)):
+        for bi in range(nb):
+            src, dst = 'layer%d.%d' % (li + 1, bi), 'encoder.stages.%d.layers.%d' % (li, bi)
+            for ci in range(2):
+                new['%s.layer.%d.convolution.weight' % (dst, ci)] = torch.from_numpy(sd['%s.conv%d.weight' % (src, ci + 1)])
+                bn('%s.layer.%d.normalization' % (dst, ci), '%s.bn%d' % (src, ci + 1))
+            if (src + '.downsample.0.weight') in sd:
+                new[dst + '.shortcut.convolution.weight'] = torch.from_numpy(sd[src + '.downsample.0.weight'])
+                bn(dst + '.shortcut.normalization', src + '.downsample.1')
+    missing, unexpected = m.load_state_dict(new, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    fr = synth.smooth_frames(4, 2, 128, 128)
+    x = eo.preprocess(fr)
+    with torch.no_grad():
+        ours = eo.resnet50_features(sd, x, 'r34').reshape(2, 512).numpy()
+        hf = m(pixel_values=x).pooler_output.reshape(2, 512).numpy()
+    np.testing.assert_allclose(ours, hf, rtol=2e-4, atol=2e-5)
+
+
 def test_out_sizes_and_heads():
     torch.set_num_threads(8)
     fr = synth.frames(5, 1, 64, 64)
