@@ -114,7 +114,7 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
     if (S > 1) {
         const size_t need = (size_t)S * M * N;
         if (need > g_splitk_elems) {
-            if (g_splitk_scratch) { PVR_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_splitk_scratch); }
+            // (a superseded buffer is deliberately not freed: launches already enqueued, or captured in a hipGraph, may still use it)
             PVR_HIP_TRY(hipMalloc((void **)&g_splitk_scratch, need * sizeof(float)));
             g_splitk_elems = need;
         }
@@ -146,7 +146,7 @@ static float *g_col_scratch = nullptr;
 static size_t g_col_scratch_elems = 0;
 static pvr_status col_scratch(size_t elems, float **out) {
     if (elems > g_col_scratch_elems) {
-        if (g_col_scratch) { PVR_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_col_scratch); }
+        // (a superseded buffer is deliberately not freed: launches already enqueued, or captured in a hipGraph, may still use it)
         PVR_HIP_TRY(hipMalloc((void **)&g_col_scratch, elems * sizeof(float)));
         g_col_scratch_elems = elems;
     }
