@@ -1,0 +1,47 @@
+"""bench.py prints ONE JSON line with the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` object; the N > 1 path (one process
+per GPU, barrier + MAX over ranks) is exercised with two ranks sharing the one test GPU (PVR_BENCH_ONE_GPU=1, gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ['--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-bc', '--no-vit', '--no-pcie']
+
+
+def _check(line, n):
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['metric'].startswith('frames/sec embedded (ResNet50') and d['unit'] == 'frames/s' and d['n_gpus'] == n and d['steps'] == 4
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'bf16'
+    assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['global_batch'] == 256 * n
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['peak'] == 2500.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['frac'] > 0.05
+    assert d['value'] > 8000 * n                                       # north-star floor: 8 k frames/s per GPU
+    return d
+
+
+def test_bench_line_single_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + FAST, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    _check(lines[0], 1)
+
+
+def test_bench_line_two_ranks_on_one_gpu():
+    env = dict(os.environ, PVR_BENCH_ONE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + FAST
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                             # rank 0 only
+    _check(lines[0], 2)
