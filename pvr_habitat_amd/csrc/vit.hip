@@ -164,19 +164,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
     const size_t rs = (size_t)3 * W;
     const u16 *base = qkv + (size_t)b * T * rs + hd * HD;
     auto kaddr = [&](int row, int ch) { return HD == 64 ? row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) : row * KS + (ch << 4); };
-    for (int idx = tid; idx < TK * KCH; idx += 256) {
-        const int row = idx / KCH, ch = idx % KCH;
-        u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-        const bool real = ch * 8 < HD;
-        if (row < T && real) {
-            kv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + W + ch * 8);
-            vv = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + 2 * W + ch * 8);
-        }
-        *reinterpret_cast<u32x4 *>(Ks + kaddr(row, ch)) = kv;
-        if (real) {
-            const u16 *ve = reinterpret_cast<const u16 *>(&vv);
+    // K / V fill: all global loads of a batch are issued before the first LDS write, so a wave pays the load latency once per
+    // batch instead of once per 16-byte chunk (the kernel is latency-bound: SQ_WAIT_ANY 53 %, MFMA busy 6 %)
+    constexpr int NIT = (MAXNT * 16 * KCH + 255) / 256, FB = 7;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+    for (int i0 = 0; i0 < NIT; i0 += FB) {
+        u32x4 kv[FB], vv[FB];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            const int idx = tid + 256 * (i0 + i);
+            const int row = idx / KCH, ch = idx % KCH;
+            kv[i] = u32x4{0u, 0u, 0u, 0u}; vv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (i0 + i < NIT && idx < TK * KCH && row < T && ch * 8 < HD) {
+                kv[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + W + ch * 8);
+                vv[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + 2 * W + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            const int idx = tid + 256 * (i0 + i);
+            if (i0 + i >= NIT || idx >= TK * KCH) continue;
+            const int row = idx / KCH, ch = idx % KCH;
+            *reinterpret_cast<u32x4 *>(Ks + kaddr(row, ch)) = kv[i];
+            if (ch * 8 < HD) {
+                const u16 *ve = reinterpret_cast<const u16 *>(&vv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+            }
         }
     }
     __syncthreads();
