@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // Multi-head attention, head dim HD (64: CLIP / MAE-B / MAE-L; 80: MAE-H).  qkv: [N*T][3W] 16-bit (q | k | v, head h at columns
 // h*HD..), out: [N*T][W].  grid (heads, N), 4 waves.  Keys are padded to TK (multiple of 32, <= 16*MAXNT): padded scores are -inf,
 // padded V rows zero.  The contraction dim of QK^T is padded to KP = 32*ceil(HD/32) with zero chunks.
-template <bool F16, int HD, int MAXNT>
+// EXACT: TK == 16 * MAXNT (every shape the plans use), so the key-tile count is a compile-time constant and only the last two tiles
+// carry key-validity masks; the runtime-NT form cost ~40 % more VALU work per query tile (selects and moves on every score tile)
+template <bool F16, int HD, int MAXNT, bool EXACT = true>
 __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ qkv, u16 *__restrict__ out, int T, int TK, int W) {
     typedef typename HT<F16>::V8 V8;
     constexpr int KP = (HD + 31) / 32 * 32, KCH = KP / 8, KSTEPS = KP / 32, MT = HD / 16;
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
     const int hd = blockIdx.x, b = blockIdx.y;
     const size_t rs = (size_t)3 * W;
     const u16 *base = qkv + (size_t)b * T * rs + hd * HD;
+    // branch-free loads: out-of-range rows / padded chunks take an offset past num_records and read zeros (a per-element
+    // "load or zero" select makes hipcc branch around every load and serialise them)
+    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(base), 0, (unsigned)((size_t)T * rs * 2), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
     auto kaddr = [&](int row, int ch) { return HD == 64 ? row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) : row * KS + (ch << 4); };
     // K / V fill: all global loads of a batch are issued before the first LDS write, so a wave pays the load latency once per
     // batch instead of once per 16-byte chunk (the kernel is latency-bound: SQ_WAIT_ANY 53 %, MFMA busy 6 %)
@@ -174,11 +180,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
         for (int i = 0; i < FB; ++i) {
             const int idx = tid + 256 * (i0 + i);
             const int row = idx / KCH, ch = idx % KCH;
-            kv[i] = u32x4{0u, 0u, 0u, 0u}; vv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (i0 + i < NIT && idx < TK * KCH && row < T && ch * 8 < HD) {
-                kv[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + W + ch * 8);
-                vv[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)row * rs + 2 * W + ch * 8);
-            }
+            const bool okl = i0 + i < NIT && idx < TK * KCH && row < T && ch * 8 < HD;
+            const int off = okl ? (int)(((size_t)row * rs + W + ch * 8) * 2) : OOB;
+            kv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, off, 0, 0));
+            vv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, okl ? off + W * 2 : OOB, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < FB; ++i) {
@@ -194,19 +199,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
         }
     }
     __syncthreads();
-    const int NT = TK / 16;                                       // key tiles (<= MAXNT)
+    const int NT = EXACT ? MAXNT : TK / 16;                       // key tiles (<= MAXNT)
     const float scale = HD == 64 ? 0.125f : 1.0f / sqrtf((float)HD);
+    // B operand of S^T = K Q^T : Q[query = fr][d = ks*32 + 8*fq + j]; the next tile's Q is fetched while this one is computed
+    auto load_q = [&](int qt_, u32x4 (&t)[KSTEPS]) {
+        const int q_ = qt_ * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int off = (q_ < T && ks * 32 + fq * 8 < HD) ? (int)(((size_t)q_ * rs + ks * 32 + fq * 8) * 2) : OOB;
+            t[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, off, 0, 0));
+        }
+    };
+    u32x4 qnext[KSTEPS];
+    load_q(wave, qnext);
     for (int qt = wave; qt * 16 < T; qt += 4) {
         const int query = qt * 16 + fr;
         const bool qok = query < T;
-        // B operand of S^T = K Q^T : Q[query = fr][d = ks*32 + 8*fq + j]
         V8 qf[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            u32x4 t = u32x4{0u, 0u, 0u, 0u};
-            if (qok && ks * 32 + fq * 8 < HD) t = *reinterpret_cast<const u32x4 *>(base + (size_t)query * rs + ks * 32 + fq * 8);
-            qf[ks] = __builtin_bit_cast(V8, t);
-        }
+        for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = __builtin_bit_cast(V8, qnext[ks]);
+        load_q(qt + 4, qnext);
         f32x4 s[MAXNT];
 #pragma unroll
         for (int nt = 0; nt < MAXNT; ++nt) {
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = nt * 16 + fq * 4 + r;
-                const float v = (nt < NT && key < T) ? s[nt][r] * scale : -INFINITY;
+                float v = s[nt][r] * scale;
+                if (!EXACT || nt >= MAXNT - 2) v = (nt < NT && key < T) ? v : -INFINITY;     // TK - T < 32: only the last two tiles can hold padding
                 s[nt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -605,6 +618,31 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
     return PVR_OK;
 }
 
+// one launch of the attention core; EXACT instantiations for the token counts the plans use, a runtime-NT fallback otherwise
+template <bool F16, int HD, int MAXNT, bool EXACT>
+static pvr_status launch_attention_inst(const u16 *qkv, u16 *out, int T, int TK, int W, int heads, int nb, hipStream_t st) {
+    const size_t lds = (size_t)TK * (HD == 64 ? 128 : ((HD + 31) / 32 * 64 + 16)) + (size_t)HD * (TK + 4) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<F16, HD, MAXNT, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<F16, HD, MAXNT, EXACT>), dim3(heads, nb), dim3(256), lds, st, qkv, out, T, TK, W);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+template <bool F16>
+static pvr_status launch_attention_any(const u16 *qkv, u16 *out, int T, int TK, int W, int heads, int nb, hipStream_t st) {
+    const int hd = W / heads, nt = TK / 16;
+    PVR_REQUIRE(W == heads * hd && (hd == 64 || hd == 80) && TK % 32 == 0 && TK >= T && TK <= 288, "attention: head dim %d / %d keys not built", hd, TK);
+    if (hd == 64 && nt == 4) return launch_attention_inst<F16, 64, 4, true>(qkv, out, T, TK, W, heads, nb, st);
+    if (hd == 64 && nt == 14) return launch_attention_inst<F16, 64, 14, true>(qkv, out, T, TK, W, heads, nb, st);
+    if (hd == 64) return launch_attention_inst<F16, 64, 18, false>(qkv, out, T, TK, W, heads, nb, st);
+    if (nt == 18) return launch_attention_inst<F16, 80, 18, true>(qkv, out, T, TK, W, heads, nb, st);
+    return launch_attention_inst<F16, 80, 18, false>(qkv, out, T, TK, W, heads, nb, st);
+}
+
 template <bool F16, int WD>
 static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
     pvr_vit *v = e->vit;
@@ -646,19 +684,12 @@ static pvr_status vit_forward_t(pvr_encoder *e, const uint8_t *frames, int n, in
         if (stop == "pe" || stop == "ln_pre") return PVR_OK;
         float *x = v->x0, *xn = v->x1;
         int bi = 0;
-        const int HDm = W / v->heads;
-        const size_t att_lds = (size_t)v->TK * (HDm == 64 ? 128 : 208) + (size_t)HDm * (v->TK + 4) * 2;
         for (auto &b : v->blocks) {
             hipLaunchKernelGGL((layernorm_kernel<F16, WD>), dim3((rows + 3) / 4), dim3(256), 0, st, x, (const float *)nullptr,
                                (const float *)nullptr, (const float *)nullptr, b.ln1_w, b.ln1_b, (float *)nullptr, v->y, rows, T, v->eps, 1);
             if ((s = launch_conv(v->y, b.w_qkv, b.b_qkv, nullptr, v->qkv, v->zero, rows, 1, 1, W, 3 * W, 1, 1, 1, 0, 0, 0, dt, st))) return s;
             if (bi == 0 && stop == "qkv0") return PVR_OK;
-            if (HDm == 64 && v->TK <= 224)
-                hipLaunchKernelGGL((attention_kernel<F16, 64, 14>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
-            else if (HDm == 64)
-                hipLaunchKernelGGL((attention_kernel<F16, 64, 18>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
-            else
-                hipLaunchKernelGGL((attention_kernel<F16, 80, 18>), dim3(v->heads, nb), dim3(256), att_lds, st, v->qkv, v->att, T, v->TK, W);
+            if ((s = launch_attention_any<F16>(v->qkv, v->att, T, v->TK, W, v->heads, nb, st))) return s;
             PVR_LAUNCH_CHECK();
             if (bi == 0 && stop == "att0") return PVR_OK;
             // x' = x + out_proj(att): fp32 residual in (bit1), fp32 out (bit0)
@@ -717,31 +748,11 @@ pvr_status vit_tap(pvr_encoder *e, const char *name, float *out, int64_t cap, in
     return launch_h_to_f32(src, out, elems, e->desc.dtype, st);
 }
 
-static pvr_status attention_attrs() {
-    static bool attr_done = false;
-    if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 64, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 64, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<true, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<false, 80, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        attr_done = true;
-    }
-    return PVR_OK;
-}
-
-// attention core for callers outside the ViT plan (CLIP RN50 attention pool): head dim 64, <= 224 keys
+// attention core for callers outside the ViT plan (CLIP RN50 attention pool)
 pvr_status launch_attention(const void *qkv, void *out, int T, int W, int heads, int nb, int dtype, hipStream_t st) {
-    PVR_REQUIRE(W == heads * 64 && T <= 224, "launch_attention: head dim must be 64 and T <= 224");
-    pvr_status s = attention_attrs();
-    if (s) return s;
     const int TK = (T + 31) / 32 * 32;
-    const size_t lds = (size_t)TK * 128 + (size_t)64 * (TK + 4) * 2;
-    if (dtype == PVR_F16) hipLaunchKernelGGL((attention_kernel<true, 64, 14>), dim3(heads, nb), dim3(256), lds, st, (const u16 *)qkv, (u16 *)out, T, TK, W);
-    else hipLaunchKernelGGL((attention_kernel<false, 64, 14>), dim3(heads, nb), dim3(256), lds, st, (const u16 *)qkv, (u16 *)out, T, TK, W);
-    PVR_LAUNCH_CHECK();
-    return PVR_OK;
+    return dtype == PVR_F16 ? launch_attention_any<true>((const u16 *)qkv, (u16 *)out, T, TK, W, heads, nb, st)
+                            : launch_attention_any<false>((const u16 *)qkv, (u16 *)out, T, TK, W, heads, nb, st);
 }
 
 // Resize(res, BICUBIC, antialias=True) + CenterCrop(res) as a stand-alone service (CLIP RN50 plan): a weight-less pvr_vit that
@@ -784,10 +795,6 @@ void resizer_destroy(pvr_encoder *e) {
 }
 
 pvr_status vit_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
-    {
-        pvr_status sa = attention_attrs();
-        if (sa) return sa;
-    }
     if (e->vit->width == 1024)
         return e->desc.dtype == PVR_F16 ? vit_forward_t<true, 1024>(e, frames, n, h, w, out, out_stride, st)
                                         : vit_forward_t<false, 1024>(e, frames, n, h, w, out, out_stride, st);
