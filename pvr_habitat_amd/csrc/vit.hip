@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
     }
     __syncthreads();
     const int NT = EXACT ? MAXNT : TK / 16;                       // key tiles (<= MAXNT)
-    const float scale = HD == 64 ? 0.125f : 1.0f / sqrtf((float)HD);
+    // scores are kept in the log2 domain (scale * log2(e) folded into one multiply) so the softmax exponent is a bare v_exp_f32
+    const float scale = (HD == 64 ? 0.125f : 1.0f / sqrtf((float)HD)) * 1.44269504088896341f;
     // B operand of S^T = K Q^T : Q[query = fr][d = ks*32 + 8*fq + j]; the next tile's Q is fetched while this one is computed
     auto load_q = [&](int qt_, u32x4 (&t)[KSTEPS]) {
         const int q_ = qt_ * 16 + fr;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
         for (int nt = 0; nt < MAXNT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[nt][r] - mx);            // exp(-inf) = 0 for padded keys
+                const float e = __builtin_amdgcn_exp2f(s[nt][r] - mx);    // 2^(-inf) = 0 for padded keys
                 s[nt][r] = e;
                 sum += e;
             }
