@@ -538,18 +538,28 @@ static __device__ __forceinline__ void lstm_bwd_rec_body(const LstmRecP &p) {
             f32x4 acc[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < kper / 64; ++c) {               // 16-k chunks of this wave
-                const int k0 = kbeg + c * 16;
-                f32x4 a = *reinterpret_cast<const f32x4 *>(drow + k0 + fq * 4);
-                if (!bok) a = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 w[4];
+            // 16-k chunks of this wave, four at a time: all 20 loads of a group are issued before its 64 MFMAs, so the L2 latency of
+            // the weight slab is paid once per group, not once per chunk (the ISA of the rolled loop waited vmcnt(0) per chunk)
+            for (int c0 = 0; c0 < kper / 64; c0 += 4) {
+                f32x4 a[4], w[4][4];
 #pragma unroll
-                for (int e1 = 0; e1 < 4; ++e1)
-                    w[e1] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)(k0 + fq * 4 + e1) * H + u0 + ub + fr * 4);
+                for (int c = 0; c < 4; ++c) {
+                    const int k0 = kbeg + (c0 + c) * 16;
+                    a[c] = *reinterpret_cast<const f32x4 *>(drow + k0 + fq * 4);
 #pragma unroll
-                for (int e1 = 0; e1 < 4; ++e1)
+                    for (int e1 = 0; e1 < 4; ++e1)
+                        w[c][e1] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)(k0 + fq * 4 + e1) * H + u0 + ub + fr * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float bmask = bok ? 1.f : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = mfma_f32(a[e1], w[e1][e], acc[e]);
+                for (int c = 0; c < 4; ++c) {
+                    a[c] *= bmask;
+#pragma unroll
+                    for (int e1 = 0; e1 < 4; ++e1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = mfma_f32(a[c][e1], w[c][e1][e], acc[e]);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
