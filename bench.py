@@ -151,6 +151,7 @@ def vit_bench(variant, batch, steps, warmup, dtype):
         for i in range(k):
             with torch.cuda.stream(streams[i % 2]):
                 m.forward_into(fr, outs[i % 2], lane=i % 2)
+    torch.cuda.synchronize()
     run(max(warmup, 2))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -257,6 +258,7 @@ def main():
             with torch.cuda.stream(streams[i % lanes]):
                 model.forward_into(frames, outs[i % lanes], lane=i % lanes)
 
+    torch.cuda.synchronize()                                     # default-stream setup work done before the side streams start
     run_steps(max(args.warmup, lanes))
     barrier()
     t0 = time.perf_counter()

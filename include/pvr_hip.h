@@ -108,7 +108,10 @@ pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos);
 /* Same forward on one of up to four activation workspaces ("lanes" 0..3; lanes > 0 are allocated on first use).  Forwards on
  * DIFFERENT lanes may be in flight at once on different streams - e.g. batch k+1 on lane 1 while batch k drains on lane 0,
  * which fills the CUs that tile tails and HBM-bound launches of a single batch-256 forward leave idle (+15 % frames/s
- * measured).  Forwards on the SAME lane must be stream-ordered by the caller.  pvr_encoder_forward == lane 0.
+ * measured).  Forwards on the SAME lane issued on different streams are chained by the library (each forward records a
+ * per-lane event on its stream, the next forward on that lane waits for it on the device), so a workspace is never shared
+ * by two forwards in flight; calls on one encoder handle must still come from one host thread at a time.
+ * pvr_encoder_forward == lane 0.
  * replaces: the batch loop of behavioral_cloning/save_embedded_obs.py:151-156, which runs one batch at a time. */
 pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames_dev, int32_t n, int32_t h,
                                     int32_t w, float *out_dev, int64_t out_stride, void *hip_stream);

@@ -623,6 +623,29 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
     return PVR_OK;
 }
 
+// Same-lane forwards issued on DIFFERENT streams are ordered here, not by the caller: every forward records lane_done[lane] on its
+// stream and the next forward on that lane waits for it first (a device-side event wait, no host synchronisation), so a lane's
+// workspace is never shared by two forwards in flight.  Different lanes stay independent.
+static pvr_status lane_wait(pvr_encoder *enc, int lane, void *hip_stream) {
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (enc->lane_done[lane] && enc->lane_stream[lane] != st) PVR_HIP_TRY(hipStreamWaitEvent(st, enc->lane_done[lane], 0));
+    return PVR_OK;
+}
+static pvr_status lane_mark(pvr_encoder *enc, int lane, void *hip_stream) {
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!enc->lane_done[lane]) PVR_HIP_TRY(hipEventCreateWithFlags(&enc->lane_done[lane], hipEventDisableTiming));
+    PVR_HIP_TRY(hipEventRecord(enc->lane_done[lane], st));
+    enc->lane_stream[lane] = st;
+    return PVR_OK;
+}
+static pvr_status lane_forward(pvr_encoder *enc, int lane, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
+                               int64_t out_stride, void *hip_stream) {
+    pvr_status s = lane_wait(enc, lane, hip_stream);
+    if (!s) s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+    if (!s) s = lane_mark(enc, lane, hip_stream);
+    return s;
+}
+
 extern "C" {
 
 pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
@@ -630,7 +653,8 @@ pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t 
     PVR_REQUIRE(enc, "pvr_encoder_forward: null encoder");
     if (enc->finalized && !enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, 0); if (s) return s; }
     if (enc->finalized && enc->vit) { pvr_status s = vit_use_lane(enc, 0); if (s) return s; }
-    return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+    if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
+    return lane_forward(enc, 0, frames, n, h, w, out, out_stride, hip_stream);
 }
 
 pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
@@ -641,7 +665,7 @@ pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_
     if (enc->vit) { pvr_status s = vit_use_lane(enc, lane); if (s) return s; }
     else if (!enc->rnd) { pvr_status s = use_lane(enc, lane); if (s) return s; }            // (the 'random' plan has one workspace)
     else PVR_REQUIRE(lane == 0, "pvr_encoder_forward_lane: the 'random' PVR plan has a single workspace");
-    return forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+    return lane_forward(enc, lane, frames, n, h, w, out, out_stride, hip_stream);
 }
 
 // Instrumented forward of ONE chunk: HIP events between launches on the caller's stream (synchronises).
@@ -654,6 +678,8 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
     PVR_REQUIRE(n <= enc->desc.chunk, "profile: n=%d must fit one chunk (%d)", n, enc->desc.chunk);
     std::vector<hipEvent_t> ev;
     pvr_status s = (enc->finalized && !enc->vit && !enc->rnd) ? use_lane(enc, 0) : PVR_OK;
+    if (!s && enc->finalized && enc->vit) s = vit_use_lane(enc, 0);
+    if (!s) s = lane_wait(enc, 0, hip_stream);
     if (!s) s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, &ev);
     if (!s && hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) { set_error("profile: sync failed"); s = PVR_ERR_HIP; }
     const int nl = (int)ev.size() - 1;
@@ -786,6 +812,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->d_stem_b) (void)hipFree(enc->d_stem_b);
     if (enc->d_zero) (void)hipFree(enc->d_zero);
     resizer_destroy(enc);
+    for (auto &ev : enc->lane_done) if (ev) (void)hipEventDestroy(ev);
     for (void *q : {(void *)enc->ap_wqkv, (void *)enc->ap_wc, (void *)enc->ap_bqkv, (void *)enc->ap_bc, (void *)enc->ap_pos, (void *)enc->ap_out}) if (q) (void)hipFree(q);
     delete enc;
 }

@@ -81,6 +81,8 @@ struct pvr_encoder {
     // streams; allocated on first use.  The members above are the CURRENT lane's pointers (swapped by use_lane).
     struct LaneWs { u16 *d_img = nullptr, *d_stem = nullptr; float *d_imgf = nullptr; void *d_buf[B_COUNT] = {nullptr}; bool valid = false; } lane_ws[PVR_MAX_LANES];
     int cur_lane = 0;
+    hipEvent_t lane_done[PVR_MAX_LANES] = {nullptr};   // recorded after each forward on the lane; the next forward on it waits
+    hipStream_t lane_stream[PVR_MAX_LANES] = {nullptr};   // stream of that forward (no wait when the stream is the same)
     int crop_pos = 0;                                // 0 centre (reference), 1..4 corner crops (pvr_encoder_set_crop_position)
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap

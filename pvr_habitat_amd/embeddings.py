@@ -242,8 +242,9 @@ class HipResNet50(_Node):
 
     def forward_into(self, frames_u8, out, lane=0):
         """frames_u8: cuda uint8 (N,H,W,3) contiguous; out: cuda fp32 2-D view with row stride out.stride(0).
-        lane (0 or 1) selects one of two activation workspaces: forwards on different lanes may be in flight at once on
-        different streams (pvr_encoder_forward_lane); same-lane forwards must be ordered by the caller's streams."""
+        lane selects one of the activation workspaces: forwards on different lanes may be in flight at once on different
+        streams (pvr_encoder_forward_lane); same-lane forwards issued on different streams are chained by the library
+        (a per-lane event), so a workspace is never shared by two forwards in flight."""
         _lib.require_gpu()
         if self._handle is None:
             self._build()
@@ -488,6 +489,8 @@ def stream_embed(net, frames_u8, batch=256, out=None):
     res = torch.empty((n, osz), dtype=torch.float32).pin_memory() if out is None else out
     dev = torch.device('cuda')
     h2d, d2h, comps = torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s_ in (h2d, d2h, *comps):
+        s_.wait_stream(torch.cuda.current_stream())          # whatever the caller queued (e.g. a forward on the default stream) comes first
     model = net.embedding
     if getattr(model, 'lanes', 1) < 2 or os.environ.get('PVR_STREAM_LANES', '2') == '1':
         comps[1] = comps[0]                                     # single workspace: both slots on one compute stream

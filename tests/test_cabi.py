@@ -60,7 +60,7 @@ def test_registry_matches_reference_names():
     from pvr_habitat_amd import embeddings as E
     assert E._UBER['moco_aug_places_uber_345'] == ['moco_aug_places_l3', 'moco_aug_places_l4', 'moco_aug_places']
     assert E._UBER['moco_croponly_uber_45'] == ['moco_croponly_l4', 'moco_croponly']
-    assert len(E._UBER) == 16 and len(E._SINGLE) == 26
+    assert len(E._UBER) == 16 and len(E._SINGLE) == 28                 # incl. resnet18 / resnet34 (embeddings.py:112-117)
     with pytest.raises(NotImplementedError, match='Requested model not available'):
         E._get_embedding('nonexistent')
     with pytest.raises(AssertionError):

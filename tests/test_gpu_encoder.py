@@ -380,6 +380,42 @@ def test_two_lanes_in_flight_match_sequential_forwards(variant):
     assert torch.equal(m(fb), ref_b)                                   # the default entry point still works afterwards (lane 0)
 
 
+@pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
+def test_same_lane_forwards_on_different_streams_are_ordered_by_the_library(variant):
+    """A forward on the default stream followed AT ONCE (no host or stream synchronisation by the caller) by forwards on
+    non-blocking side streams that use the same workspace lane: the library chains them with its per-lane event, so the
+    workspace is never shared by two forwards in flight and every output is the sequential one.  Batch 256 keeps each
+    forward ~10 ms long, so without the chaining the side-stream forward overlaps the first one and corrupts it."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    if variant == 'conv5':
+        sd, hw = synth.resnet50_state_dict(1, 'conv5'), 256
+    else:
+        sd, hw = synth.clip_vit_state_dict(1, patch=16), 224
+    m = HipResNet50(sd, variant, compute_dtype='bf16', max_batch=256)
+    fa = torch.from_numpy(synth.frames(21, 256, hw, hw)).cuda()
+    fb = torch.from_numpy(synth.frames(22, 256, hw, hw)).cuda()
+    ref_a, ref_b = m(fa).clone(), m(fb).clone()
+    oa, ob, oc = torch.zeros_like(ref_a), torch.zeros_like(ref_b), torch.zeros_like(ref_a)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        m.forward_into(fa, oa, lane=0)                       # default stream, lane 0
+        with torch.cuda.stream(sa):
+            m.forward_into(fb, ob, lane=0)                   # side stream, same lane, nothing in between
+        with torch.cuda.stream(sb):
+            m.forward_into(fa, oc, lane=0)                   # and a third stream
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b) and torch.equal(oc, ref_a)
+    # two lanes at the full batch size, several rounds in flight before the check
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            m.forward_into(fa, oa, lane=0)
+        with torch.cuda.stream(sb):
+            m.forward_into(fb, ob, lane=1)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+
+
 def test_stream_embed_matches_batched_calls(monkeypatch):
     """Overlapped H2D / compute / D2H path returns the same rows in the same order, bit for bit."""
     from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed
