@@ -40,17 +40,52 @@ struct ChainP {
 // and on gfx950 the store then reads overwritten data - measured here as ~6000 wrong y elements per batch-256 launch
 // in the fully unrolled group loop, where the next pixel tile's packing reuses the registers immediately
 // (scripts/debug_determinism.py; the data dword clobbered was exactly the first VALU destination after the store).
+// 16-byte global -> LDS DMA of one wave: lane l lands at lds + 16*l (the LDS address must be wave-uniform), range misses write zeros
+__device__ __forceinline__ void ch_dma16(__amdgpu_buffer_rsrc_t rs, char *lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) with a compile-time n (the loops that call it are fully unrolled); also a compiler barrier for memory
+__device__ __forceinline__ void ch_wait_vmcnt(int n) {
+    {
+        switch (n) {                              // folds to one instruction once the caller's loop is unrolled
+#define CH_W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); return;
+        CH_W(0) CH_W(1) CH_W(2) CH_W(3) CH_W(4) CH_W(5) CH_W(6) CH_W(7) CH_W(8) CH_W(9) CH_W(10) CH_W(11) CH_W(12) CH_W(13) CH_W(14) CH_W(15)
+        CH_W(16) CH_W(17) CH_W(18) CH_W(19) CH_W(20) CH_W(21) CH_W(22) CH_W(23) CH_W(24) CH_W(25) CH_W(26) CH_W(27) CH_W(28) CH_W(29) CH_W(30)
+        CH_W(31) CH_W(32) CH_W(33) CH_W(34) CH_W(35) CH_W(36) CH_W(37) CH_W(38) CH_W(39) CH_W(40)
+#undef CH_W
+        default: break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
 }
 
+// Diagnostic build only (scripts/chain_stamps.hip defines CHAIN_STAMP): s_memrealtime (100 MHz) stamps per block
+#ifdef CHAIN_STAMP
+__device__ unsigned long long chain_stamps[8192][6];
+#define CH_T(i_) { if (threadIdx.x == 0) ch_tt[i_] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define CH_T(i_)
+#endif
+
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
-template <int CM, int CMN, bool F16, int RD, int OCC>
+// HALO (stride-1 blocks): phase A reads its pixels from ONE contiguous halo run of t1 held in LDS (see "phase A, halo form")
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
 __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BM = 128, BK = 64, BN = CM;
     constexpr int A_CH = BM / 32, B_CH = BN / 32, TM = 4, TN = BN / 32;
-    constexpr int STAGE = (BM + BN) * 128;
+    // halo form: KS channel slices x [HROWS][64] halo rows, then a ring of NST W2 slices [CM][64]; the last halo row is all zeros
+    // (OCC = 3, Cm = 64: 248 halo rows + a 2-stage ring = 47 KB, three blocks per CU)
+    constexpr int KS = CM / 64, HROWS = CM == 64 ? (OCC == 3 ? 248 : 256) : 192, NST = CM == 64 ? (OCC == 3 ? 2 : 4) : 2, LOOK = NST - 1;
+    constexpr int HSL = HROWS * 128, RING_OFF = KS * HSL, SLICE = CM * 128, ZERO_OFF = (HROWS - 1) * 128;
+    constexpr int HWOPS = KS * HROWS / 8;                      // wave-level DMA operations of the halo
+    constexpr int HOPS = (HWOPS + 3) / 4, SOPS = CM / 32;      // 16-byte LDS-DMA operations per thread: halo, one W2 slice
+    constexpr int STAGE = HALO ? (RING_OFF + NST * SLICE) / 2 : (BM + BN) * 128;      // 2*STAGE = bytes of the phase-A area
     constexpr int C4 = 4 * CM, G = C4 / 64, KS3 = CM / 64;     // conv3: G groups of 64 couts over KS3 K-slices
     constexpr int TN1 = CMN / 32;                              // conv1': 16-cout tiles per wave
     constexpr int W3_CH = CM / 32, W1_CH = CMN / 32;           // 16-B staging chunks per thread
@@ -58,13 +93,16 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     constexpr int T2_OFF = 0;                                  // KS3 x [128][64]
     constexpr int YG_OFF = KS3 * 16384;                        // [128][64]
     constexpr int W3_OFF = YG_OFF + 16384;                     // KS3 x [64][64]
-    constexpr int W1_IN = W3_OFF + KS3 * 8192 + CMN * 128 <= 2 * STAGE;   // the W1' slice fits the pipeline buffers too
-    constexpr int W1_OFF = W1_IN ? W3_OFF + KS3 * 8192 : 2 * STAGE;        // [CMN][64]
-    static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE, "phase-B tiles must fit the phase-A pipeline buffers");
+    constexpr int W1_OFF = W3_OFF + KS3 * 8192;                // [CMN][64]; the block's LDS is max(phase-A area, W1_OFF + CMN * 128)
+    static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE || HALO, "phase-B tiles must fit the phase-A pipeline buffers");
     static_assert(RD >= 1 && RD <= G, "residual prefetch depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CHAIN_STAMP
+    unsigned long long ch_tt[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    CH_T(0);
     const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
     const int srow = tid >> 3, pch = tid & 7;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
@@ -75,6 +113,34 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
+
+    // ---- phase A, halo form: everything phase A needs is requested before anything else ---------------------------
+    // Stride 1: output pixel m (flattened n,h,w) at tap (kh,kw) reads input pixel m + (kh-1)*W + (kw-1), so the 128 pixels of
+    // the tile need the CONTIGUOUS run of 128 + 2W + 2 rows of t1 starting at m0 - W - 1, whatever image borders it crosses;
+    // taps outside their image are redirected to a zero row at fragment-read time.  The run is fetched once by LDS-DMA (t1 is
+    // read 1.9x instead of 9x through L2) and the nine taps then run from LDS with no global load on the critical path; the
+    // W2 slices stream through a ring of NST LDS stages, LOOK slices ahead, with hand-counted vmcnt waits.
+    int w2_src[HALO ? SOPS : 1];
+    if constexpr (HALO) {
+        const int HR = 128 + 2 * p.W + 2, hbase = m0 - p.W - 1;
+#pragma unroll
+        for (int i = 0; i < HOPS; ++i) {
+            const int o = i * 4 + wave, sl = o / (HROWS / 8), rb = o % (HROWS / 8);
+            const int r = rb * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            const int vo = (r < HR && hbase + r >= 0) ? ((hbase + r) * CM + sl * 64 + c * 8) * 2 : OOB;   // past the tensor: range miss -> zeros
+            if (HWOPS % 4 == 0 || o < HWOPS) ch_dma16(rs_in, smem + sl * HSL + rb * 1024, vo, 0);       // (wave-uniform)
+        }
+#pragma unroll
+        for (int i = 0; i < SOPS; ++i) {
+            const int r = (i * 4 + wave) * 8 + (lane >> 3);
+            w2_src[i] = (r * (9 * CM) + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2;
+        }
+#pragma unroll
+        for (int kt = 0; kt < LOOK; ++kt)
+#pragma unroll
+            for (int i = 0; i < SOPS; ++i)
+                ch_dma16(rs_w2, smem + RING_OFF + kt * SLICE + (i * 4 + wave) * 1024, w2_src[i], kt * 128);
+    }
 
     // ---- phase A staging (conv_igemm.hip's scheme: one byte offset per chunk + 9-bit tap masks) ----------------
     int a_off[A_CH], a_mask[A_CH];
@@ -173,16 +239,19 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             w1_l[i] = W1_OFF + r * 128 + (q & 7) * 16;
         }
     }
-    u32x4 rres[RD][TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
-#pragma unroll
-    for (int d = 0; d < RD; ++d)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0));
-#pragma unroll
-    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));
-    if constexpr (CMN > 0) {
-#pragma unroll
-        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));
+    u32x4 rres[RD][TM], w3r[2][W3_CH], w1r[2][CMN ? W1_CH : 1];   // w3r / w1r[g & 1]: register stage of weight group g
+    constexpr int PREF_OPS = RD * TM + W3_CH + (CMN ? W1_CH : 0);   // plain loads PVR_PHASE_B_PREFETCH issues per thread
+#define PVR_PHASE_B_PREFETCH()                                                                                              \
+    {                                                                                                                       \
+        _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                                      \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                                  \
+                rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0)); \
+        _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                                   \
+            w3r[0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));             \
+        if constexpr (CMN > 0) {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < W1_CH; ++i)                                                               \
+                w1r[0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));         \
+        }                                                                                                                   \
     }
 
     // ---- phase A: conv2 3x3 as implicit GEMM, 128 pixels x CM couts, K = 9*CM --------------------------------
@@ -191,9 +260,74 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HALO) {
+        // fragment rows inside the halo run and the 9-bit "tap inside the image" mask of the lane's four pixels
+        int h_row[TM], h_mask[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int pr = wm * 64 + j * 16 + fr, m = m0 + pr;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int wo = mm % p.W, ho = (mm / p.W) % p.H;
+            int hb = 0, wb_ = 0;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                hb |= (int)(ok && (unsigned)(ho - 1 + t3) < (unsigned)p.H) << t3;
+                wb_ |= (int)((unsigned)(wo - 1 + t3) < (unsigned)p.W) << t3;
+            }
+            int mask = 0;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb_ << (t3 * 3)) : 0;
+            h_row[j] = pr; h_mask[j] = mask;
+        }
+        int w_rd[2][TN];                          // W2 fragment offsets inside a ring stage
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) w_rd[ks][i] = b_rd[ks][i] - BM * 128;
+        // VMEM issue order per thread: halo, W2 slices 0..LOOK-1 | step 0: slice LOOK, the PREF_OPS phase-B prefetches | step k: slice
+        // k+LOOK.  vmcnt retires in order, so "slice kt has landed" = at most (operations issued after it) still outstanding.
+#pragma unroll
+        for (int kt = 0; kt < nk; ++kt) {
+            const int last = kt + LOOK - 1 < nk - 1 ? kt + LOOK - 1 : nk - 1;              // newest slice issued so far
+            const int newer = kt == 0 ? (LOOK - 1) * SOPS : (last - kt) * SOPS + (kt <= LOOK ? PREF_OPS : 0);
+            ch_wait_vmcnt(newer);
+            __builtin_amdgcn_s_barrier();         // slice kt complete for every thread; every wave is done with stage (kt-1) % NST
+            if (kt + LOOK < nk) {
+#pragma unroll
+                for (int i = 0; i < SOPS; ++i)
+                    ch_dma16(rs_w2, smem + RING_OFF + ((kt + LOOK) % NST) * SLICE + (i * 4 + wave) * 1024, w2_src[i], (kt + LOOK) * 128);
+            }
+            if (kt == 0) { PVR_PHASE_B_PREFETCH(); CH_T(1); }
+            const int tp = kt / KS, csl = kt % KS, shift = (tp / 3) * p.W + tp % 3;
+            int xo[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = h_row[j] + shift;
+                const int a = csl * HSL + r * 128 + ((fq ^ ((r >> 1) & 7)) << 4);
+                xo[j] = ((h_mask[j] >> tp) & 1) ? a : ZERO_OFF;
+            }
+            const char *ring = smem + RING_OFF + (kt % NST) * SLICE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                V8 xa[TM], wb[TN];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(smem + (xo[j] ^ (ks * 64)));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(ring + w_rd[ks][i]);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc2[i][j] = mfma16<F16>(wb[i], xa[j], acc2[i][j]);
+            }
+        }
+        __syncthreads();                          // every wave is done with the halo and the ring: t2 overlays them
+    } else {
+    PVR_PHASE_B_PREFETCH();
     PVR_LOAD_SLICE(0);
     PVR_STORE_SLICE(0);
     __syncthreads();
+    CH_T(1);
 #define PVR_K_STEP(kt_, CUR_)                                                                           \
     {                                                                                                   \
         const bool more = (kt_) + 1 < nk;                                                               \
@@ -213,9 +347,12 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         PVR_K_STEP(kt, 0);
         if (kt + 1 < nk) PVR_K_STEP(kt + 1, 1);
     }
+    }
+    CH_T(2);
 #undef PVR_K_STEP
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
+#undef PVR_PHASE_B_PREFETCH
 
     // t2 = relu(acc2 + b2) -> 16-bit -> LDS [pixel][cout] (every wave is past the loop's last barrier)
 #pragma unroll
@@ -235,21 +372,22 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     }
     // first W3 group / W1' slice -> LDS
 #pragma unroll
-    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[0][i];
     if constexpr (CMN > 0) {
 #pragma unroll
-        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[0][i];
     }
     if (G > 1) {
 #pragma unroll
         for (int i = 0; i < W3_CH; ++i)
-            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
+            w3r[1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
         if constexpr (CMN > 0) {
 #pragma unroll
-            for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
+            for (int i = 0; i < W1_CH; ++i) w1r[1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
         }
     }
     __syncthreads();
+    CH_T(3);
 
     // ---- phase B ---------------------------------------------------------------------------------------------
     int w3_rd[2][2], w1_rd[2][CMN ? TN1 : 1], yg_wr[TM];
@@ -303,38 +441,50 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wb[t], xa[j], acc3[t][j]);
             }
+        // Program order of the group's VMEM operations: loads first (weight groups g+2 into the free register stage, the residual
+        // refill), the y stores last.  (hipcc still waits with vmcnt(0) wherever loads and stores are both outstanding - gfx9 lets
+        // them retire out of order with respect to each other - so this ordering measured the same as loads-after-stores; the
+        // launch is at the HBM read+write ceiling of this access pattern either way)
+        if (g + 2 < G) {
+#pragma unroll
+            for (int i = 0; i < W3_CH; ++i)
+                w3r[g & 1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
+            if constexpr (CMN > 0) {
+#pragma unroll
+                for (int i = 0; i < W1_CH; ++i)
+                    w1r[g & 1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
+            }
+        }
         // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane -> 16-B global store + 16-B LDS write
         const int c0 = g * 64 + wn * 32 + fq * 8;
         const float4 bA = *reinterpret_cast<const float4 *>(p.b3 + c0), bB = *reinterpret_cast<const float4 *>(p.b3 + c0 + 4);
+        u32x4 yo[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const f32x4 lo = acc3[0][j], hi = acc3[1][j];
             float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
             const u32x4 r = rres[g % RD][j];
-            u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
                 const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
-                o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                yo[j][e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
             }
-            store_b128_imm(o, rs_y, y_off[j], g * 128);
-            if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
         if (g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
                 rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + RD) * 128, 0));
         }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            store_b128_imm(yo[j], rs_y, y_off[j], g * 128);
+            if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = yo[j];
+        }
         __syncthreads();                          // y group visible; every wave is done with this W3 group
         if (g + 1 < G) {
 #pragma unroll
-            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
-            if (g + 2 < G) {
-#pragma unroll
-                for (int i = 0; i < W3_CH; ++i)
-                    w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
-            }
+            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[(g + 1) & 1][i];
         }
         if constexpr (CMN == 0) __syncthreads();  // next W3 group visible (the conv1' path has its own barrier below)
         if constexpr (CMN > 0) {
@@ -354,16 +504,12 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             __syncthreads();                      // every wave is done with the y group and this W1' slice
             if (g + 1 < G) {
 #pragma unroll
-                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
-                if (g + 2 < G) {
-#pragma unroll
-                    for (int i = 0; i < W1_CH; ++i)
-                        w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
-                }
+                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[(g + 1) & 1][i];
             }
         }
     }
 
+    CH_T(4);
     if constexpr (CMN > 0) {
         // t1' = relu(acc1 + b1'): tile pair (2q, 2q+1) = 8 consecutive couts per lane
 #pragma unroll
@@ -382,22 +528,43 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             }
         }
     }
+#ifdef CHAIN_STAMP
+    CH_T(5);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { _Pragma("unroll") for (int k = 0; k < 6; ++k) chain_stamps[blockIdx.x][k] = ch_tt[k]; }
+#endif
+}
+
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
+static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
+    const int grid = (p.M + 127) / 128;
+    const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? (OCC == 3 ? 248 : 256) : 192) * 128 + (size_t)(CM == 64 ? (OCC == 3 ? 2 : 4) : 2) * CM * 128
+                             : (size_t)2 * (128 + CM) * 128;
+    const size_t phase_b = (CM / 64) * 16384 + 16384 + (CM / 64) * 8192 + CMN * 128;      // t2, y group, W3 group, W1' slice
+    const size_t lds = phase_b <= pipe ? pipe : phase_b;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO>), dim3(grid), dim3(256), lds, stream, p);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// PVR_CHAIN_HALO=0 keeps every block on the per-tap global-load form of phase A (A/B runs; both forms are bit-identical)
+static bool chain_halo_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_CHAIN_HALO"); v = e ? atoi(e) : 1; }
+    return v != 0;
 }
 
 template <int CM, int CMN, bool F16, int RD, int OCC>
 static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
-    const int grid = (p.M + 127) / 128;
-    const size_t pipe = 2 * (128 + CM) * 128, inpipe = (CM / 64) * 16384 + 16384 + (CM / 64) * 8192 + CMN * 128;
-    const size_t lds = inpipe <= pipe ? pipe : pipe + CMN * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC>), dim3(grid), dim3(256), lds, stream, p);
-    PVR_LAUNCH_CHECK();
-    return PVR_OK;
+    // halo form: stride 1 and the 128 + 2W + 2 halo rows (+ the zero row) fit the LDS tile
+    if (p.stride == 1 && 128 + 2 * p.W + 2 <= (CM == 64 ? 248 : 192) - 1 && chain_halo_enabled())
+        return launch_chain_one<CM, CMN, F16, RD, OCC, true>(p, stream);
+    return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
 }
 
 // tuning knob for A/B runs: PVR_CHAIN_CFG = 10*RD + OCC for the Cm = 64 instances (default 12: measured best, profiles/experiments)
