@@ -40,28 +40,10 @@ struct ChainP {
 // and on gfx950 the store then reads overwritten data - measured here as ~6000 wrong y elements per batch-256 launch
 // in the fully unrolled group loop, where the next pixel tile's packing reuses the registers immediately
 // (scripts/debug_determinism.py; the data dword clobbered was exactly the first VALU destination after the store).
-// 16-byte global -> LDS DMA of one wave: lane l lands at lds + 16*l (the LDS address must be wave-uniform), range misses write zeros
+// 16-byte global -> LDS DMA of one wave: lane l lands at lds + 16*l (the LDS address must be wave-uniform), range misses write zeros.
+// (A __device__ helper, not a direct builtin call in the kernel template: hipcc's host pass silently drops the kernel stub otherwise.)
 __device__ __forceinline__ void ch_dma16(__amdgpu_buffer_rsrc_t rs, char *lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
-}
-
-// s_waitcnt vmcnt(n) with a compile-time n (the loops that call it are fully unrolled); also a compiler barrier for memory
-__device__ __forceinline__ void ch_wait_vmcnt(int n) {
-    {
-        switch (n) {                              // folds to one instruction once the caller's loop is unrolled
-#define CH_W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); return;
-        CH_W(0) CH_W(1) CH_W(2) CH_W(3) CH_W(4) CH_W(5) CH_W(6) CH_W(7) CH_W(8) CH_W(9) CH_W(10) CH_W(11) CH_W(12) CH_W(13) CH_W(14) CH_W(15)
-        CH_W(16) CH_W(17) CH_W(18) CH_W(19) CH_W(20) CH_W(21) CH_W(22) CH_W(23) CH_W(24) CH_W(25) CH_W(26) CH_W(27) CH_W(28) CH_W(29) CH_W(30)
-        CH_W(31) CH_W(32) CH_W(33) CH_W(34) CH_W(35) CH_W(36) CH_W(37) CH_W(38) CH_W(39) CH_W(40)
-#undef CH_W
-        default: break;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
 }
 
 // Diagnostic build only (scripts/chain_stamps.hip defines CHAIN_STAMP): s_memrealtime (100 MHz) stamps per block
@@ -72,6 +54,10 @@ __device__ unsigned long long chain_stamps[8192][6];
 #define CH_T(i_)
 #endif
 
+__device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
+}
+
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
 // HALO (stride-1 blocks): phase A reads its pixels from ONE contiguous halo run of t1 held in LDS (see "phase A, halo form")
 template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
@@ -79,13 +65,12 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BM = 128, BK = 64, BN = CM;
     constexpr int A_CH = BM / 32, B_CH = BN / 32, TM = 4, TN = BN / 32;
-    // halo form: KS channel slices x [HROWS][64] halo rows, then a ring of NST W2 slices [CM][64]; the last halo row is all zeros
-    // (OCC = 3, Cm = 64: 248 halo rows + a 2-stage ring = 47 KB, three blocks per CU)
-    constexpr int KS = CM / 64, HROWS = CM == 64 ? (OCC == 3 ? 248 : 256) : 192, NST = CM == 64 ? (OCC == 3 ? 2 : 4) : 2, LOOK = NST - 1;
+    // halo form: KS channel slices x [HROWS][64] halo rows (the last row all zeros), then two W2 stages [CM][64]; RL register
+    // stages of W2 slices in flight ahead of them
+    constexpr int KS = CM / 64, HROWS = CM == 64 ? 256 : 192, RL = CM == 64 ? 3 : 2;
     constexpr int HSL = HROWS * 128, RING_OFF = KS * HSL, SLICE = CM * 128, ZERO_OFF = (HROWS - 1) * 128;
-    constexpr int HWOPS = KS * HROWS / 8;                      // wave-level DMA operations of the halo
-    constexpr int HOPS = (HWOPS + 3) / 4, SOPS = CM / 32;      // 16-byte LDS-DMA operations per thread: halo, one W2 slice
-    constexpr int STAGE = HALO ? (RING_OFF + NST * SLICE) / 2 : (BM + BN) * 128;      // 2*STAGE = bytes of the phase-A area
+    constexpr int HOPS = KS * HROWS / 32;                      // 16-byte LDS-DMA operations per thread for the halo
+    constexpr int STAGE = HALO ? (RING_OFF + 2 * SLICE) / 2 : (BM + BN) * 128;        // 2*STAGE = bytes of the phase-A area
     constexpr int C4 = 4 * CM, G = C4 / 64, KS3 = CM / 64;     // conv3: G groups of 64 couts over KS3 K-slices
     constexpr int TN1 = CMN / 32;                              // conv1': 16-cout tiles per wave
     constexpr int W3_CH = CM / 32, W1_CH = CMN / 32;           // 16-B staging chunks per thread
@@ -94,7 +79,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     constexpr int YG_OFF = KS3 * 16384;                        // [128][64]
     constexpr int W3_OFF = YG_OFF + 16384;                     // KS3 x [64][64]
     constexpr int W1_OFF = W3_OFF + KS3 * 8192;                // [CMN][64]; the block's LDS is max(phase-A area, W1_OFF + CMN * 128)
-    static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE || HALO, "phase-B tiles must fit the phase-A pipeline buffers");
+    static_assert(W3_OFF + KS3 * 8192 <= 2 * STAGE, "phase-B tiles must fit the phase-A area");
     static_assert(RD >= 1 && RD <= G, "residual prefetch depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -114,13 +99,11 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
 
-    // ---- phase A, halo form: everything phase A needs is requested before anything else ---------------------------
+    // ---- phase A, halo form: the pixels phase A needs are requested before anything else ---------------------------------
     // Stride 1: output pixel m (flattened n,h,w) at tap (kh,kw) reads input pixel m + (kh-1)*W + (kw-1), so the 128 pixels of
     // the tile need the CONTIGUOUS run of 128 + 2W + 2 rows of t1 starting at m0 - W - 1, whatever image borders it crosses;
-    // taps outside their image are redirected to a zero row at fragment-read time.  The run is fetched once by LDS-DMA (t1 is
-    // read 1.9x instead of 9x through L2) and the nine taps then run from LDS with no global load on the critical path; the
-    // W2 slices stream through a ring of NST LDS stages, LOOK slices ahead, with hand-counted vmcnt waits.
-    int w2_src[HALO ? SOPS : 1];
+    // taps outside their image are redirected to a zero row at fragment-read time.  The run is fetched ONCE by LDS-DMA (t1 is
+    // read 1.9x instead of 9x through L2) and the nine taps then run from LDS with no pixel load on the critical path.
     if constexpr (HALO) {
         const int HR = 128 + 2 * p.W + 2, hbase = m0 - p.W - 1;
 #pragma unroll
@@ -128,18 +111,8 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             const int o = i * 4 + wave, sl = o / (HROWS / 8), rb = o % (HROWS / 8);
             const int r = rb * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
             const int vo = (r < HR && hbase + r >= 0) ? ((hbase + r) * CM + sl * 64 + c * 8) * 2 : OOB;   // past the tensor: range miss -> zeros
-            if (HWOPS % 4 == 0 || o < HWOPS) ch_dma16(rs_in, smem + sl * HSL + rb * 1024, vo, 0);       // (wave-uniform)
+            ch_dma16(rs_in, smem + sl * HSL + rb * 1024, vo, 0);
         }
-#pragma unroll
-        for (int i = 0; i < SOPS; ++i) {
-            const int r = (i * 4 + wave) * 8 + (lane >> 3);
-            w2_src[i] = (r * (9 * CM) + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2;
-        }
-#pragma unroll
-        for (int kt = 0; kt < LOOK; ++kt)
-#pragma unroll
-            for (int i = 0; i < SOPS; ++i)
-                ch_dma16(rs_w2, smem + RING_OFF + kt * SLICE + (i * 4 + wave) * 1024, w2_src[i], kt * 128);
     }
 
     // ---- phase A staging (conv_igemm.hip's scheme: one byte offset per chunk + 9-bit tap masks) ----------------
@@ -239,19 +212,16 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             w1_l[i] = W1_OFF + r * 128 + (q & 7) * 16;
         }
     }
-    u32x4 rres[RD][TM], w3r[2][W3_CH], w1r[2][CMN ? W1_CH : 1];   // w3r / w1r[g & 1]: register stage of weight group g
-    constexpr int PREF_OPS = RD * TM + W3_CH + (CMN ? W1_CH : 0);   // plain loads PVR_PHASE_B_PREFETCH issues per thread
-#define PVR_PHASE_B_PREFETCH()                                                                                              \
-    {                                                                                                                       \
-        _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                                      \
-            _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                                  \
-                rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0)); \
-        _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                                   \
-            w3r[0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));             \
-        if constexpr (CMN > 0) {                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < W1_CH; ++i)                                                               \
-                w1r[0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));         \
-        }                                                                                                                   \
+    u32x4 rres[RD][TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
+#pragma unroll
+    for (int d = 0; d < RD; ++d)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0));
+#pragma unroll
+    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));
+    if constexpr (CMN > 0) {
+#pragma unroll
+        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));
     }
 
     // ---- phase A: conv2 3x3 as implicit GEMM, 128 pixels x CM couts, K = 9*CM --------------------------------
@@ -261,6 +231,20 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (HALO) {
+        // W2 slices: global -> registers RL slices ahead -> LDS stage one slice ahead (plain loads: hipcc counts their vmcnt; no
+        // store is in flight in phase A, so they retire in order).  The halo DMA is waited for ONCE, with vmcnt(0), a barrier and
+        // the address set-up below between that wait and the first fragment read.
+        u32x4 w2r[RL][B_CH];
+#pragma unroll
+        for (int q = 0; q < RL; ++q)
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i)
+                w2r[q][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, b_off[i], q * (BK * 2), 0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(smem + RING_OFF + lds_st + i * 32 * 128) = w2r[0][i];
+        __syncthreads();                          // halo (every wave waited for its own DMA operations) and W2 slice 0 visible
+        CH_T(1);
         // fragment rows inside the halo run and the 9-bit "tap inside the image" mask of the lane's four pixels
         int h_row[TM], h_mask[TM];
 #pragma unroll
@@ -280,25 +264,13 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb_ << (t3 * 3)) : 0;
             h_row[j] = pr; h_mask[j] = mask;
         }
-        int w_rd[2][TN];                          // W2 fragment offsets inside a ring stage
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TN; ++i) w_rd[ks][i] = b_rd[ks][i] - BM * 128;
-        // VMEM issue order per thread: halo, W2 slices 0..LOOK-1 | step 0: slice LOOK, the PREF_OPS phase-B prefetches | step k: slice
-        // k+LOOK.  vmcnt retires in order, so "slice kt has landed" = at most (operations issued after it) still outstanding.
 #pragma unroll
         for (int kt = 0; kt < nk; ++kt) {
-            const int last = kt + LOOK - 1 < nk - 1 ? kt + LOOK - 1 : nk - 1;              // newest slice issued so far
-            const int newer = kt == 0 ? (LOOK - 1) * SOPS : (last - kt) * SOPS + (kt <= LOOK ? PREF_OPS : 0);
-            ch_wait_vmcnt(newer);
-            __builtin_amdgcn_s_barrier();         // slice kt complete for every thread; every wave is done with stage (kt-1) % NST
-            if (kt + LOOK < nk) {
+            if (kt + RL < nk) {                   // register stage kt % RL held slice kt, which reached LDS during step kt - 1
 #pragma unroll
-                for (int i = 0; i < SOPS; ++i)
-                    ch_dma16(rs_w2, smem + RING_OFF + ((kt + LOOK) % NST) * SLICE + (i * 4 + wave) * 1024, w2_src[i], (kt + LOOK) * 128);
+                for (int i = 0; i < B_CH; ++i)
+                    w2r[kt % RL][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, b_off[i], (kt + RL) * (BK * 2), 0));
             }
-            if (kt == 0) { PVR_PHASE_B_PREFETCH(); CH_T(1); }
             const int tp = kt / KS, csl = kt % KS, shift = (tp / 3) * p.W + tp % 3;
             int xo[TM];
 #pragma unroll
@@ -307,23 +279,27 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                 const int a = csl * HSL + r * 128 + ((fq ^ ((r >> 1) & 7)) << 4);
                 xo[j] = ((h_mask[j] >> tp) & 1) ? a : ZERO_OFF;
             }
-            const char *ring = smem + RING_OFF + (kt % NST) * SLICE;
+            const char *ring = smem + RING_OFF + (kt & 1) * SLICE - BM * 128;     // (b_rd carries the per-tap form's BM*128 base)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 V8 xa[TM], wb[TN];
 #pragma unroll
                 for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(smem + (xo[j] ^ (ks * 64)));
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(ring + w_rd[ks][i]);
+                for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(ring + b_rd[ks][i]);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc2[i][j] = mfma16<F16>(wb[i], xa[j], acc2[i][j]);
             }
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i)
+                    *reinterpret_cast<u32x4 *>(smem + RING_OFF + ((kt + 1) & 1) * SLICE + lds_st + i * 32 * 128) = w2r[(kt + 1) % RL][i];
+            }
+            __syncthreads();                      // slice kt + 1 visible; every wave is done with stage kt & 1 (and, at the end, the halo)
         }
-        __syncthreads();                          // every wave is done with the halo and the ring: t2 overlays them
     } else {
-    PVR_PHASE_B_PREFETCH();
     PVR_LOAD_SLICE(0);
     PVR_STORE_SLICE(0);
     __syncthreads();
@@ -352,7 +328,6 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #undef PVR_K_STEP
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
-#undef PVR_PHASE_B_PREFETCH
 
     // t2 = relu(acc2 + b2) -> 16-bit -> LDS [pixel][cout] (every wave is past the loop's last barrier)
 #pragma unroll
@@ -372,18 +347,18 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     }
     // first W3 group / W1' slice -> LDS
 #pragma unroll
-    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[0][i];
+    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
     if constexpr (CMN > 0) {
 #pragma unroll
-        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[0][i];
+        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
     }
     if (G > 1) {
 #pragma unroll
         for (int i = 0; i < W3_CH; ++i)
-            w3r[1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
+            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
         if constexpr (CMN > 0) {
 #pragma unroll
-            for (int i = 0; i < W1_CH; ++i) w1r[1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
+            for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
         }
     }
     __syncthreads();
@@ -441,50 +416,38 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wb[t], xa[j], acc3[t][j]);
             }
-        // Program order of the group's VMEM operations: loads first (weight groups g+2 into the free register stage, the residual
-        // refill), the y stores last.  (hipcc still waits with vmcnt(0) wherever loads and stores are both outstanding - gfx9 lets
-        // them retire out of order with respect to each other - so this ordering measured the same as loads-after-stores; the
-        // launch is at the HBM read+write ceiling of this access pattern either way)
-        if (g + 2 < G) {
-#pragma unroll
-            for (int i = 0; i < W3_CH; ++i)
-                w3r[g & 1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
-            if constexpr (CMN > 0) {
-#pragma unroll
-                for (int i = 0; i < W1_CH; ++i)
-                    w1r[g & 1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
-            }
-        }
         // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane -> 16-B global store + 16-B LDS write
         const int c0 = g * 64 + wn * 32 + fq * 8;
         const float4 bA = *reinterpret_cast<const float4 *>(p.b3 + c0), bB = *reinterpret_cast<const float4 *>(p.b3 + c0 + 4);
-        u32x4 yo[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const f32x4 lo = acc3[0][j], hi = acc3[1][j];
             float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
             const u32x4 r = rres[g % RD][j];
+            u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
                 const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
-                yo[j][e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
             }
+            store_b128_imm(o, rs_y, y_off[j], g * 128);
+            if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
         if (g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
                 rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + RD) * 128, 0));
         }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            store_b128_imm(yo[j], rs_y, y_off[j], g * 128);
-            if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = yo[j];
-        }
         __syncthreads();                          // y group visible; every wave is done with this W3 group
         if (g + 1 < G) {
 #pragma unroll
-            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[(g + 1) & 1][i];
+            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+            if (g + 2 < G) {
+#pragma unroll
+                for (int i = 0; i < W3_CH; ++i)
+                    w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
+            }
         }
         if constexpr (CMN == 0) __syncthreads();  // next W3 group visible (the conv1' path has its own barrier below)
         if constexpr (CMN > 0) {
@@ -504,7 +467,12 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             __syncthreads();                      // every wave is done with the y group and this W1' slice
             if (g + 1 < G) {
 #pragma unroll
-                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[(g + 1) & 1][i];
+                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+                if (g + 2 < G) {
+#pragma unroll
+                    for (int i = 0; i < W1_CH; ++i)
+                        w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
+                }
             }
         }
     }
@@ -537,8 +505,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
 static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const int grid = (p.M + 127) / 128;
-    const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? (OCC == 3 ? 248 : 256) : 192) * 128 + (size_t)(CM == 64 ? (OCC == 3 ? 2 : 4) : 2) * CM * 128
-                             : (size_t)2 * (128 + CM) * 128;
+    const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? 256 : 192) * 128 + (size_t)2 * CM * 128 : (size_t)2 * (128 + CM) * 128;
     const size_t phase_b = (CM / 64) * 16384 + 16384 + (CM / 64) * 8192 + CMN * 128;      // t2, y group, W3 group, W1' slice
     const size_t lds = phase_b <= pipe ? pipe : phase_b;
     static bool attr_done = false;
@@ -562,8 +529,8 @@ static bool chain_halo_enabled() {
 template <int CM, int CMN, bool F16, int RD, int OCC>
 static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
     // halo form: stride 1 and the 128 + 2W + 2 halo rows (+ the zero row) fit the LDS tile
-    if (p.stride == 1 && 128 + 2 * p.W + 2 <= (CM == 64 ? 248 : 192) - 1 && chain_halo_enabled())
-        return launch_chain_one<CM, CMN, F16, RD, OCC, true>(p, stream);
+    if (p.stride == 1 && 128 + 2 * p.W + 2 <= (CM == 64 ? 256 : 192) - 1 && chain_halo_enabled())
+        return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
     return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
 }
 

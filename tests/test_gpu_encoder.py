@@ -6,6 +6,7 @@ Tolerances (stated per SURVEY D6 / BASELINE north_star):
   * bf16 "throughput mode": measured, asserted <= 1e-2 (bf16 has eps 2^-8; 53 layers)
 """
 import ctypes as C
+import os
 import numpy as np
 import pytest
 import torch
@@ -414,6 +415,29 @@ def test_same_lane_forwards_on_different_streams_are_ordered_by_the_library(vari
             m.forward_into(fb, ob, lane=1)
     torch.cuda.synchronize()
     assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+
+
+def test_second_process_loading_the_gpu_does_not_change_results():
+    """Another PROCESS keeps the GPU busy with batch-256 forwards on two lanes while this one repeats its own forward: every
+    embedding must stay bit-identical to the quiet reference.  (Memory latencies several times longer than in a quiet run
+    are what exposed the hand-counted LDS-DMA ring of the first halo-form bottleneck kernel)"""
+    import subprocess, sys, time
+    from pvr_habitat_amd.embeddings import HipResNet50
+    m = HipResNet50(synth.resnet50_state_dict(1, 'conv5'), 'conv5', compute_dtype='bf16', max_batch=256)
+    fr = torch.from_numpy(synth.frames(1, 256, 256, 256)).cuda()
+    ref = m(fr).clone()
+    torch.cuda.synchronize()
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts', 'stress_two_proc.py')
+    child = subprocess.Popen([sys.executable, script, 'noise', '14'])
+    try:
+        time.sleep(6)                                   # the child's imports and weight upload
+        n, bad = 0, 0
+        while child.poll() is None and n < 3000:
+            bad += int(not torch.equal(m(fr), ref))
+            n += 1
+    finally:
+        child.wait(timeout=120)
+    assert child.returncode == 0 and n > 50 and bad == 0, (n, bad)
 
 
 def test_stream_embed_matches_batched_calls(monkeypatch):
