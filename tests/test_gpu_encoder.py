@@ -417,14 +417,19 @@ def test_same_lane_forwards_on_different_streams_are_ordered_by_the_library(vari
     assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
 
 
-def test_second_process_loading_the_gpu_does_not_change_results():
+@pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
+def test_second_process_loading_the_gpu_does_not_change_results(variant):
     """Another PROCESS keeps the GPU busy with batch-256 forwards on two lanes while this one repeats its own forward: every
     embedding must stay bit-identical to the quiet reference.  (Memory latencies several times longer than in a quiet run
     are what exposed the hand-counted LDS-DMA ring of the first halo-form bottleneck kernel)"""
     import subprocess, sys, time
     from pvr_habitat_amd.embeddings import HipResNet50
-    m = HipResNet50(synth.resnet50_state_dict(1, 'conv5'), 'conv5', compute_dtype='bf16', max_batch=256)
-    fr = torch.from_numpy(synth.frames(1, 256, 256, 256)).cuda()
+    if variant == 'conv5':
+        m = HipResNet50(synth.resnet50_state_dict(1, 'conv5'), 'conv5', compute_dtype='bf16', max_batch=256)
+        fr = torch.from_numpy(synth.frames(1, 256, 256, 256)).cuda()
+    else:                                                # every linear layer of the ViT plan runs on conv_pp256 (LDS-DMA ping-pong)
+        m = HipResNet50(synth.clip_vit_state_dict(1, patch=16), 'clip_b16', compute_dtype='bf16', max_batch=256)
+        fr = torch.from_numpy(synth.frames(1, 256, 224, 224)).cuda()
     ref = m(fr).clone()
     torch.cuda.synchronize()
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts', 'stress_two_proc.py')
