@@ -321,11 +321,31 @@ class UberModel(nn.Module):
         for m in self.models:
             m.set_crop(pos)
 
+    SMALL_BATCH = 16                  # at or below this many frames a member network leaves most of the GPU idle
+
     def forward_into(self, frames_u8, out, lane=0):
-        col = 0
+        """Members write their column blocks of `out`.  Small batches (online evaluation, EmbeddingWrapper: a handful of frames
+        per call) run the members CONCURRENTLY on side streams forked from / joined to the caller's stream - each member is its
+        own encoder with its own workspace; large batches run them one after the other (each already fills the GPU)."""
+        cols, col = [], 0
         for m in self.models:
-            m.forward_into(frames_u8, out[:, col:col + m.out_size], lane=lane)
+            cols.append((m, col))
             col += m.out_size
+        if frames_u8.shape[0] > self.SMALL_BATCH or len(self.models) == 1:
+            for m, c in cols:
+                m.forward_into(frames_u8, out[:, c:c + m.out_size], lane=lane)
+            return
+        cur = torch.cuda.current_stream()
+        if getattr(self, '_side', None) is None:
+            self._side = [torch.cuda.Stream() for _ in self.models[1:]]
+        for (m, c), st in zip(cols[1:], self._side):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                m.forward_into(frames_u8, out[:, c:c + m.out_size], lane=lane)
+        m, c = cols[0]
+        m.forward_into(frames_u8, out[:, c:c + m.out_size], lane=lane)
+        for st in self._side:
+            cur.wait_stream(st)
 
     def forward(self, frames_u8):
         out = torch.empty((frames_u8.shape[0], self.out_size), dtype=torch.float32, device=frames_u8.device)

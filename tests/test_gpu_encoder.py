@@ -270,6 +270,12 @@ def test_embeddingnet_surface_and_uber(monkeypatch):
     one = net(torch.from_numpy(fr[:1]))
     assert one.shape == (6262,)                                        # .squeeze() of N=1
     np.testing.assert_array_equal(one, out[0])                         # batch-size invariance, bit-exact
+    # small batches run the three members concurrently on side streams, larger ones one after the other: same bits
+    big = np.concatenate([fr] * 10)                                    # 20 frames > UberModel.SMALL_BATCH, 3 chunks of max_batch 8
+    assert big.shape[0] > net.embedding.SMALL_BATCH
+    np.testing.assert_array_equal(net(torch.from_numpy(big))[:2], out)
+    for _ in range(20):                                                # repeated small calls (the online-evaluation pattern)
+        np.testing.assert_array_equal(net(torch.from_numpy(fr)), out)
     # 6-channel observations: all current frames first, then all goal frames
     net1 = EmbeddingNet('resnet50', pretrained=False)
     obs = np.concatenate([fr, fr[::-1]], axis=3)                       # (2,64,64,6)
