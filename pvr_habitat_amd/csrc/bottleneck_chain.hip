@@ -48,7 +48,7 @@ __device__ __forceinline__ void ch_dma16(__amdgpu_buffer_rsrc_t rs, char *lds, i
 
 // Diagnostic build only (scripts/chain_stamps.hip defines CHAIN_STAMP): s_memrealtime (100 MHz) stamps per block
 #ifdef CHAIN_STAMP
-__device__ unsigned long long chain_stamps[8192][6];
+__device__ unsigned long long chain_stamps[8192][12];
 #define CH_T(i_) { if (threadIdx.x == 0) ch_tt[i_] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define CH_T(i_)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CHAIN_STAMP
-    unsigned long long ch_tt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ch_tt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     CH_T(0);
     const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+        if (g == 1) CH_T(6);
         // conv3 group: 128 pixels x 64 couts, K = CM
         f32x4 acc3[2][TM];
 #pragma unroll
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wb[t], xa[j], acc3[t][j]);
             }
+        if (g == 1) CH_T(7);
         // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane -> 16-B global store + 16-B LDS write
         const int c0 = g * 64 + wn * 32 + fq * 8;
         const float4 bA = *reinterpret_cast<const float4 *>(p.b3 + c0), bB = *reinterpret_cast<const float4 *>(p.b3 + c0 + 4);
@@ -439,7 +441,9 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             for (int j = 0; j < TM; ++j)
                 rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + RD) * 128, 0));
         }
+        if (g == 1) CH_T(8);
         __syncthreads();                          // y group visible; every wave is done with this W3 group
+        if (g == 1) CH_T(9);
         if (g + 1 < G) {
 #pragma unroll
             for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                     w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
             }
         }
+        if (g == 1) CH_T(10);
         if constexpr (CMN == 0) __syncthreads();  // next W3 group visible (the conv1' path has its own barrier below)
         if constexpr (CMN > 0) {
             // t1' += y_group x W1'[:, group]  (K = 64)
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                     for (int j = 0; j < TM; ++j) acc1[i][j] = mfma16<F16>(wb[i], xa[j], acc1[i][j]);
             }
             __syncthreads();                      // every wave is done with the y group and this W1' slice
+            if (g == 1) CH_T(11);
             if (g + 1 < G) {
 #pragma unroll
                 for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     }
 #ifdef CHAIN_STAMP
     CH_T(5);
-    if (threadIdx.x == 0 && blockIdx.x < 8192) { _Pragma("unroll") for (int k = 0; k < 6; ++k) chain_stamps[blockIdx.x][k] = ch_tt[k]; }
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { _Pragma("unroll") for (int k = 0; k < 12; ++k) chain_stamps[blockIdx.x][k] = ch_tt[k]; }
 #endif
 }
 

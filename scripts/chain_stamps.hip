@@ -30,12 +30,12 @@ int main(int argc, char **argv) {
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const int grid = (int)((px + 127) / 128), nb = std::min(grid, 8192);
-    std::vector<unsigned long long> st((size_t)8192 * 6);
+    std::vector<unsigned long long> st((size_t)8192 * 12);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(pvr::chain_stamps), st.size() * 8);
     double seg[5] = {0, 0, 0, 0, 0}, tot = 0;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int b_ = 0; b_ < nb; ++b_) {
-        const unsigned long long *q = &st[(size_t)b_ * 6];
+        const unsigned long long *q = &st[(size_t)b_ * 12];
         for (int k = 0; k < 5; ++k) seg[k] += (double)(q[k + 1] - q[k]);
         tot += (double)(q[5] - q[0]); tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[5]);
     }
@@ -43,5 +43,10 @@ int main(int argc, char **argv) {
     const char *nm[5] = {"prologue (addresses, first slice -> LDS)", "phase A loop (conv2 3x3)", "t2 -> LDS, W3/W1' -> LDS, barrier", "phase B loop (conv3 + res + y, conv1')", "t1' epilogue"};
     for (int k = 0; k < 5; ++k) printf("  %-44s %7.2f us  (%4.1f %%)\n", nm[k], seg[k] / nb / 100.0, 100.0 * seg[k] / tot);
     printf("  block total %.2f us\n", tot / nb / 100.0);
+    // one steady-state 64-channel group (g = 1) of phase B
+    const char *gn[5] = {"conv3 MFMAs issued", "epilogue: bias + residual + y stores + y -> LDS, residual refill issued", "barrier 1", "W3[g+1] regs -> LDS (waits for the loads: vmcnt(0)), W3[g+2] loads issued", "conv1' MFMAs + barrier 2"};
+    double gs[5] = {0, 0, 0, 0, 0};
+    for (int b_ = 0; b_ < nb; ++b_) { const unsigned long long *q = &st[(size_t)b_ * 12]; for (int k = 0; k < 5; ++k) gs[k] += (double)(q[7 + k] - q[6 + k]); }
+    for (int k = 0; k < 5; ++k) printf("    group 1: %-84s %6.2f us\n", gn[k], gs[k] / nb / 100.0);
     return 0;
 }
