@@ -278,7 +278,9 @@ def main():
     cap = 128
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
     conv_ms, conv_fl, other_ms = 0.0, 0.0, 0.0
-    algo_bytes = conv_algorithmic_bytes(chunk, [nm for nm in model.op_names()] if args.dtype != 'f32' else None)
+    plan_names = [nm for nm in model.op_names()]
+    algo_bytes = conv_algorithmic_bytes(chunk, plan_names if args.dtype != 'f32' else None)
+    grp = {}                                                 # per ResNet stage: [ms, flops, algorithmic bytes] of its conv launches
     reps = 3
     for _ in range(reps):
         _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(frames.data_ptr()), chunk, args.frame, args.frame,
@@ -287,8 +289,17 @@ def main():
         for i in range(n_ops.value):
             if i >= 3 and op_fl[i] > 0:
                 conv_ms += op_ms[i]; conv_fl += op_fl[i]
+                if args.dtype != 'f32' and i - 3 < len(plan_names):
+                    g = grp.setdefault(plan_names[i - 3].split('.')[0], [0.0, 0.0, 0.0])
+                    g[0] += op_ms[i]; g[1] += op_fl[i]; g[2] += conv_algorithmic_bytes(chunk, [plan_names[i - 3]])
             else:
                 other_ms += op_ms[i]
+    # every stage against BOTH roofs: layer1 / layer2 (fused tails, 16-bit NHWC activations) sit on the HBM roof,
+    # layer3 / layer4 (deep-K implicit GEMMs) on the MFMA roof
+    stages = {k: {'ms': round(v[0] / reps, 3), 'TFLOPs': round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                  'frac_mfma': round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 3),
+                  'algorithmic_GBps': round(v[2] / (v[0] * 1e-3) / 1e9, 1), 'frac_hbm': round(v[2] / (v[0] * 1e-3) / 8e12, 3)}
+              for k, v in sorted(grp.items())}
     n_conv = n_ops.value - 4
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_conv_traffic.json')
@@ -328,7 +339,8 @@ def main():
                              'achieved': round(traffic * n_conv / (el / args.steps) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(traffic * n_conv / (el / args.steps) / 8e12, 4),
                              'note': 'conv-launch HBM bytes per batch (PMC) / step time; layer1-2 launches alone run at 3.2-4.0 TB/s'},
-                         'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3)},
+                         'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3),
+                         'stages': stages},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, frames_np)
