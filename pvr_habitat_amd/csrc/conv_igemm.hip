@@ -42,7 +42,10 @@ struct ConvP {
 // STAGES = 2: double-buffered K loop.  STAGES = 1: single K-slice convolutions (1x1, Cin = 64): half the LDS, so
 // three blocks per CU overlap each other's load / MFMA / store phases (there is no K loop to pipeline).
 // RES: 0 no residual, 1 16-bit residual (ResNet), 2 fp32 residual (transformer residual stream)
-template <int BM, int BN, bool F16, int STAGES, int RES>
+// NK4: the K loop has exactly four slices (K = 256, the 1x1 expand convolutions of layer3): ALL their loads are issued in the
+// prologue through three register stages, so a block pays one memory latency instead of four (a 4-slice loop has nothing to hide
+// the next slice's latency behind: 32 MFMAs per wave per slice against ~1 us)
+template <int BM, int BN, bool F16, int STAGES, int RES, bool NK4 = false>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BK = 64;
@@ -156,7 +159,28 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    PVR_LOAD_SLICE(0);
+    u32x4 qa[NK4 ? 3 : 1][A_CH], qb[NK4 ? 3 : 1][B_CH];       // NK4: register stages of whole K-slices
+#define PVR_LOADQ(q_, kt_)                                                                              \
+    {                                                                                                   \
+        const int tap_off = ((kh * p.W + kw) * p.Cin + cs * BK) * 2;                                    \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                              \
+            const int vo = ((a_mask[i] >> tap) & 1) ? a_off[i] + tap_off : OOB;                         \
+            qa[q_][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0)); \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            qb[q_][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt_) * (BK * 2), 0)); \
+        if (++cs == cpt) { cs = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }                         \
+    }
+#define PVR_STOREQ(q_, buf_)                                                                            \
+    {                                                                                                   \
+        char *base = smem + (buf_) * STAGE + lds_st;                                                    \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + i * 32 * 128) = qa[q_][i];                                \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
+            *reinterpret_cast<u32x4 *>(base + BM * 128 + i * 32 * 128) = qb[q_][i];                     \
+    }
+    if constexpr (NK4) { PVR_LOADQ(0, 0); PVR_LOADQ(1, 1); PVR_LOADQ(2, 2); }
+    else PVR_LOAD_SLICE(0);
     // residual prefetch: issue the epilogue's 16-B residual loads now so their latency hides under the K loop
     constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
     constexpr int EP_IT = BM * UPR / 256;
@@ -181,7 +205,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             rres[2 * it + 1] = *reinterpret_cast<const u32x4 *>(src + 4);
         }
     }
-    PVR_STORE_SLICE(0);
+    if constexpr (NK4) { PVR_STOREQ(0, 0); PVR_LOADQ(0, 3); }  // slice 0 -> LDS; its register stage takes slice 3
+    else PVR_STORE_SLICE(0);
     __syncthreads();
     // one K-slice: loads of slice kt+1 are issued first, the MFMAs of slice kt run, then slice kt+1 is written to the
     // other stage.  CUR_ is a literal so every LDS access is base register + immediate.
@@ -200,10 +225,31 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
         if (more) PVR_STORE_SLICE((STAGES > 1 ? 1 - (CUR_) : 0));                                       \
         __syncthreads();                                                                                \
     }
+#define PVR_MATH(CUR_)                                                                                  \
+    {                                                                                                   \
+        const char *sb = smem + (CUR_) * STAGE;                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+            V8 xa[TM], wb[TN];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(sb + a_rd[ks][j]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(sb + b_rd[ks][i]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                              \
+                _Pragma("unroll") for (int j = 0; j < TM; ++j) acc[i][j] = mfma16<F16>(wb[i], xa[j], acc[i][j]); \
+        }                                                                                               \
+    }
+    if constexpr (NK4) {                          // same slice order, same MFMA order as the loop below: bit-identical
+        PVR_MATH(0); PVR_STOREQ(1, 1); __syncthreads();
+        PVR_MATH(1); PVR_STOREQ(2, 0); __syncthreads();
+        PVR_MATH(0); PVR_STOREQ(0, 1); __syncthreads();
+        PVR_MATH(1); __syncthreads();
+    } else {
     for (int kt = 0; kt < nk; kt += 2) {
         PVR_K_STEP(kt, 0);
         if (kt + 1 < nk) PVR_K_STEP(kt + 1, 1);
     }
+    }
+#undef PVR_MATH
+#undef PVR_LOADQ
+#undef PVR_STOREQ
 #undef PVR_K_STEP
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
@@ -293,23 +339,33 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     }
 }
 
-template <int BM, int BN, bool F16, int STAGES, int RES>
+template <int BM, int BN, bool F16, int STAGES, int RES, bool NK4 = false>
 static pvr_status launch_inst2(ConvP &p, hipStream_t stream) {
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = STAGES * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, RES>,
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
 
+// PVR_IGEMM_NK4=0: the four-slice launches keep the generic double-buffered loop (A/B runs; bit-identical)
+static bool nk4_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_IGEMM_NK4"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 template <int BM, int BN, bool F16, int STAGES>
 static pvr_status launch_inst(ConvP &p, hipStream_t stream) {
+    if constexpr (STAGES == 2 && BM == 128 && BN == 128) {
+        if (p.KH == 1 && p.KW == 1 && p.K == 256 && p.res && !p.res_f32 && nk4_enabled()) return launch_inst2<BM, BN, F16, 2, 1, true>(p, stream);
+    }
     if (!p.res) return launch_inst2<BM, BN, F16, STAGES, 0>(p, stream);
     return p.res_f32 ? launch_inst2<BM, BN, F16, STAGES, 2>(p, stream) : launch_inst2<BM, BN, F16, STAGES, 1>(p, stream);
 }
