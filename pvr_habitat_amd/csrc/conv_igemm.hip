@@ -39,6 +39,14 @@ struct ConvP {
     int m_tiles, n_tiles;
 };
 
+// Diagnostic build only (scripts/igemm_stamps.hip defines IGEMM_STAMP): s_memrealtime (100 MHz) stamps per block
+#ifdef IGEMM_STAMP
+__device__ unsigned long long igemm_stamps[8192][6];
+#define IG_T(i_) { if (threadIdx.x == 0) ig_tt[i_] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define IG_T(i_)
+#endif
+
 // STAGES = 2: double-buffered K loop.  STAGES = 1: single K-slice convolutions (1x1, Cin = 64): half the LDS, so
 // three blocks per CU overlap each other's load / MFMA / store phases (there is no K loop to pipeline).
 // RES: 0 no residual, 1 16-bit residual (ResNet), 2 fp32 residual (transformer residual stream)
@@ -57,6 +65,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef IGEMM_STAMP
+    unsigned long long ig_tt[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    IG_T(0);
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = swz % p.n_tiles, tm = swz / p.n_tiles;
     const int m0 = tm * BM, co0 = tn * BN;
@@ -105,7 +117,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     for (int i = 0; i < B_CH; ++i) {
         const int row = srow + 32 * i;
         const int lch = pch ^ ((row >> 1) & 7);
-        const int co = co0 + row;
+        // NK4: LDS row 32b + 16t + 4a + c holds cout 32b + 8a + 4t + c, so that a lane's accumulators of an MFMA tile PAIR are
+        // 8 consecutive output channels of one pixel and the epilogue runs straight from registers (16-B residual loads / stores)
+        const int co = co0 + (NK4 ? (row & ~31) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3) : row);
         b_off[i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
     }
     const int lds_st = srow * 128 + pch * 16;     // + 32*i*128 ; B tile after A tile
@@ -185,7 +199,15 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     constexpr int UPR = BN / 8;                                  // 8-cout units per pixel row
     constexpr int EP_IT = BM * UPR / 256;
     u32x4 rres[RES == 0 ? 1 : (RES == 1 ? EP_IT : 2 * EP_IT)];
-    if constexpr (RES == 1) {
+    if constexpr (NK4) {                                         // (pair bp, pixel tile j) -> the lane's 8 couts of its pixel
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int bp = it / TM, j = it % TM;
+            const int m = m0 + wm * (BM / 2) + j * 16 + fr, co = co0 + wn * (BN / 2) + bp * 32 + fq * 8;
+            const bool ok = m < p.M && co < p.Cout;
+            rres[it] = *reinterpret_cast<const u32x4 *>(ok ? p.res + (size_t)m * p.Cout + co : p.zero);
+        }
+    } else if constexpr (RES == 1) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
             const int u = tid + it * 256;
@@ -208,6 +230,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     if constexpr (NK4) { PVR_STOREQ(0, 0); PVR_LOADQ(0, 3); }  // slice 0 -> LDS; its register stage takes slice 3
     else PVR_STORE_SLICE(0);
     __syncthreads();
+    IG_T(1);
     // one K-slice: loads of slice kt+1 are issued first, the MFMAs of slice kt run, then slice kt+1 is written to the
     // other stage.  CUR_ is a literal so every LDS access is base register + immediate.
 #define PVR_K_STEP(kt_, CUR_)                                                                           \
@@ -240,13 +263,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
         PVR_MATH(0); PVR_STOREQ(1, 1); __syncthreads();
         PVR_MATH(1); PVR_STOREQ(2, 0); __syncthreads();
         PVR_MATH(0); PVR_STOREQ(0, 1); __syncthreads();
-        PVR_MATH(1); __syncthreads();
+        PVR_MATH(1);
     } else {
     for (int kt = 0; kt < nk; kt += 2) {
         PVR_K_STEP(kt, 0);
         if (kt + 1 < nk) PVR_K_STEP(kt + 1, 1);
     }
     }
+    IG_T(2);
 #undef PVR_MATH
 #undef PVR_LOADQ
 #undef PVR_STOREQ
@@ -261,6 +285,32 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
     // (2) the whole block walks the tile in 8-cout units: coalesced 16-B stores (a pixel's BN couts are
     //     contiguous in NHWC) with the prefetched residual, instead of 8-B stores at a 2*Cout-byte stride.
     // The tile is staged in EP_PASS passes of EP_ROWS pixel rows when it exceeds the pipeline buffers.
+    if constexpr (NK4) {
+        // epilogue straight from the accumulators (TN = 4 tiles = 2 pairs): no LDS staging, no barrier
+        static_assert(!NK4 || (TN == 4 && EP_IT == 2 * TM && RES == 1), "NK4 epilogue layout");
+        IG_T(3);
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+            const int co = co0 + wn * (BN / 2) + bp * 32 + fq * 8;
+            float4 bA = make_float4(0.f, 0.f, 0.f, 0.f), bB = bA;
+            if (co < p.Cout) { bA = *reinterpret_cast<const float4 *>(p.bias + co); bB = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + wm * (BM / 2) + j * 16 + fr;
+                const f32x4 lo = acc[2 * bp][j], hi = acc[2 * bp + 1][j];
+                float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
+                const u32x4 r = rres[bp * TM + j];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v0 = v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), v1 = v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16));
+                    if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                }
+                if (m < p.M && co < p.Cout) *reinterpret_cast<u32x4 *>((u16 *)p.out + (size_t)m * p.Cout + co) = o;
+            }
+        }
+    } else {
     constexpr int EP_FIT = STAGES * STAGE / (BN * 4);           // pixel rows the pipeline buffers can hold as fp32
     constexpr int EP_ROWS = EP_FIT >= BM ? BM : (EP_FIT >= BM / 2 ? BM / 2 : BM / 4);
     constexpr int EP_PASS = BM / EP_ROWS;
@@ -286,6 +336,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             }
         }
         __syncthreads();
+        if (pass == 0) IG_T(3);
 #pragma unroll
         for (int it = 0; it < EP_IT / EP_PASS; ++it) {
             const int itg = pass * (EP_IT / EP_PASS) + it;       // index into the prefetched residual
@@ -337,6 +388,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             }
         }
     }
+    }
+#ifdef IGEMM_STAMP
+    IG_T(4);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { _Pragma("unroll") for (int k = 0; k < 6; ++k) igemm_stamps[blockIdx.x][k] = ig_tt[k]; }
+#endif
 }
 
 template <int BM, int BN, bool F16, int STAGES, int RES, bool NK4 = false>
@@ -364,7 +420,7 @@ static bool nk4_enabled() {
 template <int BM, int BN, bool F16, int STAGES>
 static pvr_status launch_inst(ConvP &p, hipStream_t stream) {
     if constexpr (STAGES == 2 && BM == 128 && BN == 128) {
-        if (p.KH == 1 && p.KW == 1 && p.K == 256 && p.res && !p.res_f32 && nk4_enabled()) return launch_inst2<BM, BN, F16, 2, 1, true>(p, stream);
+        if (p.KH == 1 && p.KW == 1 && p.K == 256 && p.res && !p.res_f32 && !p.out_f32 && p.act <= 1 && nk4_enabled()) return launch_inst2<BM, BN, F16, 2, 1, true>(p, stream);
     }
     if (!p.res) return launch_inst2<BM, BN, F16, STAGES, 0>(p, stream);
     return p.res_f32 ? launch_inst2<BM, BN, F16, STAGES, 2>(p, stream) : launch_inst2<BM, BN, F16, STAGES, 1>(p, stream);
