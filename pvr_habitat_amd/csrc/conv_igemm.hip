@@ -37,6 +37,7 @@ struct ConvP {
     int res_f32;          // residual buffer is fp32 (out_f32 layout) instead of 16-bit
     int act, out_f32;     // act: 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x), 3 GELU (erf)
     int m_tiles, n_tiles;
+    int nk_split;         // > 0: split-K launch, blockIdx.y sums K-slices [y*nk_split, (y+1)*nk_split) into out + y*M*Cout (fp32, no bias)
 };
 
 // Diagnostic build only (scripts/igemm_stamps.hip defines IGEMM_STAMP): s_memrealtime (100 MHz) stamps per block
@@ -126,9 +127,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
 
     u32x4 ra[A_CH], rb[B_CH];                     // native vectors: HIP's uint4 struct went to scratch
     const int cpt = p.Cin / BK;                   // K-slices per filter tap
-    const int nk = p.KH * p.KW * cpt;
+    const int nk_all = p.KH * p.KW * cpt;
+    const int kt0 = p.nk_split ? (int)blockIdx.y * p.nk_split : 0;               // split-K: this block's first slice
+    const int nk = p.nk_split ? (nk_all - kt0 < p.nk_split ? nk_all - kt0 : p.nk_split) : nk_all;
 
-    int kh = 0, kw = 0, cs = 0, tap = 0;          // position of the slice being LOADED (wave-uniform)
+    int tap = kt0 / cpt, cs = kt0 % cpt, kh = tap / p.KW, kw = tap % p.KW;       // position of the slice being LOADED (wave-uniform)
 #define PVR_LOAD_SLICE(kt_)                                                                             \
     {                                                                                                   \
         const int tap_off = ((kh * p.W + kw) * p.Cin + cs * BK) * 2;                                    \
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0));  \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
-            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt_) * (BK * 2), 0)); \
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt0 + (kt_)) * (BK * 2), 0)); \
         if (++cs == cpt) { cs = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }                         \
     }
 #define PVR_STORE_SLICE(buf_)                                                                           \
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
             qa[q_][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0)); \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                \
-            qb[q_][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt_) * (BK * 2), 0)); \
+            qb[q_][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], (kt0 + (kt_)) * (BK * 2), 0)); \
         if (++cs == cpt) { cs = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }                         \
     }
 #define PVR_STOREQ(q_, buf_)                                                                            \
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(Co
                 for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
             if (p.out_f32) {
-                float *op = (float *)p.out + o;
+                float *op = (float *)p.out + o + (p.nk_split ? (size_t)blockIdx.y * p.M * p.Cout : 0);
                 *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
@@ -405,7 +408,8 @@ static pvr_status launch_inst2(ConvP &p, hipStream_t stream) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>), dim3(grid), dim3(256), lds, stream, p);
+    const int ksplit = p.nk_split ? (p.KH * p.KW * (p.Cin / 64) + p.nk_split - 1) / p.nk_split : 1;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>), dim3(grid, ksplit), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
@@ -469,6 +473,7 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
             return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, bm, stream);
     }
     ConvP p;
+    p.nk_split = 0;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;
     p.zero = (const u16 *)zero;
     p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
@@ -484,6 +489,87 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     p.act = relu; p.out_f32 = out_f32 & 1; p.res_f32 = (out_f32 >> 1) & 1;   // out_f32 bit1: residual is fp32
     if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
     return launch_cfg<128, 128>(p, dtype, stream);
+}
+
+// ---- split-K for long, narrow convolutions ---------------------------------------------------------------------------------
+// The compression heads of the *_l3 / *_l4 PVRs (3x3 on 1024 / 2048 channels down to <= 64): 196 / 98 tiles of 128 pixels, each
+// walking 144 / 288 K-slices on its own - a quarter of the CUs busy for 0.14-0.23 ms.  Smaller pixel tiles only multiply the weight
+// traffic (every block streams the whole [Cout][K] matrix) and a deeper load pipeline changes nothing (both measured).
+// Here `ksplit` blocks share a tile: block y sums K-slices [y*nk/ksplit, ...) into an fp32 partial plane, and one elementwise
+// launch adds the planes IN PLANE ORDER, then bias, residual and ReLU.  ksplit depends on the layer's shape only, never on the
+// batch size, so embeddings stay independent of how the frames are batched.
+template <bool F16>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int ksplit, size_t plane, const float *__restrict__ bias,
+                                                            const u16 *__restrict__ res, void *__restrict__ out, int cout, int relu, int out_f32) {
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u * 8 < plane; u += (size_t)gridDim.x * 256) {
+        const size_t o = u * 8;
+        const int co = (int)(o % cout);
+        float v[8];
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + o), a1 = *reinterpret_cast<const f32x4 *>(part + o + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+        for (int s = 1; s < ksplit; ++s) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(part + s * plane + o), b1 = *reinterpret_cast<const f32x4 *>(part + s * plane + o + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        const float4 bA = *reinterpret_cast<const float4 *>(bias + co), bB = *reinterpret_cast<const float4 *>(bias + co + 4);
+        v[0] += bA.x; v[1] += bA.y; v[2] += bA.z; v[3] += bA.w; v[4] += bB.x; v[5] += bB.y; v[6] += bB.z; v[7] += bB.w;
+        if (res) {
+            const u32x4 r = *reinterpret_cast<const u32x4 *>(res + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += from_h<F16>((u16)(r[e] & 0xffffu)); v[2 * e + 1] += from_h<F16>((u16)(r[e] >> 16)); }
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (out_f32) {
+            *reinterpret_cast<f32x4 *>((float *)out + o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>((float *)out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4 *>((u16 *)out + o) = r;
+        }
+    }
+}
+
+// same operands as launch_conv (16-bit residual only, ReLU or no activation) + the fp32 scratch of ksplit planes of M*cout floats
+pvr_status launch_conv_splitk(const void *in, const void *wgt, const float *bias, const void *res, void *out, const void *zero, float *scratch,
+                              int ksplit, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
+                              int dtype, hipStream_t stream) {
+    PVR_REQUIRE(cin % 64 == 0 && cout % 8 == 0 && cout <= 64 && zero && scratch && ksplit > 1, "split-K conv: unsupported shape");
+    PVR_REQUIRE(relu <= 1 && (out_f32 & 2) == 0 && kh <= 3 && kw <= 3, "split-K conv: ReLU / 16-bit residual / filters up to 3x3 only");
+    ConvP p;
+    p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = (const float *)zero; p.res = nullptr; p.out = scratch;
+    p.zero = (const u16 *)zero;
+    p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
+    p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (h + 2 * pad - kh) / stride + 1;
+    p.Wo = (w + 2 * pad - kw) / stride + 1;
+    const int64_t M = (int64_t)n * p.Ho * p.Wo;
+    PVR_REQUIRE(M < (1ll << 31), "conv: problem too large");
+    p.M = (int)M; p.K = kh * kw * cin;
+    const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2;
+    PVR_REQUIRE(inb < 0x7ffffff0ll && wb < 0x7ffffff0ll, "conv: operand larger than 2 GiB");
+    p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb;
+    p.act = 0; p.out_f32 = 1; p.res_f32 = 0;
+    const int nk = p.K / 64;
+    p.nk_split = (nk + ksplit - 1) / ksplit;
+    p.m_tiles = (p.M + 127) / 128; p.n_tiles = 1;
+    pvr_status s = dtype == PVR_F16 ? launch_inst2<128, 64, true, 2, 0>(p, stream) : launch_inst2<128, 64, false, 2, 0>(p, stream);
+    if (s) return s;
+    const size_t plane = (size_t)M * cout;
+    const int used = (nk + p.nk_split - 1) / p.nk_split;            // planes actually written
+    const int grid = (int)((plane / 8 + 255) / 256 > 4096 ? 4096 : (plane / 8 + 255) / 256);
+    if (dtype == PVR_F16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, stream, scratch, used, plane, bias, (const u16 *)res, out, cout, relu, out_f32 & 1);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(grid), dim3(256), 0, stream, scratch, used, plane, bias, (const u16 *)res, out, cout, relu, out_f32 & 1);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
 }
 
 }  // namespace pvr

@@ -236,6 +236,33 @@ static bool ends_with(const std::string &s, const char *suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// Split-K plan (conv_igemm.hip::launch_conv_splitk): long narrow convolutions (K >= 16384 against Cout <= 64: the 3x3 compression
+// head of the *_l4 PVRs, 98 pixel tiles of 288 K-slices; the *_l3 head has 392 tiles and is bound by its im2col reads instead,
+// measured) get 8 K ranges and, as scratch for the fp32 partial planes, a 16-bit ping-pong buffer that is
+// dead at that point of the plan (not read by this or any later op before it is overwritten).  PVR_SPLITK=0 turns it off.
+static void plan_splitk(pvr_encoder *e) {
+    if (const char *f = getenv("PVR_SPLITK")) if (atoi(f) == 0) return;
+    if (e->desc.dtype == PVR_F32) return;
+    const int n = (int)e->ops.size();
+    for (int i = 0; i < n; ++i) {
+        ConvOp &op = e->ops[i];
+        if (op.kind != 0 || op.cout > 64 || op.k * op.k * op.cin < 16384 || (op.out_f32 & 2)) continue;
+        const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
+        const size_t need = (size_t)8 * e->desc.chunk * ho * ho * op.cout * sizeof(float);
+        if (need > e->buf_elems * 2) continue;
+        for (int b = 0; b < B_F32 && op.ks_buf == B_NONE; ++b) {
+            if (b == op.in_buf || b == op.out_buf || b == op.res_buf) continue;
+            bool dead = true;
+            for (int j = i + 1; j < n; ++j) {
+                if (e->ops[j].in_buf == b || e->ops[j].res_buf == b) { dead = false; break; }
+                if (e->ops[j].out_buf == b) break;
+            }
+            if (dead) { op.ks_buf = b; op.ksplit = 8; }
+        }
+
+    }
+}
+
 // Build both launch schedules.  Fused: every bottleneck of width 64 / 128 (layer1, layer2) runs as
 // [conv1 unless the previous chain already produced it] [downsample] [chain: conv2 -> conv3 (+res) -> next conv1].
 static pvr_status build_schedules(pvr_encoder *e) {
@@ -466,6 +493,7 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
+    plan_splitk(enc);
     PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, 256));
     PVR_HIP_TRY(hipMemset(enc->d_zero, 0, 256));
     save_lane(enc, 0);
@@ -601,6 +629,9 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 s = launch_bottleneck_chain(enc->d_buf[l.t1_in], c2.d_w, c2.d_b, op.d_wp, op.d_b, res, enc->d_buf[op.out_buf],
                                             c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
                                             c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st);
+            } else if (op.ksplit > 1) {
+                s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, (float *)enc->d_buf[op.ks_buf],
+                                       op.ksplit, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
             } else {
                 s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h, op.w,
                                 op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);

@@ -15,6 +15,8 @@ pvr_status launch_stem_pool(const void *, const void *, const float *, void *, i
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
 pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
 pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);
+pvr_status launch_conv_splitk(const void *, const void *, const float *, const void *, void *, const void *, float *, int, int, int, int, int, int,
+                              int, int, int, int, int, int, int, hipStream_t);
 pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
                        int, int, int, int, int, int, int, int, hipStream_t);
 
@@ -44,6 +46,7 @@ struct ConvOp {
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
     std::string tap;               // non-empty: output of this op is the named tap
+    int ksplit = 0, ks_buf = B_NONE;   // split-K launch (conv_igemm.hip): number of K ranges, workspace buffer that is dead at this op
 };
 
 // one launch of the forward plan: a single convolution, or a fused bottleneck tail
