@@ -423,6 +423,22 @@ def test_same_lane_forwards_on_different_streams_are_ordered_by_the_library(vari
     assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
 
 
+def test_splitk_compression_head_matches_the_unsplit_sum(monkeypatch):
+    """The *_l4 compression head (3x3, 2048 -> 42 channels on 7x7) runs split-K (8 K ranges, fixed-order fp32 reduce): same values
+    as the one-block-per-tile sum up to the regrouping of the fp32 accumulation, and independent of how the frames are batched."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(5, 'conv4')
+    fr = torch.from_numpy(synth.smooth_frames(31, 9, 96, 128)).cuda()
+    m = HipResNet50(sd, 'conv4', compute_dtype='f16', max_batch=16)
+    a = m(fr).clone()
+    assert torch.equal(m(fr[:1]), a[:1]) and torch.equal(m(fr[4:9]), a[4:9])          # batch-size invariance, bit-exact
+    monkeypatch.setenv('PVR_SPLITK', '0')
+    m0 = HipResNet50(sd, 'conv4', compute_dtype='f16', max_batch=16)
+    b = m0(fr)
+    l2, mx = _relerr(a.cpu().numpy(), b.cpu().numpy())
+    assert 0 < mx < 2e-3 and l2 < 5e-4, (l2, mx)                                       # different grouping, same sum
+
+
 @pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
 def test_second_process_loading_the_gpu_does_not_change_results(variant):
     """Another PROCESS keeps the GPU busy with batch-256 forwards on two lanes while this one repeats its own forward: every
