@@ -19,6 +19,10 @@
 
 namespace pvr {
 
+// conv3x3_halo.hip
+bool conv3x3_halo_supported(int64_t M, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32, int64_t in_bytes);
+pvr_status launch_conv3x3_halo(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int c, int relu,
+                               int dtype, hipStream_t stream);
 // conv_pp256.hip
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
@@ -455,6 +459,8 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     PVR_REQUIRE(cin % 64 == 0, "conv: cin %d not a multiple of 64", cin);
     PVR_REQUIRE(cout % 8 == 0, "conv: cout %d not a multiple of 8", cout);
     PVR_REQUIRE(zero != nullptr, "conv: zero page missing");
+    if (conv_algo() != 0 && conv3x3_halo_supported((int64_t)n * h * w, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, (int64_t)n * h * w * cin * 2))
+        return launch_conv3x3_halo(in, wgt, bias, res, out, n, h, w, cin, relu, dtype, stream);
     {
         const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
         const int64_t M = (int64_t)n * ho * wo, K = (int64_t)kh * kw * cin;

@@ -423,6 +423,26 @@ def test_same_lane_forwards_on_different_streams_are_ordered_by_the_library(vari
     assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
 
 
+@pytest.mark.parametrize('variant,dtype,n', [('r34', 'bf16', 5), ('r18', 'f16', 3), ('clip_rn50', 'bf16', 2)])
+def test_halo_conv3x3_is_bit_identical_to_conv_igemm(variant, dtype, n):
+    """conv3x3_halo.hip (3x3 / stride 1, Cin = Cout = 64 or 128: one LDS-DMA halo run instead of nine im2col taps) keeps
+    conv_igemm's K order and rounding points: switching it off (conv algo 0 = conv_igemm only) must not change a bit.
+    Odd n and non-square frames give tiles that cross image borders and a ragged last tile."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.clip_rn50_state_dict(3) if variant == 'clip_rn50' else synth.resnet50_state_dict(3, variant)
+    fr = torch.from_numpy(synth.smooth_frames(40 + n, n, 150, 210)).cuda()
+    m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
+    a = m(fr).clone()
+    L = _lib.lib()
+    L.pvr_debug_set_conv_algo(0)
+    try:
+        b = m(fr).clone()
+    finally:
+        L.pvr_debug_set_conv_algo(-1)
+    assert torch.equal(a, b), float((a - b).abs().max())
+    assert torch.isfinite(a).all() and float(a.std()) > 0
+
+
 def test_splitk_compression_head_matches_the_unsplit_sum(monkeypatch):
     """The *_l4 compression head (3x3, 2048 -> 42 channels on 7x7) runs split-K (8 K ranges, fixed-order fp32 reduce): same values
     as the one-block-per-tile sum up to the regrouping of the fp32 accumulation, and independent of how the frames are batched."""
@@ -439,15 +459,15 @@ def test_splitk_compression_head_matches_the_unsplit_sum(monkeypatch):
     assert 0 < mx < 2e-3 and l2 < 5e-4, (l2, mx)                                       # different grouping, same sum
 
 
-@pytest.mark.parametrize('variant', ['conv5', 'clip_b16'])
+@pytest.mark.parametrize('variant', ['conv5', 'clip_b16', 'r34'])
 def test_second_process_loading_the_gpu_does_not_change_results(variant):
     """Another PROCESS keeps the GPU busy with batch-256 forwards on two lanes while this one repeats its own forward: every
     embedding must stay bit-identical to the quiet reference.  (Memory latencies several times longer than in a quiet run
     are what exposed the hand-counted LDS-DMA ring of the first halo-form bottleneck kernel)"""
     import subprocess, sys, time
     from pvr_habitat_amd.embeddings import HipResNet50
-    if variant == 'conv5':
-        m = HipResNet50(synth.resnet50_state_dict(1, 'conv5'), 'conv5', compute_dtype='bf16', max_batch=256)
+    if variant in ('conv5', 'r34'):                      # (r34: every convolution of layer1 / layer2 runs on conv3x3_halo)
+        m = HipResNet50(synth.resnet50_state_dict(1, variant), variant, compute_dtype='bf16', max_batch=256)
         fr = torch.from_numpy(synth.frames(1, 256, 256, 256)).cuda()
     else:                                                # every linear layer of the ViT plan runs on conv_pp256 (LDS-DMA ping-pong)
         m = HipResNet50(synth.clip_vit_state_dict(1, patch=16), 'clip_b16', compute_dtype='bf16', max_batch=256)
