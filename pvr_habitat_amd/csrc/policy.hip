@@ -18,6 +18,9 @@ namespace {
 struct Slot { int64_t off, numel; };
 }
 
+// most waves a conv weight-gradient launch is cut over (its partial buffer: 4096 x [32][9*32] floats = 151 MB, PolicyNetWithConv only)
+constexpr int CONV_WG_WAVES_MAX = 4096;
+
 struct pvr_policy {
     pvr_policy_desc d;
     std::map<std::string, Slot> slots;
@@ -523,7 +526,6 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         // ---- conv stack backward (models.py:107-118) ----------------------------------------------------------------
         const int nf = d.conv_frames, F = N * nf;
         hipLaunchKernelGGL(conv_feat_kernel, dim3(blocks_for((size_t)N * 128 * nf)), dim3(256), 0, st, pol->dact[4], const_cast<float *>(dfeat), N, nf, 0);
-        const int WAVES = 256;
         for (int l = 4; l >= 0; --l) {
             const int So = 64 >> (l + 1), Sin = So * 2;
             const size_t ne = (size_t)F * So * So * 32;
@@ -538,6 +540,12 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                 hipLaunchKernelGGL(rowblock_colsum_kernel, dim3(G), dim3(256), 0, st, pol->dact[l], pol->bpartial, R, per);
                 TRY(colsum(pol->bpartial, Gd + pol->o_cb[l], nullptr, G, 32, st));
             }
+            // weight gradient: the pixel range is cut over WAVES waves (each keeps a private [32][9*CP] partial, summed in wave order
+            // afterwards).  A wave's loop is one dependent gather -> MFMA round per 4 pixels, so the launch is latency-bound: its
+            // time is (pixels per wave) x (one memory latency) until the chip is full - 256 waves left three quarters of the SIMDs
+            // idle and put 3200 rounds on each wave of the first layer (4.7 ms per call)
+            const long long npix_l = (long long)F * So * So;
+            const int WAVES = npix_l >= (1 << 19) ? CONV_WG_WAVES_MAX : npix_l >= (1 << 16) ? 1024 : 256;
             ConvWP w;
             w.in = l == 0 ? obs_in : (const void *)pol->act[l - 1]; w.dpre = pol->dact[l]; w.partial = pol->cpartial;
             w.F = F; w.Sin = Sin; w.So = So; w.nf = nf; w.waves = WAVES;
@@ -645,7 +653,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
             const size_t So = 64 >> (l + 1);
             A_(act[l], F * So * So * 32); A_(dact[l], F * So * So * 32); A_(wp[l], 32 * 9 * 32); A_(wt[l], 32 * 9 * 32);
         }
-        A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)256 * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, 256 * 32);
+        A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)CONV_WG_WAVES_MAX * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, 256 * 32);
     }
     if (!s) {
         const size_t ob = desc->conv_frames > 0 ? N * 64 * 64 * 3 * desc->conv_frames : N * O * 4;
