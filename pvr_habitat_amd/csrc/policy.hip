@@ -20,6 +20,7 @@ struct Slot { int64_t off, numel; };
 
 // most waves a conv weight-gradient launch is cut over (its partial buffer: 4096 x [32][9*32] floats = 151 MB, PolicyNetWithConv only)
 constexpr int CONV_WG_WAVES_MAX = 4096;
+constexpr int CONV_BG_BLOCKS_MAX = 2048;      // row blocks of a conv bias-gradient column sum
 
 struct pvr_policy {
     pvr_policy_desc d;
@@ -532,8 +533,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
             hipLaunchKernelGGL(elu_bwd_kernel, dim3(blocks_for(ne / 4)), dim3(256), 0, st, pol->dact[l], pol->act[l], ne / 4);
             // bias gradient: per-block partial column sums over a row range, then a fixed-order sum of the partials
             {
-                const int R = F * So * So, G = R < 1024 ? 1 : 256, per = (R + G - 1) / G;
-                for (int g = 0; g < G; ++g) (void)g;
+                const int R = F * So * So, G = R < 1024 ? 1 : R >= (1 << 19) ? CONV_BG_BLOCKS_MAX : 256, per = (R + G - 1) / G;
                 ColP c = {};
                 c.X = pol->dact[l]; c.out0 = pol->bpartial; c.out1 = nullptr; c.R = per; c.C = 32;
                 // one launch per partial would be slow: view [R][32] as G row blocks through a strided colreduce
@@ -653,7 +653,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
             const size_t So = 64 >> (l + 1);
             A_(act[l], F * So * So * 32); A_(dact[l], F * So * So * 32); A_(wp[l], 32 * 9 * 32); A_(wt[l], 32 * 9 * 32);
         }
-        A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)CONV_WG_WAVES_MAX * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, 256 * 32);
+        A_(feat, N * O); A_(dfeat, N * O); A_(cpartial, (size_t)CONV_WG_WAVES_MAX * 32 * 9 * 32); A_(cgpacked, 32 * 9 * 32); A_(bpartial, CONV_BG_BLOCKS_MAX * 32);
     }
     if (!s) {
         const size_t ob = desc->conv_frames > 0 ? N * 64 * 64 * 3 * desc->conv_frames : N * O * 4;

@@ -229,20 +229,26 @@ static __global__ __launch_bounds__(256) void conv_feat_kernel(float *__restrict
     }
 }
 
-// partial[g][c] = sum over rows [g*per, min((g+1)*per, R)) of X[r][c], C = 32 (bias gradients of the conv stack)
+// partial[g][c] = sum over rows [g*per, min((g+1)*per, R)) of X[r][c], C = 32 (bias gradients of the conv stack).
+// A thread owns 4 channels of every 32nd row of its block's range (16-byte loads, 8 lanes per row); fixed summation order.
 static __global__ __launch_bounds__(256) void rowblock_colsum_kernel(const float *__restrict__ X, float *__restrict__ partial, int R, int per) {
-    __shared__ float s[8][33];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    __shared__ float s[32][33];
+    const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
     const int beg = blockIdx.x * per, end = beg + per < R ? beg + per : R;
-    float a = 0.f;
-    for (int r = beg + g; r < end; r += 8) a += X[(size_t)r * 32 + c];
-    s[g][c] = a;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int r = beg + g; r < end; r += 32) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(X + (size_t)r * 32 + q * 4);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[g][q * 4 + e] = a[e];
     __syncthreads();
-    if (g == 0) {
+    if (threadIdx.x < 32) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += s[i][c];
-        partial[blockIdx.x * 32 + c] = t;
+        for (int i = 0; i < 32; ++i) t += s[i][threadIdx.x];
+        partial[blockIdx.x * 32 + threadIdx.x] = t;
     }
 }
 
