@@ -559,7 +559,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                 hipLaunchKernelGGL(conv_wt_kernel, dim3(36), dim3(256), 0, st, pol->wp[l], pol->wt[l]);
                 ConvDP g;
                 g.dpre = pol->dact[l]; g.Wt = pol->wt[l]; g.din = pol->dact[l - 1]; g.F = F; g.Sin = Sin; g.So = So;
-                const long long tiles = ((long long)F * Sin * Sin + 15) / 16;
+                const long long tiles = 4 * (((long long)F * (Sin / 2) * (Sin / 2) + 15) / 16);     // per parity class
                 hipLaunchKernelGGL(conv_s2_dgrad_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g);
             }
             PVR_LAUNCH_CHECK();

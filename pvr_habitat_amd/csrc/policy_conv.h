@@ -161,21 +161,29 @@ struct ConvDP {
     int F, Sin, So;
 };
 
+// A wave owns 16 input pixels of ONE parity class (iy & 1, ix & 1): with stride 2 / pad 1 / 3x3 an input pixel is reached by
+// tap ky only when ky = iy + 1 (mod 2), so a class uses 1, 2, 2 or 4 of the 9 taps and the other taps are skipped for the whole
+// wave (a mixed tile multiplied zeros for 75 % of its MFMAs).  Skipped taps contributed exact zeros: results are unchanged.
 static __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int H2 = p.Sin >> 1;
+    const long long nq = (long long)p.F * H2 * H2;                  // pixels per parity class
+    const long long tpc = (nq + 15) / 16;                            // tiles per class
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long npix = (long long)p.F * p.Sin * p.Sin;
-    if (tile * 16 >= npix) return;
-    const long long pix = tile * 16 + fr;
-    const bool pok = pix < npix;
-    const long long pp = pok ? pix : 0;
-    const int ix = (int)(pp % p.Sin), iy = (int)((pp / p.Sin) % p.Sin);
-    const int f = (int)(pp / ((long long)p.Sin * p.Sin));
+    if (tile >= 4 * tpc) return;
+    const int cls = (int)(tile / tpc), py = cls >> 1, px = cls & 1;
+    const long long t = tile % tpc;
+    const long long q = t * 16 + fr;
+    const bool pok = q < nq;
+    const long long qq = pok ? q : 0;
+    const int ix = 2 * (int)(qq % H2) + px, iy = 2 * (int)((qq / H2) % H2) + py;
+    const int f = (int)(qq / ((long long)H2 * H2));
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const int ty = iy + 1 - tap / 3, tx = ix + 1 - tap % 3;     // = 2*oy, 2*ox when this tap reached the pixel
-        const bool ok = pok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.So && (tx >> 1) < p.So;
+        if (((tap / 3) & 1) == py || ((tap % 3) & 1) == px) continue;           // wave-uniform: this class never meets the tap
+        const int ty = iy + 1 - tap / 3, tx = ix + 1 - tap % 3;     // = 2*oy, 2*ox
+        const bool ok = pok && ty >= 0 && tx >= 0 && (ty >> 1) < p.So && (tx >> 1) < p.So;
         const float *src = p.dpre + (((size_t)f * p.So + (ty >> 1)) * p.So + (tx >> 1)) * 32;
 #pragma unroll
         for (int c0 = 0; c0 < 32; c0 += 16) {
@@ -190,12 +198,14 @@ static __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 4; ++r) {
+        const long long qo = t * 16 + fq * 4 + r;
+        if (qo >= nq) continue;
+        const int ox = 2 * (int)(qo % H2) + px, oy = 2 * (int)((qo / H2) % H2) + py;
+        const size_t o = (((size_t)(qo / ((long long)H2 * H2)) * p.Sin + oy) * p.Sin + ox) * 32;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long q = tile * 16 + fq * 4 + r;
-            if (q < npix) p.din[(size_t)q * 32 + j * 16 + fr] = acc[j][r];
-        }
+        for (int j = 0; j < 2; ++j) p.din[o + j * 16 + fr] = acc[j][r];
+    }
 }
 
 // W [32 co][9][32 ci] -> Wt [9][32 ci][32 co]
