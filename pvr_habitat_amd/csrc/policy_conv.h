@@ -111,12 +111,13 @@ static __global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ls = 31 - __builtin_clz(p.So);              // So is a power of two (64 >> layer): shifts, not 64-bit divisions, per step
     for (long long p0 = beg; p0 < end; p0 += 4) {
         const long long pix = p0 + fq;                    // k-slot fq = pixel
         const bool pok = pix < end;
-        const long long pp = pok ? pix : 0;
-        const int ox = (int)(pp % p.So), oy = (int)((pp / p.So) % p.So);
-        const int f = (int)(pp / ((long long)p.So * p.So));
+        const unsigned pp = pok ? (unsigned)pix : 0u;     // (npix < 2^31, checked by the launcher)
+        const int ox = (int)(pp & (unsigned)(p.So - 1)), oy = (int)((pp >> ls) & (unsigned)(p.So - 1));
+        const int f = (int)(pp >> (2 * ls));
         float a[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = pok ? p.dpre[(size_t)pp * 32 + i * 16 + fr] : 0.f;
