@@ -36,25 +36,27 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
         const bool ok = pok && (unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin;
         if constexpr (CIN == 3) {
             // k-slot fq = input channel; conv input I'[iy][ix][c] = x[n][ix][iy][3*fr_ + c] / 255  (H<->W swap)
-            float a = 0.f;
-            if (ok && fq < 3) {
-                const int n = f / p.nf, fi = f % p.nf;
-                const uint8_t *x = (const uint8_t *)p.in;
-                a = (float)x[(((size_t)n * p.Sin + ix) * p.Sin + iy) * (3 * p.nf) + 3 * fi + fq] / 255.0f;
-            }
+            // (clamped address + select instead of a branch around the load: hipcc waits for every load inside a branch on its own,
+            //  nine serial memory latencies per tile; unconditional loads are issued back to back)
+            const bool in = ok && fq < 3;
+            const int n = f / p.nf, fi = f % p.nf;
+            const uint8_t *x = (const uint8_t *)p.in;
+            const uint8_t xv = x[(((size_t)n * p.Sin + (in ? ix : 0)) * p.Sin + (in ? iy : 0)) * (3 * p.nf) + 3 * fi + (in ? fq : 0)];
+            const float a = in ? (float)xv / 255.0f : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
         } else if constexpr (CIN == 4) {
             // 'random' PVR first layer: normalised fp32 image, k-slot fq = channel (slot 3 is the zero pad)
-            const float a = ok ? ((const float *)p.in)[(((size_t)f * p.Sin + iy) * p.Sin + ix) * 4 + fq] : 0.f;
+            const float av = ((const float *)p.in)[(((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 4 + fq];
+            const float a = ok ? av : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
         } else {
-            const float *src = (const float *)p.in + (((size_t)f * p.Sin + iy) * p.Sin + ix) * 32;
+            const float *src = (const float *)p.in + (((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 32;
 #pragma unroll
             for (int c0 = 0; c0 < 32; c0 += 16) {
-                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);
+                f32x4 a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);
+                if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + ((size_t)(j * 16 + fr) * 9 + tap) * CP + c0 + fq * 4);
@@ -121,26 +123,28 @@ static __global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
         float a[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = pok ? p.dpre[(size_t)pp * 32 + i * 16 + fr] : 0.f;
+        // all NT gathers of the step are issued back to back (clamped addresses, no branch around a load - inside branches hipcc
+        // waited for every load separately: NT serial memory latencies per step), then the MFMAs consume them
+        float b[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = j * 16 + fr, tap = col / CP, ci = col % CP;
-            float b = 0.f;
-            if (pok && tap < 9) {
-                const int iy = 2 * oy + tap / 3 - 1, ix = 2 * ox + tap % 3 - 1;
-                if ((unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin) {
-                    if constexpr (CIN == 3) {
-                        if (ci < 3) {
-                            const int n = f / p.nf, fi = f % p.nf;
-                            b = (float)((const uint8_t *)p.in)[(((size_t)n * p.Sin + ix) * p.Sin + iy) * (3 * p.nf) + 3 * fi + ci] / 255.0f;
-                        }
-                    } else {
-                        b = ((const float *)p.in)[(((size_t)f * p.Sin + iy) * p.Sin + ix) * 32 + ci];
-                    }
-                }
+            const int iy = 2 * oy + tap / 3 - 1, ix = 2 * ox + tap % 3 - 1;
+            const bool in = pok && tap < 9 && (unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin && (CIN != 3 || ci < 3);
+            const int cy = in ? iy : 0, cx = in ? ix : 0, cf = in ? f : 0, cc = in ? ci : 0;
+            float v;
+            if constexpr (CIN == 3) {
+                const int n = cf / p.nf, fi = cf % p.nf;
+                v = (float)((const uint8_t *)p.in)[(((size_t)n * p.Sin + cx) * p.Sin + cy) * (3 * p.nf) + 3 * fi + cc] / 255.0f;
+            } else {
+                v = ((const float *)p.in)[(((size_t)cf * p.Sin + cy) * p.Sin + cx) * 32 + cc];
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = mfma_f32(a[i], b, acc[i][j]);
+            b[j] = in ? v : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = mfma_f32(a[i], b[j], acc[i][j]);
     }
     // D: row = co (4*fq + r + 16 i), col = column fr + 16 j
     float *out = p.partial + (size_t)wv * 32 * 9 * CP;
@@ -185,11 +189,11 @@ static __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
         if (((tap / 3) & 1) == py || ((tap % 3) & 1) == px) continue;           // wave-uniform: this class never meets the tap
         const int ty = iy + 1 - tap / 3, tx = ix + 1 - tap % 3;     // = 2*oy, 2*ox
         const bool ok = pok && ty >= 0 && tx >= 0 && (ty >> 1) < p.So && (tx >> 1) < p.So;
-        const float *src = p.dpre + (((size_t)f * p.So + (ty >> 1)) * p.So + (tx >> 1)) * 32;
+        const float *src = p.dpre + (((size_t)f * p.So + (ok ? ty >> 1 : 0)) * p.So + (ok ? tx >> 1 : 0)) * 32;
 #pragma unroll
         for (int c0 = 0; c0 < 32; c0 += 16) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);
+            f32x4 a = *reinterpret_cast<const f32x4 *>(src + c0 + fq * 4);      // unconditional (clamped) load + select, see the forward kernel
+            if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(p.Wt + ((size_t)tap * 32 + j * 16 + fr) * 32 + c0 + fq * 4);
