@@ -134,6 +134,31 @@ def bc_bench(steps, warmup, with_cpu):
     return res
 
 
+def finetune_bench(steps, warmup):
+    """BASELINE config 4 on one GPU: the end-to-end BC iteration of main_bc_finetune.py - PolicyNetWithConv (5 x (conv3x3 s2 + ELU) over
+    every frame of the (T, B) batch, forward and backward) + the PolicyNet step; T = 100, B = 16, 64x64x6 uint8 observations, BN."""
+    from pvr_habitat_amd.models import PolicyNetWithConv, HipRMSprop
+    T, B = 100, 16
+    torch.manual_seed(0)
+    net = PolicyNetWithConv((64, 64, 6), 4, True, max_unroll=T, max_batch=B).to(device='cuda')
+    opt = HipRMSprop(net, max_epochs=10 ** 6)
+    g = torch.Generator().manual_seed(1)
+    o = torch.randint(0, 256, (T, B, 64, 64, 6), dtype=torch.uint8, generator=g).cuda()
+    d = (torch.rand((T, B), generator=g) < 0.02).cuda()
+    a = torch.randint(0, 4, (T, B), generator=g).cuda()
+    for _ in range(warmup):
+        opt.scheduler_step(); opt.step(o, d, a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.scheduler_step(); loss, gn = opt.step(o, d, a)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {'metric': 'finetune steps/sec (PolicyNetWithConv T=100 B=16, 64x64x6 uint8, BN, fp32)', 'value': round(steps / el, 2), 'unit': 'steps/s',
+            'ms_per_step': round(el / steps * 1e3, 3), 'frames_per_s_through_conv_stack': round(steps * T * B * 2 / el), 'dtype': 'f32',
+            'final_loss': round(float(loss), 5)}
+
+
 VIT_GFLOP = {'clip_b32': 8.82, 'clip_b16': 35.13}      # per frame (SURVEY 8d)
 
 
@@ -351,6 +376,7 @@ def main():
             line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, vdt), vit_bench('clip_b32', args.batch, 5, 2, vdt)]
         if world == 1 and not args.no_bc:
             line['bc'] = bc_bench(max(args.steps, 10), args.warmup, not args.no_cpu_baseline)
+            line['bc_finetune'] = finetune_bench(max(args.steps, 10), args.warmup)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
