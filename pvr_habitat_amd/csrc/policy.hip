@@ -530,7 +530,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         for (int l = 4; l >= 0; --l) {
             const int So = 64 >> (l + 1), Sin = So * 2;
             const size_t ne = (size_t)F * So * So * 32;
-            hipLaunchKernelGGL(elu_bwd_kernel, dim3(blocks_for(ne / 4)), dim3(256), 0, st, pol->dact[l], pol->act[l], ne / 4);
+            if (l == 4) hipLaunchKernelGGL(elu_bwd_kernel, dim3(blocks_for(ne / 4)), dim3(256), 0, st, pol->dact[l], pol->act[l], ne / 4);   // (lower layers: fused into the input-gradient kernel above them)
             // bias gradient: per-block partial column sums over a row range, then a fixed-order sum of the partials
             {
                 const int R = F * So * So, G = R < 1024 ? 1 : R >= (1 << 19) ? CONV_BG_BLOCKS_MAX : 256, per = (R + G - 1) / G;
@@ -558,7 +558,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
             if (l > 0) {
                 hipLaunchKernelGGL(conv_wt_kernel, dim3(36), dim3(256), 0, st, pol->wp[l], pol->wt[l]);
                 ConvDP g;
-                g.dpre = pol->dact[l]; g.Wt = pol->wt[l]; g.din = pol->dact[l - 1]; g.F = F; g.Sin = Sin; g.So = So;
+                g.dpre = pol->dact[l]; g.Wt = pol->wt[l]; g.din = pol->dact[l - 1]; g.act_in = pol->act[l - 1]; g.F = F; g.Sin = Sin; g.So = So;
                 const long long tiles = 4 * (((long long)F * (Sin / 2) * (Sin / 2) + 15) / 16);     // per parity class
                 hipLaunchKernelGGL(conv_s2_dgrad_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g);
             }

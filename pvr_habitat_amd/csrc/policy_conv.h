@@ -163,6 +163,7 @@ static __global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
 struct ConvDP {
     const float *dpre, *Wt;  // [F][So][So][32], [9][32 ci][32 co]
     float *din;              // [F][Sin][Sin][32]
+    const float *act_in;     // the lower layer's ELU output, same shape as din: its ELU' is applied on the way out (elu_bwd_kernel fused)
     int F, Sin, So;
 };
 
@@ -209,7 +210,10 @@ static __global__ __launch_bounds__(256) void conv_s2_dgrad_kernel(ConvDP p) {
         const int ox = 2 * (int)(qo % H2) + px, oy = 2 * (int)((qo / H2) % H2) + py;
         const size_t o = (((size_t)(qo / ((long long)H2 * H2)) * p.Sin + oy) * p.Sin + ox) * 32;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) p.din[o + j * 16 + fr] = acc[j][r];
+        for (int j = 0; j < 2; ++j) {
+            const float ov = p.act_in[o + j * 16 + fr];
+            p.din[o + j * 16 + fr] = acc[j][r] * (ov > 0.f ? 1.f : ov + 1.f);   // d(pre-activation) of the lower layer, as elu_bwd_kernel
+        }
     }
 }
 
