@@ -44,13 +44,13 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
             const uint8_t xv = x[(((size_t)n * p.Sin + (in ? ix : 0)) * p.Sin + (in ? iy : 0)) * (3 * p.nf) + 3 * fi + (in ? fq : 0)];
             const float a = in ? (float)xv / 255.0f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(p.W[((j * 16 + fr) * 9 + tap) * CP + fq], a, acc[j]);
         } else if constexpr (CIN == 4) {
             // 'random' PVR first layer: normalised fp32 image, k-slot fq = channel (slot 3 is the zero pad)
             const float av = ((const float *)p.in)[(((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 4 + fq];
             const float a = ok ? av : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(a, p.W[((j * 16 + fr) * 9 + tap) * CP + fq], acc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(p.W[((j * 16 + fr) * 9 + tap) * CP + fq], a, acc[j]);
         } else {
             const float *src = (const float *)p.in + (((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 32;
 #pragma unroll
@@ -61,21 +61,25 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
                 for (int j = 0; j < 2; ++j) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(p.W + ((size_t)(j * 16 + fr) * 9 + tap) * CP + c0 + fq * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[j] = mfma_f32(a[e], w[e], acc[j]);
+                    for (int e = 0; e < 4; ++e) acc[j] = mfma_f32(w[e], a[e], acc[j]);
                 }
             }
         }
     }
-    // D: row = 4*fq + r = pixel in tile, col = fr = channel (+16 j)
+    // The weights are the A operand (rows = channels), the pixels the B operand (columns): D row = 4*fq + r = channel (+16 j),
+    // col = fr = pixel, so a lane owns 4 consecutive channels of its pixel -> one 16-byte store per j (the transposed product gave
+    // four scattered 4-byte stores per j; same multiplies and the same accumulation order per element, bit-identical).
+    if (pok) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float b = p.bias[j * 16 + fr];
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.bias + j * 16 + fq * 4);
+            f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long q = tile * 16 + fq * 4 + r;
-            if (q >= npix) continue;
-            const float v = acc[j][r] + b;
-            p.out[(size_t)q * 32 + j * 16 + fr] = v > 0.f ? v : expf(v) - 1.f;      // ELU (alpha 1)
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[j][r] + b[r];
+                o[r] = v > 0.f ? v : expf(v) - 1.f;                                 // ELU (alpha 1)
+            }
+            *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * 32 + j * 16 + fq * 4) = o;
         }
     }
 }
