@@ -208,7 +208,7 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
             ConvFP c;
             c.in = in; c.W = pol->wp[l]; c.bias = P + pol->o_cb[l]; c.out = pol->act[l]; c.F = F; c.Sin = S; c.So = So; c.nf = nf;
             const long long tiles = ((long long)F * So * So + 15) / 16;
-            if (l == 0) hipLaunchKernelGGL(conv_s2_fwd_kernel<3>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
+            if (l == 0) hipLaunchKernelGGL(conv_s2_fwd_kernel<3>, dim3((unsigned)((tiles + 4 * CONV_TPW - 1) / (4 * CONV_TPW))), dim3(256), 0, st, c);
             else hipLaunchKernelGGL(conv_s2_fwd_kernel<32>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
             in = pol->act[l]; S = So;
         }

@@ -16,15 +16,28 @@ struct ConvFP {
     int F, Sin, So, nf;      // F frames (= N*nf)
 };
 
+constexpr int CONV_TPW = 8;      // 16-pixel tiles per wave of the few-channel forward kernel
+
 // forward: wave = 16 output pixels x 32 channels
 template <int CIN>
 static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
     constexpr int CP = CIN <= 4 ? 4 : 32;
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long npix = (long long)p.F * p.So * p.So;
+    // few-channel first layer: the lane's 18 weight values stay in registers over CONV_TPW consecutive tiles (one tile per wave meant
+    // 18 weight loads + 9 pixel loads for 18 MFMAs)
+    constexpr int TPW = CIN <= 4 ? CONV_TPW : 1;
+    float wv[CIN <= 4 ? 9 : 1][2];
+    if constexpr (CIN <= 4) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wv[tap][j] = p.W[((j * 16 + fr) * 9 + tap) * CP + fq];
+    }
+    for (int tt = 0; tt < TPW; ++tt) {
+    const long long tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + tt;
     if (tile * 16 >= npix) return;
-    const long long pix = tile * 16 + fr;                 // A-operand row of this lane
+    const long long pix = tile * 16 + fr;                 // B-operand column of this lane
     const bool pok = pix < npix;
     const long long pp = pok ? pix : 0;
     const int ox = (int)(pp % p.So), oy = (int)((pp / p.So) % p.So);
@@ -44,13 +57,13 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
             const uint8_t xv = x[(((size_t)n * p.Sin + (in ? ix : 0)) * p.Sin + (in ? iy : 0)) * (3 * p.nf) + 3 * fi + (in ? fq : 0)];
             const float a = in ? (float)xv / 255.0f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(p.W[((j * 16 + fr) * 9 + tap) * CP + fq], a, acc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(wv[tap][j], a, acc[j]);
         } else if constexpr (CIN == 4) {
             // 'random' PVR first layer: normalised fp32 image, k-slot fq = channel (slot 3 is the zero pad)
             const float av = ((const float *)p.in)[(((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 4 + fq];
             const float a = ok ? av : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(p.W[((j * 16 + fr) * 9 + tap) * CP + fq], a, acc[j]);
+            for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(wv[tap][j], a, acc[j]);
         } else {
             const float *src = (const float *)p.in + (((size_t)f * p.Sin + (ok ? iy : 0)) * p.Sin + (ok ? ix : 0)) * 32;
 #pragma unroll
@@ -81,6 +94,7 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
             }
             *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * 32 + j * 16 + fq * 4) = o;
         }
+    }
     }
 }
 

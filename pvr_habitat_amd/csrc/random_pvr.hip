@@ -104,7 +104,7 @@ pvr_status random5_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, 
             ConvFP c;
             c.in = in; c.W = r->w[l]; c.bias = r->b[l]; c.out = r->act[l]; c.F = nb; c.Sin = S; c.So = S / 2; c.nf = 1;
             const long long tiles = ((long long)nb * c.So * c.So + 15) / 16;
-            if (l == 0) hipLaunchKernelGGL(conv_s2_fwd_kernel<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
+            if (l == 0) hipLaunchKernelGGL(conv_s2_fwd_kernel<4>, dim3((unsigned)((tiles + 4 * CONV_TPW - 1) / (4 * CONV_TPW))), dim3(256), 0, st, c);
             else hipLaunchKernelGGL(conv_s2_fwd_kernel<32>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, c);
             in = r->act[l]; S /= 2;
         }
