@@ -101,6 +101,38 @@ def _run_case(golden_dir, name, seed, bn, conv=False):
     return m
 
 
+def test_policy_with_conv_medium_matches_autograd_oracle():
+    """PolicyNetWithConv at a size where the conv backward takes its large-grid paths (T*B*2 = 768 frames: the first two layers have
+    >= 2^19 pixels -> 4096-wave weight gradients, 2048-block bias sums): every gradient tensor of the first iteration against the
+    torch-autograd oracle, then loss and gradient norm of two iterations against the oracle's own RMSprop steps."""
+    from pvr_habitat_amd.models import HipRMSprop
+    from oracle import policy_oracle as po
+    T, B, A, S, seed = 24, 16, 4, 2, 11
+    m, sd = _model(seed, 256, A, True, T, B, conv=True)
+    obs, done, act = synth.bc_conv_batches(seed, T, B, S, A)
+    opt = HipRMSprop(m, lr=1e-4, alpha=0.99, eps=1e-5, max_grad_norm=40.0, max_epochs=50)
+    m.train()
+    torch.set_num_threads(8)
+    p = po.to_params(sd)
+    o = po.RMSpropState(p, lr=1e-4, alpha=0.99, eps=1e-5, max_epochs=50, max_grad_norm=40.0)
+    for s_ in range(S):
+        ref_loss, ref_gn = po.bc_step(p, o, torch.from_numpy(obs[s_]), torch.from_numpy(done[s_]), torch.from_numpy(act[s_]), True, conv=True)[:2]
+        if s_ == 0:
+            ref_grads = {k: v.grad.detach().clone().numpy() for k, v in p.items() if v.grad is not None}
+        opt.scheduler_step()
+        loss, gn = opt.step(torch.from_numpy(obs[s_]), torch.from_numpy(done[s_]), torch.from_numpy(act[s_]))
+        if s_ == 0:
+            grads = m.last_grads()
+            for k, gt in grads.items():
+                if not k.startswith('feat_extract'):
+                    continue
+                ref = ref_grads[k]
+                err = float(np.abs(gt.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12))
+                assert err < 2e-4, (k, err)
+        assert float(loss) == pytest.approx(float(ref_loss), rel=5e-5), s_
+        assert float(gn) == pytest.approx(float(ref_gn), rel=1e-3), s_
+
+
 def test_policy_small_bn(golden_dir):
     _run_case(golden_dir, 'policy_small_bn.npz', 1, True)
 
