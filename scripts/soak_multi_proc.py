@@ -29,8 +29,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'worker':
         sys.exit(1 if bad else 0)
     if variant == 'conv5':
         m = HipResNet50(synth.resnet50_state_dict(1, 'conv5'), 'conv5', compute_dtype='bf16', max_batch=256); hw = 256
-    elif variant == 'uber':
-        m = HipResNet50(synth.resnet50_state_dict(2, 'conv3'), 'conv3', compute_dtype='f16', max_batch=256); hw = 256
+    elif variant in ('r18', 'r34', 'conv3', 'conv4'):        # BasicBlock nets (conv3x3_halo), compressed heads (split-K on conv4)
+        m = HipResNet50(synth.resnet50_state_dict(2, variant), variant, compute_dtype='f16' if variant == 'conv3' else 'bf16', max_batch=256); hw = 256
     else:
         m = HipResNet50(synth.clip_vit_state_dict(1, patch=16 if variant == 'clip_b16' else 32), variant, compute_dtype='bf16', max_batch=256); hw = 224
     fa = torch.from_numpy(synth.frames(seed, 256, hw, hw)).cuda(); fb = torch.from_numpy(synth.frames(seed + 100, 256, hw, hw)).cuda()
