@@ -15,6 +15,7 @@ pvr_status launch_stem_pool(const void *, const void *, const float *, void *, i
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
 pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
 pvr_status launch_h_to_f32(const void *, float *, size_t, int, hipStream_t);
+pvr_status launch_f32_to_h(const float *, void *, size_t, int, hipStream_t);
 pvr_status launch_conv_splitk(const void *, const void *, const float *, const void *, void *, const void *, float *, int, int, int, int, int, int,
                               int, int, int, int, int, int, int, hipStream_t);
 pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
@@ -33,13 +34,15 @@ struct HostTensor {
 };
 
 constexpr int PVR_MAX_LANES = 4;
-enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_COUNT, B_STEM = B_COUNT };   // B_STEM: d_stem (112x112x64), not in d_buf
+// B_Y0 / B_Y1: fp32 residual stream of the compressed PVRs' parity plan (allocated only for that plan); B_STEM: d_stem (112x112x64), not in d_buf
+enum BufId { B_NONE = -1, B_X0 = 0, B_X1, B_T1, B_T2, B_DS, B_F32, B_Y0, B_Y1, B_COUNT, B_STEM = B_COUNT };
 
 struct ConvOp {
     std::string conv, bn;          // state_dict prefixes
     int in_buf, out_buf, res_buf;
     int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
-    int kind = 0;                  // 0 convolution, 1 AvgPool2d(2) on NHWC 16-bit (CLIP ModifiedResNet; cin = channels)
+    int kind = 0;                  // 0 convolution, 1 AvgPool2d(2) on NHWC 16-bit (CLIP ModifiedResNet; cin = channels), 2 fp32 -> 16-bit copy
+    bool f32op = false;            // convolution on fp32 buffers with fp32 weights on the f32-input MFMA (conv_f32.hip) inside a 16-bit plan
     u16 *d_w = nullptr;
     u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
@@ -72,6 +75,7 @@ struct pvr_encoder {
     std::vector<ConvOp> ops;
     std::vector<Launch> sched_plain, sched_fused;   // one launch per op / with the layer1-layer2 bottleneck tails fused
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
+    bool resid32 = false;                           // compressed PVRs, f16: fp32 residual stream from layer3 on + fp32 compression head
     bool finalized = false;
     int out_size = 0;
     int final_hw = 0, final_c = 0, final_creal = 0;   // geometry of the last activation

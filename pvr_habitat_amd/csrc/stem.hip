@@ -251,6 +251,32 @@ __global__ __launch_bounds__(256) void h_to_f32_kernel(const u16 *__restrict__ i
         out[i] = from_h<F16>(in[i]);
 }
 
+// 16-bit copy of an fp32 activation (the conv-operand view of the fp32 residual stream of the compressed PVRs' parity plan):
+// 8 elements per thread, 2 x 16-byte loads -> one 16-byte store
+template <bool F16>
+__global__ __launch_bounds__(256) void f32_to_h_kernel(const float *__restrict__ in, u16 *__restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(in + i * 8), b = *reinterpret_cast<const f32x4 *>(in + i * 8 + 4);
+        u32x4 r;
+        r[0] = (unsigned)to_h<F16>(a[0]) | ((unsigned)to_h<F16>(a[1]) << 16);
+        r[1] = (unsigned)to_h<F16>(a[2]) | ((unsigned)to_h<F16>(a[3]) << 16);
+        r[2] = (unsigned)to_h<F16>(b[0]) | ((unsigned)to_h<F16>(b[1]) << 16);
+        r[3] = (unsigned)to_h<F16>(b[2]) | ((unsigned)to_h<F16>(b[3]) << 16);
+        *reinterpret_cast<u32x4 *>(out + i * 8) = r;
+    }
+}
+
+pvr_status launch_f32_to_h(const float *in, void *out, size_t n, int dtype, hipStream_t stream) {
+    PVR_REQUIRE(n % 8 == 0, "f32_to_h: element count %zu not a multiple of 8", n);
+    const size_t n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == PVR_F16) hipLaunchKernelGGL(f32_to_h_kernel<true>, dim3(blocks), dim3(256), 0, stream, in, (u16 *)out, n8);
+    else hipLaunchKernelGGL(f32_to_h_kernel<false>, dim3(blocks), dim3(256), 0, stream, in, (u16 *)out, n8);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
 pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void *out, int n, int crop, int dtype,
                        hipStream_t stream) {
     PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);

@@ -212,10 +212,11 @@ class HipResNet50(_Node):
 
     def _build(self):
         L = _lib.lib()
+        tr = transforms_for('clip' if self._clip else 'mae' if self._mae else '')     # (the interpolation mode follows from the arch)
         desc = _lib.EncoderDesc(arch=_ARCH[self.variant], dtype=self._dtype, max_batch=self._max_batch,
-                                chunk=self._chunk, resize=224 if self._clip else 256, crop=224)     # 'mae': Resize(256, bicubic)
-        desc.mean[:] = CLIP_MEAN if self._clip else IMAGENET_MEAN          # embeddings.py:313 / :84
-        desc.std_[:] = CLIP_STD if self._clip else IMAGENET_STD
+                                chunk=self._chunk, resize=tr.resize, crop=tr.crop)
+        desc.mean[:] = tr.mean                                             # embeddings.py:313 / :84
+        desc.std_[:] = tr.std
         h = C.c_void_p()
         _lib.check(L.pvr_encoder_create(C.byref(desc), C.byref(h)))
         try:
@@ -389,9 +390,27 @@ class FiveCrop(nn.Module):
 
 
 class _Transforms(nn.Module):
-    """Stand-in for the reference's nn.Sequential of torchvision transforms (embeddings.py:80-85): the
-    Resize/CenterCrop/ConvertImageDtype/Normalize arithmetic is fused into the HIP preprocess + stem kernels."""
-    resize, crop, mean, std = 256, 224, IMAGENET_MEAN, IMAGENET_STD
+    """Stand-in for the reference's nn.Sequential of torchvision transforms (embeddings.py:80-85, 309-314): it only records
+    the parameters; the Resize / CenterCrop / ConvertImageDtype / Normalize arithmetic is fused into the HIP preprocess + stem
+    (or patchify) kernels, which receive exactly these values through pvr_encoder_desc."""
+
+    def __init__(self, resize=256, crop=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, mode='bilinear', antialias=False):
+        super().__init__()
+        self.resize, self.crop, self.mean, self.std, self.mode, self.antialias = resize, crop, tuple(mean), tuple(std), mode, antialias
+
+    def spec(self):
+        """[op, args...] in application order - the form tests/golden/glue_registry.json records from the reference"""
+        return [['Resize', self.resize, self.mode, self.antialias], ['CenterCrop', self.crop], ['ConvertImageDtype'],
+                ['Normalize', [float(m) for m in self.mean], [float(x) for x in self.std]]]
+
+
+def transforms_for(embedding_name):
+    """The transforms the reference builds for a name: Resize(256) bilinear - bicubic if 'mae' is in the name (embeddings.py:81)
+    - CenterCrop(224), /255, ImageNet Normalize (:80-85); the 'clip' names replace them by Resize(224, bicubic, antialias),
+    CenterCrop(224), /255, CLIP Normalize (:309-314)."""
+    if 'clip' in embedding_name:
+        return _Transforms(224, 224, CLIP_MEAN, CLIP_STD, 'bicubic', True)
+    return _Transforms(256, 224, IMAGENET_MEAN, IMAGENET_STD, 'bicubic' if 'mae' in embedding_name else 'bilinear', False)
 
 
 def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, train=False, **hip_kw):
@@ -449,7 +468,7 @@ def _get_embedding(embedding_name='random', in_channels=3, pretrained=True, trai
     model.eval()
     for p in model.parameters():
         p.requires_grad = False
-    return model, _Transforms()
+    return model, transforms_for(embedding_name)
 
 
 class EmbeddingNet(nn.Module):
@@ -493,7 +512,17 @@ class EmbeddingNet(nn.Module):
         # observation.shape -> (N, H, W, 3); transposes + transforms + model are one HIP plan
         with torch.no_grad():
             out = self.embed_device(observation)
-            return out.view(-1, self.out_size).squeeze().cpu().numpy()
+            return _checked(out.view(-1, self.out_size).squeeze().cpu().numpy(), self.embedding)
+
+
+def _checked(host_out, model):
+    """The embeddings are on the host anyway: a non-finite value means an activation left the 16-bit storage range (f16 has
+    5 exponent bits; the reference computes in fp32).  Fail loudly instead of handing garbage to the BC stage."""
+    if not np.isfinite(host_out).all():
+        raise FloatingPointError('non-finite embedding: activations overflowed the encoder storage type (%s); '
+                                 "use compute_dtype='bf16' (8 exponent bits) or 'f32' for this checkpoint"
+                                 % {_lib.PVR_F16: 'f16', _lib.PVR_BF16: 'bf16', _lib.PVR_F32: 'f32'}.get(getattr(model, '_dtype', None), 'mixed'))
+    return host_out
 
 
 def stream_embed(net, frames_u8, batch=256, out=None):
@@ -548,15 +577,53 @@ def stream_embed(net, frames_u8, batch=256, out=None):
             res[lo:lo + m].copy_(dev_out[b][:m], non_blocking=True)
             out_free[b].record(d2h)
     torch.cuda.synchronize()
+    _checked(res.numpy(), model)
     return res.numpy() if out is None else res
 
 
-class EmbeddingWrapper(object):
-    """reference src/embeddings.py:409-444 without the gym dependency: `observation((H,W,3n)) -> (n*O,)`.
-    If gym is importable the class can be mixed into gym.ObservationWrapper by the caller."""
+try:                                          # the reference subclasses gym.ObservationWrapper (embeddings.py:409); gym is optional here
+    import gym as _gym
+    from gym.spaces.box import Box as _Box
+    _WrapperBase = _gym.ObservationWrapper
+except Exception:                             # no gym in this image: same attributes, no simulator dependency
+    _gym = None
+
+    class _Box(object):
+        """the two attributes of gym.spaces.Box the BC scripts read (`.shape`, main_bc_2.py:76; `.low/.high`)"""
+
+        def __init__(self, low, high, shape):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.float32
+
+    class _WrapperBase(object):
+        """gym.Wrapper's surface as far as the reference uses it: `.env`, attribute forwarding, reset/step through
+        `observation()` (gym.ObservationWrapper.reset / step)."""
+
+        def __init__(self, env):
+            self.env = env
+            self.observation_space = getattr(env, 'observation_space', None)
+            self.action_space = getattr(env, 'action_space', None)
+
+        def __getattr__(self, name):
+            if name.startswith('_') or name == 'env':
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+        def reset(self, **kwargs):
+            return self.observation(self.env.reset(**kwargs))
+
+        def step(self, action):
+            observation, reward, done, info = self.env.step(action)
+            return self.observation(observation), reward, done, info
+
+
+class EmbeddingWrapper(_WrapperBase):
+    """reference src/embeddings.py:409-444: places the embedding over the observation.  The original observation shape must be
+    (H, W, n * 3); each of the n frames passes through the embedding separately and the outputs are stacked:
+    `observation((H,W,3n)) -> (n*O,)`, `observation_space = Box(-inf, inf, shape=(O*n,))`.  Subclasses gym.ObservationWrapper
+    when gym is importable, otherwise a base with the same surface.  The n frames go to the GPU as ONE batch."""
 
     def __init__(self, env, embedding):
-        self.env = env
+        _WrapperBase.__init__(self, env)
         in_channels = env.observation_space.shape[2]
         assert in_channels % 3 == 0, \
             """ Only RGB images are supported.
@@ -565,8 +632,9 @@ class EmbeddingWrapper(object):
         self.in_channels = 3
         self.n_frames = in_channels // 3
         self.embedding = embedding
-        self.observation_shape = (self.embedding.out_size * self.n_frames,)
+        self.observation_space = _Box(low=-np.inf, high=np.inf, shape=(self.embedding.out_size * self.n_frames,))
 
     def observation(self, observation):
+        # (H, W, n_frames * 3) -> (n_frames, H, W, 3); if n_frames > 1, each passes through the embedding separately
         observation = np.stack(np.split(observation, self.n_frames, axis=-1))
         return self.embedding(torch.from_numpy(observation)).flatten()

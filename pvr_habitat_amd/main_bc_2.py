@@ -14,23 +14,8 @@ import torch
 
 from .arguments import make_parser
 from .models import PolicyNet, HipRMSprop
+from .test_model import test
 from .utils_bc import is_essential_save, sample_with_minimum_distance, gather_unrolls
-
-
-def test(model, env, stat_keys, n_episodes):
-    """reference src/test_model.py:4-22: greedy rollouts with T=B=1 policy forwards."""
-    stats = {k: [] for k in stat_keys}
-    for _ in range(n_episodes):
-        env_output = env.initial()
-        agent_state = model.initial_state(batch_size=1)
-        while True:
-            agent_output, agent_state = model(env_output, agent_state)
-            env_output = env.step(agent_output['action'])
-            if env_output['done']:
-                for k in stat_keys:
-                    stats[k].append(env_output[k].item())
-                break
-    return stats
 
 
 def run(flags, make_env=None):

@@ -153,7 +153,7 @@ def run(flags):
     if flags.source == 'png':
         assert world == 1, 'png source: shard by trajectory directory, one process per shard'
         data = read_habitat_data_from_png(os.path.join(flags.data_path, flags.env), embedding_model, flags.n_trajectories, batch)
-        data.pop('png', None)
+        # (the reference dumps this dict as it is, 'png' file list included: save_embedded_obs.py:53,78,171-172)
     else:
         data = read_habitat_data_from_pickle(os.path.join(flags.data_path, flags.env), flags.n_trajectories)
         print('  ', 'passing observations through embedding model')

@@ -81,6 +81,25 @@ def save(name, rec, extra=None, keep_params=None):
     print('wrote', name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in flat.items() if not k.startswith('final/')})
 
 
+def init_fixture():
+    """Reference constructor under torch.manual_seed(1): per-tensor checksums of the initial weights."""
+    out = {}
+    for bn in (True, False):
+        torch.manual_seed(1)
+        m = PolicyNet((64,), 3, bn)
+        sd = m.state_dict()
+        out['keys_bn%d' % bn] = np.array(list(sd.keys()))
+        out['shapes_bn%d' % bn] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out['sum_bn%d' % bn] = np.array([float(v.double().sum()) for v in sd.values()])
+        out['sq_bn%d' % bn] = np.array([float((v.double() ** 2).sum()) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, 'policy_init_seed1.npz'), **out)
+    print('wrote policy_init_seed1.npz')
+
+
+if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1':
+    init_fixture()
+
+
 def main():
     torch.manual_seed(1); random.seed(1); np.random.seed(1)
     torch.set_num_threads(8)
@@ -120,24 +139,8 @@ def main():
     init_fixture()
 
 
-if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') != '1':
-    main()
-
-
-def init_fixture():
-    """Reference constructor under torch.manual_seed(1): per-tensor checksums of the initial weights."""
-    out = {}
-    for bn in (True, False):
-        torch.manual_seed(1)
-        m = PolicyNet((64,), 3, bn)
-        sd = m.state_dict()
-        out['keys_bn%d' % bn] = np.array(list(sd.keys()))
-        out['shapes_bn%d' % bn] = np.array([str(tuple(v.shape)) for v in sd.values()])
-        out['sum_bn%d' % bn] = np.array([float(v.double().sum()) for v in sd.values()])
-        out['sq_bn%d' % bn] = np.array([float((v.double() ** 2).sum()) for v in sd.values()])
-    np.savez_compressed(os.path.join(HERE, 'policy_init_seed1.npz'), **out)
-    print('wrote policy_init_seed1.npz')
-
-
-if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1':
-    init_fixture()
+if __name__ == '__main__':
+    if os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1':      # regenerate policy_init_seed1.npz alone
+        init_fixture()
+    else:
+        main()

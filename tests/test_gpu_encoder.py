@@ -223,7 +223,7 @@ def test_resnet50_stagewise_parity(dt, tol):
     report['embedding'] = _relerr(out, ref_out.reshape(3, 2048).numpy())
     print('\n[%s] stage rel-L2 / max-norm errors:' % dt, {k: ('%.2e' % v[0], '%.2e' % v[1]) for k, v in report.items()})
     for k, v in report.items():
-        assert v[0] < tol * (1.5 if k != 'embedding' else 1.0), (k, v)
+        assert v[0] < tol, (k, v)
     assert report['embedding'][1] < tol
 
 
@@ -240,9 +240,57 @@ def test_compressed_variants(variant, osz):
     assert out.shape == (2, osz)
     l2, mx = _relerr(out, ref)
     print('\n[%s f16] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
-    # no averaging at the end of the compressed variants: the f16 trunk error (~9e-4, see stagewise test) reaches
-    # the output un-averaged, so the bound here is 1.5e-3 (the split-f16 parity mode is the tighter path)
-    assert l2 < 1.5e-3 and mx < 3e-3
+    # no averaging at the end of the compressed variants, so the trunk's storage rounding reaches the output element by element
+    # (all-f16 plan: 1.09e-3 / 9.6e-4).  The f16 plan of these variants keeps the residual stream in fp32 from layer3 on and runs
+    # the compression head in fp32 (encoder.hip::build_resnet50, PVR_RESID32): 9.8e-4 / 8.0e-4 measured, inside the north-star 1e-3
+    assert l2 < 1e-3 and mx < 2e-3
+    m0 = None
+    os.environ['PVR_RESID32'] = '0'                                    # A/B: the all-16-bit plan is measurably further away
+    try:
+        m0 = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
+        l2_16, _ = _relerr(m0(torch.from_numpy(fr).cuda()).cpu().numpy(), ref)
+    finally:
+        del os.environ['PVR_RESID32']
+    print('[%s f16, all-16-bit plan] rel-L2 %.2e' % (variant, l2_16))
+    assert l2 < l2_16
+
+
+def test_f16_activation_range(monkeypatch):
+    """f16 storage has 5 exponent bits: a checkpoint whose activations grow towards 65504 is the risk of the parity mode.
+    Scaling bn1's affine by S scales every downstream activation by ~S (eval BatchNorm is affine, ReLU positively homogeneous).
+    (a) S chosen so the largest stage activation is ~2.4e4 (internal pre-activations reach further): parity unchanged, all finite;
+    (b) S 16x larger: the f16 plan overflows and EmbeddingNet raises FloatingPointError instead of returning garbage, while the
+    bf16 plan (8 exponent bits) still embeds the same frames."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import EmbeddingNet, HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    fr = synth.smooth_frames(24, 2, 128, 128)
+    _, taps = _oracle_taps(sd, fr)
+    peak = max(float(t.abs().max()) for t in taps.values())
+
+    def scaled(S):
+        s2 = dict(sd)
+        s2['bn1.weight'] = sd['bn1.weight'] * S
+        s2['bn1.bias'] = sd['bn1.bias'] * S
+        return s2
+    S = 2.4e4 / peak
+    ref = eo.embed(scaled(S), fr, 'conv5')
+    assert np.abs(ref).max() > 1e3
+    m = HipResNet50(scaled(S), 'conv5', compute_dtype='f16', max_batch=4)
+    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+    l2, mx = _relerr(out, ref)
+    print('\n[f16 range] scale %.0f, oracle peak stage activation %.3g: rel-L2 %.2e' % (S, peak * S, l2))
+    assert np.isfinite(out).all() and l2 < 1e-3
+    monkeypatch.setenv('PVR_SYNTHETIC_WEIGHTS', '1')
+    net = EmbeddingNet('resnet50', pretrained=False, compute_dtype='f16', max_batch=4)
+    net.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
+    with pytest.raises(FloatingPointError):
+        net(torch.from_numpy(fr))
+    netb = EmbeddingNet('resnet50', pretrained=False, compute_dtype='bf16', max_batch=4)
+    netb.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
+    ob = netb(torch.from_numpy(fr))
+    assert np.isfinite(ob).all() and _relerr(ob, eo.embed(scaled(16 * S), fr, 'conv5'))[0] < 1e-2
 
 
 def test_embeddingnet_surface_and_uber(monkeypatch):
@@ -305,7 +353,9 @@ def test_resnet18_34_match_oracle(monkeypatch, name, variant):
         m.debug_stop_after(tname); m(d)
         r = taps[tname].permute(0, 2, 3, 1).contiguous().numpy()
         g = m.tap(tname, r.size).cpu().numpy().reshape(r.shape)
-        assert _relerr(g, r)[0] < 2e-3, tname
+        e = _relerr(g, r)[0]
+        print('[%s f16] %s rel-L2 %.2e' % (variant, tname, e))
+        assert e < 1e-3, tname
     m.debug_stop_after('')
     out = m(d).cpu().numpy()
     l2, mx = _relerr(out, ref)
