@@ -52,16 +52,24 @@ typedef struct pvr_policy_bn {
     int64_t *num_batches_tracked;
 } pvr_policy_bn;
 
-/* SyncBN for the data-parallel finetune (BASELINE config 4; the reference itself is single-GPU, src/models.py:132-136 is a plain
- * BatchNorm1d): with a callback installed and world_size > 1, training-mode BatchNorm uses the statistics of the GLOBAL batch
- * (world_size x T x B rows, equal rows per rank), which makes N ranks x B/N sequences equal to one rank x B.  The library writes
- * per-rank column sums into sync_buf (device, 2 * obs_size floats, caller-owned) and calls fn(offset, count, user) from inside
- * pvr_policy_backward / _step / _forward(training); fn must enqueue, on the stream of that call, an in-place SUM all-reduce of
- * sync_buf[offset, offset+count) over the ranks (torch.distributed.all_reduce on the current stream: RCCL over xGMI).  Three
- * calls per iteration: mean (obs_size floats), centred second moment (obs_size), backward sums (2 * obs_size).  fn = NULL
- * restores per-rank statistics. */
-typedef void (*pvr_policy_sync_fn)(int64_t offset, int64_t count, void *user);
-pvr_status pvr_policy_set_bn_sync(pvr_policy *pol, float *sync_buf, int32_t world_size, pvr_policy_sync_fn fn, void *user);
+/* Data-parallel finetune (BASELINE config 4; the reference's main_bc_finetune.py:167-208 is single-GPU and src/models.py:132-136
+ * is a plain BatchNorm1d).  The caller hands the library ONE collective as a C function pointer:
+ *     fn(buf, count, hip_stream, user) = in-place SUM all-reduce over the ranks of `count` fp32 values at device address `buf`,
+ *     enqueued on hip_stream (RCCL over xGMI: ncclAllReduce, or torch.distributed.all_reduce under backend "nccl"); returns 0 on
+ *     success, non-zero makes the calling entry point fail with PVR_ERR_COMM.
+ * With world_size > 1 installed, pvr_policy_backward / pvr_policy_step on every rank
+ *   - all-reduce the gradient in four buckets, in the order backward finalises them (LSTM layer 1 + policy head, LSTM layer 0,
+ *     the two fc layers, conv stack + BatchNorm affine), each on a library-owned communication stream that waits only for the
+ *     event recorded after the bucket's last kernel, so the transfers overlap the rest of the backward pass; the buckets (and
+ *     the loss) are divided by world_size there and the compute stream re-joins before the entry point returns: `grads` then
+ *     holds the gradient of the GLOBAL batch mean and stats_out[0] the global loss;
+ *   - with sync_bn != 0, use BatchNorm statistics of the global batch (world_size x T x B rows, equal rows per rank): per-rank
+ *     column sums are all-reduced on the compute stream between the statistic kernels (mean, centred second moment, and - for
+ *     PolicyNetWithConv - the two backward sums), so N ranks x B/N sequences equal one rank x B.
+ * world_size <= 1 or fn == NULL restores single-rank behaviour. */
+typedef int32_t (*pvr_allreduce_fn)(void *buf_dev, int64_t count, void *hip_stream, void *user);
+#define PVR_ERR_COMM 5
+pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int32_t sync_bn, pvr_allreduce_fn fn, void *user);
 
 /* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32 (uint8 (T,B,64,64,3n) when conv_frames = n > 0), done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
  * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82), h_out/c_out
@@ -80,16 +88,24 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
                            float lr, float alpha, float eps, float max_grad_norm, float *stats_out,
                            float *logits_out, void *hip_stream);
 
-/* Data-parallel training (finetune configuration): the same iteration in two halves so the caller can
- * all-reduce the flat gradient (RCCL / torch.distributed) between them.  pvr_policy_backward leaves the UNCLIPPED
- * local gradient of the mean loss in grads (device, trainable_count floats, caller-owned) and the loss in
- * stats_out[0]; pvr_policy_apply computes the norm of whatever grads now holds (e.g. the rank average), clips and
- * applies RMSprop; stats_out[1] = that norm. */
+/* The same iteration in two halves (data-parallel training, autograd bridge).  pvr_policy_backward leaves the UNCLIPPED
+ * gradient of the mean loss in grads (device, trainable_count floats, caller-owned) and the loss in stats_out[0] - the local
+ * batch's, or the global batch's when pvr_policy_set_data_parallel is installed; pvr_policy_apply computes the norm of whatever
+ * grads holds, clips and applies RMSprop; stats_out[1] = that norm. */
 pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
                                const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float *grads,
                                float *stats_out, float *logits_out, void *hip_stream);
 pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr,
                             float alpha, float eps, float max_grad_norm, float *stats_out, void *hip_stream);
+
+/* BC batch assembly on the device: replaces the host gather of main_bc_2.py:186-204 (identical in main_bc_1.py:193-211 and
+ * main_bc_finetune.py:173-188).  The dataset stays resident in HBM: obs_dev (n_samples rows of row_bytes bytes: fp32 embeddings, or
+ * raw uint8 frames for the finetune model), action_dev (int64), done_dev (uint8).  For the B start indices of
+ * sample_with_minimum_distance (starts_dev, int64) row (t, b) of every output is dataset row (starts[b] + t) mod n_samples, i.e.
+ * out_obs is the (T, B, ...) batch np.stack(..., axis=1) builds.  action / done may both be NULL. */
+pvr_status pvr_bc_gather(const void *obs_dev, const int64_t *action_dev, const uint8_t *done_dev, int64_t n_samples,
+                         int64_t row_bytes, const int64_t *starts_dev, int32_t T, int32_t B, void *out_obs,
+                         int64_t *out_action, uint8_t *out_done, void *hip_stream);
 
 /* parity/debug: copy the flat gradient of the last pvr_policy_step (pre-clip) to grads_out (device, trainable_count) */
 pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_stream);

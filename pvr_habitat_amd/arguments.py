@@ -51,6 +51,11 @@ def make_parser():
                         help='encoder storage/MFMA input type (default: $PVR_DTYPE or bf16)')
     parser.add_argument('--embed_batch', type=int, default=256, help='frames per encoder launch (the reference '
                         'pushes batch_size x n_frames = 64 per forward, save_embedded_obs.py:151-153)')
+    parser.add_argument('--num_actions', type=int, default=3, help='size of the policy head when no simulator is attached (the reference '
+                        'reads env.gym_env.action_space.n, main_bc_2.py:77; Habitat ImageNav without STOP has 3 actions, gym_wrappers.py:173). '
+                        'The data is checked against it - it is never derived from the data')
+    parser.add_argument('--optimizer', type=str, default='rmsprop', choices=['rmsprop', 'adam'],
+                        help="'rmsprop' is the reference's optimiser (main_bc_2.py:80-86); 'adam' is an extension")
     return parser
 
 

@@ -1,0 +1,52 @@
+"""BC training data resident in HBM and gathered on the device.
+
+The reference assembles every (T, B) batch on the host - B fancy-index gathers of (T, obs) rows, np.stack, torch.from_numpy,
+then a synchronous pageable H2D of 26 MB per iteration (main_bc_2.py:186-204, main_bc_1.py:193-211, main_bc_finetune.py:173-188).
+Here the whole dataset is uploaded ONCE (a Replica scene of 50 k pre-embedded observations is 0.8 GB; 288 GB of HBM hold
+every sweep the reference runs) and `pvr_bc_gather` builds the batch from the B start indices in one launch; per iteration only the
+8 * B bytes of indices cross PCIe.  Same rows, same order, same values as the host loop (tests/test_gpu_policy.py)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _bind():
+    L = _lib.lib()
+    if not getattr(L, '_gather_bound', False):
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        L.pvr_bc_gather.restype = C.c_int
+        L.pvr_bc_gather.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp, vp, vp, vp]
+        L._gather_bound = True
+    return L
+
+
+class DeviceDataset(object):
+    def __init__(self, obs, action, done, device='cuda'):
+        _lib.require_gpu()
+        obs = obs if isinstance(obs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(obs))
+        if obs.dtype not in (torch.uint8, torch.float32):
+            obs = obs.float()                                   # (true_state is float64 on disk; the policy computes in fp32)
+        self.obs = obs.contiguous().to(device)
+        self.action = torch.from_numpy(np.ascontiguousarray(np.asarray(action)).astype(np.int64)).to(device)
+        self.done = torch.from_numpy(np.ascontiguousarray(np.asarray(done)).astype(np.uint8)).to(device)
+        self.n = int(self.obs.shape[0])
+        assert self.action.shape[0] == self.n and self.done.shape[0] == self.n, 'data length does not match'
+        self.row_bytes = int(self.obs[0].numel() * self.obs.element_size())
+        assert self.row_bytes % 16 == 0, 'observation rows must be a multiple of 16 bytes (got %d)' % self.row_bytes
+
+    def gather(self, starting_i, unroll_length):
+        """(T, B, ...) observations, (T, B) int64 actions, (T, B) bool dones for the start indices of
+        sample_with_minimum_distance: row (t, b) = dataset row (starting_i[b] + t) mod n  (main_bc_2.py:194-201)."""
+        B, T = len(starting_i), int(unroll_length)
+        dev = self.obs.device
+        starts = torch.tensor(list(starting_i), dtype=torch.int64).to(dev)
+        o = torch.empty((T, B) + tuple(self.obs.shape[1:]), dtype=self.obs.dtype, device=dev)
+        a = torch.empty((T, B), dtype=torch.int64, device=dev)
+        d = torch.empty((T, B), dtype=torch.uint8, device=dev)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_bind().pvr_bc_gather(vp(self.obs), vp(self.action), vp(self.done), self.n, self.row_bytes, vp(starts), T, B,
+                                         vp(o), vp(a), vp(d), _lib.stream_ptr()))
+        return o, a, d.bool()

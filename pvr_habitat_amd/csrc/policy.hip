@@ -8,6 +8,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "policy_kernels.h"
 #include "policy_conv.h"
 #include "../../include/pvr_policy.h"
@@ -73,11 +74,18 @@ struct pvr_policy {
                    T == o.T && B == o.B && alpha == o.alpha && eps == o.eps && mgn == o.mgn;
         }
     } graph_key, eager_key;
-    // SyncBN for the data-parallel finetune (pvr_policy_set_bn_sync): BatchNorm statistics over the global batch
-    float *sync_buf = nullptr;              // caller-owned device buffer of 2 * obs_size floats, all-reduced (SUM) by the callback
-    pvr_policy_sync_fn sync_cb = nullptr;
-    void *sync_user = nullptr;
-    int sync_world = 1;
+    // Data parallelism (pvr_policy_set_data_parallel): the caller's collective as a C function pointer.  Gradients are all-reduced
+    // in four buckets on comm_stream as each becomes final (LSTM l1 + heads, LSTM l0, fc, conv + BatchNorm), overlapping the rest
+    // of the backward pass; SyncBN statistics are all-reduced on the compute stream (they are true dependencies).
+    int dp_world = 1, dp_sync_bn = 0;
+    pvr_allreduce_fn dp_fn = nullptr;
+    void *dp_user = nullptr;
+    float *sync_buf = nullptr;              // 2 * obs_size floats (library-owned)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready[4] = {nullptr}, ev_comm = nullptr;
+    // scratch of the split-K GEMMs and two-stage column reductions: per policy (two policies may step concurrently on different
+    // streams / host threads); superseded buffers are kept until destroy (launches already enqueued may still use them)
+    struct Scratch { float *splitk = nullptr, *col = nullptr; size_t splitk_elems = 0, col_elems = 0; std::vector<void *> retired; } scratch;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;       // capture happens on a private stream (the caller's may be the legacy stream, which cannot capture)
@@ -100,8 +108,30 @@ pvr_status dalloc(T **ptr, size_t n) {
     return PVR_OK;
 }
 
-static float *g_splitk_scratch = nullptr;
-static size_t g_splitk_elems = 0;
+// Scratch owner of the calling thread: every extern "C" entry installs its policy's scratch (ScratchScope); the unit-parity entry
+// pvr_op_gemm_f32 has no policy and uses a process-wide one under a mutex.
+static thread_local pvr_policy::Scratch *tls_scratch = nullptr;
+static pvr_policy::Scratch g_scratch;
+static std::mutex g_scratch_mu;
+struct ScratchScope {
+    pvr_policy::Scratch *prev;
+    bool locked = false;
+    explicit ScratchScope(pvr_policy *pol) : prev(tls_scratch) {
+        if (pol) tls_scratch = &pol->scratch;
+        else { g_scratch_mu.lock(); locked = true; tls_scratch = &g_scratch; }
+    }
+    ~ScratchScope() { tls_scratch = prev; if (locked) g_scratch_mu.unlock(); }
+};
+static pvr_status scratch_grow(float **buf, size_t *have, size_t need) {
+    pvr_policy::Scratch *S = tls_scratch;
+    if (!S) { set_error("policy: internal error, no scratch owner"); return PVR_ERR_STATE; }
+    if (need > *have) {
+        if (*buf) S->retired.push_back(*buf);
+        PVR_HIP_TRY(hipMalloc((void **)buf, need * sizeof(float)));
+        *have = need;
+    }
+    return PVR_OK;
+}
 
 pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
                 bool a_km, bool b_kn, int relu, hipStream_t st) {
@@ -115,18 +145,17 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
     // too few output tiles for the chip and a long K: split K over blockIdx.y into fp32 partial products, summed in slice order
     int S = 1;
     if (grid < 192 && K >= 2048 && K % 128 == 0) S = 4;
+    float *splitk_buf = nullptr;
     if (S > 1) {
         const size_t need = (size_t)S * M * N;
-        if (need > g_splitk_elems) {
-            // (a superseded buffer is deliberately not freed: launches already enqueued, or captured in a hipGraph, may still use it)
-            PVR_HIP_TRY(hipMalloc((void **)&g_splitk_scratch, need * sizeof(float)));
-            g_splitk_elems = need;
-        }
+        if (!tls_scratch) { set_error("policy: internal error, no scratch owner"); return PVR_ERR_STATE; }
+        { pvr_status gs = scratch_grow(&tls_scratch->splitk, &tls_scratch->splitk_elems, need); if (gs) return gs; }
+        splitk_buf = tls_scratch->splitk;
         g.K = K / S;
         g.a_kstride = a_km ? (long long)g.K * g.lda : g.K;
         g.b_kstride = b_kn ? (long long)g.K * g.ldb : g.K;
         g.c_stride = (long long)M * N;
-        g.C = g_splitk_scratch; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
+        g.C = splitk_buf; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
     }
     const dim3 gd(grid, S);
     if (!a_km && !b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), gd, dim3(256), 0, st, g);
@@ -136,7 +165,7 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
     if (S > 1) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st,
-                           g_splitk_scratch, C, bias, mask, S, n, N, relu);
+                           splitk_buf, C, bias, mask, S, n, N, relu);
     }
     PVR_LAUNCH_CHECK();
     return PVR_OK;
@@ -146,15 +175,11 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
 #define TRY_(x) TRY(x)
 
 // scratch of the two-stage column reductions: [2 * row groups][C] floats, grown on demand (first, eager, iteration)
-static float *g_col_scratch = nullptr;
-static size_t g_col_scratch_elems = 0;
 static pvr_status col_scratch(size_t elems, float **out) {
-    if (elems > g_col_scratch_elems) {
-        // (a superseded buffer is deliberately not freed: launches already enqueued, or captured in a hipGraph, may still use it)
-        PVR_HIP_TRY(hipMalloc((void **)&g_col_scratch, elems * sizeof(float)));
-        g_col_scratch_elems = elems;
-    }
-    *out = g_col_scratch;
+    if (!tls_scratch) { set_error("policy: internal error, no scratch owner"); return PVR_ERR_STATE; }
+    pvr_status gs = scratch_grow(&tls_scratch->col, &tls_scratch->col_elems, elems);
+    if (gs) return gs;
+    *out = tls_scratch->col;
     return PVR_OK;
 }
 
@@ -184,6 +209,31 @@ pvr_status colsum(const float *X, float *out0, float *out1, int R, int C, hipStr
 inline int blocks_for(size_t n, int cap = 4096) {
     size_t b = (n + 255) / 256;
     return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+
+
+static inline bool dp_active(const pvr_policy *pol) { return pol->dp_fn && pol->dp_world > 1; }
+
+// one collective through the caller's function pointer
+static pvr_status dp_allreduce(pvr_policy *pol, float *buf, int64_t count, hipStream_t s_) {
+    if (pol->dp_fn((void *)buf, count, (void *)s_, pol->dp_user) != 0) {
+        set_error("policy: the data-parallel all-reduce callback failed (%lld floats)", (long long)count);
+        return PVR_ERR_COMM;
+    }
+    return PVR_OK;
+}
+
+// gradient bucket [off, off+count) of Gd is final on `st`: all-reduce it on the communication stream and divide by the world size
+static pvr_status dp_bucket(pvr_policy *pol, float *Gd, int64_t off, int64_t count, int idx, hipStream_t st) {
+    if (!dp_active(pol) || count <= 0) return PVR_OK;
+    PVR_HIP_TRY(hipEventRecord(pol->ev_ready[idx], st));
+    PVR_HIP_TRY(hipStreamWaitEvent(pol->comm_stream, pol->ev_ready[idx], 0));
+    pvr_status s = dp_allreduce(pol, Gd + off, count, pol->comm_stream);
+    if (s) return s;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pol->comm_stream, Gd + off,
+                       1.0f / (float)pol->dp_world, (long long)count);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
 }
 
 
@@ -224,19 +274,19 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
             {
                 // mean, then centred second moment (two passes, as torch): per-rank, or over the global batch under SyncBN with an
                 // all-reduce of obs_size floats after each pass
-                const bool sync = pol->sync_cb && pol->sync_world > 1;
-                const float ng = (float)N * (float)(sync ? pol->sync_world : 1);
+                const bool sync = dp_active(pol) && pol->dp_sync_bn;
+                const float ng = (float)N * (float)(sync ? pol->dp_world : 1);
                 float *sums = sync ? pol->sync_buf : pol->bn_invstd;                // (bn_invstd doubles as scratch until the final kernel)
                 float *sq = sync ? pol->sync_buf + O : pol->da0;                    // (da0 is free during the forward pass)
                 TRY(colsum(obs, sums, nullptr, N, O, st));
-                if (sync) pol->sync_cb(0, O, pol->sync_user);
+                if (sync) TRY(dp_allreduce(pol, pol->sync_buf, O, st));
                 hipLaunchKernelGGL(scale_kernel, dim3((O + 255) / 256), dim3(256), 0, st, pol->bn_mean, sums, 1.0f / ng, O);
                 ColP c2 = {};
                 c2.X = obs; c2.mean_in = pol->bn_mean; c2.out0 = sq; c2.R = N; c2.C = O;
                 if (N >= 512 && O % 4 == 0) TRY(colreduce2<3>(c2, st));
                 else hipLaunchKernelGGL(colreduce_kernel<3>, dim3((O + 31) / 32), dim3(256), 0, st, c2);
                 PVR_LAUNCH_CHECK();
-                if (sync) pol->sync_cb(O, O, pol->sync_user);
+                if (sync) TRY(dp_allreduce(pol, pol->sync_buf + O, O, st));
                 hipLaunchKernelGGL(bn_sync_final_kernel, dim3((O + 255) / 256), dim3(256), 0, st, sq, pol->bn_mean, ng,
                                    pol->bn_invstd, bn->running_mean, bn->running_var, (long long *)bn->num_batches_tracked, O);
             }
@@ -406,6 +456,8 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         return colsum(pol->G[l], Gd + pol->o_bih[l], Gd + pol->o_bhh[l], N, 4 * H, s_);
     };
     float *dh1 = pol->dA, *dh0 = pol->dB;          // d(loss)/d(h) arriving from above: layer 1 <- heads, layer 0 <- layer 1's dx
+    // data-parallel gradient buckets = contiguous ranges of the flat layout, in the order backward finalises them
+    const int64_t b_l1 = pol->o_wih[1], b_l0 = pol->o_wih[0], b_fc = pol->o_fc1w;
     const int NCH = (pol->pipeline || pol->chunkwave) && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
     auto rec_job = [&](int l, int t) {
         LstmRecP r;
@@ -453,12 +505,19 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                     TRY(gemm(pol->G[1] + r0 * 4 * H, P + pol->o_wih[1], nullptr, nullptr, dh0 + r0 * H, (t1 - t0) * B, H, 4 * H, false, true, 0, st));
                 }
             }
+            if (c == 0 && dp_active(pol)) {
+                // data parallel: layer 1 has finished its BPTT here - its weight gradients (33.5 MB with the policy head) go out now
+                // and travel while layer 0 runs its last chunk and everything below it
+                TRY(weight_grads(1, st));
+                TRY(dp_bucket(pol, Gd, b_l1, pol->n_train - b_l1, 0, st));
+            }
         }
-        TRY(weight_grads(1, st));
+        if (!dp_active(pol)) TRY(weight_grads(1, st));
     } else if (NCH == 1 || !pol->pipeline) {
         bwd_steps(1, T, 0, dh1, st);
         PVR_LAUNCH_CHECK();
         TRY(weight_grads(1, st));
+        TRY(dp_bucket(pol, Gd, b_l1, pol->n_train - b_l1, 0, st));
         TRY(gemm(pol->G[1], P + pol->o_wih[1], nullptr, nullptr, dh0, N, H, 4 * H, false, true, 0, st));
         bwd_steps(0, T, 0, dh0, st);
         PVR_LAUNCH_CHECK();
@@ -485,8 +544,10 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         PVR_HIP_TRY(hipEventRecord(pol->ev_join_b, sb));
         PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_a, 0));
         PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_join_b, 0));
+        TRY(dp_bucket(pol, Gd, b_l1, pol->n_train - b_l1, 0, st));
     }
     TRY(weight_grads(0, st));
+    TRY(dp_bucket(pol, Gd, b_l0, b_l1 - b_l0, 1, st));
     // dx_in of layer 0 = dG W_ih with the ReLU of fc2 applied as a mask (a2 > 0); dh1's buffer is free again
     TRY(gemm(pol->G[0], P + pol->o_wih[0], nullptr, pol->a2, dh1, N, H, 4 * H, false, true, 0, st));
     float *dh_ext = dh1, *dx = dh0;
@@ -498,6 +559,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     TRY(gemm(dz2, P + pol->o_fc2w, nullptr, pol->a1, dz1, N, H, H, false, true, 0, st));      // masked by a1 > 0
     TRY(gemm(dz1, x0, nullptr, nullptr, Gd + pol->o_fc1w, H, O, N, true, true, 0, st));
     TRY(colsum(dz1, Gd + pol->o_fc1b, nullptr, N, H, st));
+    TRY(dp_bucket(pol, Gd, b_fc, b_l0 - b_fc, 2, st));
     const bool need_dobs = d.conv_frames > 0;
     if (d.batch_norm || need_dobs) TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
     const float *dfeat = pol->da0;
@@ -510,12 +572,12 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         if (need_dobs) {
             const float *dg = Gd + pol->o_bnw, *db = Gd + pol->o_bnb;
             int n_bn = N;
-            if (pol->sync_cb && pol->sync_world > 1) {
+            if (dp_active(pol) && pol->dp_sync_bn) {
                 // dx needs the sums over the GLOBAL batch; the gradient buffer keeps the local ones (they are averaged with the rest)
                 PVR_HIP_TRY(hipMemcpyAsync(pol->sync_buf, dg, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
                 PVR_HIP_TRY(hipMemcpyAsync(pol->sync_buf + O, db, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
-                pol->sync_cb(0, 2 * O, pol->sync_user);
-                dg = pol->sync_buf; db = pol->sync_buf + O; n_bn = N * pol->sync_world;
+                TRY(dp_allreduce(pol, pol->sync_buf, 2 * O, st));
+                dg = pol->sync_buf; db = pol->sync_buf + O; n_bn = N * pol->dp_world;
             }
             hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks_for((size_t)N * O)), dim3(256), 0, st, obs, pol->da0, pol->bn_mean, pol->bn_invstd,
                                P + pol->o_bnw, dg, db, pol->dfeat, N, O, n_bn);
@@ -564,6 +626,17 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
             }
             PVR_LAUNCH_CHECK();
         }
+    }
+    if (dp_active(pol)) {
+        TRY(dp_bucket(pol, Gd, 0, b_fc, 3, st));                 // conv stack + BatchNorm affine (everything in front of fc.1)
+        // the loss of the global batch: mean of the per-rank means (equal rows per rank)
+        PVR_HIP_TRY(hipEventRecord(pol->ev_ready[3], st));
+        PVR_HIP_TRY(hipStreamWaitEvent(pol->comm_stream, pol->ev_ready[3], 0));
+        TRY(dp_allreduce(pol, pol->stats, 1, pol->comm_stream));
+        hipLaunchKernelGGL(scale_inplace_kernel, dim3(1), dim3(256), 0, pol->comm_stream, pol->stats, 1.0f / (float)pol->dp_world, 1LL);
+        PVR_LAUNCH_CHECK();
+        PVR_HIP_TRY(hipEventRecord(pol->ev_comm, pol->comm_stream));
+        PVR_HIP_TRY(hipStreamWaitEvent(st, pol->ev_comm, 0));   // the compute stream re-joins: grads are the global-batch gradient from here on
     }
     pol->have_grads = true;
     return PVR_OK;
@@ -693,15 +766,27 @@ void pvr_policy_destroy(pvr_policy *p) {
     for (int i = 0; i < 8; ++i) if (p->ev_chunk[i]) (void)hipEventDestroy(p->ev_chunk[i]);
     drop_graph(p);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+    for (hipEvent_t ev : p->ev_ready) if (ev) (void)hipEventDestroy(ev);
+    if (p->ev_comm) (void)hipEventDestroy(p->ev_comm);
+    for (void *q : {(void *)p->sync_buf, (void *)p->scratch.splitk, (void *)p->scratch.col}) if (q) (void)hipFree(q);
+    for (void *q : p->scratch.retired) (void)hipFree(q);
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (int l = 0; l < 5; ++l) { void *c[] = {p->act[l], p->dact[l], p->wp[l], p->wt[l]}; for (void *q : c) if (q) (void)hipFree(q); }
     delete p;
 }
 
-pvr_status pvr_policy_set_bn_sync(pvr_policy *pol, float *sync_buf, int32_t world_size, pvr_policy_sync_fn fn, void *user) {
-    PVR_REQUIRE(pol, "pvr_policy_set_bn_sync: null policy");
-    PVR_REQUIRE(!fn || (sync_buf && world_size >= 1), "pvr_policy_set_bn_sync: callback needs a buffer of 2*obs_size floats and the world size");
-    pol->sync_buf = fn ? sync_buf : nullptr; pol->sync_cb = fn; pol->sync_user = user; pol->sync_world = fn ? world_size : 1;
+pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int32_t sync_bn, pvr_allreduce_fn fn, void *user) {
+    PVR_REQUIRE(pol, "pvr_policy_set_data_parallel: null policy");
+    const bool on = fn && world_size > 1;
+    if (on && !pol->comm_stream) {
+        PVR_HIP_TRY(hipStreamCreateWithFlags(&pol->comm_stream, hipStreamNonBlocking));
+        for (auto &ev : pol->ev_ready) PVR_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        PVR_HIP_TRY(hipEventCreateWithFlags(&pol->ev_comm, hipEventDisableTiming));
+        PVR_HIP_TRY(hipMalloc((void **)&pol->sync_buf, (size_t)2 * pol->d.obs_size * sizeof(float)));
+    }
+    pol->dp_fn = on ? fn : nullptr; pol->dp_user = on ? user : nullptr; pol->dp_world = on ? world_size : 1;
+    pol->dp_sync_bn = on && sync_bn && pol->d.batch_norm;
     return PVR_OK;
 }
 
@@ -720,6 +805,7 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
                               float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
+    ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
@@ -739,6 +825,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
                                const int64_t *actions, int32_t T, int32_t B, float *grads, float *stats_out, float *logits_out,
                                void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done && actions && grads, "pvr_policy_backward: null argument");
+    ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;
@@ -751,6 +838,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
 pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr, float alpha, float eps,
                             float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && grads, "pvr_policy_apply: null argument");
+    ScratchScope scratch_scope(pol);
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     TRY(apply_core(pol, params, square_avg, grads, alpha, eps, max_grad_norm, st));
@@ -762,11 +850,12 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
                            const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
                            float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;
     TRY(set_lr(pol, lr, st));
-    if (!pol->use_graph || pol->sync_cb) {      // (a host callback cannot run inside a stream capture)
+    if (!pol->use_graph || dp_active(pol)) {    // (the collective callback cannot run inside a stream capture)
         TRY(loss_backward(pol, params, bn, obs, done, (const long long *)actions, T, B, pol->grads, st));
         TRY(apply_core(pol, params, square_avg, pol->grads, alpha, eps, max_grad_norm, st));
     } else {
@@ -819,6 +908,7 @@ pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_st
 pvr_status pvr_op_gemm_f32(const float *A, const float *B, const float *bias, float *C, int32_t M, int32_t N, int32_t K,
                            int32_t a_km, int32_t b_kn, int32_t relu, void *hip_stream) {
     PVR_REQUIRE(A && B && C, "pvr_op_gemm_f32: null pointer");
+    ScratchScope scratch_scope(nullptr);
     return gemm(A, B, bias, nullptr, C, M, N, K, a_km != 0, b_kn != 0, relu, (hipStream_t)hip_stream);
 }
 

@@ -682,8 +682,10 @@ static __global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
         float se = 0.f;
         for (int a = 0; a < p.A; ++a) se += expf(l[a] - mx);
         const float lse = mx + logf(se);
-        const int tg = (int)p.target[n];
-        p.loss_row[n] = lse - l[tg];
+        const long long tgl = p.target[n];
+        const bool tg_ok = tgl >= 0 && tgl < p.A;                 // torch's nll_loss raises for a target outside [0, A): fail loudly here too
+        const int tg = tg_ok ? (int)tgl : 0;
+        p.loss_row[n] = tg_ok ? lse - l[tg] : __builtin_nanf("");   // NaN loss (and NaN gradient norm downstream) instead of an out-of-bounds read
         const float inv = 1.0f / (float)p.N;
         for (int a = 0; a < 16; ++a)
             p.dlogits[(size_t)n * 16 + a] = a < p.A ? (expf(l[a] - lse) - (a == tg ? 1.f : 0.f)) * inv : 0.f;
@@ -848,6 +850,10 @@ static __global__ void set_scalar_kernel(float *dst, float v) { *dst = v; }
 static __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ out, const float *__restrict__ in, float s, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i] * s;
+}
+static __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, float s, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= s;
 }
 static __global__ __launch_bounds__(256) void bn_sync_final_kernel(const float *__restrict__ sumsq, const float *__restrict__ mean,
                                                             float n_global, float *__restrict__ invstd, float *__restrict__ running_mean,

@@ -63,8 +63,7 @@ def run(flags, make_env=None):
         env = make_env(flags, embedding_model)
         obs_shape, n_actions = env.gym_env.observation_space.shape, env.gym_env.action_space.n
     else:
-        obs_shape, n_actions = (obs.shape[1],), int(np.max(action)) + 1
-    n_actions = int(getattr(flags, 'num_actions', n_actions))
+        obs_shape, n_actions = (obs.shape[1],), int(getattr(flags, 'num_actions', 3))      # never derived from the data
 
     actor_model = PolicyNet(obs_shape, n_actions, flags.batch_norm, max_unroll=flags.unroll_length,
                             max_batch=flags.batch_size).to(device=flags.device)
@@ -103,14 +102,15 @@ def run(flags, make_env=None):
 
     print('=== Training policy ===')
     actor_model.train()
-    obs_t = torch.from_numpy(np.ascontiguousarray(obs))          # host-resident dataset; batches are gathered per step
+    # torch's nll_loss raises for a target outside [0, A); the fused loss kernel only turns it into a NaN loss: check the data once
+    assert int(np.min(action)) >= 0 and int(np.max(action)) < n_actions, \
+        'actions in the data (%d..%d) do not fit num_actions=%d' % (int(np.min(action)), int(np.max(action)), n_actions)
+    from .bc_data import DeviceDataset
+    dataset = DeviceDataset(obs, action, done, flags.device)    # resident in HBM; every (T,B) batch is gathered there (pvr_bc_gather)
     for frames in range(init_frames, flags.max_frames, flags.batch_size * flags.unroll_length):
         epoch = frames // (flags.batch_size * flags.unroll_length)
         starting_i = sample_with_minimum_distance(n=n_samples, k=flags.batch_size, d=flags.unroll_length)
-        idx = np.mod(np.asarray(starting_i)[None, :] + np.arange(flags.unroll_length)[:, None], n_samples)
-        o = obs_t[torch.from_numpy(idx)]                          # (T,B,obs) == np.stack(..., axis=1) of main_bc_2.py:194-201
-        a = torch.from_numpy(action[idx])
-        d = torch.from_numpy(done[idx])
+        o, a, d = dataset.gather(starting_i, flags.unroll_length)   # (T,B,obs) == np.stack(..., axis=1) of main_bc_2.py:194-201
         optimizer.scheduler_step()                                # precedes the update (main_bc_2.py:216)
         loss, gradient_norm = optimizer.step(o, d, a)
         if (epoch + 1) % flags.eval_frequency == 0:

@@ -4,9 +4,13 @@ update rule as reference main_bc_finetune.py:25-242 (model :70, data :102-128, l
 Data parallel (BASELINE config 4 / SURVEY 8e; the reference `main` is single-GPU): under an initialised
 torch.distributed group every rank draws the SAME `sample_with_minimum_distance` list (same `random.seed(run_id)`),
 takes its contiguous slice of the B start indices (the LSTM keeps T whole), runs forward/backward on it, and the
-flat 18.1 M-float gradient is averaged with one all-reduce (RCCL over xGMI with backend "nccl") before the
-clipped RMSprop update, which is then identical on every rank.  Habitat evaluation needs the simulator: pass
-`make_env` as in main_bc_2.run."""
+flat 18.1 M-float gradient is averaged in four buckets (RCCL over xGMI with backend "nccl") that leave while backward is still
+running (HipRMSprop.step_data_parallel / pvr_policy_set_data_parallel) before the clipped RMSprop update, which is then
+identical on every rank.  Launch:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m pvr_habitat_amd.main_bc_finetune ...
+(`__main__` reads RANK / LOCAL_RANK / WORLD_SIZE, picks the GPU and creates the process group before the first GPU call).
+Interrupted runs resume, completed runs return early (main_bc_finetune.py:47-56,84-89,135-143).  Habitat evaluation needs the
+simulator: pass `make_env` as in main_bc_2.run."""
 import os
 import pickle
 import random
@@ -17,14 +21,8 @@ import torch
 from .arguments import make_parser
 from .models import PolicyNetWithConv, HipRMSprop
 from .utils_bc import is_essential_save, sample_with_minimum_distance, shard_bounds
-from .main_bc_2 import test
-
-
-def _dist():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+from .test_model import test
+from .dist_utils import rank_world, init_distributed, finalize_distributed
 
 
 def load_raw(flags, from_env):
@@ -45,13 +43,21 @@ def load_raw(flags, from_env):
 
 
 def run(flags, make_env=None):
-    rank, world = _dist()
+    rank, world = rank_world()
     torch.manual_seed(flags.run_id)
     np.random.seed(flags.run_id)
     random.seed(flags.run_id)                                   # identical sampler stream on every rank
     from_env, to_env = flags.env, flags.to_env
     os.makedirs(flags.save_path, exist_ok=True)
     save_path = os.path.join(flags.save_path, from_env + '_emrandom_finetuned_s' + str(flags.run_id) + '_' + to_env)
+    # a finished run returns early, an interrupted one resumes (main_bc_finetune.py:47-56); every rank reads the same files
+    resume = False
+    if os.path.isfile(save_path + '.pickle'):
+        stats = pickle.load(open(save_path + '.pickle', 'rb'))
+        if stats[to_env]['frames'][-1] >= flags.max_frames:
+            print('   WARNING! This run was already completed. Stopping now.')
+            return stats
+        resume = os.path.isfile(save_path + '.tar')
     flags.device = torch.device('cuda') if torch.cuda.is_available() and not flags.disable_cuda else torch.device('cpu')
     print('=== Loading trajectories ===')
     obs, action, reward, done = load_raw(flags, from_env)
@@ -63,7 +69,10 @@ def run(flags, make_env=None):
         env = make_env(flags, None)
         obs_shape, n_actions = env.gym_env.observation_space.shape, env.gym_env.action_space.n
     else:
-        obs_shape, n_actions = obs.shape[1:], int(getattr(flags, 'num_actions', int(np.max(action)) + 1))
+        obs_shape, n_actions = obs.shape[1:], int(getattr(flags, 'num_actions', 3))           # never derived from the data
+    # torch's nll_loss raises for a target outside [0, A); the fused loss kernel would only turn it into a NaN loss: check once here
+    assert int(np.min(action)) >= 0 and int(np.max(action)) < n_actions, \
+        'actions in the data (%d..%d) do not fit num_actions=%d' % (int(np.min(action)), int(np.max(action)), n_actions)
     assert flags.batch_size % world == 0, 'batch_size must divide evenly over the ranks'
     b_lo, b_hi = shard_bounds(flags.batch_size, rank, world)
     actor_model = PolicyNetWithConv(obs_shape, n_actions, flags.batch_norm, max_unroll=flags.unroll_length,
@@ -74,16 +83,24 @@ def run(flags, make_env=None):
     test_model = PolicyNetWithConv(obs_shape, n_actions, flags.batch_norm, max_unroll=1, max_batch=1).to(device=flags.device)
     test_model.eval()
     stat_keys = ['episode_return', 'episode_success']
-    stats = {to_env: {**{k: [np.nan] for k in stat_keys}, 'frames': [0], 'training_loss': [np.nan], 'gradient_norm': [np.nan]}}
+    init_frames = 0
+    if resume:                                                  # (:84-89,135-143) weights, optimizer state and schedule position
+        print('=== Resuming previous run ===')
+        checkpoint = torch.load(save_path + '.tar', weights_only=False, map_location='cpu')
+        actor_model.load_state_dict(checkpoint['actor_model_state_dict'])
+        optimizer.load_state_dict(checkpoint['actor_model_optimizer_state_dict'])
+        optimizer.last_epoch = checkpoint['scheduler_state_dict']['last_epoch']
+        init_frames = stats[to_env]['frames'][-1]                # (the sampler stream restarts from the seed, as in the reference)
+    else:
+        stats = {to_env: {**{k: [np.nan] for k in stat_keys}, 'frames': [0], 'training_loss': [np.nan], 'gradient_norm': [np.nan]}}
     print('=== Training policy ===')
     actor_model.train()
-    obs_t = torch.from_numpy(obs)
-    for frames in range(0, flags.max_frames, flags.batch_size * flags.unroll_length):
+    from .bc_data import DeviceDataset
+    dataset = DeviceDataset(obs, action, done, flags.device)    # raw uint8 frames resident in HBM (24.6 KB per sample)
+    for frames in range(init_frames, flags.max_frames, flags.batch_size * flags.unroll_length):
         epoch = frames // (flags.batch_size * flags.unroll_length)
         starting_i = sample_with_minimum_distance(n=n_samples, k=flags.batch_size, d=flags.unroll_length)
-        idx = np.mod(np.asarray(starting_i[b_lo:b_hi])[None, :] + np.arange(flags.unroll_length)[:, None], n_samples)
-        o = obs_t[torch.from_numpy(idx)]                        # (T, B/world, 64, 64, 6) uint8
-        a, d = torch.from_numpy(action[idx]), torch.from_numpy(done[idx])
+        o, a, d = dataset.gather(starting_i[b_lo:b_hi], flags.unroll_length)     # (T, B/world, 64, 64, 6) uint8, this rank's sequences
         optimizer.scheduler_step()
         loss, gradient_norm = optimizer.step_data_parallel(o, d, a)
         if (epoch + 1) % flags.eval_frequency == 0:
@@ -111,5 +128,14 @@ def run(flags, make_env=None):
     return stats
 
 
+def main(argv=None):
+    flags = make_parser().parse_args(argv)
+    init_distributed()                                          # device + process group first, before any GPU call
+    try:
+        return run(flags)
+    finally:
+        finalize_distributed()
+
+
 if __name__ == '__main__':
-    run(make_parser().parse_args())
+    main()

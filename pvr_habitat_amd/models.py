@@ -31,7 +31,7 @@ class PolicyDesc(C.Structure):
                 ('max_t', C.c_int32), ('max_b', C.c_int32), ('conv_frames', C.c_int32)]
 
 
-SYNC_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)     # pvr_policy_sync_fn (include/pvr_policy.h)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)     # pvr_allreduce_fn (include/pvr_policy.h)
 
 
 def _plib():
@@ -56,8 +56,8 @@ def _plib():
         L.pvr_policy_backward.argtypes = [vp, vp, C.POINTER(PolicyBN), vp, vp, vp, i32, i32, vp, vp, vp, vp]
         L.pvr_policy_apply.restype = C.c_int
         L.pvr_policy_apply.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, vp, vp]
-        L.pvr_policy_set_bn_sync.restype = C.c_int
-        L.pvr_policy_set_bn_sync.argtypes = [vp, vp, i32, SYNC_FN, vp]
+        L.pvr_policy_set_data_parallel.restype = C.c_int
+        L.pvr_policy_set_data_parallel.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
         L.pvr_op_gemm_f32.restype = C.c_int
@@ -270,16 +270,44 @@ class PolicyNet(nn.Module):
         return out
 
 
-def average_gradients(flat_grads, stats, group=None):
-    """Sum the flat gradient (and the loss) over ranks, divide by the world size.  One collective for the whole
-    model: 18.1 M fp32 = 72.6 MB for PolicyNetWithConv.  Works on any backend (gloo in the CPU tests)."""
+class _DevMem(object):
+    """`count` fp32 values at a raw device address, as an object torch.as_tensor can wrap without a copy"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def make_allreduce_fn(group=None, device='cuda'):
+    """The collective libpvr_hip.so calls for data-parallel training (pvr_allreduce_fn, include/pvr_policy.h): an in-place SUM
+    all-reduce of `count` floats at `buf`, enqueued on the HIP stream the library names - its communication stream for the
+    gradient buckets, the compute stream for SyncBN statistics.  torch.distributed under backend "nccl" is RCCL over xGMI;
+    "gloo" (CPU tests, or ranks sharing one GPU) works too.  ctypes would print and swallow an exception raised inside the
+    callback, so it is caught here, kept in `errors`, and turned into a non-zero status: the library entry point then fails
+    with PVR_ERR_COMM and the caller re-raises the original exception.
+    Returns (ctypes thunk - keep it alive while installed -, errors list)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-    flat_grads.div_(world)
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    stats.div_(world)
-    return flat_grads
+    errors, streams = [], {}
+
+    def _cb(buf, count, stream, user):
+        try:
+            if device == 'cuda':
+                t = torch.as_tensor(_DevMem(buf, count), device='cuda')
+                sp = int(stream or 0)
+                if sp == torch.cuda.current_stream().cuda_stream:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                else:
+                    if sp not in streams:
+                        streams[sp] = torch.cuda.ExternalStream(sp)
+                    with torch.cuda.stream(streams[sp]):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                t = torch.from_numpy(np.ctypeslib.as_array((C.c_float * int(count)).from_address(buf)))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except BaseException as e:            # noqa: B902 - nothing may propagate into the C caller
+            errors.append(e)
+            return 1
+    return ALLREDUCE_FN(_cb), errors
 
 
 class PolicyNetWithConv(PolicyNet):
@@ -306,7 +334,7 @@ class HipRMSprop(object):
         self.steps = 0
         self._stats = None
         self._grads = None            # caller-owned flat gradient (data-parallel path)
-        self._sync_buf = self._sync_cb = self._sync_group = None   # SyncBN plumbing (data-parallel path)
+        self._dp_cb, self._dp_errors, self._dp_key = None, [], None   # data-parallel plumbing (the ctypes thunk must stay alive)
 
     def scheduler_step(self):
         self.last_epoch += 1
@@ -337,37 +365,47 @@ class HipRMSprop(object):
         self.steps += 1
         return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
 
-    def _install_bn_sync(self, group, world):
-        """SyncBN: BatchNorm statistics over the global batch.  The library calls back between its statistic
-        kernels; the callback all-reduces a slice of a small device buffer on the current stream (pvr_policy.h)."""
-        import torch.distributed as dist
+    def _install_data_parallel(self, group, world, sync_bn):
+        """Hand the library its collective (pvr_policy_set_data_parallel).  Re-installed when the policy handle, the group or the
+        SyncBN choice changes; world == 1 uninstalls."""
         m = self.model
-        if self._sync_buf is None or self._sync_buf.device != m.device:
-            self._sync_buf = torch.zeros(2 * m.obs_size, dtype=torch.float32, device=m.device)
+        key = (m._handle.value if m._handle is not None else None, id(group), world, bool(sync_bn))
+        if getattr(self, '_dp_key', None) == key:
+            return
+        if world > 1:
+            import torch.distributed as dist
+            gloo = dist.get_backend(group) == 'gloo'
+            self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda')
+            self._dp_gloo = gloo
+            _lib.check(_plib().pvr_policy_set_data_parallel(m._handle, world, int(bool(sync_bn)), self._dp_cb, None))
+        else:
+            _lib.check(_plib().pvr_policy_set_data_parallel(m._handle, 1, 0, ALLREDUCE_FN(), None))
+            self._dp_cb, self._dp_errors = None, []
+        self._dp_key = key
 
-            def _cb(offset, count, user, _buf=self._sync_buf):
-                dist.all_reduce(_buf[offset:offset + count], op=dist.ReduceOp.SUM, group=self._sync_group)
-            self._sync_cb = SYNC_FN(_cb)                      # keep the ctypes thunk alive
-        self._sync_group = group
-        _lib.check(_plib().pvr_policy_set_bn_sync(m._handle, C.c_void_p(self._sync_buf.data_ptr()), world, self._sync_cb, None))
+    def _checked(self, status):
+        """a failed collective: re-raise the exception the callback caught instead of the library's generic message"""
+        if status != 0 and getattr(self, '_dp_errors', None):
+            e = self._dp_errors[-1]
+            del self._dp_errors[:]
+            raise e
+        _lib.check(status)
 
     def step_data_parallel(self, obs, done, actions, group=None, sync_bn=True):
-        """Finetune configuration: every rank runs forward/backward on its slice of the batch, the flat
-        gradient is summed over ranks with ONE all-reduce (RCCL over xGMI under backend 'nccl') and divided by the
-        world size (loss is a mean over the global batch), then every rank applies the identical clipped RMSprop
-        update.  With sync_bn (default) BatchNorm uses global-batch statistics (three more all-reduces of <= 2*obs_size
-        floats), so N ranks x B/N sequences reproduce one rank x B; sync_bn=False keeps per-rank statistics (torch DDP
-        default)."""
+        """Finetune configuration (BASELINE config 4): every rank runs forward/backward on its slice of the batch.
+        Inside pvr_policy_backward the gradient leaves in four buckets, each all-reduced (RCCL over xGMI under backend 'nccl') on
+        the library's communication stream as soon as backward has finalised it - LSTM layer 1 + policy head while layer 0 still
+        runs its BPTT, layer 0 during the fc / conv backward, ... - and divided by the world size (the loss is a mean over the
+        global batch); every rank then applies the identical clipped RMSprop update.  With sync_bn (default) BatchNorm uses
+        global-batch statistics, so N ranks x B/N sequences reproduce one rank x B; sync_bn=False keeps per-rank statistics
+        (torch DDP default).  Without an initialised process group (or world size 1) this is the single-GPU iteration."""
         import torch.distributed as dist
         m = self.model
         T, B = obs.shape[0], obs.shape[1]
         m._ensure(T, B)
         dev = m.device
-        world0 = dist.get_world_size(group) if dist.is_initialized() else 1
-        if m.batch_norm and sync_bn and world0 > 1:
-            self._install_bn_sync(group, world0)
-        elif self._sync_cb is not None:
-            _lib.check(_plib().pvr_policy_set_bn_sync(m._handle, None, 1, SYNC_FN(), None))
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._install_data_parallel(group, world, m.batch_norm and sync_bn)
         if self.square_avg.device != dev:
             self.square_avg = self.square_avg.to(dev)
         if self._grads is None or self._grads.device != dev:
@@ -379,11 +417,8 @@ class HipRMSprop(object):
         bn = m._bn_struct()
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         L = _plib()
-        _lib.check(L.pvr_policy_backward(m._handle, vp(m._flat), C.byref(bn) if bn else None, vp(x), vp(d), vp(a), T, B,
-                                         vp(self._grads), vp(stats), None, _lib.stream_ptr()))
-        world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if world > 1:
-            average_gradients(self._grads, stats, group)
+        self._checked(L.pvr_policy_backward(m._handle, vp(m._flat), C.byref(bn) if bn else None, vp(x), vp(d), vp(a), T, B,
+                                            vp(self._grads), vp(stats), None, _lib.stream_ptr()))
         _lib.check(L.pvr_policy_apply(m._handle, vp(m._flat), vp(self.square_avg), vp(self._grads), self.current_lr(), self.alpha,
                                       self.eps, self.max_grad_norm, vp(stats), _lib.stream_ptr()))
         self.steps += 1

@@ -1,7 +1,10 @@
 """Offline embedding of saved trajectories: same `run(flags)` contract, flags and output files as reference
 behavioral_cloning/save_embedded_obs.py:96-172, with the frames pushed through the HIP encoder in large
 batches and, under torch.distributed, sharded across the GPUs of one node with NO collective on the data
-path (each rank embeds a contiguous row range; rank 0 concatenates in rank order and writes the pickle).
+path: each rank embeds a contiguous row range (pickle source) or a contiguous range of trajectories (png source: the goal frame
+is per trajectory) and writes its own shard file `<env>_<emb>.rank<r>.pickle`; after a barrier rank 0 stitches the shard files
+in rank order into the reference's output file and removes them.  Launch:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m pvr_habitat_amd.save_embedded_obs ...
 
   pickle source: <data_path>/<env>.pickle  {obs:[(L,H,W,3n) u8], action, reward, done, true_state}  (:29-47)
   png source:    <data_path>/<env>/<t>_<s>.png, <t>_goal.png, <t>.pickle                             (:50-93)
@@ -18,6 +21,7 @@ import torch
 from .arguments import make_parser
 from .embeddings import EmbeddingNet
 from .utils_bc import shard_bounds
+from .dist_utils import init_distributed, finalize_distributed
 
 
 def _dist():
@@ -87,7 +91,16 @@ def _load_png_trajectory(data_path, t, pool):
     return goal, tmp, (np.stack(frames) if frames else None), names
 
 
-def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None):
+def count_png_trajectories(data_path, n_trajectories=-1):
+    """trajectories the reference's reader would visit: 0, 1, ... up to the first missing <t>.pickle / <t>_goal.png (:57-68)"""
+    t = 0
+    while (n_trajectories < 0 or t < n_trajectories) and os.path.isfile(os.path.join(data_path, '%d.pickle' % t)) \
+            and os.path.isfile(os.path.join(data_path, '%d_goal.png' % t)):
+        t += 1
+    return t
+
+
+def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None):
     """PNG layout of save_opt_trajectories_png.py:44-58.  The reference decodes and embeds one frame per forward (:69-77);
     here a trajectory's frames are decoded by a host thread pool and embedded together (same rows, same order), and
     trajectory t+1 is decoded while trajectory t is on the GPU (keeping the GPU fed from the PNG source)."""
@@ -97,14 +110,15 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     if n_trajectories == -1:
         n_trajectories = 100000
     workers = decode_workers or min(16, os.cpu_count() or 1)
-    t = 0
+    t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
+    t = t_lo
     with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectory, data_path, 0, pool) if n_trajectories > 0 else None
-        for t in range(n_trajectories):
+        nxt = ahead.submit(_load_png_trajectory, data_path, t_lo, pool) if t_hi > t_lo else None
+        for t in range(t_lo, t_hi):
             cur = nxt.result()
             if cur is None:
                 break
-            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, pool) if t + 1 < n_trajectories else None
+            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, pool) if t + 1 < t_hi else None
             goal, tmp, frames, names = cur
             for k in data.keys():
                 if k in tmp:
@@ -120,11 +134,11 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
                 data['obs'].extend(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
             data['png'] += names
         else:
-            t = n_trajectories
-    n_trajectories = t
-    data['obs'] = np.stack(data['obs'])
+            t = t_hi
+    n_trajectories = t - t_lo
+    data['obs'] = np.stack(data['obs']) if data['obs'] else np.zeros((0, 0), np.float32)
     for k in ('action', 'reward', 'done', 'true_state'):
-        data[k] = np.concatenate(data[k])
+        data[k] = np.concatenate(data[k]) if data[k] else np.zeros((0,))
     n_samples = len(data['reward'])
     print('  ', '%d trajectories for a total of %d samples' % (n_trajectories, n_samples))
     return data
@@ -150,10 +164,16 @@ def run(flags):
         torch.save({'embedding_model_state_dict': embedding_model.state_dict()}, emb_path + '.tar')
     print('=== Loading trajectories ===')
     batch = getattr(flags, 'embed_batch', 256)
+    keys = ('obs', 'action', 'reward', 'done', 'true_state')
     if flags.source == 'png':
-        assert world == 1, 'png source: shard by trajectory directory, one process per shard'
-        data = read_habitat_data_from_png(os.path.join(flags.data_path, flags.env), embedding_model, flags.n_trajectories, batch)
-        # (the reference dumps this dict as it is, 'png' file list included: save_embedded_obs.py:53,78,171-172)
+        # the goal frame is per trajectory, so the png source shards on trajectory boundaries: rank r takes trajectories [t_lo, t_hi)
+        png_dir = os.path.join(flags.data_path, flags.env)
+        t_range = None
+        if world > 1:
+            t_range = shard_bounds(count_png_trajectories(png_dir, flags.n_trajectories), rank, world)
+        data = read_habitat_data_from_png(png_dir, embedding_model, flags.n_trajectories, batch, t_range=t_range)
+        keys = keys + ('png',)          # (the reference dumps this dict as it is, 'png' file list included: save_embedded_obs.py:53,78,171-172)
+        data = {k: data[k] for k in keys}
     else:
         data = read_habitat_data_from_pickle(os.path.join(flags.data_path, flags.env), flags.n_trajectories)
         print('  ', 'passing observations through embedding model')
@@ -170,20 +190,44 @@ def run(flags):
                                    for f in range(n_frames)], axis=-1) if hi > lo else np.zeros((0, 0), np.float32)
         else:
             mine = embed_rows(embedding_model, data['obs'][lo:hi], n_frames, max(1, batch // n_frames))
-        if world > 1:
-            parts = [None] * world if rank == 0 else None
-            dist.gather_object(mine, parts, dst=0)              # host-side concat only; no device collective
-            if rank != 0:
-                return
-            mine = np.concatenate(parts)
-        data = dict(obs=np.array(mine), action=data['action'][:n_samples], reward=data['reward'][:n_samples],
-                    done=data['done'][:n_samples], true_state=data['true_state'][:n_samples])
+        data = dict(obs=np.array(mine), action=data['action'][lo:hi], reward=data['reward'][lo:hi],
+                    done=data['done'][lo:hi], true_state=data['true_state'][lo:hi])
+    if world > 1:
+        # every rank writes its own shard file; rank 0 stitches them in rank order (= the reference's row order): nothing but a
+        # barrier crosses ranks, and no rank ever holds another rank's rows in a collective buffer (cfg 5: 125 GB of embeddings)
+        with open(shard_name(save_name, rank), 'wb') as handle:
+            pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
+        dist.barrier()
+        if rank != 0:
+            return
+        parts = []
+        for r in range(world):
+            with open(shard_name(save_name, r), 'rb') as handle:
+                parts.append(pickle.load(handle))
+        parts = [q for q in parts if len(q['reward']) > 0] or parts[:1]
+        data = {k: (sum((list(q[k]) for q in parts), []) if k == 'png' else np.concatenate([q[k] for q in parts])) for k in keys}
     n_samples = len(data['reward'])
     assert n_samples > 0, 'no data found'
     print('  ', 'total number of samples', n_samples)
     with open(save_name, 'wb') as handle:
         pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
+    for r in range(world if world > 1 else 0):
+        os.remove(shard_name(save_name, r))
+
+
+def shard_name(save_name, rank):
+    """<data_path>/<env>_<embedding>.rank<r>.pickle: rank r's rows while a multi-GPU run is in progress"""
+    return save_name[:-len('.pickle')] + '.rank%d.pickle' % rank
+
+
+def main(argv=None):
+    flags = make_parser().parse_args(argv)
+    init_distributed()                                          # device + process group first, before any GPU call
+    try:
+        run(flags)
+    finally:
+        finalize_distributed()
 
 
 if __name__ == '__main__':
-    run(make_parser().parse_args())
+    main()

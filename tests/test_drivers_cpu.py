@@ -143,22 +143,25 @@ def test_save_embedded_obs_sharded_gloo_world2(tmp_path):
 
 
 _DP_WORKER = r'''
-import os, sys, torch, torch.distributed as dist
+import ctypes as C, os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
-from pvr_habitat_amd.models import average_gradients
+from pvr_habitat_amd.models import make_allreduce_fn
 dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
 r = dist.get_rank()
-g = torch.arange(10, dtype=torch.float32) * (r + 1)           # rank 0: k, rank 1: 2k -> mean 1.5k
-stats = torch.tensor([float(r + 1), 0.0])
-average_gradients(g, stats)
-assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * 1.5), g
-assert float(stats[0]) == 1.5
+fn, errors = make_allreduce_fn(None, device='cpu')
+g = (np.arange(10, dtype=np.float32) * (r + 1))               # rank 0: k, rank 1: 2k -> sum 3k
+assert fn(g.ctypes.data, 10, None, None) == 0 and not errors
+assert np.allclose(g, np.arange(10, dtype=np.float32) * 3), g
+# a failing collective must not vanish inside the ctypes callback: non-zero status + the exception kept for the caller
+bad, berr = make_allreduce_fn('not a process group', device='cpu')
+assert bad(g.ctypes.data, 10, None, None) == 1 and len(berr) == 1
 dist.barrier()
 '''
 
 
-def test_gradient_averaging_gloo_world2(tmp_path):
-    """The one exchange step of the finetune configuration (SURVEY 8e): sum over ranks / world size, on gloo."""
+def test_allreduce_callback_gloo_world2(tmp_path):
+    """The one collective the library calls in the finetune configuration (pvr_allreduce_fn, SURVEY 8e): in-place SUM over the
+    ranks of a raw buffer, on gloo; errors come back as a status, not as a swallowed exception."""
     script = tmp_path / 'dp.py'
     script.write_text(_DP_WORKER % dict(root=ROOT))
     procs = []
@@ -166,3 +169,45 @@ def test_gradient_averaging_gloo_world2(tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29741')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
     assert all(p.wait(timeout=120) == 0 for p in procs)
+
+
+_PNG_WORKER = r'''
+import os, sys, pickle, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+os.environ['PVR_DIST_BACKEND'] = 'gloo'
+import pvr_habitat_amd.save_embedded_obs as S
+from test_glue_golden import OracleEmbeddingNet
+S.EmbeddingNet = OracleEmbeddingNet
+S.main(['--data_path', sys.argv[1], '--env', 'scene', '--embedding_name', 'resnet50', '--disable_pretrained_embedding',
+        '--source', sys.argv[2], '--embed_batch', '4'])
+'''
+
+
+@pytest.mark.parametrize('source', ['png', 'pickle'])
+def test_save_embedded_obs_cli_entry_shards_and_stitches(tmp_path, source):
+    """`python -m pvr_habitat_amd.save_embedded_obs` under torch.distributed.run's environment (RANK / WORLD_SIZE / MASTER_*), gloo,
+    world 2: main() creates the process group itself, the png source shards on trajectory boundaries, every rank writes
+    <env>_<emb>.rank<r>.pickle, rank 0 stitches them in rank order and removes them - same file as the reference fixture."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import glue_inputs as GI
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'glue_save_obs.npz'))
+    GI.write_scene(str(tmp_path))
+    script = tmp_path / 'w.py'
+    script.write_text(_PNG_WORKER % dict(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29761' if source == 'png' else '29763',
+                   OMP_NUM_THREADS='4')
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path), source], env=env))
+    assert all(p.wait(timeout=600) == 0 for p in procs)
+    res = pickle.load(open(tmp_path / 'scene_resnet50.pickle', 'rb'))
+    assert list(res.keys()) == list(g[source + '/keys'])
+    assert res['obs'].shape == g[source + '/obs'].shape
+    err = np.linalg.norm(res['obs'] - g[source + '/obs'], axis=1) / np.linalg.norm(g[source + '/obs'], axis=1)
+    assert err.max() < 5e-5, err
+    for k in ('action', 'reward', 'done', 'true_state'):
+        np.testing.assert_array_equal(res[k], g['%s/%s' % (source, k)])
+    if source == 'png':
+        assert [os.path.relpath(q, str(tmp_path)) for q in res['png']] == list(g['png/png'])
+    assert not [f for f in os.listdir(tmp_path) if '.rank' in f]

@@ -73,3 +73,17 @@ def test_finetune_pipeline(tmp_path):
     assert len(stats['frames']) == 3 and all(np.isfinite(stats['training_loss'][1:]))
     ck = torch.load(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar', weights_only=False)
     assert ck['actor_model_state_dict']['feat_extract.8.weight'].shape == (32, 32, 3, 3)
+    # resume / completed-run guard (main_bc_finetune.py:47-56,84-89,135-143): the last saved point is frames=288 < 320, so a relaunch
+    # reloads weights + optimizer + schedule from the .tar, runs the one remaining iteration and appends its evaluation point;
+    # a relaunch of a finished run returns without touching the files
+    w_before = ck['actor_model_state_dict']['fc.1.weight'].clone()
+    again = Fz.run(make_parser().parse_args(args))['scene']
+    assert again['frames'] == stats['frames'] + [288]
+    ck2 = torch.load(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar', weights_only=False)
+    assert ck2['scheduler_state_dict']['last_epoch'] == ck['scheduler_state_dict']['last_epoch'] + 1
+    assert not torch.equal(ck2['actor_model_state_dict']['fc.1.weight'], w_before)
+    assert float((ck2['actor_model_state_dict']['fc.1.weight'] - w_before).abs().max()) < 1e-2      # continued from the checkpoint, not re-initialised
+    mtime = os.path.getmtime(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar')
+    done_args = [a if a != '320' else '288' for a in args]
+    finished = Fz.run(make_parser().parse_args(done_args))['scene']
+    assert finished['frames'] == again['frames'] and os.path.getmtime(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar') == mtime

@@ -309,8 +309,8 @@ dist.barrier()
 
 @pytest.mark.parametrize('kind', ['vec', 'conv', 'vec_bn', 'conv_bn'])
 def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
-    """Finetune DP: 2 ranks x B/2 sequences + one all-reduce of the flat gradient == 1 rank x B, with BatchNorm
-    too (SyncBN: global-batch statistics through pvr_policy_set_bn_sync, incl. the running buffers and, for the conv
+    """Finetune DP: 2 ranks x B/2 sequences + the bucketed all-reduce of the flat gradient == 1 rank x B, with BatchNorm
+    too (SyncBN: global-batch statistics through pvr_policy_set_data_parallel's collective, incl. the running buffers and, for the conv
     variant, the BN input gradient).  Both ranks run on the one test GPU."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
