@@ -98,6 +98,25 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
 pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr,
                             float alpha, float eps, float max_grad_norm, float *stats_out, void *hip_stream);
 
+/* Autograd bridge: the backward half for a caller that computes the loss itself (the reference's own lines, main_bc_2.py:211-220:
+ * F.nll_loss(F.log_softmax(logits)) ... loss.backward()).  Call after a training-mode pvr_policy_forward of the same (obs, T, B):
+ * dlogits (device, (T,B,A) contiguous) is d(loss)/d(policy_logits); leaves d(loss)/d(params) in grads (trainable_count floats) -
+ * all-reduced over the ranks when pvr_policy_set_data_parallel is installed.  The baseline head receives no gradient (the BC loss
+ * does not read it; torch leaves its .grad None too).  One backward per forward. */
+pvr_status pvr_policy_backward_dlogits(pvr_policy *pol, const float *params, const void *obs, const float *dlogits, int32_t T,
+                                       int32_t B, float *grads, void *hip_stream);
+
+/* Other update rules on the same flat buffers (grad norm + clip as in pvr_policy_apply; stats_out[1] = pre-clip norm):
+ * torch.optim.RMSprop with momentum != 0 (src/arguments.py:63 exposes --momentum; the reference default 0 is pvr_policy_apply) and
+ * torch.optim.Adam(betas, eps; amsgrad off, no weight decay) - an extension, BASELINE.json's north_star names Adam.  step = 1, 2, ...
+ * is the update count (bias correction). */
+pvr_status pvr_policy_apply_momentum(pvr_policy *pol, float *params, float *square_avg, float *momentum_buf, const float *grads,
+                                     float lr, float alpha, float eps, float momentum, float max_grad_norm, float *stats_out,
+                                     void *hip_stream);
+pvr_status pvr_policy_apply_adam(pvr_policy *pol, float *params, float *exp_avg, float *exp_avg_sq, const float *grads, float lr,
+                                 float beta1, float beta2, float eps, int64_t step, float max_grad_norm, float *stats_out,
+                                 void *hip_stream);
+
 /* BC batch assembly on the device: replaces the host gather of main_bc_2.py:186-204 (identical in main_bc_1.py:193-211 and
  * main_bc_finetune.py:173-188).  The dataset stays resident in HBM: obs_dev (n_samples rows of row_bytes bytes: fp32 embeddings, or
  * raw uint8 frames for the finetune model), action_dev (int64), done_dev (uint8).  For the B start indices of

@@ -54,6 +54,8 @@ def make_parser():
     parser.add_argument('--num_actions', type=int, default=3, help='size of the policy head when no simulator is attached (the reference '
                         'reads env.gym_env.action_space.n, main_bc_2.py:77; Habitat ImageNav without STOP has 3 actions, gym_wrappers.py:173). '
                         'The data is checked against it - it is never derived from the data')
+    parser.add_argument('--autograd_step', action='store_true', help="run the reference's own training lines (loss.backward(), "
+                        'clip_grad_norm_, torch.optim.RMSprop.step(): main_bc_2.py:206-227) through the autograd bridge instead of the fused step')
     parser.add_argument('--optimizer', type=str, default='rmsprop', choices=['rmsprop', 'adam'],
                         help="'rmsprop' is the reference's optimiser (main_bc_2.py:80-86); 'adam' is an extension")
     return parser

@@ -55,6 +55,7 @@ struct pvr_policy {
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
     float *grads = nullptr;
     bool have_grads = false;
+    int fwd_T = 0, fwd_B = 0;               // shape of the last training-mode forward (pvr_policy_backward_dlogits needs its activations)
     // PolicyNetWithConv front end (conv_frames > 0)
     float *act[5] = {nullptr}, *dact[5] = {nullptr}, *wp[5] = {nullptr}, *wt[5] = {nullptr}, *feat = nullptr, *dfeat = nullptr;
     float *cpartial = nullptr, *cgpacked = nullptr, *bpartial = nullptr;
@@ -811,6 +812,7 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
     const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
     const float *h_in = h0 ? h0 : pol->zeros, *c_in = c0 ? c0 : pol->zeros;
     TRY(forward_core(pol, params, bn, obs, done, h_in, c_in, T, B, training, nullptr, st));
+    pol->fwd_T = training ? T : 0; pol->fwd_B = training ? B : 0;
     if (logits) PVR_HIP_TRY(hipMemcpyAsync(logits, pol->logits, (size_t)N * A * 4, hipMemcpyDeviceToDevice, st));
     if (baseline) PVR_HIP_TRY(hipMemcpyAsync(baseline, pol->baseline, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
     if (action) PVR_HIP_TRY(hipMemcpyAsync(action, pol->action, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
@@ -842,6 +844,54 @@ pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, c
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     TRY(apply_core(pol, params, square_avg, grads, alpha, eps, max_grad_norm, st));
+    if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out + 1, pol->stats + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_backward_dlogits(pvr_policy *pol, const float *params, const void *obs, const float *dlogits, int32_t T, int32_t B,
+                                       float *grads, void *hip_stream) {
+    PVR_REQUIRE(pol && params && obs && dlogits && grads, "pvr_policy_backward_dlogits: null argument");
+    ScratchScope scratch_scope(pol);
+    if (pol->fwd_T != T || pol->fwd_B != B) {
+        set_error("pvr_policy_backward_dlogits: needs the activations of a training-mode pvr_policy_forward with T=%d, B=%d (last: %d, %d)", T, B,
+                  pol->fwd_T, pol->fwd_B);
+        return PVR_ERR_STATE;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = T * B;
+    hipLaunchKernelGGL(dlogits_pad_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, st, dlogits, pol->dlogits, N, pol->d.num_actions);
+    PVR_LAUNCH_CHECK();
+    pol->fwd_T = pol->fwd_B = 0;                                  // (backward reuses activation buffers as scratch: one backward per forward)
+    return backward_core(pol, params, obs, T, B, grads, st);
+}
+
+pvr_status pvr_policy_apply_momentum(pvr_policy *pol, float *params, float *square_avg, float *momentum_buf, const float *grads, float lr,
+                                     float alpha, float eps, float momentum, float max_grad_norm, float *stats_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && square_avg && momentum_buf && grads, "pvr_policy_apply_momentum: null argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    TRY(set_lr(pol, lr, st));
+    const size_t nt = (size_t)pol->n_train;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, st, grads, nt, pol->partial);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, pol->partial, 1024, max_grad_norm, pol->stats);
+    hipLaunchKernelGGL(rmsprop_momentum_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, square_avg, momentum_buf, grads, pol->stats,
+                       nt / 4, alpha, eps, momentum);
+    PVR_LAUNCH_CHECK();
+    if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out + 1, pol->stats + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PVR_OK;
+}
+
+pvr_status pvr_policy_apply_adam(pvr_policy *pol, float *params, float *exp_avg, float *exp_avg_sq, const float *grads, float lr, float beta1,
+                                 float beta2, float eps, int64_t step, float max_grad_norm, float *stats_out, void *hip_stream) {
+    PVR_REQUIRE(pol && params && exp_avg && exp_avg_sq && grads && step >= 1, "pvr_policy_apply_adam: null argument or step < 1");
+    hipStream_t st = (hipStream_t)hip_stream;
+    TRY(set_lr(pol, lr, st));
+    const size_t nt = (size_t)pol->n_train;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, st, grads, nt, pol->partial);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, pol->partial, 1024, max_grad_norm, pol->stats);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(nt / 4, 8192)), dim3(256), 0, st, params, exp_avg, exp_avg_sq, grads, pol->stats, nt / 4, beta1,
+                       beta2, eps, (float)bc1, (float)sqrt(bc2));
+    PVR_LAUNCH_CHECK();
     if (stats_out) PVR_HIP_TRY(hipMemcpyAsync(stats_out + 1, pol->stats + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     return PVR_OK;
 }

@@ -844,6 +844,58 @@ static __global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__
     }
 }
 
+// torch.optim.RMSprop with momentum > 0 (not centred): buf = momentum * buf + g / (sqrt(v) + eps);  p -= lr * buf
+static __global__ __launch_bounds__(256) void rmsprop_momentum_kernel(float *__restrict__ p, float *__restrict__ v, float *__restrict__ buf,
+                                                               const float *__restrict__ g, const float *__restrict__ stats, size_t n4,
+                                                               float alpha, float eps, float momentum) {
+    const float coef = stats[2], lr = stats[3];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 vv = reinterpret_cast<f32x4 *>(v)[i], bv = reinterpret_cast<f32x4 *>(buf)[i], pv = reinterpret_cast<f32x4 *>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * coef;
+            vv[e] = vv[e] * alpha + (1.f - alpha) * (ge * ge);
+            bv[e] = bv[e] * momentum + ge / (sqrtf(vv[e]) + eps);
+            pv[e] = pv[e] - lr * bv[e];
+        }
+        reinterpret_cast<f32x4 *>(v)[i] = vv;
+        reinterpret_cast<f32x4 *>(buf)[i] = bv;
+        reinterpret_cast<f32x4 *>(p)[i] = pv;
+    }
+}
+
+// torch.optim.Adam (amsgrad off, weight_decay 0): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)       (bias corrections bc1, bc2 computed on the host from the step count)
+static __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                   const float *__restrict__ g, const float *__restrict__ stats, size_t n4, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt) {
+    const float coef = stats[2], lr = stats[3];
+    const float step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4 *>(m)[i], vv = reinterpret_cast<f32x4 *>(v)[i], pv = reinterpret_cast<f32x4 *>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * coef;
+            mv[e] = mv[e] * b1 + (1.f - b1) * ge;
+            vv[e] = vv[e] * b2 + (1.f - b2) * (ge * ge);
+            pv[e] = pv[e] - step_size * (mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps));
+        }
+        reinterpret_cast<f32x4 *>(m)[i] = mv;
+        reinterpret_cast<f32x4 *>(v)[i] = vv;
+        reinterpret_cast<f32x4 *>(p)[i] = pv;
+    }
+}
+
+// upstream gradient of the logits (autograd bridge): [N][A] contiguous -> the workspace's zero-padded [N][16]
+static __global__ __launch_bounds__(256) void dlogits_pad_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * 16) return;
+    const int n = i >> 4, a = i & 15;
+    out[i] = a < A ? in[(size_t)n * A + a] : 0.f;
+}
+
 static __global__ void set_scalar_kernel(float *dst, float v) { *dst = v; }
 
 // SyncBN (data-parallel finetune): statistics over the GLOBAL batch of n_global rows, from all-reduced column sums

@@ -7,7 +7,12 @@ main_bc_2.py:80-90 (`RMSprop` + `LambdaLR(1 - epoch/max_epochs)`) and the update
 All parameters are views of ONE flat fp32 buffer (layout from `pvr_policy_param_offset`), so the fused
 HIP step (forward, loss, BPTT, grad-norm, clip, RMSprop) updates them in place while `state_dict()` keeps
 the reference's keys and shapes (`fc.0.*` BatchNorm, `fc.1/fc.3` linears, `core.*_l{0,1}`, `policy.*`,
-`baseline.*`).  There is no autograd graph: training goes through `HipRMSprop.step(...)`, not `loss.backward()`.
+`baseline.*`).  Two ways to train, same arithmetic:
+  * `HipRMSprop.step(obs, done, actions)`: the whole iteration of main_bc_2.py:206-227 as ONE enqueue (no autograd graph);
+  * the reference's own lines, unchanged: in training mode with grad enabled `forward` returns `policy_logits` attached to a
+    `torch.autograd.Function` whose backward is `pvr_policy_backward_dlogits`; it hands every parameter a view of one flat
+    gradient buffer, so `loss.backward(); nn.utils.clip_grad_norm_(model.parameters(), 40); torch.optim.RMSprop(...).step()`
+    (main_bc_2.py:209-227) run as written and update the flat buffer through the parameter views.
 """
 import ctypes as C
 import math
@@ -58,6 +63,12 @@ def _plib():
         L.pvr_policy_apply.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, vp, vp]
         L.pvr_policy_set_data_parallel.restype = C.c_int
         L.pvr_policy_set_data_parallel.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]
+        L.pvr_policy_backward_dlogits.restype = C.c_int
+        L.pvr_policy_backward_dlogits.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+        L.pvr_policy_apply_momentum.restype = C.c_int
+        L.pvr_policy_apply_momentum.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp]
+        L.pvr_policy_apply_adam.restype = C.c_int
+        L.pvr_policy_apply_adam.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, f32, vp, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
         L.pvr_op_gemm_f32.restype = C.c_int
@@ -100,6 +111,38 @@ def _reference_init(obs_size, num_actions, batch_norm, hidden, conv=False):
         for k, v in mod.state_dict().items():
             sd[pfx + '.' + k] = v.detach().clone()
     return sd
+
+
+class _PolicyFunction(torch.autograd.Function):
+    """Training-mode forward of the whole policy as one autograd node.  Inputs: the model, the prepared device tensors, then every
+    trainable parameter (so autograd routes a gradient to each of them); outputs: logits (differentiable), baseline / action /
+    final state (not differentiable: the BC loss reads only the logits, main_bc_2.py:211-214)."""
+
+    @staticmethod
+    def forward(ctx, model, x, done, h0, c0, T, B, *params):
+        out = model._forward_raw(x, done, h0, c0, T, B, training=True)
+        model._fwd_gen = getattr(model, '_fwd_gen', 0) + 1           # the workspace holds the activations of THIS forward only
+        ctx.model, ctx.x, ctx.T, ctx.B, ctx.gen = model, x, T, B, model._fwd_gen
+        ctx.mark_non_differentiable(*out[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits, *unused):
+        m = ctx.model
+        if ctx.gen != getattr(m, '_fwd_gen', 0):
+            raise RuntimeError('PolicyNet backward: the activations of this forward are gone - a later training-mode pvr_policy_forward '
+                               'of the same policy overwrote its workspace (one backward per forward, right after it, as in the BC loop)')
+        g = torch.empty(m._n_train, dtype=torch.float32, device=m.device)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        status = _plib().pvr_policy_backward_dlogits(m._handle, vp(m._flat), vp(ctx.x), vp(dlogits.contiguous().float()), ctx.T, ctx.B,
+                                                     vp(g), _lib.stream_ptr())
+        m._checked(status)
+        m._last_flat_grad = g
+        grads = []
+        for k in m._order:
+            o, shp = m._slots[k]
+            grads.append(g[o:o + int(np.prod(shp))].view(shp) if o < m._n_train else None)     # baseline head: no gradient
+        return (None,) * 7 + tuple(grads)
 
 
 class PolicyNet(nn.Module):
@@ -184,6 +227,7 @@ class PolicyNet(nn.Module):
         if self._handle is not None:
             _plib().pvr_policy_destroy(self._handle)
             self._handle = None
+        self._dp_key = None                              # (a new handle has no collective installed)
 
     def __del__(self):
         try:
@@ -225,19 +269,9 @@ class PolicyNet(nn.Module):
     def initial_state(self, batch_size):
         return tuple(torch.zeros(2, batch_size, self.hidden) for _ in range(2))
 
-    def forward(self, inputs, core_state=()):
-        x = inputs['obs']                                     # (unroll_length, batch_size, obs_size)
-        T, B = x.shape[0], x.shape[1]
-        self._ensure(T, B)
-        dev = self.device
-        x = self._prep_obs(x, dev)
-        done = inputs['done'].to(device=dev).to(torch.uint8).contiguous()
-        if len(core_state) == 2:
-            h0 = core_state[0].to(device=dev, dtype=torch.float32).contiguous()
-            c0 = core_state[1].to(device=dev, dtype=torch.float32).contiguous()
-        else:
-            h0 = c0 = None
-        A = self.num_actions
+    def _forward_raw(self, x, done, h0, c0, T, B, training):
+        """one pvr_policy_forward enqueue on prepared device tensors -> (logits, baseline, action, h, c)"""
+        dev, A = self.device, self.num_actions
         logits = torch.empty((T, B, A), dtype=torch.float32, device=dev)
         baseline = torch.empty((T, B), dtype=torch.float32, device=dev)
         action = torch.empty((T, B), dtype=torch.int64, device=dev)
@@ -246,11 +280,65 @@ class PolicyNet(nn.Module):
         bn = self._bn_struct()
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(_plib().pvr_policy_forward(self._handle, vp(self._flat), C.byref(bn) if bn else None, vp(x), vp(done),
-                                              vp(h0), vp(c0), T, B, int(self.training), vp(logits), vp(baseline), vp(action),
+                                              vp(h0), vp(c0), T, B, int(training), vp(logits), vp(baseline), vp(action),
                                               vp(h), vp(c), _lib.stream_ptr()))
+        return logits, baseline, action, h, c
+
+    def forward(self, inputs, core_state=()):
+        x = inputs['obs']                                     # (unroll_length, batch_size, obs_size)
+        T, B = x.shape[0], x.shape[1]
+        self._ensure(T, B)
+        dev = self.device
+        x = self._prep_obs(x, dev)
+        done = inputs['done'].to(device=dev).to(torch.uint8).contiguous()
+        want_grad = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        h0 = c0 = None
+        if len(core_state) == 2:
+            if want_grad:
+                # BPTT starts from a zero state (main_bc_2.py:207-209 passes initial_state() every iteration); a non-zero state would
+                # need its own terms in the weight gradients, which the backward plan does not carry
+                assert not bool(core_state[0].any()) and not bool(core_state[1].any()), \
+                    'training with autograd starts every unroll from model.initial_state() (zeros), as the reference loop does'
+            else:
+                h0 = core_state[0].to(device=dev, dtype=torch.float32).contiguous()
+                c0 = core_state[1].to(device=dev, dtype=torch.float32).contiguous()
+        A = self.num_actions
+        if want_grad:
+            params = [self._param(k)[0]._parameters[self._param(k)[1]] for k in self._order]
+            logits, baseline, action, h, c = _PolicyFunction.apply(self, x, done, h0, c0, T, B, *params)
+        else:
+            logits, baseline, action, h, c = self._forward_raw(x, done, h0, c0, T, B, self.training)
         if self.training:                                     # models.py:78-80 (sample is unused by the BC loss)
-            action = torch.multinomial(F.softmax(logits.view(T * B, A), dim=1), num_samples=1).view(T, B)
+            action = torch.multinomial(F.softmax(logits.detach().view(T * B, A), dim=1), num_samples=1).view(T, B)
         return dict(policy_logits=logits, baseline=baseline, action=action), (h, c)
+
+    def set_data_parallel(self, group=None, sync_bn=True):
+        """Hand the library its collective (pvr_policy_set_data_parallel) for this policy's handle: every following training
+        backward - fused step, step_data_parallel or loss.backward() through the autograd bridge - all-reduces its gradient
+        buckets over `group` (and uses global-batch BatchNorm statistics with sync_bn).  World size 1 / no process group
+        uninstalls.  Re-installed when the handle, the group or the SyncBN choice changes."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        sync = bool(self.batch_norm and sync_bn)
+        key = (self._handle.value if self._handle is not None else None, id(group), world, sync)
+        if getattr(self, '_dp_key', None) == key:
+            return world
+        if world > 1:
+            self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda')       # (the ctypes thunk must stay alive while installed)
+            _lib.check(_plib().pvr_policy_set_data_parallel(self._handle, world, int(sync), self._dp_cb, None))
+        else:
+            _lib.check(_plib().pvr_policy_set_data_parallel(self._handle, 1, 0, ALLREDUCE_FN(), None))
+            self._dp_cb, self._dp_errors = None, []
+        self._dp_key = key
+        return world
+
+    def _checked(self, status):
+        """a failed collective: re-raise the exception the callback caught instead of the library's generic message"""
+        if status != 0 and getattr(self, '_dp_errors', None):
+            e = self._dp_errors[-1]
+            del self._dp_errors[:]
+            raise e
+        _lib.check(status)
 
     def _prep_obs(self, x, dev):
         if self._conv_frames:
@@ -318,23 +406,19 @@ class PolicyNetWithConv(PolicyNet):
         return int(observation_shape[2]) // 3
 
 
-class HipRMSprop(object):
-    """torch.optim.RMSprop(momentum=0, centered=False) + LambdaLR(1 - epoch/max_epochs) as used by
-    main_bc_2.py:80-90, fused with the forward/backward of the BC loss (main_bc_2.py:206-227).
+class _HipOptimizer(object):
+    """Shared plumbing of the fused optimisers: LambdaLR(1 - epoch/max_epochs) stepped BEFORE the update as the reference does
+    (main_bc_2.py:216), flat state buffers with the parameter layout, torch-compatible state_dict, the data-parallel step."""
+    _state_names = ()
 
-    `scheduler_step()` mirrors the reference's `scheduler.step()` call, which precedes `optimizer.step()`
-    (main_bc_2.py:216), so update k uses lr * (1 - (k+1)/max_epochs)."""
-
-    def __init__(self, model, lr=1e-4, alpha=0.99, eps=1e-5, momentum=0, max_grad_norm=40.0, max_epochs=None):
-        assert momentum == 0, 'momentum != 0 is not built (reference default is 0, src/arguments.py:63-64)'
-        self.model, self.lr0, self.alpha, self.eps = model, float(lr), float(alpha), float(eps)
+    def __init__(self, model, lr, max_grad_norm, max_epochs):
+        self.model, self.lr0 = model, float(lr)
         self.max_grad_norm, self.max_epochs = float(max_grad_norm), max_epochs
         self.last_epoch = 0
-        self.square_avg = torch.zeros_like(model._flat)
         self.steps = 0
-        self._stats = None
-        self._grads = None            # caller-owned flat gradient (data-parallel path)
-        self._dp_cb, self._dp_errors, self._dp_key = None, [], None   # data-parallel plumbing (the ctypes thunk must stay alive)
+        self._grads = None            # caller-owned flat gradient (two-half path)
+        for n in self._state_names:
+            setattr(self, n, torch.zeros_like(model._flat))
 
     def scheduler_step(self):
         self.last_epoch += 1
@@ -344,70 +428,17 @@ class HipRMSprop(object):
             return self.lr0
         return self.lr0 * (1 - self.last_epoch / self.max_epochs)
 
-    def step(self, obs, done, actions, return_logits=False):
-        """obs (T,B,obs) float, done (T,B) bool, actions (T,B) int -> (loss, grad_norm) device scalars."""
+    def _state_to(self, dev):
+        for n in self._state_names:
+            if getattr(self, n).device != dev:
+                setattr(self, n, getattr(self, n).to(dev))
+
+    def _backward(self, obs, done, actions):
+        """forward + loss + backward into the flat gradient (all-reduced over the ranks when data parallelism is installed)"""
         m = self.model
         T, B = obs.shape[0], obs.shape[1]
-        m._ensure(T, B)
         dev = m.device
-        if self.square_avg.device != dev:
-            self.square_avg = self.square_avg.to(dev)
-        x = m._prep_obs(obs, dev)
-        d = done.to(device=dev).to(torch.uint8).contiguous()
-        a = actions.to(device=dev).long().contiguous()
-        stats = torch.empty(2, dtype=torch.float32, device=dev)
-        logits = torch.empty((T, B, m.num_actions), dtype=torch.float32, device=dev) if return_logits else None
-        bn = m._bn_struct()
-        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(_plib().pvr_policy_step(m._handle, vp(m._flat), vp(self.square_avg), C.byref(bn) if bn else None, vp(x), vp(d),
-                                           vp(a), T, B, self.current_lr(), self.alpha, self.eps, self.max_grad_norm, vp(stats),
-                                           vp(logits), _lib.stream_ptr()))
-        self.steps += 1
-        return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
-
-    def _install_data_parallel(self, group, world, sync_bn):
-        """Hand the library its collective (pvr_policy_set_data_parallel).  Re-installed when the policy handle, the group or the
-        SyncBN choice changes; world == 1 uninstalls."""
-        m = self.model
-        key = (m._handle.value if m._handle is not None else None, id(group), world, bool(sync_bn))
-        if getattr(self, '_dp_key', None) == key:
-            return
-        if world > 1:
-            import torch.distributed as dist
-            gloo = dist.get_backend(group) == 'gloo'
-            self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda')
-            self._dp_gloo = gloo
-            _lib.check(_plib().pvr_policy_set_data_parallel(m._handle, world, int(bool(sync_bn)), self._dp_cb, None))
-        else:
-            _lib.check(_plib().pvr_policy_set_data_parallel(m._handle, 1, 0, ALLREDUCE_FN(), None))
-            self._dp_cb, self._dp_errors = None, []
-        self._dp_key = key
-
-    def _checked(self, status):
-        """a failed collective: re-raise the exception the callback caught instead of the library's generic message"""
-        if status != 0 and getattr(self, '_dp_errors', None):
-            e = self._dp_errors[-1]
-            del self._dp_errors[:]
-            raise e
-        _lib.check(status)
-
-    def step_data_parallel(self, obs, done, actions, group=None, sync_bn=True):
-        """Finetune configuration (SURVEY 8e, BASELINE config 4): every rank runs forward/backward on its slice of the batch.
-        Inside pvr_policy_backward the gradient leaves in four buckets, each all-reduced (RCCL over xGMI under backend 'nccl') on
-        the library's communication stream as soon as backward has finalised it - LSTM layer 1 + policy head while layer 0 still
-        runs its BPTT, layer 0 during the fc / conv backward, ... - and divided by the world size (the loss is a mean over the
-        global batch); every rank then applies the identical clipped RMSprop update.  With sync_bn (default) BatchNorm uses
-        global-batch statistics, so N ranks x B/N sequences reproduce one rank x B; sync_bn=False keeps per-rank statistics
-        (torch DDP default).  Without an initialised process group (or world size 1) this is the single-GPU iteration."""
-        import torch.distributed as dist
-        m = self.model
-        T, B = obs.shape[0], obs.shape[1]
-        m._ensure(T, B)
-        dev = m.device
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self._install_data_parallel(group, world, m.batch_norm and sync_bn)
-        if self.square_avg.device != dev:
-            self.square_avg = self.square_avg.to(dev)
+        self._state_to(dev)
         if self._grads is None or self._grads.device != dev:
             self._grads = torch.zeros(m._n_train, dtype=torch.float32, device=dev)
         x = m._prep_obs(obs, dev)
@@ -416,30 +447,137 @@ class HipRMSprop(object):
         stats = torch.zeros(2, dtype=torch.float32, device=dev)
         bn = m._bn_struct()
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        L = _plib()
-        self._checked(L.pvr_policy_backward(m._handle, vp(m._flat), C.byref(bn) if bn else None, vp(x), vp(d), vp(a), T, B,
-                                            vp(self._grads), vp(stats), None, _lib.stream_ptr()))
-        _lib.check(L.pvr_policy_apply(m._handle, vp(m._flat), vp(self.square_avg), vp(self._grads), self.current_lr(), self.alpha,
-                                      self.eps, self.max_grad_norm, vp(stats), _lib.stream_ptr()))
+        m._checked(_plib().pvr_policy_backward(m._handle, vp(m._flat), C.byref(bn) if bn else None, vp(x), vp(d), vp(a), T, B,
+                                               vp(self._grads), vp(stats), None, _lib.stream_ptr()))
+        return stats
+
+    def _apply(self, stats):
+        raise NotImplementedError
+
+    def step(self, obs, done, actions):
+        """obs (T,B,obs) float, done (T,B) bool, actions (T,B) int -> (loss, grad_norm) device scalars."""
+        self.model._ensure(obs.shape[0], obs.shape[1])
+        stats = self._backward(obs, done, actions)
+        self._apply(stats)
         self.steps += 1
         return stats[0], stats[1]
 
-    # torch-compatible checkpoint layout (main_bc_2.py:255-257)
+    def step_data_parallel(self, obs, done, actions, group=None, sync_bn=True):
+        """Finetune configuration (SURVEY 8e, BASELINE config 4): every rank runs forward/backward on its slice of the batch.
+        Inside pvr_policy_backward the gradient leaves in four buckets, each all-reduced (RCCL over xGMI under backend 'nccl') on
+        the library's communication stream as soon as backward has finalised it - LSTM layer 1 + policy head while layer 0 still
+        runs its BPTT, layer 0 during the fc / conv backward, ... - and divided by the world size (the loss is a mean over the
+        global batch); every rank then applies the identical clipped update.  With sync_bn (default) BatchNorm uses
+        global-batch statistics, so N ranks x B/N sequences reproduce one rank x B; sync_bn=False keeps per-rank statistics
+        (torch DDP default).  Without an initialised process group (or world size 1) this is the single-GPU iteration."""
+        m = self.model
+        m._ensure(obs.shape[0], obs.shape[1])
+        m.set_data_parallel(group, sync_bn)
+        stats = self._backward(obs, done, actions)
+        self._apply(stats)
+        self.steps += 1
+        return stats[0], stats[1]
+
+    # torch-compatible checkpoint layout (main_bc_2.py:255-257): state[i] per trainable parameter in model.parameters() order
+    def _param_group(self):
+        raise NotImplementedError
+
     def state_dict(self):
         state = {}
-        for i, k in enumerate(k for k in self.model._order):
+        for i, k in enumerate(self.model._order):
             o, shp = self.model._slots[k]
             if o < self.model._n_train:
-                state[i] = {'step': torch.tensor(float(self.steps)), 'square_avg': self.square_avg[o:o + int(np.prod(shp))].view(shp).clone()}
-        return {'state': state, 'param_groups': [{'lr': self.current_lr(), 'initial_lr': self.lr0, 'momentum': 0, 'alpha': self.alpha,
-                                                  'eps': self.eps, 'centered': False, 'weight_decay': 0,
-                                                  'params': list(range(len(self.model._order)))}],
-                'last_epoch': self.last_epoch}
+                state[i] = {'step': torch.tensor(float(self.steps))}
+                for n in self._state_names:
+                    state[i][n] = getattr(self, n)[o:o + int(np.prod(shp))].view(shp).clone()
+        g = dict(self._param_group(), lr=self.current_lr(), initial_lr=self.lr0, params=list(range(len(self.model._order))))
+        return {'state': state, 'param_groups': [g], 'last_epoch': self.last_epoch}
 
     def load_state_dict(self, sd):
         for i, k in enumerate(self.model._order):
             if i in sd['state']:
                 o, shp = self.model._slots[k]
-                self.square_avg[o:o + int(np.prod(shp))].copy_(sd['state'][i]['square_avg'].reshape(-1))
+                for n in self._state_names:
+                    if n in sd['state'][i]:
+                        getattr(self, n)[o:o + int(np.prod(shp))].copy_(sd['state'][i][n].reshape(-1))
                 self.steps = int(sd['state'][i]['step'])
         self.last_epoch = sd.get('last_epoch', self.last_epoch)
+
+
+class HipRMSprop(_HipOptimizer):
+    """torch.optim.RMSprop(centered=False) + LambdaLR(1 - epoch/max_epochs) as used by main_bc_2.py:80-90, fused with the
+    forward/backward of the BC loss (main_bc_2.py:206-227).  momentum == 0 (the reference default, src/arguments.py:63-64) runs the
+    whole iteration as one enqueue (pvr_policy_step); momentum != 0 keeps torch's extra buffer (pvr_policy_apply_momentum).
+
+    `scheduler_step()` mirrors the reference's `scheduler.step()` call, which precedes `optimizer.step()`
+    (main_bc_2.py:216), so update k uses lr * (1 - (k+1)/max_epochs)."""
+
+    def __init__(self, model, lr=1e-4, alpha=0.99, eps=1e-5, momentum=0, max_grad_norm=40.0, max_epochs=None):
+        self.alpha, self.eps, self.momentum = float(alpha), float(eps), float(momentum)
+        self._state_names = ('square_avg', 'momentum_buffer') if self.momentum != 0 else ('square_avg',)
+        super().__init__(model, lr, max_grad_norm, max_epochs)
+
+    def _param_group(self):
+        return {'momentum': self.momentum, 'alpha': self.alpha, 'eps': self.eps, 'centered': False, 'weight_decay': 0}
+
+    def _apply(self, stats):
+        m = self.model
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        if self.momentum != 0:
+            _lib.check(_plib().pvr_policy_apply_momentum(m._handle, vp(m._flat), vp(self.square_avg), vp(self.momentum_buffer), vp(self._grads),
+                                                         self.current_lr(), self.alpha, self.eps, self.momentum, self.max_grad_norm, vp(stats),
+                                                         _lib.stream_ptr()))
+        else:
+            _lib.check(_plib().pvr_policy_apply(m._handle, vp(m._flat), vp(self.square_avg), vp(self._grads), self.current_lr(), self.alpha,
+                                                self.eps, self.max_grad_norm, vp(stats), _lib.stream_ptr()))
+
+    def step(self, obs, done, actions, return_logits=False):
+        """obs (T,B,obs) float, done (T,B) bool, actions (T,B) int -> (loss, grad_norm) device scalars."""
+        if self.momentum != 0:
+            assert not return_logits
+            return super().step(obs, done, actions)
+        m = self.model
+        T, B = obs.shape[0], obs.shape[1]
+        m._ensure(T, B)
+        dev = m.device
+        self._state_to(dev)
+        x = m._prep_obs(obs, dev)
+        d = done.to(device=dev).to(torch.uint8).contiguous()
+        a = actions.to(device=dev).long().contiguous()
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        logits = torch.empty((T, B, m.num_actions), dtype=torch.float32, device=dev) if return_logits else None
+        bn = m._bn_struct()
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        m._checked(_plib().pvr_policy_step(m._handle, vp(m._flat), vp(self.square_avg), C.byref(bn) if bn else None, vp(x), vp(d),
+                                           vp(a), T, B, self.current_lr(), self.alpha, self.eps, self.max_grad_norm, vp(stats),
+                                           vp(logits), _lib.stream_ptr()))
+        self.steps += 1
+        return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
+
+
+class HipAdam(_HipOptimizer):
+    """torch.optim.Adam(betas, eps; amsgrad off, no weight decay) on the same flat buffers, with the same clip and LambdaLR order.
+    Not in the reference (its scripts use RMSprop, main_bc_2.py:80-86): `--optimizer adam`, for BASELINE.json's north_star."""
+    _state_names = ('exp_avg', 'exp_avg_sq')
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=40.0, max_epochs=None):
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        super().__init__(model, lr, max_grad_norm, max_epochs)
+
+    def _param_group(self):
+        return {'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False}
+
+    def _apply(self, stats):
+        m = self.model
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_plib().pvr_policy_apply_adam(m._handle, vp(m._flat), vp(self.exp_avg), vp(self.exp_avg_sq), vp(self._grads), self.current_lr(),
+                                                 self.betas[0], self.betas[1], self.eps, self.steps + 1, self.max_grad_norm, vp(stats),
+                                                 _lib.stream_ptr()))
+
+
+def make_optimizer(flags, model, max_epochs):
+    """the optimiser of main_bc_2.py:80-90 from the reference's flags (+ --optimizer adam)"""
+    if getattr(flags, 'optimizer', 'rmsprop') == 'adam':
+        return HipAdam(model, lr=flags.learning_rate, max_grad_norm=flags.max_grad_norm, max_epochs=max_epochs)
+    return HipRMSprop(model, lr=flags.learning_rate, momentum=flags.momentum, eps=flags.epsilon, alpha=flags.alpha,
+                      max_grad_norm=flags.max_grad_norm, max_epochs=max_epochs)

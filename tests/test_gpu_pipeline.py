@@ -87,3 +87,36 @@ def test_finetune_pipeline(tmp_path):
     done_args = [a if a != '320' else '288' for a in args]
     finished = Fz.run(make_parser().parse_args(done_args))['scene']
     assert finished['frames'] == again['frames'] and os.path.getmtime(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar') == mtime
+
+
+def test_main_bc_1_random_pvr_in_process(tmp_path):
+    """main_bc_1.run (main_bc_1.py:25-262): raw scene pickle -> in-process embedding with the seed-dependent 'random' PVR -> BC, in
+    both forms of the iteration (fused step / the reference's own autograd lines), which must produce the same statistics."""
+    from pvr_habitat_amd import main_bc_1 as M1
+    from pvr_habitat_amd.arguments import make_parser
+    from pvr_habitat_amd.embeddings import EmbeddingNet
+    lens = (60, 50)
+    fr = synth.smooth_frames(41, sum(lens), 64, 128).reshape(sum(lens), 64, 64, 6)
+    cuts = np.cumsum((0,) + lens)
+    rng = np.random.default_rng(1)
+    raw = dict(obs=[fr[a:b] for a, b in zip(cuts[:-1], cuts[1:])], action=[rng.integers(0, 3, L) for L in lens],
+               reward=[np.zeros(L, np.float32) for L in lens], done=[np.eye(1, L, L - 1, dtype=bool)[0] for L in lens],
+               true_state=[np.zeros((L, 12), np.float32) for L in lens])
+    pickle.dump(raw, open(tmp_path / 'scene.pickle', 'wb'))
+    res = {}
+    for mode in ('fused', 'autograd'):
+        args = ['--data_path', str(tmp_path), '--save_path', str(tmp_path / mode), '--env', 'scene', '--to_env', 'scene',
+                '--embedding_name', 'random', '--run_id', '3', '--unroll_length', '8', '--batch_size', '4', '--batch_norm',
+                '--max_frames', '320', '--eval_frequency', '5'] + (['--autograd_step'] if mode == 'autograd' else [])
+        res[mode] = M1.run(make_parser().parse_args(args))['scene']
+        ck = torch.load(tmp_path / mode / 'scene_emrandom_s3_scene.tar', weights_only=False)
+        assert ck['actor_model_state_dict']['fc.1.weight'].shape == (1024, 2 * 1568)
+        assert list(ck['embedding_model_state_dict'].keys())[0] == 'embedding.0.weight'
+    assert res['fused']['frames'] == res['autograd']['frames'] == [0, 128, 288]
+    np.testing.assert_allclose(res['fused']['training_loss'][1:], res['autograd']['training_loss'][1:], rtol=1e-5)
+    np.testing.assert_allclose(res['fused']['gradient_norm'][1:], res['autograd']['gradient_norm'][1:], rtol=1e-4)
+    # the random PVR is a function of run_id: the checkpointed embedding equals a fresh EmbeddingNet built under that seed
+    torch.manual_seed(3)
+    net = EmbeddingNet('random', pretrained=True)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), ck['embedding_model_state_dict'][k].cpu()), k

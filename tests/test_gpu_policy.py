@@ -331,3 +331,156 @@ def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
     for k in res[1].files:
         if 'running' in k:
             np.testing.assert_allclose(res[2][k], res[1][k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# autograd bridge: the reference's own training lines (main_bc_2.py:206-227), unchanged, on the HIP policy
+# ----------------------------------------------------------------------------------------------------------------------------
+def _reference_lines(model, optimizer, scheduler, o, d, a, max_grad_norm=40.0):
+    """main_bc_2.py:206-227, as written there"""
+    from torch import nn
+    from torch.nn import functional as F
+    initial_agent_state = model.initial_state(batch_size=o.shape[1])
+    output, _ = model(dict(obs=o, done=d), initial_agent_state)
+    loss = F.nll_loss(F.log_softmax(torch.flatten(output['policy_logits'], 0, 1), dim=-1), target=torch.flatten(a, 0, 1).long())
+    scheduler.step()
+    optimizer.zero_grad()
+    loss.backward()
+    gradient_norm = 0.
+    for p in model.parameters():
+        if p.grad is not None and p.requires_grad:
+            gradient_norm += p.grad.detach().data.norm(2).item() ** 2
+    gradient_norm = gradient_norm ** 0.5
+    nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    optimizer.step()
+    return float(loss), gradient_norm, output['policy_logits'].detach()
+
+
+@pytest.mark.parametrize('name,seed,bn,conv', [('policy_small_bn.npz', 1, True, False), ('policy_small_nobn.npz', 2, False, False),
+                                                ('policy_full_bn.npz', 1, True, False), ('policy_conv_small.npz', 3, True, True)])
+def test_reference_training_lines_run_unchanged_through_the_autograd_bridge(name, seed, bn, conv):
+    """loss.backward(); clip_grad_norm_; torch.optim.RMSprop.step() with LambdaLR, exactly as main_bc_2.py:80-90,206-227 write them,
+    against the fixtures the reference's own PolicyNet produced with those same lines (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name))
+    T, B, A, S = int(g['T']), int(g['B']), int(g['A']), int(g['steps'])
+    O = 256 if conv else int(g['O'])
+    m, sd = _model(seed, O, A, bn, T, B, conv)
+    obs, done, act = synth.bc_conv_batches(seed, T, B, S, A) if conv else synth.bc_batches(seed, T, B, O, A, S)
+    m.train()
+    max_epochs = int(g['max_epochs'])
+    optimizer = torch.optim.RMSprop(m.parameters(), lr=1e-4, momentum=0, eps=1e-5, alpha=0.99)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: 1 - e / max_epochs)
+    for s in range(S):
+        loss, gn, logits = _reference_lines(m, optimizer, scheduler, torch.from_numpy(obs[s]).cuda(), torch.from_numpy(done[s]).cuda(),
+                                            torch.from_numpy(act[s]).cuda())
+        assert loss == pytest.approx(float(g['loss'][s]), rel=2e-5), s
+        assert gn == pytest.approx(float(g['grad_norm'][s]), rel=3e-4), s
+        np.testing.assert_allclose(logits.cpu().numpy(), g['logits'][s], rtol=1e-4, atol=5e-5)
+    assert m.baseline.weight.grad is None and m.baseline.bias.grad is None          # no gradient from the BC loss, as in torch
+    sdm = m.state_dict()
+    for k, s1, s2 in zip([str(k) for k in g['param_keys']], g['param_sum'], g['param_sq']):
+        v = sdm[k].double()
+        assert float(v.sum()) == pytest.approx(float(s1), rel=1e-5, abs=2e-4), k
+        assert float((v ** 2).sum()) == pytest.approx(float(s2), rel=1e-5, abs=1e-6), k
+    for k in g.files:
+        if k.startswith('final/'):
+            np.testing.assert_allclose(sdm[k[6:]].cpu().numpy(), g[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    # the parameters torch.optim updated ARE the flat buffer the fused kernels read: an eval forward sees the new weights
+    m.eval()
+    with torch.no_grad():
+        out, _ = m(dict(obs=torch.from_numpy(obs[0]), done=torch.from_numpy(done[0])), m.initial_state(B))
+    assert np.array_equal(out['action'].cpu().numpy(), g['eval_action'])
+
+
+def test_autograd_bridge_equals_fused_step_bit_for_bit():
+    """same kernels behind both forms of the iteration: fused pvr_policy_step vs forward -> torch loss -> pvr_policy_backward_dlogits.
+    The upstream dlogits differ only by torch's log_softmax rounding, so parameters agree to fp32 noise; a second backward on one
+    forward is refused."""
+    from pvr_habitat_amd.models import HipRMSprop
+    T, B, O, A = 12, 4, 256, 3
+    obs, done, act = synth.bc_batches(5, T, B, O, A, 2)
+    ma, _ = _model(5, O, A, True, T, B)
+    mb, _ = _model(5, O, A, True, T, B)
+    ma.train(); mb.train()
+    opt = HipRMSprop(ma, max_epochs=50)
+    optimizer = torch.optim.RMSprop(mb.parameters(), lr=1e-4, momentum=0, eps=1e-5, alpha=0.99)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: 1 - e / 50)
+    for s in range(2):
+        opt.scheduler_step()
+        la, ga = opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+        lb, gb, _ = _reference_lines(mb, optimizer, scheduler, torch.from_numpy(obs[s]).cuda(), torch.from_numpy(done[s]).cuda(), torch.from_numpy(act[s]).cuda())
+        assert float(la) == pytest.approx(lb, rel=1e-6) and float(ga) == pytest.approx(gb, rel=1e-5)
+    np.testing.assert_allclose(ma._flat.cpu().numpy(), mb._flat.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    inp = dict(obs=torch.from_numpy(obs[0]).cuda(), done=torch.from_numpy(done[0]).cuda())
+    out2, _ = mb(inp, mb.initial_state(B))
+    out3, _ = mb(inp, mb.initial_state(B))                       # overwrites the workspace out2's backward would need
+    with pytest.raises(RuntimeError, match='training-mode pvr_policy_forward'):
+        out2['policy_logits'].sum().backward()
+    out3['policy_logits'].sum().backward()
+    with pytest.raises(RuntimeError, match='training-mode pvr_policy_forward'):
+        out3['policy_logits'].sum().backward()                   # a second backward through the same forward
+
+
+@pytest.mark.parametrize('kind', ['adam', 'rmsprop_momentum'])
+def test_fused_adam_and_momentum_rmsprop_match_torch_optim(kind):
+    """HipAdam / HipRMSprop(momentum) against torch.optim.Adam / RMSprop(momentum=0.9) driven by the same gradients through the
+    autograd bridge (clip + LambdaLR in the reference's order), three updates."""
+    from pvr_habitat_amd.models import HipAdam, HipRMSprop
+    T, B, O, A = 10, 4, 128, 3
+    obs, done, act = synth.bc_batches(6, T, B, O, A, 3)
+    ma, _ = _model(6, O, A, True, T, B)
+    mb, _ = _model(6, O, A, True, T, B)
+    ma.train(); mb.train()
+    if kind == 'adam':
+        opt = HipAdam(ma, lr=1e-3, max_grad_norm=0.5, max_epochs=20)
+        optimizer = torch.optim.Adam(mb.parameters(), lr=1e-3)
+    else:
+        opt = HipRMSprop(ma, lr=1e-3, momentum=0.9, max_grad_norm=0.5, max_epochs=20)
+        optimizer = torch.optim.RMSprop(mb.parameters(), lr=1e-3, momentum=0.9, eps=1e-5, alpha=0.99)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: 1 - e / 20)
+    for s in range(3):
+        opt.scheduler_step()
+        la, ga = opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+        lb, gb, _ = _reference_lines(mb, optimizer, scheduler, torch.from_numpy(obs[s]).cuda(), torch.from_numpy(done[s]).cuda(),
+                                     torch.from_numpy(act[s]).cuda(), max_grad_norm=0.5)
+        assert float(la) == pytest.approx(lb, rel=2e-5) and float(ga) == pytest.approx(gb, rel=1e-4), s
+    # (both rules divide by sqrt(v): where a gradient entry is at fp32-noise level the two runs may disagree by a fraction of lr)
+    np.testing.assert_allclose(ma._flat[:ma._n_train].cpu().numpy(), mb._flat[:mb._n_train].cpu().numpy(), rtol=2e-4, atol=3e-5)
+    sd = opt.state_dict()
+    assert set(sd['state'][0]) == ({'step', 'exp_avg', 'exp_avg_sq'} if kind == 'adam' else {'step', 'square_avg', 'momentum_buffer'})
+
+
+def test_device_gather_equals_reference_host_loop():
+    """pvr_bc_gather vs the loop of main_bc_2.py:194-201 (np.mod(arange(i, i+T), n) rows stacked on axis 1), incl. wrap-around,
+    for fp32 embeddings and raw uint8 frames."""
+    from pvr_habitat_amd.bc_data import DeviceDataset
+    rng = np.random.default_rng(0)
+    for shape, dt in (((4096,), np.float32), ((64, 64, 6), np.uint8), ((12,), np.float64)):
+        n = 57
+        obs = (rng.standard_normal((n,) + shape) * 40).astype(dt)
+        action, done = rng.integers(0, 3, n), rng.random(n) < 0.1
+        ds = DeviceDataset(obs, action, done)
+        starts, T = [50, 3, 56, 20], 10
+        o, a, d = ds.gather(starts, T)
+        ro = np.stack([obs[np.mod(np.arange(i, i + T), n)] for i in starts], axis=1)
+        ra = np.stack([action[np.mod(np.arange(i, i + T), n)] for i in starts], axis=1)
+        rd = np.stack([done[np.mod(np.arange(i, i + T), n)] for i in starts], axis=1)
+        np.testing.assert_array_equal(o.cpu().numpy(), ro.astype(np.float32) if dt == np.float64 else ro)
+        np.testing.assert_array_equal(a.cpu().numpy(), ra)
+        np.testing.assert_array_equal(d.cpu().numpy(), rd)
+        assert a.dtype == torch.int64 and d.dtype == torch.bool
+
+
+def test_out_of_range_action_fails_loudly():
+    """torch's nll_loss raises for a target outside [0, A); the fused loss turns it into a NaN loss / gradient norm instead of
+    reading out of bounds, and the drivers check the data before training."""
+    from pvr_habitat_amd.models import HipRMSprop
+    T, B, O, A = 6, 2, 64, 3
+    m, _ = _model(7, O, A, False, T, B)
+    m.train()
+    obs, done, act = synth.bc_batches(7, T, B, O, A, 1)
+    act[0][2, 1] = 5
+    opt = HipRMSprop(m, max_epochs=10)
+    before = m._flat.clone()
+    loss, gn = opt.step(torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(act[0]))
+    assert not np.isfinite(float(loss))
