@@ -7,6 +7,7 @@ ResNet50 MoCo-v2 frozen, 256x256 uint8 frames, batch 256, bf16, synthetic frames
 batch of 256 frames that is already resident in HBM.  Frames shard across ranks with no collective
 (SURVEY 8e): weak scaling, value = frames all ranks embedded / max-over-ranks time.
 
+  python bench.py                      (N = 1, 320 timed steps ~ 1 s over a 4096-frame pool, + parity / f16 / PCIe / ViT / BC legs)
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
@@ -93,13 +94,23 @@ def cpu_baseline(sd, frames_u8, budget_s=12.0):
 
 
 BC_GFLOP_PER_STEP = 211.4         # PolicyNet T=100,B=16,obs 4096: 3 x fwd of 22.02 MMAC x 1600
+INFINITY_CACHE_GBPS = 8600.0      # MI355X_MICROARCH.md: uniformly gathered rows of a 38 MB table served from the Infinity Cache, chip-wide
 
 
 def bc_bench(steps, warmup, with_cpu):
     """Second half of the BASELINE metric: BC steps/sec (main_bc_2.py:186-227 iteration, slurm_bc.py:121-128
-    configuration T=100, B=16, obs 4096, BatchNorm on, RMSprop) on one GPU, batches resident in HBM."""
+    configuration T=100, B=16, obs 4096, BatchNorm on, RMSprop) on one GPU.
+      value        the iteration alone on two batches resident in HBM (the kernel path)
+      loop         what main_bc_2.run's loop delivers: Python sampler (sample_with_minimum_distance) -> device gather of the (T,B)
+                   batch from the HBM-resident dataset (pvr_bc_gather) -> scheduler step -> the same iteration, 20 k samples
+      roofline     the step against the f32-MFMA roof (algorithmic 211.4 GFLOP), and the LSTM recurrences against the weight stream
+                   they are bound by: every one of the 2 x T recurrent launches re-reads its layer's 16.8 MB W_hh (it does not fit
+                   one XCD's 4 MB L2, so it streams from the Infinity Cache), forward and again in BPTT"""
+    import random
     from pvr_habitat_amd import synth
+    from pvr_habitat_amd.bc_data import DeviceDataset
     from pvr_habitat_amd.models import PolicyNet, HipRMSprop
+    from pvr_habitat_amd.utils_bc import sample_with_minimum_distance
     T, B, O, A = 100, 16, 4096, 3
     m = PolicyNet((O,), A, True, max_unroll=T, max_batch=B)
     sd = synth.policy_state_dict(1, O, A, True)
@@ -117,8 +128,46 @@ def bc_bench(steps, warmup, with_cpu):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     res = {'metric': 'BC steps/sec (PolicyNet T=100 B=16 obs=4096 BN, fp32)', 'value': round(steps / el, 2), 'unit': 'steps/s',
-           'ms_per_step': round(el / steps * 1e3, 3), 'tflops': round(BC_GFLOP_PER_STEP * steps / el / 1e3, 2),
-           'dtype': 'f32', 'final_loss': round(float(loss), 5)}
+           'ms_per_step': round(el / steps * 1e3, 3), 'dtype': 'f32', 'final_loss': round(float(loss), 5)}
+    # the loop of main_bc_2.run (bc_loop.train): sampler + device gather + step, dataset resident in HBM
+    n = 20000
+    data_obs = np.abs(synth.normal(2, 'bc_loop_obs', (n, O)))
+    ds = DeviceDataset(data_obs, (synth.uniform(2, 'bc_loop_act', (n,)) * A).astype(np.int64).clip(0, A - 1), synth.uniform(2, 'bc_loop_done', (n,)) < 0.02)
+    random.seed(1)
+    for _ in range(max(warmup, 2)):
+        o, a, d = ds.gather(sample_with_minimum_distance(n=n, k=B, d=T), T); opt.scheduler_step(); opt.step(o, d, a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o, a, d = ds.gather(sample_with_minimum_distance(n=n, k=B, d=T), T)
+        opt.scheduler_step(); loss, gn = opt.step(o, d, a)
+    torch.cuda.synchronize()
+    el_loop = time.perf_counter() - t0
+    res['loop'] = {'value': round(steps / el_loop, 2), 'unit': 'steps/s', 'ms_per_step': round(el_loop / steps * 1e3, 3),
+                   'what': 'sample_with_minimum_distance + pvr_bc_gather from a %d-sample dataset in HBM + scheduler + fused step '
+                           '(the loop of main_bc_2.run); per step %d bytes of start indices cross PCIe' % (n, 8 * B)}
+    # recurrences: an eval-mode forward of the same (T,B) is BN-apply + 2 fc GEMMs + 2 hoisted projections + 2*T recurrent launches + heads
+    m.eval()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    inp = dict(obs=obs_d[0], done=done_d[0])
+    with torch.no_grad():
+        for _ in range(3):
+            m(inp, m.initial_state(B))
+        ev0.record()
+        for _ in range(10):
+            m(inp, m.initial_state(B))
+        ev1.record()
+    torch.cuda.synchronize()
+    fwd_ms = ev0.elapsed_time(ev1) / 10
+    whh_bytes = 2 * T * 4 * 1024 * 1024 * 4                   # 2 layers x T steps x [4H][H] fp32
+    tf = BC_GFLOP_PER_STEP * steps / el / 1e3
+    res['roofline'] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_TFLOPS, 4),
+                       'traffic': None, 'kernel': 'whole iteration (f32-input MFMA GEMMs + recurrences), algorithmic %.1f GFLOP/step' % BC_GFLOP_PER_STEP,
+                       'recurrence_weight_stream': {
+                           'bound': 'infinity-cache', 'achieved': round(whh_bytes / (fwd_ms * 1e-3) / 1e9, 1), 'peak': INFINITY_CACHE_GBPS, 'unit': 'GB/s',
+                           'frac': round(whh_bytes / (fwd_ms * 1e-3) / 1e9 / INFINITY_CACHE_GBPS, 4), 'forward_ms': round(fwd_ms, 3),
+                           'note': 'W_hh bytes the %d recurrent launches of one forward re-read (%.2f GB) / wall time of that forward (incl. its '
+                                   'five GEMMs): a lower bound on the rate of the recurrent launches themselves' % (2 * T, whh_bytes / 1e9)}}
     if with_cpu:
         from oracle import policy_oracle as po
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -132,6 +181,62 @@ def bc_bench(steps, warmup, with_cpu):
         res['cpu_baseline'] = {'value': round(n / (time.perf_counter() - t0), 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
                                'kind': 'port', 'sample': '%d oracle steps (torch fp32 autograd restatement)' % n}
     return res
+
+
+def finetune_dp_bench(dist, steps, warmup):
+    """BASELINE config 4 (N > 1): data-parallel finetune iteration - PolicyNetWithConv, T=100, B=16 sequences PER RANK (weak), SyncBN,
+    gradient buckets all-reduced on RCCL while backward still runs.  Reports steps/s, the time of the same all-reduces issued alone
+    (nothing to hide behind), and the fraction of that time the overlap hides: 1 - (t_dp - t_local) / t_allreduce."""
+    from pvr_habitat_amd.models import PolicyNetWithConv, HipRMSprop, make_allreduce_fn
+    T, B = 100, 16
+    world, rank = dist.get_world_size(), dist.get_rank()
+    torch.manual_seed(0)
+    net = PolicyNetWithConv((64, 64, 6), 4, True, max_unroll=T, max_batch=B).to(device='cuda')
+    opt = HipRMSprop(net, max_epochs=10 ** 6)
+    g = torch.Generator().manual_seed(1 + rank)
+    o = torch.randint(0, 256, (T, B, 64, 64, 6), dtype=torch.uint8, generator=g).cuda()
+    d = (torch.rand((T, B), generator=g) < 0.02).cuda()
+    a = torch.randint(0, 4, (T, B), generator=g).cuda()
+
+    def timed(fn, k):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        return (time.perf_counter() - t0) / k
+
+    def dp_step():
+        opt.scheduler_step(); opt.step_data_parallel(o, d, a)
+
+    def local_step():
+        opt.scheduler_step(); opt.step(o, d, a)
+    for _ in range(warmup):
+        dp_step()
+    t_dp = timed(dp_step, steps)
+    # the same collectives alone: four bucket-sized all-reduces of the flat gradient, back to back, on an idle GPU
+    fn, errors = make_allreduce_fn(None, 'cuda')
+    grads = torch.zeros(net._n_train, dtype=torch.float32, device='cuda')
+    bounds = [0, net._slots['fc.1.weight'][0], net._slots['core.weight_ih_l0'][0], net._slots['core.weight_ih_l1'][0], net._n_train]
+
+    def comm_only():
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if hi > lo:
+                assert fn(grads.data_ptr() + 4 * lo, hi - lo, torch.cuda.current_stream().cuda_stream, None) == 0, errors
+    comm_only()
+    t_comm = timed(comm_only, steps)
+    # uninstall the collective for the local leg: the same iteration without any all-reduce
+    import pvr_habitat_amd.models as _M
+    _M._lib.check(_M._plib().pvr_policy_set_data_parallel(net._handle, 1, 0, _M.ALLREDUCE_FN(), None)); net._dp_key = None
+    for _ in range(2):
+        local_step()
+    t_local = timed(local_step, steps)
+    hidden = 1.0 - max(t_dp - t_local, 0.0) / t_comm if t_comm > 0 else None
+    return {'metric': 'finetune DP steps/sec (PolicyNetWithConv T=100, B=16 per rank, SyncBN, fp32, bucketed RCCL all-reduce overlapped with backward)',
+            'value': round(1.0 / t_dp, 2), 'unit': 'steps/s', 'n_gpus': world, 'global_batch_sequences': B * world, 'scaling': 'weak',
+            'ms_per_step': round(t_dp * 1e3, 3), 'ms_per_step_without_collectives': round(t_local * 1e3, 3),
+            'allreduce_ms': round(t_comm * 1e3, 3), 'allreduce_bytes': int(net._n_train * 4), 'overlap_fraction': None if hidden is None else round(hidden, 3),
+            'backend': dist.get_backend()}
 
 
 def finetune_bench(steps, warmup):
@@ -190,10 +295,11 @@ def vit_bench(variant, batch, steps, warmup, dtype):
             'frac_of_mfma_peak': round(fps * VIT_GFLOP[variant] / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 
-def pcie_bench(model_sd, batch, frame, dtype, nbatches=8):
-    """PCIe-inclusive rate (never the headline `value`): host-resident uint8 frames -> pinned staging -> H2D ->
-    encoder -> D2H fp32 embeddings, overlapped on separate HIP streams (embeddings.stream_embed)."""
-    from pvr_habitat_amd import synth
+def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
+    """PCIe-inclusive rate (never the headline `value`): host-resident uint8 frames -> (pinned staging ->) H2D ->
+    encoder -> D2H fp32 embeddings, overlapped on separate HIP streams (embeddings.stream_embed, the path save_embedded_obs uses).
+    The whole frame pool (4096 frames = 16 batches) is streamed `passes` times per measurement, so pipeline fill / drain and the
+    one-off buffer set-up are a small part of the timed region."""
     from pvr_habitat_amd.embeddings import HipResNet50, stream_embed
 
     class _Net:                                           # minimal EmbeddingNet-like holder
@@ -201,35 +307,49 @@ def pcie_bench(model_sd, batch, frame, dtype, nbatches=8):
     net = _Net()
     net.embedding = HipResNet50(model_sd, 'conv5', compute_dtype=dtype, max_batch=batch)
     net.out_size = net.embedding.out_size
-    fr = torch.from_numpy(synth.frames(9, batch, frame, frame)).repeat(nbatches, 1, 1, 1)
-    stream_embed(net, fr[:2 * batch], batch)              # warm-up (allocations, first launches)
+    fr = torch.from_numpy(frames_np).repeat(passes, 1, 1, 1)
+    stream_embed(net, fr[:4 * batch], batch)              # warm-up (allocations, first launches, both lanes)
     res = {}
     for kind, src in (('pageable_source', fr), ('pinned_source', fr.pin_memory())):
-        stream_embed(net, src, batch)                     # first pass touches / page-locks the host pages
+        stream_embed(net, src[:4 * batch], batch)
         t0 = time.perf_counter()
         out = stream_embed(net, src, batch)
         el = time.perf_counter() - t0
         assert np.isfinite(out).all()
         res[kind] = {'value': round(fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(fr.numel() / el / 1e9, 2)}
     res['frames'] = int(fr.shape[0])
-    res['note'] = 'host uint8 frames -> (pinned double buffer ->) H2D -> encode -> D2H fp32, copies overlapped with compute on separate HIP streams'
+    res['note'] = ('host uint8 frames -> (pinned staging ring, threaded memcpy ->) H2D -> encode (two lanes) -> D2H fp32, copies overlapped with '
+                   'compute on separate HIP streams; includes allocating / page-locking the result buffer')
     return res
+
+
+def parity_rel_l2(model, sd, frames_np):
+    """the TIMED model (same handle, same dtype) against the CPU oracle on a few frames of the bench's own pool"""
+    from oracle import encoder_oracle as eo
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    fr = frames_np[:4]
+    ref = eo.embed(sd, fr, 'conv5', squeeze=False)
+    out = model(torch.from_numpy(fr).cuda()).cpu().numpy()
+    return float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=320, help='timed steps; the default makes the timed region ~1 s and cycles the 4096-frame pool 20 times')
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--frame', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--lanes', type=int, default=2, help='batches in flight per GPU (1 = strictly one forward at a time)')
+    ap.add_argument('--pool', type=int, default=4096, help='distinct frames resident in HBM, cycled batch by batch (SURVEY 8d frame pool)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec leg')
+    ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec legs')
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
+    ap.add_argument('--no-f16', action='store_true', help='skip the f16 (parity-mode) leg')
+    ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel finetune leg (N > 1)')
     ap.add_argument('--no-fuse', action='store_true', help='one launch per convolution (A/B against the fused bottleneck tails)')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
     args = ap.parse_args()
@@ -255,50 +375,82 @@ def main():
     from pvr_habitat_amd import synth, _lib
     from pvr_habitat_amd.embeddings import HipResNet50
     sd = synth.resnet50_state_dict(1, 'conv5')               # MoCo-v2 encoder_q layout == torchvision resnet50
-    model = HipResNet50(sd, 'conv5', compute_dtype=args.dtype, max_batch=args.batch, chunk=args.chunk)
-    if args.no_fuse:
-        model.set_fusion(False)
-    # each rank owns its own shard of the frame stream (different seed = different frames)
-    frames_np = synth.frames(1 + rank, args.batch, args.frame, args.frame)
-    frames = torch.from_numpy(frames_np).cuda()
+    n_pool = max(args.batch, args.pool // args.batch * args.batch)
+    # each rank owns its own shard of the frame stream (different seed = different frames); the pool is generated once and stays in HBM
+    pool_np = synth.frames(1 + rank, n_pool, args.frame, args.frame)
+    pool = torch.from_numpy(pool_np).cuda()
+    batches = [pool[i:i + args.batch] for i in range(0, n_pool, args.batch)]
+
+    def make_model(dtype, lanes_req):
+        model = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=args.batch, chunk=args.chunk)
+        if args.no_fuse:
+            model.set_fusion(False)
+        o_ = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
+        for lane in range(max(1, min(lanes_req, model.lanes))):      # allocates the lane's workspace (off the timed path)
+            model.forward_into(batches[0], o_, lane=lane)
+        torch.cuda.synchronize()
+        return model
+
+    # Both models exist before either leg is timed.  Measured on this pool (scripts/leg_order_ab.py): a model whose workspace is
+    # allocated right after another model's 5 GB workspace was freed runs 14 % slower (67 k vs 78 k frames/s, either dtype) - the
+    # recycled device memory is laid out worse - so the legs must not free / re-allocate between them.
+    models = {args.dtype: make_model(args.dtype, args.lanes)}
+    if not args.no_f16 and args.dtype != 'f16':
+        # (the SECOND workspace set a process allocates is the slow one, whichever dtype and whether or not the first is still alive;
+        # the third and later ones are not: the f16 model takes the third)
+        del_me = make_model('f16', args.lanes)
+        models['f16'] = make_model('f16', args.lanes)
+        del del_me
+
+    def embed_leg(dtype, steps, warmup, lanes_req):
+        """K full forwards, each of its own batch of the pool, `lanes` of them in flight; barrier + synchronize on both sides."""
+        model = models[dtype]
+        lanes = max(1, min(lanes_req, model.lanes))
+        outs = [torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda') for _ in range(lanes)]
+        streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [torch.cuda.current_stream()]
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def run_steps(k, first=0):
+            for i in range(first, first + k):
+                with torch.cuda.stream(streams[i % lanes]):
+                    model.forward_into(batches[i % len(batches)], outs[i % lanes], lane=i % lanes)
+
+        torch.cuda.synchronize()                                 # default-stream setup work done before the side streams start
+        run_steps(max(warmup, lanes))
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        for o_ in outs:
+            assert torch.isfinite(o_).all()
+        # the last batch each lane embedded, against a fresh forward of the same frames: what was timed produced these embeddings
+        last = [(steps - 1 - j) for j in range(lanes)]
+        for j, i in enumerate(last):
+            chk = torch.empty_like(outs[0])
+            model.forward_into(batches[i % len(batches)], chk, lane=0)
+            torch.cuda.synchronize()
+            assert torch.equal(chk, outs[i % lanes]), 'lane %d result differs from a sequential forward' % (i % lanes)
+        return model, el, lanes
+
+    model, el, lanes = embed_leg(args.dtype, args.steps, args.warmup, args.lanes)
     out = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
-    # Batches in flight per GPU: consecutive steps alternate between two activation workspaces ("lanes") on two streams, as the
-    # streaming path (stream_embed / save_embedded_obs) does, so batch k+1 starts while batch k drains; every step is a full
-    # forward of its own 256-frame batch into its own output buffer and all K steps finish inside the timed region.
-    lanes = max(1, min(args.lanes, model.lanes))
-    outs = [out] + [torch.empty_like(out) for _ in range(lanes - 1)]
-    streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [torch.cuda.current_stream()]
+    frames = batches[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(k):
-        if lanes == 1:
-            for _ in range(k):
-                model.forward_into(frames, out)
-            return
-        for i in range(k):
-            with torch.cuda.stream(streams[i % lanes]):
-                model.forward_into(frames, outs[i % lanes], lane=i % lanes)
-
-    torch.cuda.synchronize()                                     # default-stream setup work done before the side streams start
-    run_steps(max(args.warmup, lanes))
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    if lanes > 1:
-        assert torch.equal(outs[0], outs[1])                     # same frames on both lanes: identical embeddings
-    assert torch.isfinite(out).all()
-
-    # roofline of the dominant kernel (conv_igemm): HIP events between launches on the launch stream
+    # roofline of the dominant kernel family (implicit-GEMM convolutions): HIP events between launches on the launch stream
     chunk = args.chunk if args.chunk else args.batch
     cap = 128
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
@@ -306,9 +458,9 @@ def main():
     plan_names = [nm for nm in model.op_names()]
     algo_bytes = conv_algorithmic_bytes(chunk, plan_names if args.dtype != 'f32' else None)
     grp = {}                                                 # per ResNet stage: [ms, flops, algorithmic bytes] of its conv launches
-    reps = 3
-    for _ in range(reps):
-        _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(frames.data_ptr()), chunk, args.frame, args.frame,
+    reps = 5
+    for r_ in range(reps):
+        _lib.check(_lib.lib().pvr_encoder_profile(model._handle, C.c_void_p(batches[r_ % len(batches)].data_ptr()), chunk, args.frame, args.frame,
                                                   C.c_void_p(out.data_ptr()), out.stride(0), _lib.stream_ptr(), op_ms, op_fl,
                                                   cap, C.byref(n_ops)))
         for i in range(n_ops.value):
@@ -326,60 +478,101 @@ def main():
                   'algorithmic_GBps': round(v[2] / (v[0] * 1e-3) / 1e9, 1), 'frac_hbm': round(v[2] / (v[0] * 1e-3) / 8e12, 3)}
               for k, v in sorted(grp.items())}
     n_conv = n_ops.value - 4
-    traffic = None
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, 'profiles', 'pmc_conv_traffic.json')
-    if os.path.isfile(tf):                                   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-        traffic = round(json.load(open(tf))['avg_hbm_bytes_per_launch'])
+    if os.path.isfile(tf) and args.dtype != 'f32':           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bf16 kernels)
+        tj = json.load(open(tf))
+        traffic = round(tj['avg_hbm_bytes_per_launch'])
+        traffic_source = 'committed rocprofv3 PMC passes of this command (%s), NOT measured in this run: profiles/pmc_conv_traffic.json' % tj.get('captured', 'round 1 build')
     if args.per_op and rank == 0:
         names = ['preprocess', 'stem', 'maxpool'] + [op for op in model.op_names()] + ['pool/flatten']
         for i in range(n_ops.value):
-            tf = op_fl[i] / (op_ms[i] * 1e-3) / 1e12 if op_ms[i] > 0 else 0.0
-            print('%-28s %8.3f ms %8.1f TFLOP/s' % (names[i] if i < len(names) else '?', op_ms[i], tf), file=sys.stderr)
+            tfl = op_fl[i] / (op_ms[i] * 1e-3) / 1e12 if op_ms[i] > 0 else 0.0
+            print('%-28s %8.3f ms %8.1f TFLOP/s' % (names[i] if i < len(names) else '?', op_ms[i], tfl), file=sys.stderr)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     peak = PEAK_F32_TFLOPS if args.dtype == 'f32' else PEAK_BF16_TFLOPS
-    if args.dtype == 'f32':
-        traffic = None                                       # the PMC passes were taken on the bf16 kernel
     barrier()
 
+    line = None
     if rank == 0:
         fps = world * args.steps * args.batch / el
         line = {
             'metric': 'frames/sec embedded (ResNet50, 256x256)', 'value': round(fps, 1), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'timed_region_s': round(el, 3),
             'config': {'workload': 'configs[1]: ResNet50 (MoCo-v2 layout) frozen, %dx%d uint8 frames resident in HBM, batch %d/GPU, '
                                    'random-init synthetic weights' % (args.frame, args.frame, args.batch),
                        'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk, 'batches_in_flight': lanes,
+                       'frame_pool': '%d distinct frames per GPU resident in HBM, cycled batch by batch (every step embeds a different batch)' % n_pool,
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
             'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': traffic,
-                         'traffic_note': 'avg HBM bytes per conv launch, rocprofv3 PMC passes (profiles/pmc_conv_traffic.json); algorithmic '
-                                         'in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel') + ' %d conv launches of one %d-frame chunk, HIP events)' % (n_conv, chunk),
+                         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+                         'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, one batch in flight)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)
                          'hbm_step': None if traffic is None else {
                              'achieved': round(traffic * n_conv / (el / args.steps) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(traffic * n_conv / (el / args.steps) / 8e12, 4),
-                             'note': 'conv-launch HBM bytes per batch (PMC) / step time; layer1-2 launches alone run at 3.2-4.0 TB/s'},
+                             'note': 'conv-launch HBM bytes per batch (committed PMC passes) / step time of THIS run'},
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3),
                          'stages': stages},
         }
+        # parity of what was timed: the same model handle / dtype vs the fp32 CPU oracle (north-star tolerance 1e-3 relative fp32)
+        line['parity_rel_l2'] = round(parity_rel_l2(model, sd, pool_np), 6)
+        line['parity_note'] = ('rel-L2 of the timed %s embeddings vs the fp32 CPU oracle on 4 frames of the pool; north-star bound 1e-3: '
+                               'met by the f16 leg below (same kernels, same speed class), bf16 storage (8-bit mantissa) sits at ~3e-3' % args.dtype)
+    if not args.no_f16 and args.dtype != 'f16':
+        # the parity mode at the headline configuration: f16 storage, same plan, same lanes, same pool (all ranks run it: weak scaling)
+        m16, el16, l16 = embed_leg('f16', max(args.steps // 2, 2 * args.lanes), args.warmup, args.lanes)
+        if rank == 0:
+            k16 = max(args.steps // 2, 2 * args.lanes)
+            line['f16'] = {'metric': 'frames/sec embedded (ResNet50, 256x256), f16 storage (parity mode)', 'value': round(world * k16 * args.batch / el16, 1),
+                           'unit': 'frames/s', 'dtype': 'f16', 'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 3), 'batches_in_flight': l16,
+                           'timed_region_s': round(el16, 3), 'parity_rel_l2': round(parity_rel_l2(m16, sd, pool_np), 6)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, frames_np)
+            line['cpu_baseline'] = cpu_baseline(sd, pool_np[:args.batch])
         if world == 1 and not args.no_pcie:
-            line['pcie_inclusive'] = pcie_bench(sd, args.batch, args.frame, args.dtype)
+            line['pcie_inclusive'] = pcie_bench(sd, args.batch, pool_np, args.dtype)
+            # host uint8 -> H2D -> encode -> D2H fp32, the end-to-end rate of the "embeddings streamed to host" path (never `value`)
+            line['value_pcie_inclusive'] = line['pcie_inclusive']['pinned_source']['value']
         if world == 1 and not args.no_vit:
             vdt = 'f16' if args.dtype == 'f32' else args.dtype   # the fp32 mode covers the ResNet50 family only
-            line['vit'] = [vit_bench('clip_b16', args.batch, 5, 2, vdt), vit_bench('clip_b32', args.batch, 5, 2, vdt)]
+            line['vit'] = [vit_bench('clip_b16', args.batch, 20, 2, vdt), vit_bench('clip_b32', args.batch, 20, 2, vdt)]
         if world == 1 and not args.no_bc:
-            line['bc'] = bc_bench(max(args.steps, 10), args.warmup, not args.no_cpu_baseline)
-            line['bc_finetune'] = finetune_bench(max(args.steps, 10), args.warmup)
+            line['bc'] = bc_bench(100, args.warmup, not args.no_cpu_baseline)
+            line['bc_finetune'] = finetune_bench(60, args.warmup)
+    if world > 1 and not args.no_dp:
+        # BASELINE config 4.  A failure or a stuck collective here must not cost the headline line: a watchdog prints it and exits.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(240.0):
+                if rank == 0:
+                    line['bc_finetune_dp'] = {'error': 'data-parallel leg did not finish within 240 s'}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res = finetune_dp_bench(dist, 20, 3)
+            if rank == 0:
+                line['bc_finetune_dp'] = res
+        except Exception as e:                                  # noqa: BLE001 - reported, not fatal
+            if rank == 0:
+                line['bc_finetune_dp'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        done.set()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == '__main__':

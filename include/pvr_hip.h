@@ -115,6 +115,12 @@ pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos);
  * replaces: the batch loop of behavioral_cloning/save_embedded_obs.py:151-156, which runs one batch at a time. */
 pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames_dev, int32_t n, int32_t h,
                                     int32_t w, float *out_dev, int64_t out_stride, void *hip_stream);
+/* Low-latency plan for the online path - EmbeddingWrapper.observation (src/embeddings.py:441-444) embeds the N = 2 frames of one
+ * environment step per call, inside the evaluation loop of src/test_model.py:4-22.  on != 0: forwards of <= 4 frames run their deep
+ * convolutions split over K (several blocks per pixel tile), 0.88 -> ~0.5 ms per N = 2 ResNet50 call.  Results are independent of N
+ * within the plan and differ from the default plan by fp32 regrouping only (<= 1 ulp of the storage type); larger forwards are
+ * unaffected.  Default off (batch-size independence of the default plan is bit-exact).  ResNet50 family. */
+pvr_status pvr_encoder_set_low_latency(pvr_encoder *enc, int32_t on);
 /* debug: make pvr_encoder_forward return right after the named tap has been produced (NULL/"" = off) */
 pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap);
 /* Instrumented forward of one chunk (n <= chunk): HIP events between launches on the caller's stream;

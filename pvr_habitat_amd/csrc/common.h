@@ -8,6 +8,8 @@
 #include "../../include/pvr_hip.h"
 
 namespace pvr {
+constexpr size_t PVR_ZERO_BYTES = 16384;   // size of an encoder's zero page (>= 4 * the widest Cout of a split-K launch)
+
 
 // ---- error plumbing (thread-local message, integer status across the ABI) -------------------
 void set_error(const char *fmt, ...);

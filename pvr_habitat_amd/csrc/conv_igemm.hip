@@ -546,7 +546,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 pvr_status launch_conv_splitk(const void *in, const void *wgt, const float *bias, const void *res, void *out, const void *zero, float *scratch,
                               int ksplit, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
                               int dtype, hipStream_t stream) {
-    PVR_REQUIRE(cin % 64 == 0 && cout % 8 == 0 && cout <= 64 && zero && scratch && ksplit > 1, "split-K conv: unsupported shape");
+    PVR_REQUIRE(cin % 64 == 0 && cout % 8 == 0 && zero && scratch && ksplit > 1, "split-K conv: unsupported shape");
+    // the K-range blocks read their (all-zero) bias from the zero page: 64 floats fit any zero page, wider outputs need the encoder's
+    PVR_REQUIRE(cout <= 64 || (size_t)cout * sizeof(float) <= PVR_ZERO_BYTES, "split-K conv: cout %d wider than the zero page", cout);
     PVR_REQUIRE(relu <= 1 && (out_f32 & 2) == 0 && kh <= 3 && kw <= 3, "split-K conv: ReLU / 16-bit residual / filters up to 3x3 only");
     ConvP p;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = (const float *)zero; p.res = nullptr; p.out = scratch;
@@ -564,8 +566,15 @@ pvr_status launch_conv_splitk(const void *in, const void *wgt, const float *bias
     p.act = 0; p.out_f32 = 1; p.res_f32 = 0;
     const int nk = p.K / 64;
     p.nk_split = (nk + ksplit - 1) / ksplit;
-    p.m_tiles = (p.M + 127) / 128; p.n_tiles = 1;
-    pvr_status s = dtype == PVR_F16 ? launch_inst2<128, 64, true, 2, 0>(p, stream) : launch_inst2<128, 64, false, 2, 0>(p, stream);
+    p.m_tiles = (p.M + 127) / 128;
+    pvr_status s;
+    if (cout <= 64) {
+        p.n_tiles = 1;
+        s = dtype == PVR_F16 ? launch_inst2<128, 64, true, 2, 0>(p, stream) : launch_inst2<128, 64, false, 2, 0>(p, stream);
+    } else {                                                  // wide outputs (small-batch plan): 128-cout tiles
+        p.n_tiles = (cout + 127) / 128;
+        s = dtype == PVR_F16 ? launch_inst2<128, 128, true, 2, 0>(p, stream) : launch_inst2<128, 128, false, 2, 0>(p, stream);
+    }
     if (s) return s;
     const size_t plane = (size_t)M * cout;
     const int used = (nk + p.nk_split - 1) / p.nk_split;            // planes actually written

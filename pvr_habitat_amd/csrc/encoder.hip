@@ -526,8 +526,8 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
     plan_splitk(enc);
-    PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, 256));
-    PVR_HIP_TRY(hipMemset(enc->d_zero, 0, 256));
+    PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, PVR_ZERO_BYTES));      // zero page: padding rows, and the all-zero bias of split-K launches
+    PVR_HIP_TRY(hipMemset(enc->d_zero, 0, PVR_ZERO_BYTES));
     save_lane(enc, 0);
     // the memsets above run on the null stream; forwards run on the caller's stream (torch's current
     // stream need not be ordered against it), so drain the device once here, off the hot path
@@ -576,6 +576,27 @@ static pvr_status clip_rn50_chunk(pvr_encoder *enc, const uint8_t *fr, int nb, i
     if ((s = launch_conv(enc->d_buf[B_T2], enc->ap_wc, enc->ap_bc, nullptr, dense, enc->d_zero, nb, T, 1, C, 1024, 1, 1, T, 0, 0, 1, dt, st))) return s;
     PVR_HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride * 4, dense, 1024 * 4, 1024 * 4, nb, hipMemcpyDeviceToDevice, st));
     return PVR_OK;
+}
+
+// Low-latency plan (pvr_encoder_set_low_latency; the online pattern of EmbeddingWrapper: N = 2 frames per environment step).
+// A forward of <= 4 frames has 1-7 pixel tiles in layer3 / layer4, so every deep convolution is a handful of blocks each
+// walking its whole K range alone: 21 such launches x 27 us were 65 % of a 0.88 ms N = 2 forward (rocprofv3,
+// profiles/r02_small_batch_kernel_stats.csv).  Here K is cut into ranges of ~4 slices over blockIdx.y (conv_igemm split-K: fp32
+// partial planes + a fixed-order reduce with bias / residual / ReLU).  The split depends on the layer's K only, so results do
+// not depend on N within the plan; against the unsplit plan they differ by fp32 regrouping (<= 1 ulp of the storage type), which
+// is why the plan is opt-in and batch-size independence of the default plan stays bit-exact.
+constexpr size_t SMALLK_BYTES = (size_t)32 << 20;
+static int small_batch_ksplit(const pvr_encoder *enc, const ConvOp &op, int nb) {
+    if (!enc->low_latency || nb > 4 || op.kind != 0 || op.f32op || op.ksplit > 1 || op.relu > 1 || (op.out_f32 & 2)) return 0;
+    const int K = op.k * op.k * op.cin, nk = K / 64;
+    if (nk < 8) return 0;                                        // K < 512: nothing to share
+    const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
+    const long long M = (long long)nb * ho * ho, blocks = ((M + 127) / 128) * ((op.cout + 127) / 128);
+    if (blocks > 64) return 0;
+    int ks = nk / 4;
+    if (ks > 16) ks = 16;
+    if ((size_t)ks * M * op.cout * sizeof(float) > SMALLK_BYTES) return 0;
+    return ks;
 }
 
 // ev != nullptr: record one event before the first launch and one after every launch of the FIRST chunk
@@ -666,6 +687,11 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             } else if (op.f32op) {
                 s = launch_conv_f32((const float *)enc->d_buf[op.in_buf], op.d_wf, op.d_b, (const float *)res, (float *)enc->d_buf[op.out_buf], nb,
                                     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st);
+            } else if (int ks = small_batch_ksplit(enc, op, nb)) {
+                // low-latency plan: the few pixel tiles of a <= 4-frame forward share each K loop between `ks` blocks
+                if (!enc->d_smallk[enc->cur_lane]) PVR_HIP_TRY(hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES));
+                s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, enc->d_smallk[enc->cur_lane],
+                                       ks, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
             } else if (op.ksplit > 1) {
                 s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, (float *)enc->d_buf[op.ks_buf],
                                        op.ksplit, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
@@ -787,6 +813,12 @@ pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos) {
     return PVR_OK;
 }
 
+pvr_status pvr_encoder_set_low_latency(pvr_encoder *enc, int32_t on) {
+    PVR_REQUIRE(enc, "null encoder");
+    enc->low_latency = on != 0;
+    return PVR_OK;
+}
+
 pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on) {
     PVR_REQUIRE(enc, "null encoder");
     enc->fuse = on != 0;
@@ -881,6 +913,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->d_zero) (void)hipFree(enc->d_zero);
     resizer_destroy(enc);
     for (auto &ev : enc->lane_done) if (ev) (void)hipEventDestroy(ev);
+    for (float *q : enc->d_smallk) if (q) (void)hipFree(q);
     for (void *q : {(void *)enc->ap_wqkv, (void *)enc->ap_wc, (void *)enc->ap_bqkv, (void *)enc->ap_bc, (void *)enc->ap_pos, (void *)enc->ap_out}) if (q) (void)hipFree(q);
     delete enc;
 }

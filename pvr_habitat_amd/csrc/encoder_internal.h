@@ -75,6 +75,8 @@ struct pvr_encoder {
     std::vector<ConvOp> ops;
     std::vector<Launch> sched_plain, sched_fused;   // one launch per op / with the layer1-layer2 bottleneck tails fused
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
+    bool low_latency = false;                       // pvr_encoder_set_low_latency: split-K plan for forwards of <= 4 frames
+    float *d_smallk[PVR_MAX_LANES] = {nullptr};     // its fp32 partial planes, per lane (allocated on first use)
     bool resid32 = false;                           // compressed PVRs, f16: fp32 residual stream from layer3 on + fp32 compression head
     bool finalized = false;
     int out_size = 0;

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const void *__restrict__ i
     float s = 0.f;
     if constexpr (IN_F32) {
         const float *p = (const float *)in + (size_t)b * hw * c + ch;
-        for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];
+#pragma unroll 7
+        for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];      // (same summation order; the unroll only lets the loads go out together)
     } else {
         const u16 *p = (const u16 *)in + (size_t)b * hw * c + ch;
         for (int i = 0; i < hw; ++i) s += from_h<F16>(p[(size_t)i * c]);

@@ -231,6 +231,8 @@ class HipResNet50(_Node):
             L.pvr_encoder_destroy(h)
             raise
         self._handle = h
+        if getattr(self, '_low_latency', False):
+            self.set_low_latency(True)
 
     @property
     def max_batch(self):
@@ -273,6 +275,12 @@ class HipResNet50(_Node):
         if self._handle is None:
             self._build()
         _lib.check(_lib.lib().pvr_encoder_set_crop_position(self._handle, int(pos)))
+
+    def set_low_latency(self, on=True):
+        """split-K plan for forwards of <= 4 frames (pvr_encoder_set_low_latency): the online EmbeddingWrapper pattern"""
+        self._low_latency = bool(on)
+        if self._handle is not None and not (self._clip or self._mae or self.variant == 'random5'):
+            _lib.check(_lib.lib().pvr_encoder_set_low_latency(self._handle, int(self._low_latency)))
 
     def set_fusion(self, on):
         """A/B switch between the fused layer1/layer2 bottleneck-tail plan (default) and one launch per convolution;
@@ -321,6 +329,10 @@ class UberModel(nn.Module):
     def set_crop(self, pos):
         for m in self.models:
             m.set_crop(pos)
+
+    def set_low_latency(self, on=True):
+        for m in self.models:
+            m.set_low_latency(on)
 
     SMALL_BATCH = 16                  # at or below this many frames a member network leaves most of the GPU idle
 
@@ -525,12 +537,15 @@ def _checked(host_out, model):
     return host_out
 
 
-def stream_embed(net, frames_u8, batch=256, out=None):
-    """Embed a large host-resident uint8 (N,H,W,3) array with H2D copies, HIP compute and D2H copies overlapped:
-    pinned double buffers, one copy stream each way and TWO compute streams (one per double-buffer slot, each on its own
-    encoder workspace lane, so batch k+1 starts while batch k drains) chained by events.  Same rows, same order, same values as calling `net` batch by batch; this is the
-    "embeddings streamed to host" path of BASELINE config 5 and what save_embedded_obs uses for big scenes.
-    Returns np.float32 (N, out_size) (no squeeze)."""
+def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
+    """Embed a large host-resident uint8 (N,H,W,3) array with H2D copies, HIP compute and D2H copies overlapped: a ring of `depth`
+    device input / output buffers, one copy stream each way and TWO compute streams (each on its own encoder workspace lane, so
+    batch k+1 starts while batch k drains) chained by events.  The ring is deeper than the number of batches in flight on the
+    compute side: with only one buffer per lane the upload of batch k+2 cannot start before batch k has been computed, and the lane
+    then idles for the whole copy (measured: 60 k frames/s at 11.8 GB/s on a link that sustains 56 GB/s).  Pageable sources are
+    staged through pinned buffers by a small thread pool (one memcpy thread moves ~3 GB/s).  Same rows, same order, same values as
+    calling `net` batch by batch; this is the "embeddings streamed to host" path of BASELINE config 5 and what save_embedded_obs
+    uses for big scenes.  Returns np.float32 (N, out_size) (no squeeze)."""
     _lib.require_gpu()
     x = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames_u8))
     assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3
@@ -541,42 +556,61 @@ def stream_embed(net, frames_u8, batch=256, out=None):
     for s_ in (h2d, d2h, *comps):
         s_.wait_stream(torch.cuda.current_stream())          # whatever the caller queued (e.g. a forward on the default stream) comes first
     model = net.embedding
-    if getattr(model, 'lanes', 1) < 2 or os.environ.get('PVR_STREAM_LANES', '2') == '1':
-        comps[1] = comps[0]                                     # single workspace: both slots on one compute stream
+    two_lanes = getattr(model, 'lanes', 1) >= 2 and os.environ.get('PVR_STREAM_LANES', '2') != '1'
+    depth = max(2, min(int(depth), (n + batch - 1) // batch + 1))
     pinned_src = x.is_pinned()                               # caller already holds page-locked frames: no staging copy
-    stage_in = [None, None] if pinned_src else [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.uint8).pin_memory() for _ in range(2)]
-    dev_in = [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
-    dev_out = [torch.empty((batch, osz), dtype=torch.float32, device=dev) for _ in range(2)]
-    in_free = [torch.cuda.Event() for _ in range(2)]       # compute finished reading dev_in[b]
-    out_free = [torch.cuda.Event() for _ in range(2)]      # D2H finished reading dev_out[b]
-    host_free = [torch.cuda.Event() for _ in range(2)]     # H2D finished reading stage_in[b]
+    shape = (batch,) + tuple(x.shape[1:])
+    stage_in = None if pinned_src else [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    dev_in = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    dev_out = [torch.empty((batch, osz), dtype=torch.float32, device=dev) for _ in range(depth)]
+    in_free = [torch.cuda.Event() for _ in range(depth)]    # compute finished reading dev_in[b]
+    out_free = [torch.cuda.Event() for _ in range(depth)]   # D2H finished reading dev_out[b]
+    host_free = [torch.cuda.Event() for _ in range(depth)]  # H2D finished reading stage_in[b]
     for e in in_free + out_free + host_free:
         e.record()
-    for i, lo in enumerate(range(0, n, batch)):
-        b, m = i & 1, min(batch, n - lo)
-        if pinned_src:
-            src = x[lo:lo + m]
-        else:
-            host_free[b].synchronize()                      # pinned staging buffer reusable
-            stage_in[b][:m].copy_(x[lo:lo + m])             # pageable -> pinned (host memcpy; ~3 GB/s on one core)
-            src = stage_in[b][:m]
-        with torch.cuda.stream(h2d):
-            h2d.wait_event(in_free[b])
-            dev_in[b][:m].copy_(src, non_blocking=True)
-            host_free[b].record(h2d)
-            ready = torch.cuda.Event(); ready.record(h2d)
-        comp = comps[b]
-        with torch.cuda.stream(comp):
-            comp.wait_event(ready)
-            comp.wait_event(out_free[b])
-            model.forward_into(dev_in[b][:m], dev_out[b][:m], lane=b if comps[1] is not comps[0] else 0)
-            in_free[b].record(comp)
-            done = torch.cuda.Event(); done.record(comp)
-        with torch.cuda.stream(d2h):
-            d2h.wait_event(done)
-            res[lo:lo + m].copy_(dev_out[b][:m], non_blocking=True)
-            out_free[b].record(d2h)
-    torch.cuda.synchronize()
+    pool = None
+    if not pinned_src and stage_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=stage_threads)
+
+    def stage(dst, lo, m):
+        """pageable -> pinned, split over the pool's threads (torch's copy releases the GIL)"""
+        if pool is None or m < 2 * stage_threads:
+            dst[:m].copy_(x[lo:lo + m])
+            return
+        step = (m + stage_threads - 1) // stage_threads
+        list(pool.map(lambda a: dst[a:min(a + step, m)].copy_(x[lo + a:lo + min(a + step, m)]), range(0, m, step)))
+
+    try:
+        for i, lo in enumerate(range(0, n, batch)):
+            b, m = i % depth, min(batch, n - lo)
+            if pinned_src:
+                src = x[lo:lo + m]
+            else:
+                host_free[b].synchronize()                      # pinned staging buffer reusable
+                stage(stage_in[b], lo, m)
+                src = stage_in[b][:m]
+            with torch.cuda.stream(h2d):
+                h2d.wait_event(in_free[b])
+                dev_in[b][:m].copy_(src, non_blocking=True)
+                host_free[b].record(h2d)
+                ready = torch.cuda.Event(); ready.record(h2d)
+            lane = (i & 1) if two_lanes else 0
+            comp = comps[lane]
+            with torch.cuda.stream(comp):
+                comp.wait_event(ready)
+                comp.wait_event(out_free[b])
+                model.forward_into(dev_in[b][:m], dev_out[b][:m], lane=lane)
+                in_free[b].record(comp)
+                done = torch.cuda.Event(); done.record(comp)
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(done)
+                res[lo:lo + m].copy_(dev_out[b][:m], non_blocking=True)
+                out_free[b].record(d2h)
+        torch.cuda.synchronize()
+    finally:
+        if pool is not None:
+            pool.shutdown()
     _checked(res.numpy(), model)
     return res.numpy() if out is None else res
 
@@ -633,6 +667,11 @@ class EmbeddingWrapper(_WrapperBase):
         self.n_frames = in_channels // 3
         self.embedding = embedding
         self.observation_space = _Box(low=-np.inf, high=np.inf, shape=(self.embedding.out_size * self.n_frames,))
+        # one environment step = one forward of n_frames (2) frames: ask the HIP encoder for its low-latency plan for such calls
+        # (larger batches through the same EmbeddingNet are unaffected)
+        model = getattr(self.embedding, 'embedding', None)
+        if hasattr(model, 'set_low_latency'):
+            model.set_low_latency(True)
 
     def observation(self, observation):
         # (H, W, n_frames * 3) -> (n_frames, H, W, 3); if n_frames > 1, each passes through the embedding separately

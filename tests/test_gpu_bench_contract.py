@@ -25,6 +25,10 @@ def _check(line, n):
     r = d['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['peak'] == 2500.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['frac'] > 0.05
     assert d['value'] > 8000 * n                                       # north-star floor: 8 k frames/s per GPU
+    assert 'frame_pool' in d['config'] and 'traffic_source' in r
+    if n == 1:
+        # parity of the timed dtype is part of the line; the f16 leg is the configuration that meets the north-star 1e-3
+        assert 0 < d['parity_rel_l2'] < 1e-2 and 0 < d['f16']['parity_rel_l2'] < 1e-3 and d['f16']['value'] > 8000
     return d
 
 
@@ -44,4 +48,7 @@ def test_bench_line_two_ranks_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                                             # rank 0 only
-    _check(lines[0], 2)
+    d = _check(lines[0], 2)
+    dp = d['bc_finetune_dp']                                           # BASELINE config 4 leg: data-parallel finetune over the two ranks
+    assert 'error' not in dp, dp
+    assert dp['n_gpus'] == 2 and dp['value'] > 0 and dp['allreduce_ms'] > 0 and dp['allreduce_bytes'] == 4 * 18148868 - 4 * 1028 or dp['allreduce_bytes'] > 7e7

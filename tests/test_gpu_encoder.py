@@ -499,6 +499,7 @@ def test_splitk_compression_head_matches_the_unsplit_sum(monkeypatch):
     from pvr_habitat_amd.embeddings import HipResNet50
     sd = synth.resnet50_state_dict(5, 'conv4')
     fr = torch.from_numpy(synth.smooth_frames(31, 9, 96, 128)).cuda()
+    monkeypatch.setenv('PVR_RESID32', '0')                    # the all-16-bit plan (the f16 parity plan runs this head in fp32, unsplit)
     m = HipResNet50(sd, 'conv4', compute_dtype='f16', max_batch=16)
     a = m(fr).clone()
     assert torch.equal(m(fr[:1]), a[:1]) and torch.equal(m(fr[4:9]), a[4:9])          # batch-size invariance, bit-exact
@@ -619,3 +620,40 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n):
     again = m(fr)
     assert torch.equal(fused, plain), float((fused - plain).abs().max())
     assert torch.equal(fused, again)
+
+
+def test_low_latency_plan_for_online_embedding(monkeypatch):
+    """pvr_encoder_set_low_latency (EmbeddingWrapper embeds N = 2 frames per environment step): forwards of <= 4 frames
+    split their deep convolutions over K.  Within the plan the embedding of a frame does not depend on N (bit-exact); against the
+    default plan it differs by fp32 regrouping only; against the fp32 oracle it meets the same bound; larger batches are untouched;
+    and it is what makes the call faster (timed here, reported)."""
+    import time
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    fr = synth.smooth_frames(61, 8, 64, 64)
+    ref = eo.embed(sd, fr[:2], 'conv5', squeeze=False)
+    d = torch.from_numpy(fr).cuda()
+    for dt, tol in (('f16', 1e-3), ('bf16', 1e-2)):
+        base = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=8)
+        fast = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=8)
+        fast.set_low_latency(True)
+        o_base, o_fast = base(d[:2]), fast(d[:2])
+        assert not torch.equal(o_base, o_fast)                            # the plan really changed the summation grouping
+        l2 = _relerr(o_fast.cpu().numpy(), o_base.cpu().numpy())[0]
+        assert l2 < (3e-4 if dt == 'f16' else 3e-3), l2                  # a few one-ulp flips of the storage type
+        assert _relerr(o_fast.cpu().numpy(), ref)[0] < tol
+        assert torch.equal(fast(d[:1]), o_fast[:1]) and torch.equal(fast(d[1:2]), o_fast[1:2]) and torch.equal(fast(d[:4])[:2], o_fast)
+        assert torch.equal(fast(d), base(d))                               # 8 frames: outside the plan, same launches as the default
+        out = torch.empty((2, 2048), device='cuda')
+        t = {}
+        for name, m in (('default', base), ('low-latency', fast)):
+            for _ in range(10):
+                m.forward_into(d[:2], out)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(100):
+                m.forward_into(d[:2], out)
+            torch.cuda.synchronize(); t[name] = (time.perf_counter() - t0) / 100 * 1e3
+        print('\n[%s] N=2 device-resident forward: default %.3f ms, low-latency plan %.3f ms (plans differ by rel-L2 %.1e)' % (dt, t['default'], t['low-latency'], l2))
+        assert t['low-latency'] < t['default']

@@ -81,8 +81,12 @@ def test_finetune_pipeline(tmp_path):
     assert again['frames'] == stats['frames'] + [288]
     ck2 = torch.load(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar', weights_only=False)
     assert ck2['scheduler_state_dict']['last_epoch'] == ck['scheduler_state_dict']['last_epoch'] + 1
-    assert not torch.equal(ck2['actor_model_state_dict']['fc.1.weight'], w_before)
-    assert float((ck2['actor_model_state_dict']['fc.1.weight'] - w_before).abs().max()) < 1e-2      # continued from the checkpoint, not re-initialised
+    # (this extra iteration runs at LambdaLR factor 1 - 11/11 = 0: the weights must be exactly the checkpoint's - i.e. reloaded, not
+    # re-initialised - while the RMSprop state moves on)
+    assert torch.equal(ck2['actor_model_state_dict']['fc.1.weight'], w_before)
+    sq1, sq2 = ck['actor_model_optimizer_state_dict']['state'], ck2['actor_model_optimizer_state_dict']['state']
+    k0 = sorted(sq1)[0]
+    assert not torch.equal(sq1[k0]['square_avg'], sq2[k0]['square_avg']) and float(sq2[k0]['step']) == float(sq1[k0]['step']) + 1
     mtime = os.path.getmtime(tmp_path / 'ft' / 'scene_emrandom_finetuned_s1_scene.tar')
     done_args = [a if a != '320' else '288' for a in args]
     finished = Fz.run(make_parser().parse_args(done_args))['scene']
