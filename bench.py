@@ -318,8 +318,8 @@ def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
         assert np.isfinite(out).all()
         res[kind] = {'value': round(fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(fr.numel() / el / 1e9, 2)}
     res['frames'] = int(fr.shape[0])
-    res['note'] = ('host uint8 frames -> (pinned staging ring, threaded memcpy ->) H2D -> encode (two lanes) -> D2H fp32, copies overlapped with '
-                   'compute on separate HIP streams; includes allocating / page-locking the result buffer')
+    res['note'] = ('host uint8 frames (a pageable source is page-locked in place for the call: hipHostRegister) -> H2D -> encode (two lanes) -> D2H fp32, '
+                   'copies overlapped with compute on separate HIP streams; includes registering the source and allocating the page-locked result buffer')
     return res
 
 
