@@ -59,7 +59,7 @@ __device__ unsigned long long igemm_stamps[8192][6];
 // prologue through three register stages, so a block pays one memory latency instead of four (a 4-slice loop has nothing to hide
 // the next slice's latency behind: 32 MFMAs per wave per slice against ~1 us)
 template <int BM, int BN, bool F16, int STAGES, int RES, bool NK4 = false>
-__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256, (STAGES == 1 || BM == 64) ? 3 : 2) void conv_igemm_kernel(ConvP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BK = 64;
     constexpr int A_CH = BM / 32;                 // 16-B chunks per thread, activation tile
@@ -482,6 +482,8 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     p.nk_split = 0;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.bias = bias; p.res = (const u16 *)res; p.out = out;
     p.zero = (const u16 *)zero;
+    static int bm64 = -1;
+    if (bm64 < 0) { const char *e = getenv("PVR_IGEMM_BM64"); bm64 = e ? atoi(e) : 0; }
     p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
     p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
     p.Ho = (h + 2 * pad - kh) / stride + 1;
@@ -494,6 +496,11 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
     p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb;
     p.act = relu; p.out_f32 = out_f32 & 1; p.res_f32 = (out_f32 >> 1) & 1;   // out_f32 bit1: residual is fp32
     if (cout <= 64) return launch_cfg<128, 64>(p, dtype, stream);
+    // experiment (PVR_IGEMM_BM64=1): 64-pixel tiles for the K = 256 expand convolutions with residual -> three blocks per CU
+    if (bm64 && kh == 1 && kw == 1 && p.K == 256 && res && !p.res_f32 && !p.out_f32 && relu <= 1 && nk4_enabled()) {
+        p.m_tiles = (p.M + 63) / 64; p.n_tiles = (p.Cout + 127) / 128;
+        return dtype == PVR_F16 ? launch_inst2<64, 128, true, 2, 1, true>(p, stream) : launch_inst2<64, 128, false, 2, 1, true>(p, stream);
+    }
     return launch_cfg<128, 128>(p, dtype, stream);
 }
 

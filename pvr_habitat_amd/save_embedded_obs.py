@@ -45,17 +45,7 @@ def read_habitat_data_from_pickle(data_path, n_trajectories=-1):
     return data
 
 
-def _imread(path):
-    """cv2.imread equivalent (the reference writes RGB arrays with cv2.imwrite and reads them back with
-    cv2.imread, so the array round-trips; PIL returns the file's RGB, i.e. the array reversed)."""
-    try:
-        import cv2
-        return cv2.imread(path)
-    except ImportError:
-        from PIL import Image
-        if not os.path.isfile(path):
-            return None
-        return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[..., ::-1])
+from .png_decode import imread as _imread, decode_parallel
 
 
 def embed_rows(embed_fn, obs, n_frames, batch):
@@ -72,9 +62,9 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def _load_png_trajectory(data_path, t, pool):
+def _load_png_trajectory(data_path, t, workers):
     """Decode trajectory t: (goal, meta dict, frames (L,H,W,3) uint8, file names) or None past the last trajectory.
-    Frames are decoded by the thread pool (PIL / cv2 release the GIL while decoding)."""
+    Frames are decoded by worker processes (png_decode.decode_parallel: PNG decoding holds the GIL, threads do not scale it)."""
     meta_path = os.path.join(data_path, '%d.pickle' % t)
     goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
     if goal is None:
@@ -87,8 +77,8 @@ def _load_png_trajectory(data_path, t, pool):
         if not os.path.isfile(p):
             break
         names.append(p)
-    frames = list(pool.map(_imread, names)) if names else []
-    return goal, tmp, (np.stack(frames) if frames else None), names
+    frames = decode_parallel(names, workers) if names else None
+    return goal, tmp, frames, names
 
 
 def count_png_trajectories(data_path, n_trajectories=-1):
@@ -102,23 +92,24 @@ def count_png_trajectories(data_path, n_trajectories=-1):
 
 def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None):
     """PNG layout of save_opt_trajectories_png.py:44-58.  The reference decodes and embeds one frame per forward (:69-77);
-    here a trajectory's frames are decoded by a host thread pool and embedded together (same rows, same order), and
-    trajectory t+1 is decoded while trajectory t is on the GPU (keeping the GPU fed from the PNG source)."""
+    here a trajectory's frames are decoded by a pool of worker processes and embedded together (same rows, same order), and
+    trajectory t+1 is decoded while trajectory t is on the GPU (keeping the GPU fed from the PNG source).
+    decode_workers: processes (default min(32, cores)); <= 1 decodes in this process."""
     from concurrent.futures import ThreadPoolExecutor
     print('loading %s ...' % data_path)
     data = dict(obs=[], action=[], reward=[], done=[], true_state=[], png=[])
     if n_trajectories == -1:
         n_trajectories = 100000
-    workers = decode_workers or min(16, os.cpu_count() or 1)
+    workers = decode_workers if decode_workers is not None else min(32, os.cpu_count() or 1)
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
     t = t_lo
-    with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectory, data_path, t_lo, pool) if t_hi > t_lo else None
+    with ThreadPoolExecutor(max_workers=1) as ahead:
+        nxt = ahead.submit(_load_png_trajectory, data_path, t_lo, workers) if t_hi > t_lo else None
         for t in range(t_lo, t_hi):
             cur = nxt.result()
             if cur is None:
                 break
-            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, pool) if t + 1 < t_hi else None
+            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, workers) if t + 1 < t_hi else None
             goal, tmp, frames, names = cur
             for k in data.keys():
                 if k in tmp:

@@ -64,5 +64,16 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-52s %.3f ms per launch, %.2f TB/s (read + write %.0f MB)\n", names[pat], ms / 10, 2.0 * bytes / (ms / 10 * 1e-3) / 1e12, 2.0 * bytes / 1e6);
     }
+    // size sweep, coalesced pattern: how much of a short launch is ramp / tail?  (layer3 conv3 moves 103 MB in + 103 MB out + 26 MB)
+    for (size_t mb : {26, 52, 103, 206, 411}) {
+        const int Mx = (int)(mb * 1000000 / (C4 * 2) / BM * BM);
+        for (int it = 0; it < 12; ++it) {
+            if (it == 2) hipEventRecord(e0);
+            hipLaunchKernelGGL(k<2>, dim3(Mx / BM), dim3(256), 0, 0, a, b, Mx);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("coalesced copy of %4zu MB (+ %4zu MB written): %.1f us per launch, %.2f TB/s\n", mb, mb, ms * 100, 2.0 * Mx * C4 * 2 / (ms / 10 * 1e-3) / 1e12);
+    }
     return 0;
 }

@@ -281,7 +281,11 @@ sys.path.insert(0, %(root)r)
 from pvr_habitat_amd import synth
 from pvr_habitat_amd.models import PolicyNet, PolicyNetWithConv, HipRMSprop
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-dist.init_process_group('gloo', rank=rank, world_size=world)       # two ranks share the single test GPU: gloo, not RCCL
+if os.environ.get('PVR_TEST_BACKEND', 'gloo') == 'nccl':            # one GPU per rank, RCCL over xGMI
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+else:
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # two ranks share the single test GPU: gloo, not RCCL
 conv = sys.argv[2].startswith('conv')
 bn = sys.argv[2].endswith('_bn')                                    # SyncBN: global-batch statistics through the callback
 T, B, O, A = 6, 8, 128, 3
@@ -307,11 +311,23 @@ dist.barrier()
 '''
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks on one device)')
+@pytest.mark.parametrize('kind', ['vec_bn', 'conv_bn'])
+def test_data_parallel_two_gpus_rccl_equal_one_rank(tmp_path, kind):
+    """the same equivalence over RCCL: one rank per GPU, backend 'nccl', the library's communication stream handed to
+    torch.distributed as an ExternalStream.  Self-skips on single-GPU boxes (the gloo variant below covers the logic there)."""
+    _dp_equivalence(tmp_path, kind, 'nccl')
+
+
 @pytest.mark.parametrize('kind', ['vec', 'conv', 'vec_bn', 'conv_bn'])
 def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
     """Finetune DP: 2 ranks x B/2 sequences + the bucketed all-reduce of the flat gradient == 1 rank x B, with BatchNorm
     too (SyncBN: global-batch statistics through pvr_policy_set_data_parallel's collective, incl. the running buffers and, for the conv
     variant, the BN input gradient).  Both ranks run on the one test GPU."""
+    _dp_equivalence(tmp_path, kind, 'gloo')
+
+
+def _dp_equivalence(tmp_path, kind, backend):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'dp_gpu.py'
@@ -321,7 +337,8 @@ def test_data_parallel_two_ranks_equal_one_rank(tmp_path, kind):
         out = tmp_path / ('w%d.npz' % world)
         procs = []
         for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29751 + world))
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29751 + world),
+                       PVR_TEST_BACKEND=backend)
             procs.append(subprocess.Popen([sys.executable, str(script), str(out), kind], env=env))
         assert all(p.wait(timeout=300) == 0 for p in procs)
         res[world] = np.load(out)
