@@ -447,11 +447,23 @@ static void save_lane(pvr_encoder *enc, int lane) {
 static pvr_status use_lane(pvr_encoder *enc, int lane) {
     if (lane == enc->cur_lane) return PVR_OK;
     if (!enc->lane_ws[lane].valid) {                            // first use: allocate, off the hot path
+        // allocate into the encoder's current-pointer slots, but keep the previous lane's pointers aside: if any hipMalloc fails
+        // (a ~3 GB workspace can), free what was allocated and put the previous lane back, so the encoder stays usable
+        const int prev = enc->cur_lane;
         enc->d_img = nullptr; enc->d_stem = nullptr; enc->d_imgf = nullptr;
         for (int b = 0; b < B_COUNT; ++b) enc->d_buf[b] = nullptr;
         pvr_status s = alloc_workspace(enc);
-        if (s) return s;
-        PVR_HIP_TRY(hipDeviceSynchronize());
+        if (!s && hipDeviceSynchronize() != hipSuccess) { set_error("use_lane: device sync failed"); s = PVR_ERR_HIP; }
+        if (s) {
+            for (int b = 0; b < B_COUNT; ++b) if (enc->d_buf[b]) (void)hipFree(enc->d_buf[b]);
+            if (enc->d_img) (void)hipFree(enc->d_img);
+            if (enc->d_stem) (void)hipFree(enc->d_stem);
+            if (enc->d_imgf) (void)hipFree(enc->d_imgf);
+            const auto &l = enc->lane_ws[prev];
+            enc->d_img = l.d_img; enc->d_stem = l.d_stem; enc->d_imgf = l.d_imgf;
+            for (int b = 0; b < B_COUNT; ++b) enc->d_buf[b] = l.d_buf[b];
+            return s;
+        }
         save_lane(enc, lane);
         return PVR_OK;
     }

@@ -173,6 +173,42 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
             assert torch.equal(out, ref), (algo, rep, int((out != ref).sum()))
 
 
+EXPAND_CASES = [
+    # n, h, w, cin, cout, stride, act, res   -- 1x1 launches conv_expand takes under the automatic choice (K <= 512, persistent grid)
+    (96, 14, 14, 256, 1024, 1, 1, 1),            # layer3 conv3 + residual
+    (131, 14, 14, 256, 1024, 1, 1, 1),           # ragged: 25676 pixels = 401 tiles + 12 pixels
+    (256, 7, 7, 512, 2048, 1, 1, 1),             # layer4 conv3 + residual (K = 512, 64-cout tiles)
+    (22, 56, 56, 64, 256, 1, 0, 0),              # layer1.0.downsample: K = 64, ONE slice per tile (stage parity alternates per tile)
+    (43, 56, 56, 64, 64, 1, 1, 0),               # layer1.0.conv1 (one n-tile: 512 pixel-tile groups)
+    (48, 56, 56, 256, 512, 2, 0, 0),             # layer2.0.downsample, stride 2
+    (700, 30, 26, 64, 128, 2, 0, 0),             # resnet18/34 layer2 downsample, stride 2, non-square, ragged (136500 pixels)
+]
+
+
+@pytest.mark.parametrize('case', EXPAND_CASES)
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_conv_expand_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
+    """The persistent weight-stationary 1x1 kernel (conv_expand.hip: cross-tile prefetch, LDS stages shared across tile boundaries)
+    accumulates in conv_igemm's K order: bit-identical outputs, on every repeat."""
+    n, h, w, cin, cout, stride, act, res = case
+    tdt, cdt = DT[dt]
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    x = torch.from_numpy(synth.normal(8, 'ex%s' % (case,), (n, h, w, cin))).to(tdt).cuda()
+    wk = torch.from_numpy(synth.normal(8, 'ew%s' % (case,), (cout, cin), std=float(np.sqrt(2.0 / cin)))).to(tdt).cuda()
+    b = torch.from_numpy(synth.uniform(8, 'eb%s' % (case,), (cout,), -0.5, 0.5)).cuda()
+    r = torch.from_numpy(synth.normal(8, 'er%s' % (case,), (n, ho, wo, cout))).to(tdt).cuda() if res else None
+    conv_algo(0)
+    ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, 1, stride, act, 0, False, cdt, tdt)
+    conv_algo(-1)
+    before = _lib.lib().pvr_debug_conv_expand_launches()
+    for rep in range(6):
+        out = _run_conv(x, wk, b, r, n, h, w, cin, cout, 1, stride, act, 0, False, cdt, tdt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+    assert _lib.lib().pvr_debug_conv_expand_launches() == before + 6           # the automatic choice really took conv_expand
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
 def test_maxpool_avgpool(dt):
     tdt, cdt = DT[dt]
