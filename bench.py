@@ -267,7 +267,7 @@ def finetune_bench(steps, warmup):
 VIT_GFLOP = {'clip_b32': 8.82, 'clip_b16': 35.13}      # per frame
 
 
-def vit_bench(variant, batch, steps, warmup, dtype):
+def vit_bench(variant, batch, steps, warmup, dtype, streams=None):
     """BASELINE config 3: CLIP-layout ViT frozen, 224x224 frames resident in HBM, frames/s on one GPU."""
     from pvr_habitat_amd import synth
     from pvr_habitat_amd.embeddings import HipResNet50
@@ -275,7 +275,7 @@ def vit_bench(variant, batch, steps, warmup, dtype):
     m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=batch)
     fr = torch.from_numpy(synth.frames(3, batch, 224, 224)).cuda()
     outs = [torch.empty((batch, 512), dtype=torch.float32, device='cuda') for _ in range(2)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]     # two batches in flight, as in the headline loop
+    streams = streams or [torch.cuda.Stream(), torch.cuda.Stream()]     # two batches in flight, as in the headline loop (streams shared with it)
 
     def run(k):
         for i in range(k):
@@ -391,23 +391,23 @@ def main():
         torch.cuda.synchronize()
         return model
 
-    # Both models exist before either leg is timed.  Measured on this pool (scripts/leg_order_ab.py): a model whose workspace is
-    # allocated right after another model's 5 GB workspace was freed runs 14 % slower (67 k vs 78 k frames/s, either dtype) - the
-    # recycled device memory is laid out worse - so the legs must not free / re-allocate between them.
+    # Both models exist before either leg is timed and nothing is freed in between (scripts/leg_order_ab.py: a model whose workspace
+    # is allocated right after another model's 5 GB workspace was freed ran 14 % slower; scripts/sustained_rate.py: with both
+    # resident, ten back-to-back 1 s legs give bf16 80.3 k and f16 79.3 k frames/s, flat).
     models = {args.dtype: make_model(args.dtype, args.lanes)}
     if not args.no_f16 and args.dtype != 'f16':
-        # (the SECOND workspace set a process allocates is the slow one, whichever dtype and whether or not the first is still alive;
-        # the third and later ones are not: the f16 model takes the third)
-        del_me = make_model('f16', args.lanes)
         models['f16'] = make_model('f16', args.lanes)
-        del del_me
+
+    # the compute streams of every leg, created once: HIP maps streams onto a few hardware queues in creation order, and two lanes whose
+    # streams land on the same hardware queue serialise (a leg on freshly created streams measured the one-lane rate)
+    lane_streams = [torch.cuda.Stream() for _ in range(max(1, args.lanes))]
 
     def embed_leg(dtype, steps, warmup, lanes_req):
         """K full forwards, each of its own batch of the pool, `lanes` of them in flight; barrier + synchronize on both sides."""
         model = models[dtype]
         lanes = max(1, min(lanes_req, model.lanes))
         outs = [torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda') for _ in range(lanes)]
-        streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [torch.cuda.current_stream()]
+        streams = lane_streams[:lanes] if lanes > 1 else [torch.cuda.current_stream()]
 
         def barrier():
             if dist is not None:
@@ -442,6 +442,12 @@ def main():
         return model, el, lanes
 
     model, el, lanes = embed_leg(args.dtype, args.steps, args.warmup, args.lanes)
+    # the parity mode at the headline configuration, back to back with the headline leg (all ranks run it: weak scaling)
+    leg16 = None
+    if 'f16' in models and args.dtype != 'f16':
+        k16 = max(args.steps // 2, 2 * args.lanes)
+        m16, el16, l16 = embed_leg('f16', k16, args.warmup, args.lanes)
+        leg16 = (m16, el16, l16, k16)
     out = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
     frames = batches[0]
 
@@ -510,7 +516,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, one batch in flight)' % (n_conv, chunk),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, one batch in flight)' % (n_conv, chunk),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)
@@ -525,14 +531,11 @@ def main():
         line['parity_rel_l2'] = round(parity_rel_l2(model, sd, pool_np), 6)
         line['parity_note'] = ('rel-L2 of the timed %s embeddings vs the fp32 CPU oracle on 4 frames of the pool; north-star bound 1e-3: '
                                'met by the f16 leg below (same kernels, same speed class), bf16 storage (8-bit mantissa) sits at ~3e-3' % args.dtype)
-    if not args.no_f16 and args.dtype != 'f16':
-        # the parity mode at the headline configuration: f16 storage, same plan, same lanes, same pool (all ranks run it: weak scaling)
-        m16, el16, l16 = embed_leg('f16', max(args.steps // 2, 2 * args.lanes), args.warmup, args.lanes)
-        if rank == 0:
-            k16 = max(args.steps // 2, 2 * args.lanes)
-            line['f16'] = {'metric': 'frames/sec embedded (ResNet50, 256x256), f16 storage (parity mode)', 'value': round(world * k16 * args.batch / el16, 1),
-                           'unit': 'frames/s', 'dtype': 'f16', 'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 3), 'batches_in_flight': l16,
-                           'timed_region_s': round(el16, 3), 'parity_rel_l2': round(parity_rel_l2(m16, sd, pool_np), 6)}
+    if leg16 is not None and rank == 0:
+        m16, el16, l16, k16 = leg16
+        line['f16'] = {'metric': 'frames/sec embedded (ResNet50, 256x256), f16 storage (parity mode)', 'value': round(world * k16 * args.batch / el16, 1),
+                       'unit': 'frames/s', 'dtype': 'f16', 'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 3), 'batches_in_flight': l16,
+                       'timed_region_s': round(el16, 3), 'parity_rel_l2': round(parity_rel_l2(m16, sd, pool_np), 6)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, pool_np[:args.batch])
@@ -542,7 +545,8 @@ def main():
             line['value_pcie_inclusive'] = line['pcie_inclusive']['pinned_source']['value']
         if world == 1 and not args.no_vit:
             vdt = 'f16' if args.dtype == 'f32' else args.dtype   # the fp32 mode covers the ResNet50 family only
-            line['vit'] = [vit_bench('clip_b16', args.batch, 20, 2, vdt), vit_bench('clip_b32', args.batch, 20, 2, vdt)]
+            line['vit'] = [vit_bench('clip_b16', args.batch, 20, 2, vdt, lane_streams[:2] if len(lane_streams) >= 2 else None),
+                           vit_bench('clip_b32', args.batch, 20, 2, vdt, lane_streams[:2] if len(lane_streams) >= 2 else None)]
         if world == 1 and not args.no_bc:
             line['bc'] = bc_bench(100, args.warmup, not args.no_cpu_baseline)
             line['bc_finetune'] = finetune_bench(60, args.warmup)

@@ -19,13 +19,16 @@ is restated from its public definition:
     AdaptiveAvgPool2d(1), BasicBlock (conv3x3-bn-relu-conv3x3-bn + downsample, relu)
 
 PARITY PINNING: torchvision / MoCo checkpoints are not installable/fetchable offline and the
-reference has no tests, so the arithmetic of this file is pinned by
-  (a) topology + primitive semantics cross-check against transformers.ResNetModel with
-      name-remapped weights (tests/test_oracle_encoder.py), and
-  (b) the glue of the reference's own EmbeddingNet/save_embedded_obs exercised with stub
-      modules (tests/golden/make_golden.py, this container only).
-torchvision's uint8 rounding of Resize is restated, not executed: "parity unpinned" at that
-single boundary.
+reference has no tests, so
+  (a) the ARITHMETIC of this file (torchvision's ResNet / transforms definitions) is "parity unpinned": it is restated from the
+      public definitions and cross-checked against an independent implementation (transformers.ResNetModel with name-remapped
+      weights, tests/test_oracle_encoder.py);
+  (b) the GLUE (layout, transform order and parameters per name, reshape / squeeze, UberModel concat order, the moco.py /
+      resnet.py loaders' surgery and key handling, save_embedded_obs split / concat rows and pickle schema, EmbeddingWrapper,
+      test()) is pinned by fixtures the reference's OWN code produced: tests/golden/make_glue_golden.py (build container only)
+      runs /root/reference/src/embeddings.py etc. with stand-in gym / cv2 / clip / timm / detectron2 / torchvision modules;
+      tests/test_glue_golden.py checks this oracle against them.
+torchvision's uint8 rounding of Resize is restated, not executed.
 """
 import numpy as np
 import torch

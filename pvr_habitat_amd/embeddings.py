@@ -537,6 +537,19 @@ def _checked(host_out, model):
     return host_out
 
 
+_STREAM_CACHE = {}
+
+
+def _streams(dev_index):
+    """The four streams of stream_embed (H2D, D2H, two compute lanes), created ONCE per device and process.  HIP maps streams onto a
+    small number of hardware queues round-robin in creation order; creating fresh streams per call eventually puts both compute
+    lanes on one hardware queue, where they serialise (measured in bench.py: a leg on two NEW streams ran at the one-lane rate,
+    69.8 k instead of 79.3 k frames/s)."""
+    if dev_index not in _STREAM_CACHE:
+        _STREAM_CACHE[dev_index] = (torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()])
+    return _STREAM_CACHE[dev_index]
+
+
 def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     """Embed a large host-resident uint8 (N,H,W,3) array with H2D copies, HIP compute and D2H copies overlapped: a ring of `depth`
     device input / output buffers, one copy stream each way and TWO compute streams (each on its own encoder workspace lane, so
@@ -552,7 +565,8 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     n, osz = x.shape[0], net.out_size
     res = torch.empty((n, osz), dtype=torch.float32, pin_memory=True) if out is None else out
     dev = torch.device('cuda')
-    h2d, d2h, comps = torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()]
+    h2d, d2h, comps = _streams(torch.cuda.current_device())
+    comps = list(comps)
     for s_ in (h2d, d2h, *comps):
         s_.wait_stream(torch.cuda.current_stream())          # whatever the caller queued (e.g. a forward on the default stream) comes first
     model = net.embedding

@@ -18,7 +18,7 @@ for t in range(T):
     pickle.dump(dict(action=np.zeros(L, np.int64), reward=np.zeros(L), done=np.zeros(L, bool), true_state=np.zeros((L, 12))), open(os.path.join(d, '%d.pickle' % t), 'wb'))
 net = EmbeddingNet('resnet50', pretrained=False, max_batch=256)
 net(torch.from_numpy(fr[:256]))
-for workers in (1, 8, 32):
+for workers in (1, 8, 32):          # worker processes (png_decode.decode_parallel)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, None, -1, decode_workers=workers); el = time.perf_counter() - t0
     print('decode only, %2d threads: %6.0f frames/s' % (workers, T * L / el), flush=True)
 for workers in (8, 32):
