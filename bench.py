@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # five busy streams (see pvr_habitat_amd/__init__.py); read at the first GPU call
+
 import numpy as np
 import torch
 
@@ -311,7 +313,7 @@ def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
     stream_embed(net, fr[:4 * batch], batch)              # warm-up (allocations, first launches, both lanes)
     res = {}
     for kind, src in (('pageable_source', fr), ('pinned_source', fr.pin_memory())):
-        stream_embed(net, src[:4 * batch], batch)
+        stream_embed(net, src, batch)                     # untimed full pass: the GPU has idled through the CPU legs before this one (clock ramp)
         t0 = time.perf_counter()
         out = stream_embed(net, src, batch)
         el = time.perf_counter() - t0
@@ -400,7 +402,10 @@ def main():
 
     # the compute streams of every leg, created once: HIP maps streams onto a few hardware queues in creation order, and two lanes whose
     # streams land on the same hardware queue serialise (a leg on freshly created streams measured the one-lane rate)
-    lane_streams = [torch.cuda.Stream() for _ in range(max(1, args.lanes))]
+    from pvr_habitat_amd.embeddings import lane_streams as _pkg_lane_streams
+    lane_streams = _pkg_lane_streams()
+    while len(lane_streams) < args.lanes:
+        lane_streams.append(torch.cuda.Stream())
 
     def embed_leg(dtype, steps, warmup, lanes_req):
         """K full forwards, each of its own batch of the pool, `lanes` of them in flight; barrier + synchronize on both sides."""

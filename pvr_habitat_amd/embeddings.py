@@ -540,14 +540,31 @@ def _checked(host_out, model):
 _STREAM_CACHE = {}
 
 
-def _streams(dev_index):
-    """The four streams of stream_embed (H2D, D2H, two compute lanes), created ONCE per device and process.  HIP maps streams onto a
-    small number of hardware queues round-robin in creation order; creating fresh streams per call eventually puts both compute
-    lanes on one hardware queue, where they serialise (measured in bench.py: a leg on two NEW streams ran at the one-lane rate,
-    69.8 k instead of 79.3 k frames/s)."""
+def _streams(dev_index=None):
+    """The four side streams this package uses (two compute lanes, H2D, D2H), created ONCE per device and process, together and in
+    this order.  HIP maps streams onto a few hardware queues at creation; which queue a stream lands on changes what overlaps with
+    what (scripts/stream_queue_ab.py, stream_embed from pinned memory in a fresh process: creation order lanes-then-copies 77.8 k
+    frames/s, copies-then-lanes 56.1 k; bench.py: a leg on two freshly created streams ran at the one-lane rate, 69.8 k instead of
+    79.8 k).  Every user of side streams in this package (stream_embed, bench.py's legs) takes them from here, so the process
+    has one fixed, known-good set instead of whatever the creation history produced."""
+    if dev_index is None:
+        dev_index = torch.cuda.current_device()
     if dev_index not in _STREAM_CACHE:
-        _STREAM_CACHE[dev_index] = (torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()])
-    return _STREAM_CACHE[dev_index]
+        # a / b = compute lanes, h = H2D, d = D2H, x = a spare stream that is never used.  'xabhd' was the one order that measured the
+        # full rate in every context tried (fresh process, after other streams, GPU_MAX_HW_QUEUES 4 and 8; 'abhd' and 'hdab' each lose
+        # 25 % in one of them): profiles/experiments/r02_stream_creation_order.txt
+        order = os.environ.get('PVR_STREAM_ORDER', 'xabhd')
+        made = {}
+        with torch.cuda.device(dev_index):
+            for ch in order:
+                made[ch if ch != 'x' else 'x%d' % len(made)] = torch.cuda.Stream()
+        _STREAM_CACHE[dev_index] = (made['h'], made['d'], [made['a'], made['b']], made)
+    return _STREAM_CACHE[dev_index][:3]
+
+
+def lane_streams(dev_index=None):
+    """the two compute-lane streams (batch k+1 on lane 1 while batch k drains on lane 0)"""
+    return list(_streams(dev_index)[2])
 
 
 def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
@@ -565,8 +582,11 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     n, osz = x.shape[0], net.out_size
     res = torch.empty((n, osz), dtype=torch.float32, pin_memory=True) if out is None else out
     dev = torch.device('cuda')
-    h2d, d2h, comps = _streams(torch.cuda.current_device())
-    comps = list(comps)
+    if os.environ.get('PVR_STREAM_FRESH', '0') == '1':       # experiment: new streams per call
+        h2d, d2h, comps = torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()]
+    else:
+        h2d, d2h, comps = _streams(torch.cuda.current_device())
+        comps = list(comps)
     for s_ in (h2d, d2h, *comps):
         s_.wait_stream(torch.cuda.current_stream())          # whatever the caller queued (e.g. a forward on the default stream) comes first
     model = net.embedding
