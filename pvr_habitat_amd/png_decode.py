@@ -80,11 +80,15 @@ class _Pool(object):
 _POOL = None
 
 
-def decode_parallel(paths, workers, chunk=32):
-    """decode `paths` in order with `workers` processes (<= 1, or few files: in this process)"""
+def decode_parallel(paths, workers, chunk=None):
+    """decode `paths` in order with `workers` processes (<= 1, or few files: in this process).  chunk: files per task; by default
+    the list is cut so that every worker gets one task (a trajectory has at most 500 frames: with a fixed chunk of 32 only 8-16
+    workers ever had work)"""
     global _POOL
-    if workers <= 1 or len(paths) < 2 * chunk:
+    if workers <= 1 or len(paths) < 64:
         return decode_many(paths) if paths else None
+    if chunk is None:
+        chunk = max(4, (len(paths) + workers - 1) // workers)
     if _POOL is None or len(_POOL.procs) != workers:
         shutdown()
         _POOL = _Pool(workers)

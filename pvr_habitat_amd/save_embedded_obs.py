@@ -62,23 +62,33 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def _load_png_trajectory(data_path, t, workers):
-    """Decode trajectory t: (goal, meta dict, frames (L,H,W,3) uint8, file names) or None past the last trajectory.
-    Frames are decoded by worker processes (png_decode.decode_parallel: PNG decoding holds the GIL, threads do not scale it)."""
-    meta_path = os.path.join(data_path, '%d.pickle' % t)
-    goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
-    if goal is None:
-        return None
-    with open(meta_path, 'rb') as f:
-        tmp = pickle.load(f)
-    names = []
-    for s in range(500):                                       # max steps per trajectory (habitat_config/nav_task.yaml:4)
-        p = os.path.join(data_path, '%d_%d.png' % (t, s))
-        if not os.path.isfile(p):
+def _load_png_trajectories(data_path, t0, t1, workers):
+    """Decode trajectories t0 .. t1-1 (stopping at the first missing one): a list of (goal, meta dict, frames (L,H,W,3) uint8 or None,
+    file names).  All frames of the group are decoded in ONE call by the worker processes (png_decode.decode_parallel: PNG decoding
+    holds the GIL, threads do not scale it; a group gives every worker a task)."""
+    group, all_names = [], []
+    for t in range(t0, t1):
+        meta_path = os.path.join(data_path, '%d.pickle' % t)
+        goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
+        if goal is None:
             break
-        names.append(p)
-    frames = decode_parallel(names, workers) if names else None
-    return goal, tmp, frames, names
+        with open(meta_path, 'rb') as f:
+            tmp = pickle.load(f)
+        names = []
+        for s in range(500):                                   # max steps per trajectory (habitat_config/nav_task.yaml:4)
+            p = os.path.join(data_path, '%d_%d.png' % (t, s))
+            if not os.path.isfile(p):
+                break
+            names.append(p)
+        group.append([goal, tmp, None, names])
+        all_names += names
+    if all_names:
+        frames, lo = decode_parallel(all_names, workers), 0
+        for g in group:
+            if g[3]:
+                g[2] = frames[lo:lo + len(g[3])]
+                lo += len(g[3])
+    return group, len(group) < t1 - t0                          # (trajectories, "the scene ends inside this group")
 
 
 def count_png_trajectories(data_path, n_trajectories=-1):
@@ -102,32 +112,32 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
         n_trajectories = 100000
     workers = decode_workers if decode_workers is not None else min(32, os.cpu_count() or 1)
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
+    G = 4                                                       # trajectories decoded per call (<= 2000 frames in flight on the host)
     t = t_lo
     with ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectory, data_path, t_lo, workers) if t_hi > t_lo else None
-        for t in range(t_lo, t_hi):
-            cur = nxt.result()
-            if cur is None:
-                break
-            nxt = ahead.submit(_load_png_trajectory, data_path, t + 1, workers) if t + 1 < t_hi else None
-            goal, tmp, frames, names = cur
-            for k in data.keys():
-                if k in tmp:
-                    data[k].append(tmp[k])
-            if frames is None:
-                continue
-            if model is not None:
-                g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
-                e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
-                                    for i in range(0, len(frames), batch)])
-                data['obs'].extend(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
-            else:
-                data['obs'].extend(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
-            data['png'] += names
-        else:
-            t = t_hi
+        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers) if t_hi > t_lo else None
+        g0 = t_lo
+        while nxt is not None:
+            group, ended = nxt.result()
+            g0 += G
+            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers) if (not ended and g0 < t_hi) else None
+            for goal, tmp, frames, names in group:
+                t += 1
+                for k in data.keys():
+                    if k in tmp:
+                        data[k].append(tmp[k])
+                if frames is None:
+                    continue
+                if model is not None:
+                    g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
+                    e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
+                                        for i in range(0, len(frames), batch)])
+                    data['obs'].append(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+                else:
+                    data['obs'].append(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
+                data['png'] += names
     n_trajectories = t - t_lo
-    data['obs'] = np.stack(data['obs']) if data['obs'] else np.zeros((0, 0), np.float32)
+    data['obs'] = np.concatenate(data['obs']) if data['obs'] else np.zeros((0, 0), np.float32)
     for k in ('action', 'reward', 'done', 'true_state'):
         data[k] = np.concatenate(data[k]) if data[k] else np.zeros((0,))
     n_samples = len(data['reward'])

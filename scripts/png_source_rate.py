@@ -18,10 +18,12 @@ for t in range(T):
     pickle.dump(dict(action=np.zeros(L, np.int64), reward=np.zeros(L), done=np.zeros(L, bool), true_state=np.zeros((L, 12))), open(os.path.join(d, '%d.pickle' % t), 'wb'))
 net = EmbeddingNet('resnet50', pretrained=False, max_batch=256)
 net(torch.from_numpy(fr[:256]))
-for workers in (1, 8, 32):          # worker processes (png_decode.decode_parallel)
+for workers in (1, 8, 32, 64):      # worker processes (png_decode.decode_parallel); first call per count = untimed pool start-up
+    S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, None, -1, decode_workers=workers); el = time.perf_counter() - t0
     print('decode only, %2d threads: %6.0f frames/s' % (workers, T * L / el), flush=True)
-for workers in (8, 32):
+for workers in (32, 64):
+    S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, net, -1, batch=256, decode_workers=workers); el = time.perf_counter() - t0
     print('decode + embed (ResNet50 bf16), %2d threads: %6.0f frames/s, obs %s' % (workers, T * L / el, data['obs'].shape), flush=True)
 x = torch.from_numpy(np.stack([fr[i % 512] for i in range(T * L)]))
