@@ -56,7 +56,10 @@ def conv_algorithmic_bytes(n, names=None):
         layer, block, kind = int(head[0][5:]), int(head[1]), head[2]
         planes, hi, ho, inpl = geom(layer, block)
         if len(parts) > 1:                                   # conv2 -> conv3 (+ residual) [-> next conv1]
-            tot += hi * hi * planes + 2 * ho * ho * planes * 4
+            if '&downsample' in parts[1]:                        # identity branch computed from the block input: x in, y out
+                tot += hi * hi * planes + hi * hi * inpl + ho * ho * planes * 4
+            else:
+                tot += hi * hi * planes + 2 * ho * ho * planes * 4
             if len(parts) > 2:
                 nh = parts[2].split('.')
                 tot += ho * ho * geom(int(nh[0][5:]), int(nh[1]))[0]

@@ -32,6 +32,10 @@ struct ChainP {
     u16 *y, *t1n;
     int N, H, W, Ho, Wo, stride, M;
     unsigned in_bytes, w2_bytes, w3_bytes, w1n_bytes, y_bytes, t1n_bytes;
+    // DS form (block 0 of layer1): the identity branch is a 1x1 stride-1 convolution of the block input x (64 channels); it is
+    // accumulated into conv3's fp32 accumulators (a K extension of 64) instead of being read back as a 16-bit residual tensor
+    const u16 *xds = nullptr, *wds = nullptr;      // x [M][64]; Wd [4Cm][64] with W3's row permutation; b3 then holds b3 + bd
+    unsigned xds_bytes = 0, wds_bytes = 0;
 };
 
 // 16-byte buffer store with a compile-time byte offset.  The offset goes into the instruction's immediate field
@@ -60,7 +64,8 @@ __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t r
 
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
 // HALO (stride-1 blocks): phase A reads its pixels from ONE contiguous halo run of t1 held in LDS (see "phase A, halo form")
-template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
+// DS: the block's downsample convolution (64 input channels, stride 1) runs inside conv3's accumulation; no residual tensor is read
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false>
 __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BM = 128, BK = 64, BN = CM;
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
     const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
     const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1n), 0, p.w1n_bytes, 0x00020000);
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.y_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DS ? p.xds : p.res), 0, DS ? p.xds_bytes : p.y_bytes, 0x00020000);
+    const auto rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DS ? p.wds : p.w3), 0, DS ? p.wds_bytes : p.w3_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
@@ -188,40 +194,33 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 
     // ---- phase-B addressing and the first group's prefetches (their latency hides under phase A) ----------------
     // lane's 8 consecutive couts of a 64-cout group start at wn*32 + fq*8; pixel of tile j is wm*64 + 16j + fr
-    int y_off[TM];                                // byte offset of (pixel, group 0) in res / y
-    int t_off[TM];                                // byte offset of the pixel row in t1'
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        y_off[j] = m < p.M ? (m * C4 + wn * 32 + fq * 8) * 2 : OOB;
-        t_off[j] = m < p.M ? (m * CMN + wn * (CMN / 2) + fq * 8) * 2 : OOB;
-    }
-    int w3_g[W3_CH], w3_l[W3_CH];                 // W3 group staging: global byte offset (group 0), LDS byte offset
-#pragma unroll
-    for (int i = 0; i < W3_CH; ++i) {
-        const int q = tid + 256 * i, r = (q >> 3) & 63, s = q >> 9;
-        w3_g[i] = (r * CM + s * 64 + ((q & 7) ^ ((r >> 1) & 7)) * 8) * 2;
-        w3_l[i] = W3_OFF + s * 8192 + r * 128 + (q & 7) * 16;
-    }
-    int w1_g[CMN ? W1_CH : 1], w1_l[CMN ? W1_CH : 1];
-    if constexpr (CMN > 0) {
-#pragma unroll
-        for (int i = 0; i < W1_CH; ++i) {
-            const int q = tid + 256 * i, r = q >> 3;
-            w1_g[i] = (r * C4 + ((q & 7) ^ ((r >> 1) & 7)) * 8) * 2;
-            w1_l[i] = W1_OFF + r * 128 + (q & 7) * 16;
-        }
-    }
+    // byte offset of (pixel, group 0) in res / y and of the pixel row in t1': tile j adds 16 rows.  Rows past M lie past the end of
+    // the buffers (num_records = M rows): the hardware range check drops those stores and returns zeros for those loads
+    const int y_off0 = ((m0 + wm * 64 + fr) * C4 + wn * 32 + fq * 8) * 2;
+    const int t_off0 = ((m0 + wm * 64 + fr) * CMN + wn * (CMN / 2) + fq * 8) * 2;
+#define Y_OFF(j_) (y_off0 + (j_) * (16 * C4 * 2))
+#define T_OFF(j_) (t_off0 + (j_) * (16 * CMN * 2))
+    // W3 group / W1' slice staging: thread q = tid + 256 i moves chunk (q & 7) of row r; r advances by 32 per i (the swizzle term
+    // (r >> 1) & 7 does not change), so every offset is ONE per-thread base + a compile-time constant (keeps the arrays out of VGPRs)
+    const int st_r = tid >> 3, st_c = ((tid & 7) ^ ((st_r >> 1) & 7)) * 16;
+    const int w3_g0 = st_r * CM * 2 + st_c, w3_l0 = W3_OFF + st_r * 128 + (tid & 7) * 16;
+    const int w1_g0 = st_r * C4 * 2 + st_c, w1_l0 = W1_OFF + st_r * 128 + (tid & 7) * 16;
+#define W3_G(i_) (w3_g0 + ((i_) & 1) * (32 * CM * 2) + ((i_) >> 1) * 128)
+#define W3_L(i_) (w3_l0 + ((i_) & 1) * 4096 + ((i_) >> 1) * 8192)
+#define W1_G(i_) (w1_g0 + (i_) * (32 * C4 * 2))
+#define W1_L(i_) (w1_l0 + (i_) * 4096)
     u32x4 rres[RD][TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
+    if constexpr (!DS) {
 #pragma unroll
-    for (int d = 0; d < RD; ++d)
+        for (int d = 0; d < RD; ++d)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], d * 128, 0));
+            for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), d * 128, 0));
+    }
 #pragma unroll
-    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 0, 0));
+    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));
     if constexpr (CMN > 0) {
 #pragma unroll
-        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 0, 0));
+        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, W1_G(i), 0, 0));
     }
 
     // ---- phase A: conv2 3x3 as implicit GEMM, 128 pixels x CM couts, K = 9*CM --------------------------------
@@ -325,6 +324,25 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     }
     }
     CH_T(2);
+    // DS form: the lane's MFMA fragments of x (pixel = wm*64 + 16j + fr, channels (4ks + fq)*8 ..) and of Wd's first 64-cout group come
+    // straight from global memory in operand layout (x is 128 B per pixel, Wd 32 KB in all: no LDS stage); requested here, where phase
+    // A's accumulators and W2 stages are dead, and first used after group 0's conv3 MFMAs
+    V8 xd[2][TM], wdr[2][2];
+    int wd_off[2];
+    if constexpr (DS) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int xo_ = (m0 + wm * 64 + j * 16 + fr) * 128 + fq * 16;      // rows past M: range miss -> zeros
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xd[ks][j] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_res, xo_, ks * 64, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            wd_off[t] = (wn * 32 + t * 16 + fr) * 128 + fq * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wdr[t][ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, wd_off[t] + ks * 64, 0, 0));
+        }
+    }
 #undef PVR_K_STEP
 #undef PVR_LOAD_SLICE
 #undef PVR_STORE_SLICE
@@ -347,18 +365,18 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     }
     // first W3 group / W1' slice -> LDS
 #pragma unroll
-    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+    for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + W3_L(i)) = w3r[i];
     if constexpr (CMN > 0) {
 #pragma unroll
-        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+        for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + W1_L(i)) = w1r[i];
     }
     if (G > 1) {
 #pragma unroll
         for (int i = 0; i < W3_CH; ++i)
-            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], 64 * CM * 2, 0));
+            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 64 * CM * 2, 0));
         if constexpr (CMN > 0) {
 #pragma unroll
-            for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], 128, 0));
+            for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, W1_G(i), 128, 0));
         }
     }
     __syncthreads();
@@ -417,6 +435,21 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wb[t], xa[j], acc3[t][j]);
             }
+        if constexpr (DS) {                       // + Wd[group] . x  (K = 64), then the next group's Wd fragments
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc3[t][j] = mfma16<F16>(wdr[t][ks], xd[ks][j], acc3[t][j]);
+            if (g + 1 < G) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        wdr[t][ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, wd_off[t] + ks * 64, (g + 1) * 8192, 0));
+            }
+        }
         if (g == 1) CH_T(7);
         // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane -> 16-B global store + 16-B LDS write
         const int c0 = g * 64 + wn * 32 + fq * 8;
@@ -425,32 +458,38 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         for (int j = 0; j < TM; ++j) {
             const f32x4 lo = acc3[0][j], hi = acc3[1][j];
             float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
-            const u32x4 r = rres[g % RD][j];
             u32x4 o;
+            if constexpr (DS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
-                const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
-                o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                for (int e = 0; e < 4; ++e)
+                    o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+            } else {
+                const u32x4 r = rres[g % RD][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
+                    const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
+                    o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                }
             }
-            store_b128_imm(o, rs_y, y_off[j], g * 128);
+            store_b128_imm(o, rs_y, Y_OFF(j), g * 128);
             if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
-        if (g + RD < G) {
+        if (!DS && g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, y_off[j], (g + RD) * 128, 0));
+                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), (g + RD) * 128, 0));
         }
         if (g == 1) CH_T(8);
         __syncthreads();                          // y group visible; every wave is done with this W3 group
         if (g == 1) CH_T(9);
         if (g + 1 < G) {
 #pragma unroll
-            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w3_l[i]) = w3r[i];
+            for (int i = 0; i < W3_CH; ++i) *reinterpret_cast<u32x4 *>(smem + W3_L(i)) = w3r[i];
             if (g + 2 < G) {
 #pragma unroll
                 for (int i = 0; i < W3_CH; ++i)
-                    w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, w3_g[i], (g + 2) * (64 * CM * 2), 0));
+                    w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), (g + 2) * (64 * CM * 2), 0));
             }
         }
         if (g == 1) CH_T(10);
@@ -473,11 +512,11 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             if (g == 1) CH_T(11);
             if (g + 1 < G) {
 #pragma unroll
-                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + w1_l[i]) = w1r[i];
+                for (int i = 0; i < W1_CH; ++i) *reinterpret_cast<u32x4 *>(smem + W1_L(i)) = w1r[i];
                 if (g + 2 < G) {
 #pragma unroll
                     for (int i = 0; i < W1_CH; ++i)
-                        w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, w1_g[i], (g + 2) * 128, 0));
+                        w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, W1_G(i), (g + 2) * 128, 0));
                 }
             }
         }
@@ -498,17 +537,23 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
-                store_b128_imm(o, rs_t, t_off[j], q * 64);
+                store_b128_imm(o, rs_t, T_OFF(j), q * 64);
             }
         }
     }
+#undef W3_G
+#undef W3_L
+#undef W1_G
+#undef W1_L
+#undef Y_OFF
+#undef T_OFF
 #ifdef CHAIN_STAMP
     CH_T(5);
     if (threadIdx.x == 0 && blockIdx.x < 8192) { _Pragma("unroll") for (int k = 0; k < 12; ++k) chain_stamps[blockIdx.x][k] = ch_tt[k]; }
 #endif
 }
 
-template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO>
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false>
 static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const int grid = (p.M + 127) / 128;
     const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? 256 : 192) * 128 + (size_t)2 * CM * 128 : (size_t)2 * (128 + CM) * 128;
@@ -516,11 +561,11 @@ static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const size_t lds = phase_b <= pipe ? pipe : phase_b;
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO>,
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
@@ -532,12 +577,24 @@ static bool chain_halo_enabled() {
     return v != 0;
 }
 
-template <int CM, int CMN, bool F16, int RD, int OCC>
+// DS instance: 184 VGPRs uncapped (two blocks per CU) or capped at 168 with 8 spilled (three); PVR_CHAIN_DS_OCC selects, default 3
+static int chain_ds_occ() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_CHAIN_DS_OCC"); v = e ? atoi(e) : 3; }
+    return v;
+}
+
+template <int CM, int CMN, bool F16, int RD, int OCC, bool DS = false>
 static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
     // halo form: stride 1 and the 128 + 2W + 2 halo rows (+ the zero row) fit the LDS tile
-    if (p.stride == 1 && 128 + 2 * p.W + 2 <= (CM == 64 ? 256 : 192) - 1 && chain_halo_enabled())
-        return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
-    return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
+    const bool halo = p.stride == 1 && 128 + 2 * p.W + 2 <= (CM == 64 ? 256 : 192) - 1 && chain_halo_enabled();
+    if constexpr (DS) {
+        if (halo) return chain_ds_occ() == 3 ? launch_chain_one<CM, CMN, F16, RD, 3, true, true>(p, stream) : launch_chain_one<CM, CMN, F16, RD, 2, true, true>(p, stream);
+        return launch_chain_one<CM, CMN, F16, RD, 2, false, true>(p, stream);
+    } else {
+        if (halo) return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
+        return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
+    }
 }
 
 // tuning knob for A/B runs: PVR_CHAIN_CFG = 10*RD + OCC for the Cm = 64 instances (default 12: measured best, profiles/experiments)
@@ -549,6 +606,11 @@ static int chain_cfg() {
 
 template <bool F16>
 static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream) {
+    if (p.xds) {                                  // downsample inside the chain: layer1's block 0 (Cm = 64, next block's conv1 64 wide)
+        if (cm == 64 && cmn == 64) return launch_chain_inst<64, 64, F16, 1, 2, true>(p, stream);
+        set_error("bottleneck chain with downsample: no instance for Cm=%d, next Cm=%d", cm, cmn);
+        return PVR_ERR_INVALID;
+    }
     const int cfg = chain_cfg();
 #define PVR_CHAIN64(CMN_)                                                                 \
     switch (cfg) {                                                                        \
@@ -572,6 +634,7 @@ static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream
     return PVR_ERR_INVALID;
 }
 
+bool chain_ds_supported(int cm, int cmn, int cin, int stride) { return cm == 64 && cmn == 64 && cin == 64 && stride == 1; }
 bool chain_supported(int cm, int cmn) { return (cm == 64 && (cmn == 0 || cmn == 64 || cmn == 128)) || (cm == 128 && (cmn == 0 || cmn == 128)); }
 
 // row permutation of the chain's 1x1 weights: inside every 32-row block, row 16t + 4a + c holds cout 8a + 4t + c
@@ -579,9 +642,11 @@ int chain_row_source(int row) { return (row & ~31) + 8 * ((row >> 2) & 3) + 4 * 
 
 pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
                                    void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
-                                   int stride, int dtype, hipStream_t stream) {
+                                   int stride, int dtype, hipStream_t stream, const void *xds, const void *wdsp) {
+    // xds != null: `res` is unused; the identity branch is Wd . x (x = xds: [pixels][64], wdsp: [4Cm][64] row-permuted) and b3 = b3 + bd
     PVR_REQUIRE(chain_supported(cm, cmn), "bottleneck chain: unsupported widths Cm=%d next=%d", cm, cmn);
-    PVR_REQUIRE(t1 && w2 && b2 && w3p && b3 && res && y && (cmn == 0 || (w1np && b1n && t1n)), "bottleneck chain: null argument");
+    PVR_REQUIRE(t1 && w2 && b2 && w3p && b3 && (res || xds) && y && (cmn == 0 || (w1np && b1n && t1n)), "bottleneck chain: null argument");
+    PVR_REQUIRE(!xds || (wdsp && chain_ds_supported(cm, cmn, 64, stride)), "bottleneck chain with downsample: unsupported shape");
     ChainP p;
     p.in = (const u16 *)t1; p.w2 = (const u16 *)w2; p.w3 = (const u16 *)w3p; p.w1n = (const u16 *)w1np; p.res = (const u16 *)res;
     p.b2 = b2; p.b3 = b3; p.b1n = b1n; p.y = (u16 *)y; p.t1n = (u16 *)t1n;
@@ -591,6 +656,8 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
     const int64_t inb = (int64_t)n * h * w * cm * 2, yb = M * 4 * cm * 2, tb = M * (cmn ? cmn : 1) * 2;
     PVR_REQUIRE(inb < 0x7ffffff0ll && yb < 0x7ffffff0ll && tb < 0x7ffffff0ll, "bottleneck chain: operand larger than 2 GiB (use a smaller chunk)");
     p.M = (int)M; p.in_bytes = (unsigned)inb; p.y_bytes = (unsigned)yb; p.t1n_bytes = (unsigned)tb;
+    p.xds = (const u16 *)xds; p.wds = (const u16 *)wdsp;
+    p.xds_bytes = xds ? (unsigned)(M * 64 * 2) : 0; p.wds_bytes = xds ? (unsigned)(4 * cm * 64 * 2) : 0;
     p.w2_bytes = (unsigned)(cm * 9 * cm * 2); p.w3_bytes = (unsigned)(4 * cm * cm * 2); p.w1n_bytes = (unsigned)(cmn * 4 * cm * 2);
     return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
 }

@@ -259,6 +259,7 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
     }
     if ((s = enc_upload(&op.d_w, hw))) return s;
     op.h_w = std::move(hw);
+    op.h_b = hb;
     return enc_upload(&op.d_b, hb);
 }
 
@@ -320,10 +321,20 @@ static pvr_status build_schedules(pvr_encoder *e) {
             ++i;
             continue;
         }
-        for (int d = i + 1; d < c3; ++d) { Launch l; l.conv2 = d; e->sched_fused.push_back(l); }   // the downsample runs first
         Launch l;
         l.conv2 = i; l.conv3 = c3; l.t1_in = cur_t1;
         const int nx = c3 + 1;
+        // layer1's block 0: its 64-channel stride-1 downsample is accumulated inside the chain's conv3 (PVR_CHAIN_DS=0: own launch)
+        const char *ds_env = getenv("PVR_CHAIN_DS");
+        const bool ds_on = !ds_env || atoi(ds_env) != 0;
+        if (c3 == i + 2 && ds_on && nx < n) {
+            const ConvOp &d = e->ops[i + 1];
+            if (d.k == 1 && d.pad == 0 && !d.relu && !d.out_f32 && !d.f32op && d.cin_real == d.cin && d.cout == 4 * op.cout &&
+                d.out_buf == e->ops[c3].res_buf && chain_ds_supported(op.cout, e->ops[nx].cout, d.cin, d.stride) && op.stride == 1)
+                l.ds = i + 1;
+        }
+        if (l.ds < 0)
+            for (int d = i + 1; d < c3; ++d) { Launch l2; l2.conv2 = d; e->sched_fused.push_back(l2); }   // the downsample runs first
         if (nx < n && ends_with(e->ops[nx].conv, ".conv1") && e->ops[nx].k == 1 && e->ops[nx].stride == 1 && e->ops[nx].relu &&
             e->ops[nx].cin == 4 * op.cout && e->ops[nx].in_buf == e->ops[c3].out_buf && e->ops[nx].cout_real == e->ops[nx].cout &&
             chain_supported(op.cout, e->ops[nx].cout)) {
@@ -332,10 +343,21 @@ static pvr_status build_schedules(pvr_encoder *e) {
             cur_t1 = l.t1_out;
             conv1_done = true;
         }
+        if (l.ds >= 0 && l.next1 < 0) {               // (the DS instance carries a next conv1)
+            for (int d = i + 1; d < c3; ++d) { Launch l2; l2.conv2 = d; e->sched_fused.push_back(l2); }
+            l.ds = -1;
+        }
         e->sched_fused.push_back(l);
+        if (l.ds >= 0) {
+            ConvOp &o3 = e->ops[c3];
+            std::vector<float> bs(o3.h_b);
+            for (size_t c = 0; c < bs.size(); ++c) bs[c] += e->ops[l.ds].h_b[c];
+            pvr_status s = enc_upload(&o3.d_bsum, bs);
+            if (s) return s;
+        }
         // row-permuted copies of the chain's 1x1 weights
-        for (int which = 0; which < 2; ++which) {
-            const int oi = which == 0 ? c3 : l.next1;
+        for (int which = 0; which < 3; ++which) {
+            const int oi = which == 0 ? c3 : which == 1 ? l.next1 : l.ds;
             if (oi < 0) continue;
             ConvOp &o = e->ops[oi];
             if (o.d_wp) continue;
@@ -533,7 +555,7 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     for (auto &op : enc->ops)
         if (op.kind == 0 && (s = finalize_conv(enc, op))) return s;
     if ((s = build_schedules(enc))) return s;
-    for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); }
+    for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); op.h_b.clear(); op.h_b.shrink_to_fit(); }
     if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
@@ -691,9 +713,11 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if (l.conv3 >= 0) {
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
-                s = launch_bottleneck_chain(enc->d_buf[l.t1_in], c2.d_w, c2.d_b, op.d_wp, op.d_b, res, enc->d_buf[op.out_buf],
+                const ConvOp *cd = l.ds >= 0 ? &enc->ops[l.ds] : nullptr;
+                s = launch_bottleneck_chain(enc->d_buf[l.t1_in], c2.d_w, c2.d_b, op.d_wp, cd ? op.d_bsum : op.d_b, res, enc->d_buf[op.out_buf],
                                             c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
-                                            c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st);
+                                            c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st,
+                                            cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr);
             } else if (op.kind == 2) {
                 s = launch_f32_to_h((const float *)enc->d_buf[op.in_buf], enc->d_buf[op.out_buf], (size_t)nb * op.h * op.w * op.cin, dt, st);
             } else if (op.f32op) {
@@ -809,7 +833,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
         const bool fused = enc->fuse && enc->desc.dtype != PVR_F32;
         for (const Launch &l : (fused ? enc->sched_fused : enc->sched_plain)) {
             if (i >= nl) break;
-            op_flops[i++] = flops(l.conv2) + flops(l.conv3) + flops(l.next1);
+            op_flops[i++] = flops(l.conv2) + flops(l.conv3) + flops(l.next1) + flops(l.ds);
         }
         *n_ops = nl;
     }
@@ -850,6 +874,7 @@ int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf
         if (i < (int)sc.size()) {
             nm = enc->ops[sc[i].conv2].conv;
             if (sc[i].conv3 >= 0) nm += "+" + enc->ops[sc[i].conv3].conv.substr(enc->ops[sc[i].conv3].conv.rfind('.') + 1);
+            if (sc[i].ds >= 0) nm += "&downsample";
             if (sc[i].next1 >= 0) nm += "+" + enc->ops[sc[i].next1].conv;
         } else if (i == (int)sc.size() && !enc->vit && !enc->rnd) nm = "pool/flatten";
     }
@@ -903,7 +928,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

@@ -48,6 +48,8 @@ struct ConvOp {
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
+    std::vector<float> h_b;        // host copy of the bias (same lifetime as h_w)
+    float *d_bsum = nullptr;       // conv3 of a block whose downsample runs inside the chain: b3 + b_downsample
     std::string tap;               // non-empty: output of this op is the named tap
     int ksplit = 0, ks_buf = B_NONE;   // split-K launch (conv_igemm.hip): number of K ranges, workspace buffer that is dead at this op
 };
@@ -56,14 +58,16 @@ struct ConvOp {
 // (conv2 3x3 -> conv3 1x1 + residual -> the next block's conv1 1x1; bottleneck_chain.hip)
 struct Launch {
     int conv2 = -1, conv3 = -1, next1 = -1;   // chain members (indices into ops); conv3 < 0: single launch of ops[conv2]
+    int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
 };
 
 bool chain_supported(int cm, int cmn);
+bool chain_ds_supported(int cm, int cmn, int cin, int stride);
 int chain_row_source(int row);
 pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
                                    void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
-                                   int stride, int dtype, hipStream_t stream);
+                                   int stride, int dtype, hipStream_t stream, const void *xds = nullptr, const void *wdsp = nullptr);
 
 }  // namespace pvr
 

@@ -21,11 +21,11 @@ net(torch.from_numpy(fr[:256]))
 for workers in (1, 8, 32, 64):      # worker processes (png_decode.decode_parallel); first call per count = untimed pool start-up
     S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, None, -1, decode_workers=workers); el = time.perf_counter() - t0
-    print('decode only, %2d threads: %6.0f frames/s' % (workers, T * L / el), flush=True)
+    print('decode only, %2d worker processes: %6.0f frames/s' % (workers, T * L / el), flush=True)
 for workers in (32, 64):
     S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, net, -1, batch=256, decode_workers=workers); el = time.perf_counter() - t0
-    print('decode + embed (ResNet50 bf16), %2d threads: %6.0f frames/s, obs %s' % (workers, T * L / el, data['obs'].shape), flush=True)
+    print('decode + embed (ResNet50 bf16), %2d worker processes: %6.0f frames/s, obs %s' % (workers, T * L / el, data['obs'].shape), flush=True)
 x = torch.from_numpy(np.stack([fr[i % 512] for i in range(T * L)]))
 from pvr_habitat_amd.embeddings import stream_embed
 stream_embed(net, x[:1024], 256); t0 = time.perf_counter(); stream_embed(net, x, 256); el = time.perf_counter() - t0

@@ -638,11 +638,13 @@ def test_fp32_reference_precision_mode(variant, frame):
 
 
 @pytest.mark.parametrize('variant,dtype,n', [('conv5', 'bf16', 3), ('conv5', 'f16', 5), ('conv3', 'bf16', 2), ('conv4', 'f16', 1)])
-def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n):
+def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch):
     """bottleneck_chain.hip (conv2 -> conv3 + residual -> next conv1 in one launch, layer1/layer2) keeps the unfused
     plan's rounding points and K order, so the two plans must agree BIT FOR BIT (n chosen so that the 128-pixel tiles
-    have tails: n*56*56 is not a multiple of 128 for odd n)."""
+    have tails: n*56*56 is not a multiple of 128 for odd n).  (PVR_CHAIN_DS=0: layer1.0's downsample as its own launch; inside the
+    chain it skips one 16-bit rounding, see test_downsample_inside_the_chain.)"""
     from pvr_habitat_amd.embeddings import HipResNet50
+    monkeypatch.setenv('PVR_CHAIN_DS', '0')
     sd = synth.resnet50_state_dict(8, variant)
     fr = torch.from_numpy(synth.smooth_frames(90 + n, n, 160, 200)).cuda()
     m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
@@ -656,6 +658,34 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n):
     again = m(fr)
     assert torch.equal(fused, plain), float((fused - plain).abs().max())
     assert torch.equal(fused, again)
+
+
+@pytest.mark.parametrize('dtype,n', [('bf16', 3), ('f16', 5), ('f16', 1)])
+def test_downsample_inside_the_chain(dtype, n):
+    """layer1.0: the downsample convolution is accumulated in fp32 inside the fused tail's conv3 (K extension by the block input's 64
+    channels, bias b3 + bd) instead of being written and re-read as a 16-bit tensor.  One rounding point fewer than the plan with
+    the downsample as its own launch: the two plans agree to a few ulps of the storage type, the fused one is at least as close to
+    the fp32 oracle, and the launch is gone from the plan."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(8, 'conv5')
+    fr_np = synth.smooth_frames(90 + n, n, 160, 200)
+    fr = torch.from_numpy(fr_np).cuda()
+    m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=8)
+    names = m.op_names()
+    assert 'layer1.0.conv2+conv3&downsample+layer1.1.conv1' in names and 'layer1.0.downsample.0' not in names, names
+    assert 'layer2.0.downsample.0' in names                    # stride-2 / wide downsamples keep their own launch
+    fused = m(fr).clone()
+    assert torch.equal(fused, m(fr))
+    m.set_fusion(False)
+    plain = m(fr).clone()
+    ref = eo.embed(sd, fr_np, 'conv5', squeeze=False)
+    d = _relerr(fused.cpu().numpy(), plain.cpu().numpy())[0]
+    ef, ep = _relerr(fused.cpu().numpy(), ref)[0], _relerr(plain.cpu().numpy(), ref)[0]
+    print('\n[%s n=%d] downsample in chain vs own launch: rel-L2 %.2e; vs fp32 oracle %.2e (in chain) / %.2e (own launch)' % (dtype, n, d, ef, ep))
+    assert 0 < d < (3e-4 if dtype == 'f16' else 3e-3)
+    assert ef < ep * 1.1 and ef < (1e-3 if dtype == 'f16' else 1e-2)
 
 
 def test_low_latency_plan_for_online_embedding(monkeypatch):
