@@ -161,6 +161,8 @@ pvr_status pvr_debug_set_conv_algo(int32_t algo);
 /* debug: launches of the persistent weight-stationary 1x1 kernel (conv_expand.hip) so far in this process - lets a test assert that the
  * automatic choice really took that kernel for a shape.  PVR_CONV_EXPAND=0 disables the kernel (A/B; bit-identical). */
 int64_t pvr_debug_conv_expand_launches(void);
+/* launches of conv_pp256's persistent form (tests: the many-tile GEMMs really took it) */
+int64_t pvr_debug_pp_persistent_launches(void);
 /* global average pool of NHWC (16-bit or fp32) -> fp32 rows at out + i*out_stride */
 pvr_status pvr_op_avgpool(const void *in_dev, float *out_dev, int64_t out_stride, int32_t n, int32_t hw,
                           int32_t c, int32_t in_f32, int32_t dtype, void *hip_stream);

@@ -25,6 +25,7 @@ pvr_status launch_conv(const void *, const void *, const float *, const void *, 
 
 void set_conv_algo(int a);
 long long conv_expand_launches();
+long long pp_persistent_launches();
 
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
@@ -46,6 +47,7 @@ extern "C" {
 const char *pvr_version(void) { return "pvr_hip 0.1.0 (gfx950)"; }
 
 int64_t pvr_debug_conv_expand_launches(void) { return (int64_t)conv_expand_launches(); }
+int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {
     const std::string &e = last_error();

@@ -65,7 +65,7 @@ __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t r
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
 // HALO (stride-1 blocks): phase A reads its pixels from ONE contiguous halo run of t1 held in LDS (see "phase A, halo form")
 // DS: the block's downsample convolution (64 input channels, stride 1) runs inside conv3's accumulation; no residual tensor is read
-template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false>
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false, int PFK = -1>
 __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int BM = 128, BK = 64, BN = CM;
@@ -210,18 +210,23 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #define W1_G(i_) (w1_g0 + (i_) * (32 * C4 * 2))
 #define W1_L(i_) (w1_l0 + (i_) * 4096)
     u32x4 rres[RD][TM], w3r[W3_CH], w1r[CMN ? W1_CH : 1];
-    if constexpr (!DS) {
-#pragma unroll
-        for (int d = 0; d < RD; ++d)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), d * 128, 0));
+    // the first group's residual / W3 / W1' prefetch: before phase A (PFK < 0), or inside its loop at slice PFK (halo form) so that
+    // their RD*16 + 4*(W3_CH + W1_CH) VGPRs are free for fragment prefetch during most of phase A
+#define PVR_PHASE_B_PREFETCH()                                                                                          \
+    {                                                                                                                   \
+        if constexpr (!DS) {                                                                                            \
+            _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                              \
+                _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                          \
+                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), d * 128, 0)); \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                               \
+            w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));            \
+        if constexpr (CMN > 0) {                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < W1_CH; ++i)                                                           \
+                w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, W1_G(i), 0, 0));        \
+        }                                                                                                               \
     }
-#pragma unroll
-    for (int i = 0; i < W3_CH; ++i) w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));
-    if constexpr (CMN > 0) {
-#pragma unroll
-        for (int i = 0; i < W1_CH; ++i) w1r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, W1_G(i), 0, 0));
-    }
+    if constexpr (!HALO || PFK < 0) PVR_PHASE_B_PREFETCH();
 
     // ---- phase A: conv2 3x3 as implicit GEMM, 128 pixels x CM couts, K = 9*CM --------------------------------
     f32x4 acc2[TN][TM];
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         }
 #pragma unroll
         for (int kt = 0; kt < nk; ++kt) {
+            if (kt == PFK) PVR_PHASE_B_PREFETCH();
             if (kt + RL < nk) {                   // register stage kt % RL held slice kt, which reached LDS during step kt - 1
 #pragma unroll
                 for (int i = 0; i < B_CH; ++i)
@@ -541,6 +547,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             }
         }
     }
+#undef PVR_PHASE_B_PREFETCH
 #undef W3_G
 #undef W3_L
 #undef W1_G
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #endif
 }
 
-template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false>
+template <int CM, int CMN, bool F16, int RD, int OCC, bool HALO, bool DS = false, int PFK = -1>
 static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const int grid = (p.M + 127) / 128;
     const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? 256 : 192) * 128 + (size_t)2 * CM * 128 : (size_t)2 * (128 + CM) * 128;
@@ -561,11 +568,11 @@ static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const size_t lds = phase_b <= pipe ? pipe : phase_b;
     static bool attr_done = false;
     if (!attr_done) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS>,
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS, PFK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS, PFK>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
@@ -584,6 +591,12 @@ static int chain_ds_occ() {
     return v;
 }
 
+static int chain_pfk() {
+    static int v = -2;
+    if (v < -1) { const char *e = getenv("PVR_CHAIN_PFK"); v = e ? atoi(e) : 12; }
+    return v;
+}
+
 template <int CM, int CMN, bool F16, int RD, int OCC, bool DS = false>
 static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
     // halo form: stride 1 and the 128 + 2W + 2 halo rows (+ the zero row) fit the LDS tile
@@ -592,7 +605,14 @@ static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
         if (halo) return chain_ds_occ() == 3 ? launch_chain_one<CM, CMN, F16, RD, 3, true, true>(p, stream) : launch_chain_one<CM, CMN, F16, RD, 2, true, true>(p, stream);
         return launch_chain_one<CM, CMN, F16, RD, 2, false, true>(p, stream);
     } else {
-        if (halo) return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
+        if (halo) {
+            // Cm = 128: phase B's first prefetch is issued at slice 12 of phase A's 18 (its 48 VGPRs are free for fragment reads until
+            // then): 0.184 -> 0.178 ms per layer2 tail; PVR_CHAIN_PFK=-1 keeps it in front of phase A
+            if constexpr (CM == 128) {
+                if (chain_pfk() == 12) return launch_chain_one<CM, CMN, F16, RD, 2, true, false, 12>(p, stream);
+            }
+            return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
+        }
         return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
     }
 }

@@ -45,6 +45,7 @@ struct PPP {
     unsigned in_bytes, w_bytes, out_bytes, res_bytes;
     int act, out_f32;
     int n_tiles;
+    int total_tiles;               // pixel tiles x cout tiles (the persistent form walks them with a stride of gridDim.x)
 };
 
 #define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
@@ -65,33 +66,11 @@ __device__ unsigned long long pp_stamps[2][8];
 #define PP_STAMP_LATCH()
 #endif
 
-// BM = 256: the structure above.  BM = 128 (launches whose 256-pixel tiles would not fill the chip, e.g. layer4 at batch 256):
-// a wave owns 64 pixels x 64 couts, X half tiles are 64 rows (one DMA instruction each), a K tile is two phases:
-//         phase 0: read X (pixel tiles 0-3), W0;  DMA W-lo(t+1), W-hi(t+1);           math W0 x X
-//         phase 1: read W1;                       DMA X-lo(t+2), X-hi(t+2), vmcnt(2); math W1 x X
-template <int BM, bool F16, int RES>
-__global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
-    typedef typename HT<F16>::V8 V8;
-    constexpr int TMW = BM / 32;                   // 16-pixel MFMA tiles per wave
-    constexpr int XH = BM / 2, XHB = XH * 128;     // rows / bytes of an X half tile
-    constexpr int XI = XH / 64;                    // DMA instructions per X half tile (8 waves x 8 rows each)
-    constexpr int HALF = 16384;                    // W half tile: 128 couts
-    constexpr int WOFF = 2 * XHB, BUF = WOFF + 2 * HALF;
-    constexpr int OOB = 0x7ffffff0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int swz = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = swz % p.n_tiles, tm = swz / p.n_tiles;
-    const int m0 = tm * BM, co0 = tn * 256;
-
-    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
-
-    // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
-    int a_off[2][XI], a_mask[2][XI], b_off[2][2];
+// per-lane staging offsets of one output tile (pixel rows m0 .., couts co0 ..): see "staging" in the kernel
+template <int BM, int XI>
+__device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int wave, int lane, int (&a_off)[2][XI], int (&a_mask)[2][XI],
+                                              int (&b_off)[2][2]) {
+    constexpr int XH = BM / 2, OOB = 0x7ffffff0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -120,6 +99,46 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             const int co = co0 + (R & ~31) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
             b_off[h][i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
         }
+}
+
+// BM = 256: the structure above.  BM = 128 (launches whose 256-pixel tiles would not fill the chip, e.g. layer4 at batch 256):
+// a wave owns 64 pixels x 64 couts, X half tiles are 64 rows (one DMA instruction each), a K tile is two phases:
+//         phase 0: read X (pixel tiles 0-3), W0;  DMA W-lo(t+1), W-hi(t+1);           math W0 x X
+//         phase 1: read W1;                       DMA X-lo(t+2), X-hi(t+2), vmcnt(2); math W1 x X
+// PERSIST (launches of many more tiles than CUs: the transformer GEMMs): gridDim.x = 256 blocks walk the tiles v = blockIdx.x,
+// blockIdx.x + 256, ... (v mod 8 = the block's XCD, so the XCD-aware tile order holds); the NEXT tile's prologue DMA (K tile 0 and the X
+// half tiles of K tile 1) is issued between the main loop and the epilogue of the current tile, so its HBM / L2 latency runs under the
+// epilogue's stores instead of in front of the first MFMA.  LDS is free at that point (every wave has passed the barrier that follows
+// its last fragment read) and the epilogue does not touch LDS.
+template <int BM, bool F16, int RES, bool PERSIST = false>
+__global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int TMW = BM / 32;                   // 16-pixel MFMA tiles per wave
+    constexpr int XH = BM / 2, XHB = XH * 128;     // rows / bytes of an X half tile
+    constexpr int XI = XH / 64;                    // DMA instructions per X half tile (8 waves x 8 rows each)
+    constexpr int HALF = 16384;                    // W half tile: 128 couts
+    constexpr int WOFF = 2 * XHB, BUF = WOFF + 2 * HALF;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int vb = blockIdx.x;                          // (virtual) block id of the tile being computed
+    int m0, co0;
+
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
+
+    // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
+    int a_off[2][XI], a_mask[2][XI], b_off[2][2];
+#define PP_TILE_SETUP(v_)                                                                                        \
+    {                                                                                                            \
+        const int swz_ = xcd_remap((v_), PERSIST ? p.total_tiles : (int)gridDim.x);                               \
+        m0 = (swz_ / p.n_tiles) * BM; co0 = (swz_ % p.n_tiles) * 256;                                             \
+        pp_tile_setup<BM, XI>(p, m0, co0, wave, lane, a_off, a_mask, b_off);                                      \
+    }
+    PP_TILE_SETUP(vb);
     const int cpt = p.Cin >> 6;                   // K tiles per filter tap
     const int nk = p.KH * p.KW * cpt;
     int xs_tap = 0, xs_kh = 0, xs_kw = 0, xs_cs = 0;   // filter position of the next X tile to stage (wave-uniform)
@@ -154,23 +173,30 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         }
 
     f32x4 acc[4][TMW];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef PP_STAMP
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long clk0_, rt0_, clk1_, rt1_;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_) :: "memory");
 #endif
-    // ---- prologue: tile 0 entirely, X of tile 1 ----------------------------------------------------------------------
-    PP_STAGE_X(0, 0); PP_STAGE_X(1, 0); PP_ADVANCE_X();
-    PP_STAGE_W(0, 0, 0); PP_STAGE_W(1, 0, 0);
-    if (nk > 1) {
-        PP_STAGE_X(0, 1); PP_STAGE_X(1, 1); PP_ADVANCE_X();
-        if constexpr (XI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // ---- prologue: K tile 0 entirely, X of K tile 1 ------------------------------------------------------------------
+#define PP_PROLOGUE_ISSUE()                                                                                      \
+    {                                                                                                            \
+        xs_tap = 0; xs_kh = 0; xs_kw = 0; xs_cs = 0;                                                             \
+        PP_STAGE_X(0, 0); PP_STAGE_X(1, 0); PP_ADVANCE_X();                                                      \
+        PP_STAGE_W(0, 0, 0); PP_STAGE_W(1, 0, 0);                                                                \
+        if (nk > 1) { PP_STAGE_X(0, 1); PP_STAGE_X(1, 1); PP_ADVANCE_X(); }                                      \
+    }
+    PP_PROLOGUE_ISSUE();
+    bool first_tile = true;
+  for (;;) {                                      // tiles of this block (one pass unless PERSIST)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nk > 1 && (!PERSIST || first_tile)) {     // (later tiles: the previous tile's epilogue loads / stores were issued after the DMA:
+        if constexpr (XI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     //  everything drains; a counted wait that leaves the
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                       //  stores in flight measured no faster)
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -266,9 +292,20 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             if (kt + 1 < nk) PP_TILE128(kt + 1, 1);
         }
     }
-#undef PP_TILE128
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
     __builtin_amdgcn_sched_barrier(0);
+    const int em0 = m0, eco0 = co0;               // the epilogue's tile
+    bool more = false;
+    if constexpr (PERSIST) {
+        vb += gridDim.x;
+        more = vb < p.total_tiles;
+        if (more) {                               // next tile: offsets, then its prologue DMA - in flight during the epilogue below
+            PP_TILE_SETUP(vb);
+            PP_PROLOGUE_ISSUE();
+        }
+        first_tile = false;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #ifdef PP_STAMP
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_) :: "memory");
     if (blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
@@ -277,15 +314,6 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         pp_stamps[wr][6] = clk1_ - clk0_; pp_stamps[wr][7] = rt1_ - rt0_;
     }
 #endif
-#undef PP_TILE
-#undef PP_MATH
-#undef PP_READ_W
-#undef PP_READ_X
-#undef PP_MATH_DONE
-#undef PP_FEED_DONE
-#undef PP_STAGE_W
-#undef PP_ADVANCE_X
-#undef PP_STAGE_X
 
     // ---- epilogue: straight from the accumulators -------------------------------------------------------------------
     // D row 4*fq + reg of tile i is A-operand row 64*wc + 16*i + 4*fq + reg = cout co0 + 64*wc + 32*(i>>1) + 8*fq + 4*(i&1) + reg,
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     bool cok[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int c = co0 + wc * 64 + q * 32 + fq * 8;
+        const int c = eco0 + wc * 64 + q * 32 + fq * 8;
         cok[q] = c < p.Cout;
         const float4 lo = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 hi = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -307,12 +335,12 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     constexpr int esz_r = RES == 2 ? 4 : 2;
 #pragma unroll
     for (int j = 0; j < TMW; ++j) {
-        const int m = m0 + wr * XH + j * 16 + fr;
+        const int m = em0 + wr * XH + j * 16 + fr;
         u32x4 rr[2][2];
         if constexpr (RES != 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int c = co0 + wc * 64 + q * 32 + fq * 8;
+                const int c = eco0 + wc * 64 + q * 32 + fq * 8;
                 const int ro = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_r : OOB;
                 rr[q][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0));
                 if constexpr (RES == 2) rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 16, 0));
@@ -320,7 +348,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int c = co0 + wc * 64 + q * 32 + fq * 8;
+            const int c = eco0 + wc * 64 + q * 32 + fq * 8;
             const f32x4 lo = acc[2 * q][j], hi = acc[2 * q + 1][j];
             float v[8] = {lo[0] + bs[q][0], lo[1] + bs[q][1], lo[2] + bs[q][2], lo[3] + bs[q][3],
                           hi[0] + bs[q][4], hi[1] + bs[q][5], hi[2] + bs[q][6], hi[3] + bs[q][7]};
@@ -359,6 +387,30 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             }
         }
     }
+    if (!more) break;
+  }
+#undef PP_TILE128
+#undef PP_TILE
+#undef PP_MATH
+#undef PP_READ_W
+#undef PP_READ_X
+#undef PP_MATH_DONE
+#undef PP_FEED_DONE
+#undef PP_PROLOGUE_ISSUE
+#undef PP_TILE_SETUP
+#undef PP_STAGE_W
+#undef PP_ADVANCE_X
+#undef PP_STAGE_X
+}
+
+static long long g_pp_persistent_launches = 0;
+long long pp_persistent_launches() { return g_pp_persistent_launches; }
+
+// PVR_PP_PERSIST: tiles per launch from which the persistent form is used (default 384 = 1.5 tiles per CU; 0 disables it)
+static int pp_persist_min() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_PP_PERSIST"); v = e ? atoi(e) : 384; }
+    return v;
 }
 
 template <int BM, bool F16, int RES>
@@ -367,9 +419,20 @@ static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (BM == 256)
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
     const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
+    p.total_tiles = grid;
+    if constexpr (BM == 256) {
+        if (pp_persist_min() > 0 && grid >= pp_persist_min()) {       // one block per CU (128 KB of LDS each), several tiles per block
+            ++g_pp_persistent_launches;
+            hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, RES, true>), dim3(256), dim3(512), lds, stream, p);
+            PVR_LAUNCH_CHECK();
+            return PVR_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, RES>), dim3(grid), dim3(512), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;

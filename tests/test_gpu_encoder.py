@@ -141,6 +141,11 @@ PP_CASES = [
     (4, 197, 1, 3072, 768, 1, 1, 0, 2, 1),       # ViT proj + fp32 residual stream
     (3, 50, 1, 768, 3072, 1, 1, 3, 0, 0),        # MAE FC + erf-GELU, M = 150 (< one tile)
     (2, 9, 11, 128, 72, 3, 1, 1, 1, 0),          # cout tail (72 of a 256 tile), ragged M
+    # >= 384 tiles of 256 x 256: the PERSISTENT form (256 blocks walk the tiles, the next tile's prologue DMA under the epilogue)
+    (64, 197, 1, 768, 2304, 1, 1, 0, 0, 0),      # ViT QKV at batch 64: 50 x 9 = 450 tiles (blocks 0..193 take two, ragged last pixel tile)
+    (176, 197, 1, 3072, 768, 1, 1, 0, 2, 1),     # ViT proj + fp32 residual stream, fp32 out: 136 x 3 = 408 tiles, 48 K tiles
+    (600, 14, 14, 256, 256, 3, 1, 1, 1, 0),      # 3x3 + 16-bit residual: 460 tiles of ONE cout tile, 36 K tiles
+    (300, 197, 1, 64, 768, 1, 1, 0, 0, 0),       # K = 64: ONE K tile per output tile (prologue == whole tile), 231 x 3 = 693 tiles
 ]
 
 
@@ -164,6 +169,8 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
         r = torch.from_numpy(synth.normal(7, 'pr%s' % (case,), (n, ho, wo, cout))).to(torch.float32 if res == 2 else tdt).cuda()
     conv_algo(0)
     ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
+    persistent = ((n * ho * wo + 255) // 256) * ((cout + 255) // 256) >= 384
+    before = _lib.lib().pvr_debug_pp_persistent_launches()
     for algo in (1, 2):                                            # 256- and 128-pixel tiles
         conv_algo(algo)
         for rep in range(4):
@@ -171,6 +178,7 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
             torch.cuda.synchronize()
             assert torch.isfinite(out.float()).all()
             assert torch.equal(out, ref), (algo, rep, int((out != ref).sum()))
+    assert _lib.lib().pvr_debug_pp_persistent_launches() == before + (4 if persistent else 0)
 
 
 EXPAND_CASES = [
