@@ -611,7 +611,7 @@ static pvr_status launch_chain_inst(ChainP &p, hipStream_t stream) {
             if constexpr (CM == 128) {
                 if (chain_pfk() == 12) return launch_chain_one<CM, CMN, F16, RD, 2, true, false, 12>(p, stream);
             }
-            return launch_chain_one<CM, CMN, F16, RD, 2, true>(p, stream);
+            return launch_chain_one<CM, CMN, F16, RD, (CM == 64 ? OCC : 2), true>(p, stream);
         }
         return launch_chain_one<CM, CMN, F16, RD, OCC, false>(p, stream);
     }
