@@ -160,6 +160,16 @@ pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *b
 pvr_status pvr_debug_set_conv_algo(int32_t algo);
 /* debug: launches of the persistent weight-stationary 1x1 kernel (conv_expand.hip) so far in this process - lets a test assert that the
  * automatic choice really took that kernel for a shape.  PVR_CONV_EXPAND=0 disables the kernel (A/B; bit-identical). */
+/* ---- PNG source (reference behavioral_cloning/save_embedded_obs.py:63-64,71-72: cv2.imread of <t>_goal.png and <t>_<s>.png) ----
+ * n whole PNG files concatenated in device memory, file i = bytes [offsets[i], offsets[i+1]); every file h x w, bit depth 8,
+ * non-interlaced, colour type grey / RGB / grey+alpha / RGBA.  out (n, h, w, 3) uint8 = cv2.imread's B,G,R layout.
+ * status[i]: 0 decoded; 1 valid-looking PNG of an unsupported kind and 12 size other than h x w (decode those on the host);
+ * anything else = corrupt file (2 signature, 3 truncated, 4 zlib header, 5 block, 6 Huffman code, 7 distance, 8 overrun,
+ * 9 short stream, 10 Adler-32, 11 filter type).  scratch: pvr_png_scratch_bytes(n, h, w) bytes of device memory. */
+int64_t pvr_png_scratch_bytes(int32_t n, int32_t h, int32_t w);
+pvr_status pvr_png_decode(const uint8_t *files_dev, const int64_t *offsets_dev, int32_t n, int32_t h, int32_t w, uint8_t *out_dev,
+                          uint8_t *scratch_dev, int64_t scratch_bytes, int32_t *status_dev, void *hip_stream);
+
 int64_t pvr_debug_conv_expand_launches(void);
 /* launches of conv_pp256's persistent form (tests: the many-tile GEMMs really took it) */
 int64_t pvr_debug_pp_persistent_launches(void);

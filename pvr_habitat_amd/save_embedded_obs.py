@@ -62,14 +62,19 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def _load_png_trajectories(data_path, t0, t1, workers):
+def _load_png_trajectories(data_path, t0, t1, workers, gpu=False):
     """Decode trajectories t0 .. t1-1 (stopping at the first missing one): a list of (goal, meta dict, frames (L,H,W,3) uint8 or None,
-    file names).  All frames of the group are decoded in ONE call by the worker processes (png_decode.decode_parallel: PNG decoding
-    holds the GIL, threads do not scale it; a group gives every worker a task)."""
-    group, all_names = [], []
+    file names).  All frames of the group are decoded in ONE call: on the GPU (gpu=True: png_gpu.decode_files, the host only reads
+    file bytes and the frames never leave HBM; goal and frames are uint8 CUDA tensors then), or by the worker processes
+    (png_decode.decode_parallel: PNG decoding holds the GIL, threads do not scale it; a group gives every worker a task)."""
+    group, all_names, goal_names = [], [], []
     for t in range(t0, t1):
         meta_path = os.path.join(data_path, '%d.pickle' % t)
-        goal = _imread(os.path.join(data_path, '%d_goal.png' % t)) if os.path.isfile(meta_path) else None
+        goal_path = os.path.join(data_path, '%d_goal.png' % t)
+        if gpu:
+            goal = goal_path if (os.path.isfile(meta_path) and os.path.isfile(goal_path)) else None
+        else:
+            goal = _imread(goal_path) if os.path.isfile(meta_path) else None
         if goal is None:
             break
         with open(meta_path, 'rb') as f:
@@ -82,13 +87,38 @@ def _load_png_trajectories(data_path, t0, t1, workers):
             names.append(p)
         group.append([goal, tmp, None, names])
         all_names += names
-    if all_names:
+        goal_names.append(goal_path)
+    if gpu and group:
+        from . import png_gpu
+        with torch.cuda.stream(_png_stream()):                 # (this runs in the read-ahead thread: keep it off the encoder's stream)
+            dec = png_gpu.decode_files(goal_names + all_names, threads=max(1, min(16, workers)))      # returns after its stream has drained
+        for i, g in enumerate(group):
+            g[0] = dec[i]
+        frames, lo = dec[len(group):], 0
+        for g in group:
+            if g[3]:
+                g[2] = frames[lo:lo + len(g[3])]
+                lo += len(g[3])
+    elif all_names:
         frames, lo = decode_parallel(all_names, workers), 0
         for g in group:
             if g[3]:
                 g[2] = frames[lo:lo + len(g[3])]
                 lo += len(g[3])
     return group, len(group) < t1 - t0                          # (trajectories, "the scene ends inside this group")
+
+
+_PNG_STREAM = []
+
+
+def _png_stream():
+    if not _PNG_STREAM:
+        _PNG_STREAM.append(torch.cuda.Stream())
+    return _PNG_STREAM[0]
+
+
+def _t(a):
+    return a if torch.is_tensor(a) else torch.from_numpy(a)
 
 
 def count_png_trajectories(data_path, n_trajectories=-1):
@@ -100,27 +130,30 @@ def count_png_trajectories(data_path, n_trajectories=-1):
     return t
 
 
-def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None):
+def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None, gpu_decode=None):
     """PNG layout of save_opt_trajectories_png.py:44-58.  The reference decodes and embeds one frame per forward (:69-77);
-    here a trajectory's frames are decoded by a pool of worker processes and embedded together (same rows, same order), and
-    trajectory t+1 is decoded while trajectory t is on the GPU (keeping the GPU fed from the PNG source).
-    decode_workers: processes (default min(32, cores)); <= 1 decodes in this process."""
+    here the frames of four trajectories are decoded in one call and embedded together (same rows, same order), and the next group
+    is decoded while this one is on the encoder (keeping the GPU fed from the PNG source).  With an encoder on a GPU
+    the files are decoded ON the GPU (csrc/png_decode.hip; PVR_PNG_GPU=0 or gpu_decode=False selects the host decoders);
+    decode_workers: host decoder processes (default min(32, cores); <= 1 decodes in this process) / file-reader threads."""
     from concurrent.futures import ThreadPoolExecutor
     print('loading %s ...' % data_path)
     data = dict(obs=[], action=[], reward=[], done=[], true_state=[], png=[])
     if n_trajectories == -1:
         n_trajectories = 100000
     workers = decode_workers if decode_workers is not None else min(32, os.cpu_count() or 1)
+    if gpu_decode is None:
+        gpu_decode = model is not None and torch.cuda.is_available() and os.environ.get('PVR_PNG_GPU', '1') != '0'
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
     G = 4                                                       # trajectories decoded per call (<= 2000 frames in flight on the host)
     t = t_lo
     with ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers) if t_hi > t_lo else None
+        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode) if t_hi > t_lo else None
         g0 = t_lo
         while nxt is not None:
             group, ended = nxt.result()
             g0 += G
-            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers) if (not ended and g0 < t_hi) else None
+            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode) if (not ended and g0 < t_hi) else None
             for goal, tmp, frames, names in group:
                 t += 1
                 for k in data.keys():
@@ -129,8 +162,10 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
                 if frames is None:
                     continue
                 if model is not None:
-                    g = np.asarray(model(torch.from_numpy(goal[None, :]))).reshape(-1,)
-                    e = np.concatenate([np.asarray(model(torch.from_numpy(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
+                    if torch.is_tensor(frames):                 # decoded on the side stream: tell the allocator who reads them
+                        frames.record_stream(torch.cuda.current_stream()); goal.record_stream(torch.cuda.current_stream())
+                    g = np.asarray(model(_t(goal)[None, :])).reshape(-1,)
+                    e = np.concatenate([np.asarray(model(_t(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
                                         for i in range(0, len(frames), batch)])
                     data['obs'].append(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
                 else:

@@ -22,10 +22,25 @@ for workers in (1, 8, 32, 64):      # worker processes (png_decode.decode_parall
     S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
     t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, None, -1, decode_workers=workers); el = time.perf_counter() - t0
     print('decode only, %2d worker processes: %6.0f frames/s' % (workers, T * L / el), flush=True)
-for workers in (32, 64):
+for workers in (32,):
     S.read_habitat_data_from_png(d, None, 2, decode_workers=workers)
-    t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, net, -1, batch=256, decode_workers=workers); el = time.perf_counter() - t0
-    print('decode + embed (ResNet50 bf16), %2d worker processes: %6.0f frames/s, obs %s' % (workers, T * L / el, data['obs'].shape), flush=True)
+    t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, net, -1, batch=256, decode_workers=workers, gpu_decode=False); el = time.perf_counter() - t0
+    print('decode + embed (ResNet50 bf16), host decode, %2d worker processes: %6.0f frames/s, obs %s' % (workers, T * L / el, data['obs'].shape), flush=True)
+host_obs = data['obs']
+# frames decoded ON the GPU (csrc/png_decode.hip): the host only reads file bytes
+from pvr_habitat_amd import png_gpu
+import glob
+names = sorted(glob.glob(os.path.join(d, '*_*.png')))[:4000]
+png_gpu.decode_files(names[:64])
+for n in (250, 1000, 4000):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); o = png_gpu.decode_files(names[:n], threads=16); torch.cuda.synchronize(); el = time.perf_counter() - t0
+    t1 = time.perf_counter(); png_gpu.read_files(names[:n], 16); rd = time.perf_counter() - t1
+    print('GPU decode only, %4d files per call: %6.0f frames/s (reading the file bytes alone: %6.0f files/s)' % (n, n / el, n / rd), flush=True)
+for threads in (4, 16):
+    S.read_habitat_data_from_png(d, net, 2, batch=256, decode_workers=threads, gpu_decode=True)
+    t0 = time.perf_counter(); data = S.read_habitat_data_from_png(d, net, -1, batch=256, decode_workers=threads, gpu_decode=True); el = time.perf_counter() - t0
+    print('decode + embed (ResNet50 bf16), GPU decode, %2d reader threads: %6.0f frames/s, bit-identical to the host-decoded run: %s'
+          % (threads, T * L / el, bool(np.array_equal(data['obs'], host_obs))), flush=True)
 x = torch.from_numpy(np.stack([fr[i % 512] for i in range(T * L)]))
 from pvr_habitat_amd.embeddings import stream_embed
 stream_embed(net, x[:1024], 256); t0 = time.perf_counter(); stream_embed(net, x, 256); el = time.perf_counter() - t0
