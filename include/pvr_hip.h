@@ -166,6 +166,10 @@ pvr_status pvr_debug_set_conv_algo(int32_t algo);
  * status[i]: 0 decoded; 1 valid-looking PNG of an unsupported kind and 12 size other than h x w (decode those on the host);
  * anything else = corrupt file (2 signature, 3 truncated, 4 zlib header, 5 block, 6 Huffman code, 7 distance, 8 overrun,
  * 9 short stream, 10 Adler-32, 11 filter type).  scratch: pvr_png_scratch_bytes(n, h, w) bytes of device memory. */
+/* host side of the per-file sources: sizes of n files, then their bytes into dst[offsets[i] .. offsets[i+1]) (offsets = prefix sums of
+ * the sizes), read by `threads` native threads - one file per frame is a system-call workload (save_embedded_obs.py:71) */
+pvr_status pvr_file_sizes(const char *const *paths, int32_t n, int64_t *sizes, int32_t threads);
+pvr_status pvr_read_files(const char *const *paths, int32_t n, uint8_t *dst, const int64_t *offsets, int32_t threads);
 int64_t pvr_png_scratch_bytes(int32_t n, int32_t h, int32_t w);
 pvr_status pvr_png_decode(const uint8_t *files_dev, const int64_t *offsets_dev, int32_t n, int32_t h, int32_t w, uint8_t *out_dev,
                           uint8_t *scratch_dev, int64_t scratch_bytes, int32_t *status_dev, void *hip_stream);

@@ -27,6 +27,8 @@ _SIGS = {
     'pvr_encoder_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'pvr_encoder_forward_lane': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'pvr_debug_set_conv_algo': (C.c_int, [C.c_int32]),
+    'pvr_file_sizes': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    'pvr_read_files': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     'pvr_png_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'pvr_png_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'pvr_debug_conv_expand_launches': (C.c_int64, []),

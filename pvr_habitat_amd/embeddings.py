@@ -568,7 +568,7 @@ def lane_streams(dev_index=None):
 
 
 def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
-    """Embed a large host-resident uint8 (N,H,W,3) array with H2D copies, HIP compute and D2H copies overlapped: a ring of `depth`
+    """Embed a large uint8 (N,H,W,3) array - host-resident, or a CUDA tensor (then only the compute and D2H stages run) - with H2D copies, HIP compute and D2H copies overlapped: a ring of `depth`
     device input / output buffers, one copy stream each way and TWO compute streams (each on its own encoder workspace lane, so
     batch k+1 starts while batch k drains) chained by events.  The ring is deeper than the number of batches in flight on the
     compute side: with only one buffer per lane the upload of batch k+2 cannot start before batch k has been computed, and the lane
@@ -592,7 +592,8 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     model = net.embedding
     two_lanes = getattr(model, 'lanes', 1) >= 2 and os.environ.get('PVR_STREAM_LANES', '2') != '1'
     depth = max(2, min(int(depth), (n + batch - 1) // batch + 1))
-    pinned_src = x.is_pinned()                               # caller already holds page-locked frames: no staging copy
+    device_src = x.is_cuda                                  # frames already in HBM (PNG source decoded on the GPU): no upload at all
+    pinned_src = device_src or x.is_pinned()                 # caller already holds page-locked frames: no staging copy
     registered = None
     if not pinned_src and stage_threads != 0 and os.environ.get('PVR_STREAM_REGISTER', '1') == '1' and x.is_contiguous() and x.numel() > 0:
         # page-lock the caller's array IN PLACE for the duration of the call (hipHostRegister): the frames then go straight from the
@@ -607,7 +608,7 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     shape = (batch,) + tuple(x.shape[1:])
     direct = pinned_src or stage_threads == 0              # stage_threads = 0: hand pageable memory to the driver's own staged copy
     stage_in = None if direct else [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
-    dev_in = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    dev_in = None if device_src else [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(depth)]
     dev_out = [torch.empty((batch, osz), dtype=torch.float32, device=dev) for _ in range(depth)]
     in_free = [torch.cuda.Event() for _ in range(depth)]    # compute finished reading dev_in[b]
     out_free = [torch.cuda.Event() for _ in range(depth)]   # D2H finished reading dev_out[b]
@@ -636,17 +637,19 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
                 host_free[b].synchronize()                      # pinned staging buffer reusable
                 stage(stage_in[b], lo, m)
                 src = stage_in[b][:m]
-            with torch.cuda.stream(h2d):
-                h2d.wait_event(in_free[b])
-                dev_in[b][:m].copy_(src, non_blocking=True)
-                host_free[b].record(h2d)
-                ready = torch.cuda.Event(); ready.record(h2d)
+            if not device_src:
+                with torch.cuda.stream(h2d):
+                    h2d.wait_event(in_free[b])
+                    dev_in[b][:m].copy_(src, non_blocking=True)
+                    host_free[b].record(h2d)
+                    ready = torch.cuda.Event(); ready.record(h2d)
             lane = (i & 1) if two_lanes else 0
             comp = comps[lane]
             with torch.cuda.stream(comp):
-                comp.wait_event(ready)
+                if not device_src:
+                    comp.wait_event(ready)
                 comp.wait_event(out_free[b])
-                model.forward_into(dev_in[b][:m], dev_out[b][:m], lane=lane)
+                model.forward_into(src if device_src else dev_in[b][:m], dev_out[b][:m], lane=lane)
                 in_free[b].record(comp)
                 done = torch.cuda.Event(); done.record(comp)
             with torch.cuda.stream(d2h):

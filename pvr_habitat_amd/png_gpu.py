@@ -6,7 +6,6 @@ copied in; a corrupt file raises (cv2.imread would have returned None and the re
 import ctypes as C
 import os
 import struct
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -17,29 +16,24 @@ from .png_decode import imread
 _STATUS = {1: 'unsupported PNG kind', 2: 'not a PNG (signature / IHDR)', 3: 'truncated file', 4: 'bad zlib header', 5: 'bad deflate block',
            6: 'bad Huffman code', 7: 'distance before the start of the stream', 8: 'more data than the image holds',
            9: 'less data than the image holds', 10: 'Adler-32 mismatch', 11: 'unknown scanline filter', 12: 'image size differs'}
-_pool = {}
-
-
-def _read(path):
-    with open(path, 'rb') as f:
-        return f.read()
 
 
 def read_files(paths, threads=16):
-    """file bytes of `paths`, concatenated: (page-locked uint8 tensor, int64 offsets of n + 1 entries, list of bytes)"""
-    threads = max(1, min(threads, len(paths)))
-    if threads not in _pool:
-        _pool[threads] = ThreadPoolExecutor(max_workers=threads)
-    blobs = list(_pool[threads].map(_read, paths, chunksize=max(1, len(paths) // (4 * threads))))
-    off = np.zeros(len(blobs) + 1, np.int64)
-    np.cumsum([len(b) for b in blobs], out=off[1:])
+    """file bytes of `paths`, concatenated: (page-locked uint8 tensor, int64 offsets of n + 1 entries).  Read by native threads
+    (pvr_read_files: the interpreter lock is not held; 16 Python threads managed ~25 k files/s on the GPU box)."""
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    off = np.zeros(n + 1, np.int64)
+    _lib.check(_lib.lib().pvr_file_sizes(arr, n, C.c_void_p(off[1:].ctypes.data), threads))
+    np.cumsum(off[1:], out=off[1:])
     buf = torch.empty((int(off[-1]) + 16,), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-    buf.numpy()[:int(off[-1])] = np.frombuffer(b''.join(blobs), np.uint8)
-    return buf, off, blobs
+    _lib.check(_lib.lib().pvr_read_files(arr, n, C.c_void_p(buf.data_ptr()), C.c_void_p(off.ctypes.data), threads))
+    return buf, off
 
 
 def png_size(blob):
-    """(H, W) from the IHDR chunk"""
+    """(H, W) from the IHDR chunk of a file's first 33 bytes"""
+    blob = bytes(blob)
     if len(blob) < 33 or blob[:8] != b'\x89PNG\r\n\x1a\n' or blob[12:16] != b'IHDR':
         raise ValueError('not a PNG file')
     w, h = struct.unpack('>II', blob[16:24])
@@ -51,8 +45,8 @@ def decode_files(paths, threads=16, size=None):
     (np.stack in the reference's loader requires it too); `size` = (H, W) if known."""
     _lib.require_gpu()
     n = len(paths)
-    buf, off, blobs = read_files(paths, threads)
-    h, w = size if size is not None else png_size(blobs[0])
+    buf, off = read_files(paths, threads)
+    h, w = size if size is not None else png_size(buf[:min(33, int(off[1]))].numpy().tobytes())
     dev = torch.device('cuda', torch.cuda.current_device())
     files = buf.to(dev, non_blocking=True)
     offsets = torch.from_numpy(off).to(dev, non_blocking=True)

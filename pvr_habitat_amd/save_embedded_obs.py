@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .arguments import make_parser
-from .embeddings import EmbeddingNet
+from .embeddings import EmbeddingNet, stream_embed
 from .utils_bc import shard_bounds
 from .dist_utils import init_distributed, finalize_distributed
 
@@ -94,6 +94,7 @@ def _load_png_trajectories(data_path, t0, t1, workers, gpu=False):
             dec = png_gpu.decode_files(goal_names + all_names, threads=max(1, min(16, workers)))      # returns after its stream has drained
         for i, g in enumerate(group):
             g[0] = dec[i]
+        group[0].append(dec)                                   # (the whole group in one tensor: goals first, then every frame in order)
         frames, lo = dec[len(group):], 0
         for g in group:
             if g[3]:
@@ -145,7 +146,7 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     if gpu_decode is None:
         gpu_decode = model is not None and torch.cuda.is_available() and os.environ.get('PVR_PNG_GPU', '1') != '0'
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
-    G = 4                                                       # trajectories decoded per call (<= 2000 frames in flight on the host)
+    G = 16 if gpu_decode else 4                                 # trajectories decoded per call (<= 8000 / 2000 frames of 12 KB in flight)
     t = t_lo
     with ThreadPoolExecutor(max_workers=1) as ahead:
         nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode) if t_hi > t_lo else None
@@ -154,14 +155,24 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
             group, ended = nxt.result()
             g0 += G
             nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode) if (not ended and g0 < t_hi) else None
-            for goal, tmp, frames, names in group:
+            emb = None
+            if group and len(group[0]) == 5 and isinstance(model, EmbeddingNet):
+                # frames decoded on the GPU: the whole group goes through the encoder in one pipelined pass (two lanes, D2H overlapped)
+                dec = group[0].pop()
+                dec.record_stream(torch.cuda.current_stream())      # decoded on the side stream: tell the allocator who reads it
+                emb, lo = stream_embed(model, dec, batch), len(group)
+            for gi, (goal, tmp, frames, names) in enumerate(g_[:4] for g_ in group):
                 t += 1
                 for k in data.keys():
                     if k in tmp:
                         data[k].append(tmp[k])
                 if frames is None:
                     continue
-                if model is not None:
+                if emb is not None:
+                    e, g = emb[lo:lo + len(names)], emb[gi]
+                    lo += len(names)
+                    data['obs'].append(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+                elif model is not None:
                     if torch.is_tensor(frames):                 # decoded on the side stream: tell the allocator who reads them
                         frames.record_stream(torch.cuda.current_stream()); goal.record_stream(torch.cuda.current_stream())
                     g = np.asarray(model(_t(goal)[None, :])).reshape(-1,)

@@ -8,7 +8,7 @@ os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
 from PIL import Image
 from pvr_habitat_amd import synth, save_embedded_obs as S
 from pvr_habitat_amd.embeddings import EmbeddingNet
-T, L = 24, 250                                         # 6000 frames
+T, L = int(os.environ.get("PNG_T", "24")), 250                   # 6000 frames (PNG_T=96: 24000, steady state)
 d = tempfile.mkdtemp(prefix='png_')
 fr = synth.smooth_frames(3, 512, 64, 64)
 for t in range(T):
@@ -34,7 +34,7 @@ names = sorted(glob.glob(os.path.join(d, '*_*.png')))[:4000]
 png_gpu.decode_files(names[:64])
 for n in (250, 1000, 4000):
     torch.cuda.synchronize(); t0 = time.perf_counter(); o = png_gpu.decode_files(names[:n], threads=16); torch.cuda.synchronize(); el = time.perf_counter() - t0
-    t1 = time.perf_counter(); png_gpu.read_files(names[:n], 16); rd = time.perf_counter() - t1
+    t1 = time.perf_counter(); png_gpu.read_files(names[:n], 16); rd = time.perf_counter() - t1  # native threads
     print('GPU decode only, %4d files per call: %6.0f frames/s (reading the file bytes alone: %6.0f files/s)' % (n, n / el, n / rd), flush=True)
 for threads in (4, 16):
     S.read_habitat_data_from_png(d, net, 2, batch=256, decode_workers=threads, gpu_decode=True)

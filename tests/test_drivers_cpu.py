@@ -211,3 +211,21 @@ def test_save_embedded_obs_cli_entry_shards_and_stitches(tmp_path, source):
     if source == 'png':
         assert [os.path.relpath(q, str(tmp_path)) for q in res['png']] == list(g['png/png'])
     assert not [f for f in os.listdir(tmp_path) if '.rank' in f]
+
+
+def test_native_file_reader(tmp_path):
+    """pvr_file_sizes / pvr_read_files (host side of the per-file PNG source): bytes land at the prefix-sum offsets, whatever the
+    thread count; a missing file is an error that names it."""
+    from pvr_habitat_amd import png_gpu
+    paths = []
+    for i in range(70):
+        p = tmp_path / ('f%d.bin' % i)
+        p.write_bytes(bytes([i]) * (i * 13 % 97) + b'x')
+        paths.append(str(p))
+    for threads in (1, 3, 64):
+        buf, off = png_gpu.read_files(paths, threads)
+        assert off[0] == 0 and off[-1] == sum(i * 13 % 97 + 1 for i in range(70))
+        for i in (0, 1, 33, 69):
+            assert buf[off[i]:off[i + 1]].numpy().tobytes() == bytes([i]) * (i * 13 % 97) + b'x'
+    with pytest.raises(Exception, match='missing.bin'):
+        png_gpu.read_files(paths + [str(tmp_path / 'missing.bin')], 4)
