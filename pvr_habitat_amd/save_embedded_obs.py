@@ -62,29 +62,30 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def _load_png_trajectories(data_path, t0, t1, workers, gpu=False):
+def _load_png_trajectories(data_path, t0, t1, workers, gpu=False, listing=None):
     """Decode trajectories t0 .. t1-1 (stopping at the first missing one): a list of (goal, meta dict, frames (L,H,W,3) uint8 or None,
     file names).  All frames of the group are decoded in ONE call: on the GPU (gpu=True: png_gpu.decode_files, the host only reads
     file bytes and the frames never leave HBM; goal and frames are uint8 CUDA tensors then), or by the worker processes
     (png_decode.decode_parallel: PNG decoding holds the GIL, threads do not scale it; a group gives every worker a task)."""
     group, all_names, goal_names = [], [], []
+    # `listing` (the directory's names, read once): the reference probes up to 500 file names per trajectory with the file system
+    exists = (lambda name: name in listing) if listing is not None else (lambda name: os.path.isfile(os.path.join(data_path, name)))
     for t in range(t0, t1):
         meta_path = os.path.join(data_path, '%d.pickle' % t)
         goal_path = os.path.join(data_path, '%d_goal.png' % t)
         if gpu:
-            goal = goal_path if (os.path.isfile(meta_path) and os.path.isfile(goal_path)) else None
+            goal = goal_path if (exists('%d.pickle' % t) and exists('%d_goal.png' % t)) else None
         else:
-            goal = _imread(goal_path) if os.path.isfile(meta_path) else None
+            goal = _imread(goal_path) if exists('%d.pickle' % t) else None
         if goal is None:
             break
         with open(meta_path, 'rb') as f:
             tmp = pickle.load(f)
         names = []
         for s in range(500):                                   # max steps per trajectory (habitat_config/nav_task.yaml:4)
-            p = os.path.join(data_path, '%d_%d.png' % (t, s))
-            if not os.path.isfile(p):
+            if not exists('%d_%d.png' % (t, s)):
                 break
-            names.append(p)
+            names.append(os.path.join(data_path, '%d_%d.png' % (t, s)))
         group.append([goal, tmp, None, names])
         all_names += names
         goal_names.append(goal_path)
@@ -148,13 +149,14 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
     G = 16 if gpu_decode else 4                                 # trajectories decoded per call (<= 8000 / 2000 frames of 12 KB in flight)
     t = t_lo
+    listing = frozenset(os.listdir(data_path)) if os.path.isdir(data_path) else frozenset()
     with ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode) if t_hi > t_lo else None
+        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode, listing) if t_hi > t_lo else None
         g0 = t_lo
         while nxt is not None:
             group, ended = nxt.result()
             g0 += G
-            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode) if (not ended and g0 < t_hi) else None
+            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode, listing) if (not ended and g0 < t_hi) else None
             emb = None
             if group and len(group[0]) == 5 and isinstance(model, EmbeddingNet):
                 # frames decoded on the GPU: the whole group goes through the encoder in one pipelined pass (two lanes, D2H overlapped)
@@ -169,21 +171,30 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
                 if frames is None:
                     continue
                 if emb is not None:
-                    e, g = emb[lo:lo + len(names)], emb[gi]
+                    data['obs'].append((emb[lo:lo + len(names)], emb[gi]))      # (frame rows, goal row): joined once, at the end
                     lo += len(names)
-                    data['obs'].append(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
                 elif model is not None:
                     if torch.is_tensor(frames):                 # decoded on the side stream: tell the allocator who reads them
                         frames.record_stream(torch.cuda.current_stream()); goal.record_stream(torch.cuda.current_stream())
                     g = np.asarray(model(_t(goal)[None, :])).reshape(-1,)
                     e = np.concatenate([np.asarray(model(_t(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
                                         for i in range(0, len(frames), batch)])
-                    data['obs'].append(np.concatenate((e, np.broadcast_to(g, (len(e), g.size))), -1))
+                    data['obs'].append((e, g))
                 else:
-                    data['obs'].append(np.concatenate((frames, np.broadcast_to(goal, frames.shape)), -1))
+                    data['obs'].append((frames, goal))
                 data['png'] += names
     n_trajectories = t - t_lo
-    data['obs'] = np.concatenate(data['obs']) if data['obs'] else np.zeros((0, 0), np.float32)
+    if data['obs']:                                             # rows = [frame | goal of its trajectory] (:73-77), written once
+        e0, g0_ = data['obs'][0]
+        obs = np.empty((sum(len(e) for e, _ in data['obs']),) + e0.shape[1:-1] + (e0.shape[-1] + g0_.shape[-1],), e0.dtype)
+        r = 0
+        for e, g in data['obs']:
+            obs[r:r + len(e), ..., :e.shape[-1]] = e
+            obs[r:r + len(e), ..., e.shape[-1]:] = g
+            r += len(e)
+        data['obs'] = obs
+    else:
+        data['obs'] = np.zeros((0, 0), np.float32)
     for k in ('action', 'reward', 'done', 'true_state'):
         data[k] = np.concatenate(data[k]) if data[k] else np.zeros((0,))
     n_samples = len(data['reward'])
