@@ -328,6 +328,43 @@ def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
     return res
 
 
+def png_source_bench(model_sd, batch, dtype, n_traj=48, length=250, hw=64):
+    """SURVEY 8f N2: the reference's per-frame PNG layout (save_opt_trajectories_png.py:44-58: <t>_<s>.png, <t>_goal.png, <t>.pickle;
+    64x64 frames as habitat_config/nav_task.yaml renders them) read by save_embedded_obs.read_habitat_data_from_png: native threads
+    read the file bytes, csrc/png_decode.hip inflates / unfilters them on the GPU, the frames go to the encoder without leaving HBM.
+    A synthetic tree of n_traj x length files is written to a temporary directory first (untimed)."""
+    import pickle, shutil, tempfile
+    from PIL import Image
+    from pvr_habitat_amd import synth, save_embedded_obs as S
+    from pvr_habitat_amd.embeddings import EmbeddingNet
+    d = tempfile.mkdtemp(prefix='pvr_png_bench_')
+    try:
+        fr = synth.smooth_frames(11, 512, hw, hw)
+        for t in range(n_traj):
+            for s_ in range(length):
+                Image.fromarray(fr[(t * length + s_) % 512][..., ::-1]).save(os.path.join(d, '%d_%d.png' % (t, s_)), compress_level=1)
+            Image.fromarray(fr[t % 512][..., ::-1]).save(os.path.join(d, '%d_goal.png' % t), compress_level=1)
+            with open(os.path.join(d, '%d.pickle' % t), 'wb') as f:
+                pickle.dump(dict(action=np.zeros(length, np.int64), reward=np.zeros(length), done=np.zeros(length, bool), true_state=np.zeros((length, 12))), f)
+        os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
+        net = EmbeddingNet('resnet50', pretrained=False, max_batch=batch, compute_dtype=dtype)
+        quiet = open(os.devnull, 'w')
+        import contextlib
+        with contextlib.redirect_stdout(quiet):
+            S.read_habitat_data_from_png(d, net, min(17, n_traj), batch=batch)       # warm-up: both decode groups' shapes, both lanes
+            t0 = time.perf_counter()
+            data = S.read_habitat_data_from_png(d, net, -1, batch=batch)
+            el = time.perf_counter() - t0
+        n = n_traj * length
+        assert data['obs'].shape == (n, 2 * net.out_size) and np.isfinite(data['obs']).all()
+        return {'metric': 'frames/sec embedded from the per-frame PNG tree (decode on the GPU + ResNet50)', 'value': round(n / el, 1), 'unit': 'frames/s',
+                'files': n, 'frame': hw, 'dtype': dtype,
+                'note': 'file bytes read by native threads, inflate + scanline filters + B,G,R packing on the GPU (bit-identical to the host decoder, '
+                        'tests/test_gpu_png.py), frames stay in HBM; goal frame embedded per trajectory; includes the loop\'s host bookkeeping and the final row assembly'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def parity_rel_l2(model, sd, frames_np):
     """the TIMED model (same handle, same dtype) against the CPU oracle on a few frames of the bench's own pool"""
     from oracle import encoder_oracle as eo
@@ -352,6 +389,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bc', action='store_true', help='skip the BC steps/sec legs')
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
+    ap.add_argument('--no-png', action='store_true', help='skip the PNG-source leg (writes 12 000 small files to a temporary directory)')
+    ap.add_argument('--png-traj', type=int, default=48, help='trajectories (x 250 frames) of the PNG-source leg')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
     ap.add_argument('--no-f16', action='store_true', help='skip the f16 (parity-mode) leg')
     ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel finetune leg (N > 1)')
@@ -547,6 +586,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, pool_np[:args.batch])
+        if world == 1 and not args.no_png:
+            line['png_source'] = png_source_bench(sd, args.batch, args.dtype, n_traj=args.png_traj)
         if world == 1 and not args.no_pcie:
             line['pcie_inclusive'] = pcie_bench(sd, args.batch, pool_np, args.dtype)
             # host uint8 -> H2D -> encode -> D2H fp32, the end-to-end rate of the "embeddings streamed to host" path (never `value`)

@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out/${1:-r02_prof}; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-FAST="--no-cpu-baseline --no-bc --no-vit --no-pcie --no-f16"
+FAST="--no-cpu-baseline --no-bc --no-vit --no-pcie --no-f16 --no-png"
 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s1 -- python3 bench.py --steps 8 --warmup 2 --lanes 1 $FAST > $OUT/bench_lanes1.json 2> $OUT/s1.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o s2 -- python3 bench.py --steps 8 --warmup 2 --lanes 2 $FAST > $OUT/bench_lanes2.json 2> $OUT/s2.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 scripts/fwd_only.py conv5 8 > $OUT/f.log 2>&1

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAST = ['--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-bc', '--no-vit', '--no-pcie']
+FAST = ['--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-bc', '--no-vit', '--no-pcie', '--png-traj', '3']
 
 
 def _check(line, n):
@@ -29,6 +29,7 @@ def _check(line, n):
     if n == 1:
         # parity of the timed dtype is part of the line; the f16 leg is the configuration that meets the north-star 1e-3
         assert 0 < d['parity_rel_l2'] < 1e-2 and 0 < d['f16']['parity_rel_l2'] < 1e-3 and d['f16']['value'] > 8000
+        assert d['png_source']['files'] == 750 and d['png_source']['value'] > 1000      # the PNG tree through the GPU decoder
     return d
 
 
