@@ -527,7 +527,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + o), a1 = *reinterpret_cast<const f32x4 *>(part + o + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
-        for (int s = 1; s < ksplit; ++s) {
+        int s = 1;
+        for (; s + 4 <= ksplit; s += 4) {             // four planes' loads in flight per round trip; the additions stay in plane order
+            f32x4 b0[4], b1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b0[q] = *reinterpret_cast<const f32x4 *>(part + (size_t)(s + q) * plane + o);
+                b1[q] = *reinterpret_cast<const f32x4 *>(part + (size_t)(s + q) * plane + o + 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[q][e]; v[4 + e] += b1[q][e]; }
+        }
+        for (; s < ksplit; ++s) {
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(part + s * plane + o), b1 = *reinterpret_cast<const f32x4 *>(part + s * plane + o + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }

@@ -627,8 +627,9 @@ static int small_batch_ksplit(const pvr_encoder *enc, const ConvOp &op, int nb) 
     const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
     const long long M = (long long)nb * ho * ho, blocks = ((M + 127) / 128) * ((op.cout + 127) / 128);
     if (blocks > 64) return 0;
-    int ks = nk / 4;
-    if (ks > 16) ks = 16;
+    static const int div = [] { const char *e = getenv("PVR_SMALLK_DIV"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();   // K slices per block (A/B)
+    int ks = nk / div;
+    if (ks > (div >= 4 ? 16 : 32)) ks = div >= 4 ? 16 : 32;
     if ((size_t)ks * M * op.cout * sizeof(float) > SMALLK_BYTES) return 0;
     return ks;
 }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const u16 *__restrict__ img, 
 // conv1 activation never goes to HBM (write 411 MB + read 411 MB per 256 frames saved).
 template <bool F16>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
-                                                        const float *__restrict__ bias, u16 *__restrict__ out, int nimg) {
+                                                        const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb) {
     typedef typename HT<F16>::V8 V8;
     constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [5][112] pixels x 128 B
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ 
     float4 bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + g * 4);
-    // the 28 weight fragments (112 VGPRs) are loaded once and reused over STEM_IPB images of this row pair
-    for (int n = blockIdx.y * STEM_IPB; n < nimg && n < (int)(blockIdx.y + 1) * STEM_IPB; ++n) {
+    // the 28 weight fragments (112 VGPRs) are loaded once and reused over the ipb images of this row pair
+    for (int n = blockIdx.y * ipb; n < nimg && n < (int)(blockIdx.y + 1) * ipb; ++n) {
     const u16 *imgn = img + (size_t)n * PH * PW * 4;
     // software pipeline: the 7 pixel fragments of this wave's NEXT tile are in flight while the current tile's 28
     // MFMAs run (the kernel is latency-bound: 9 dependent load->MFMA rounds per wave otherwise)
@@ -225,8 +225,16 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const void *__restrict__ i
     float s = 0.f;
     if constexpr (IN_F32) {
         const float *p = (const float *)in + (size_t)b * hw * c + ch;
+        if (hw == 49) {                               // the ResNet50 trunk: all 49 loads in flight at once, then the same ascending summation
+            float v[49];
+#pragma unroll
+            for (int i = 0; i < 49; ++i) v[i] = p[(size_t)i * c];
+#pragma unroll
+            for (int i = 0; i < 49; ++i) s += v[i];
+        } else {
 #pragma unroll 7
-        for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];      // (same summation order; the unroll only lets the loads go out together)
+            for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];  // (same summation order; the unroll only lets the loads go out together)
+        }
     } else {
         const u16 *p = (const u16 *)in + (size_t)b * hw * c + ch;
         for (int i = 0; i < hw; ++i) s += from_h<F16>(p[(size_t)i * c]);
@@ -300,11 +308,12 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 grid(28, (n + STEM_IPB - 1) / STEM_IPB);
+    const int ipb = n <= 8 ? 1 : STEM_IPB;        // a handful of frames (online embedding): one image per block, 28 n blocks instead of 28 n / 4
+    dim3 grid(28, (n + ipb - 1) / ipb);
     if (dtype == PVR_F16)
-        hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n);
+        hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
     else
-        hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n);
+        hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
