@@ -155,7 +155,7 @@ pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *b
                          int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                          int32_t relu, int32_t out_f32, int32_t dtype, void *hip_stream);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
- * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 tiles) whenever it
+ * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */
 pvr_status pvr_debug_set_conv_algo(int32_t algo);
 /* debug: launches of the persistent weight-stationary 1x1 kernel (conv_expand.hip) so far in this process - lets a test assert that the

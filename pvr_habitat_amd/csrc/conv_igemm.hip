@@ -479,8 +479,13 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         // CUs leaves the chip idle.  It wins for K >= 512, and for K = 256 when there is no residual to read in the epilogue.
         const int64_t nt = (cout + 255) / 256, tiles = ((M + 255) / 256) * nt, tiles128 = ((M + 127) / 128) * nt;
         const bool deep = cout >= 256 && (K >= 512 || (K >= 256 && !res));
-        // algo 1 / 2: force the 256- / 128-pixel tile; auto: 256 when that grid fills ~2/3 of the CUs, else 128 when that one does
-        const int bm = algo == 1 ? 256 : algo == 2 ? 128 : (algo == -1 && deep) ? (tiles >= 160 ? 256 : (tiles128 >= 160 ? 128 : 0)) : 0;
+        // algo 1 / 2 / 3: force the 256- / 128- / 224-pixel tile; auto: 256 when that grid fills ~2/3 of the CUs, else 128 when that one does;
+        // 224 instead of 256 when it needs fewer CU-rounds x rows (batch 256 at 14 x 14: 196 tiles of 256 on 256 CUs vs 224 tiles of 224)
+        const int64_t tiles224 = ((M + 223) / 224) * nt;
+        static const bool use224 = [] { const char *e = getenv("PVR_PP_BM224"); return !e || atoi(e) != 0; }();
+        const bool better224 = use224 && ((tiles224 + 255) / 256) * 224 < ((tiles + 255) / 256) * 256;
+        const int bm = algo == 1 ? 256 : algo == 2 ? 128 : algo == 3 ? 224
+                     : (algo == -1 && deep) ? (tiles >= 160 ? (better224 ? 224 : 256) : (tiles128 >= 160 ? 128 : 0)) : 0;
         if (ok && bm)
             return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, bm, stream);
     }

@@ -70,7 +70,7 @@ __device__ unsigned long long pp_stamps[2][8];
 template <int BM, int XI>
 __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int wave, int lane, int (&a_off)[2][XI], int (&a_mask)[2][XI],
                                               int (&b_off)[2][2]) {
-    constexpr int XH = BM / 2, OOB = 0x7ffffff0;
+    constexpr int XH = BM / 2, OOB = 0x7ffffff0;       // (BM = 224: 112 pixel rows per half tile in a 128-row LDS half; rows 112..127 stay zero)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -79,7 +79,7 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
             const int lch = (lane & 7) ^ ((r >> 1) & 7);                // logical chunk held by this physical slot
             if (i < XI) {
                 const int m = m0 + h * XH + r;
-                const bool ok = m < p.M;
+                const bool ok = m < p.M && r < XH;
                 const int mm = ok ? m : 0;
                 const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
                 const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
@@ -113,9 +113,13 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
 template <int BM, bool F16, int RES, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     typedef typename HT<F16>::V8 V8;
+    // BM = 224 (round 2): the BM = 256 structure with 7 of the 8 pixel tiles per wave.  50 176 pixels (batch 256 at 14 x 14) are 196 tiles of
+    // 256 = 77 % of the CUs for a full-length tile each, or 224 tiles of 224 = 88 % of the CUs for 7/8 of the time: the launch is 12 % shorter
     constexpr int TMW = BM / 32;                   // 16-pixel MFMA tiles per wave
-    constexpr int XH = BM / 2, XHB = XH * 128;     // rows / bytes of an X half tile
-    constexpr int XI = XH / 64;                    // DMA instructions per X half tile (8 waves x 8 rows each)
+    constexpr int XH = BM / 2;                     // pixel rows of an X half tile
+    constexpr int XHB = (BM == 224 ? 128 : XH) * 128;   // its bytes in LDS
+    constexpr int XI = (XH + 63) / 64;             // DMA instructions per X half tile (8 waves x 8 rows each)
+    constexpr int T1 = TMW - 4;                    // pixel tiles of the wave's second fragment group (x1)
     constexpr int HALF = 16384;                    // W half tile: 128 couts
     constexpr int WOFF = 2 * XHB, BUF = WOFF + 2 * HALF;
     constexpr int OOB = 0x7ffffff0;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     PP_T(sti++);
 #define PP_READ_X(dst_, j0_, B_)                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        _Pragma("unroll") for (int j = 0; j < ((j0_) == 0 ? 4 : T1); ++j)                                        \
             dst_[j][ks] = *reinterpret_cast<const V8 *>(smem + xrd[B_][ks] + ((j0_) + j) * 2048);
 #define PP_READ_W(i0_, B_)                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #define PP_MATH(i0_, x_, j0_)                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+            _Pragma("unroll") for (int j = 0; j < ((j0_) == 0 ? 4 : T1); ++j)                                    \
                 acc[(i0_) + i][(j0_) + j] = mfma16<F16>(wf[i][ks], x_[j][ks], acc[(i0_) + i][(j0_) + j]);
 
     // one K tile; B_ is a literal so that every LDS address is base register + immediate
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         }                                                                                                        \
         PP_FEED_DONE(); PP_MATH(2, x0, 0); PP_MATH_DONE();                                                       \
     }
-    if constexpr (BM == 256) {
+    if constexpr (BM != 128) {
         for (int kt = 0; kt < nk; kt += 2) {
             PP_TILE(kt, 0);
             if (kt + 1 < nk) PP_TILE(kt + 1, 1);
@@ -415,17 +419,17 @@ static int pp_persist_min() {
 
 template <int BM, bool F16, int RES>
 static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
-    constexpr int lds = 2 * (BM * 128 + 32768);
+    constexpr int lds = 2 * ((BM == 224 ? 256 : BM) * 128 + 32768);
     static bool attr_done = false;
     if (!attr_done) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if constexpr (BM == 256)
+        if constexpr (BM != 128)
             PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
     const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
     p.total_tiles = grid;
-    if constexpr (BM == 256) {
+    if constexpr (BM != 128) {
         if (pp_persist_min() > 0 && grid >= pp_persist_min()) {       // one block per CU (128 KB of LDS each), several tiles per block
             ++g_pp_persistent_launches;
             hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, RES, true>), dim3(256), dim3(512), lds, stream, p);
@@ -468,11 +472,12 @@ pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias,
     const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2, ob = M * cout * (out_f32 ? 4 : 2),
                   rb = res ? M * cout * (res_f32 ? 4 : 2) : 0;
     PVR_REQUIRE(pp256_supported(M, cin, cout, kh, kw, inb, wb, ob, rb), "conv_pp256: unsupported shape");
-    PVR_REQUIRE(bm == 256 || bm == 128, "conv_pp256: pixel tile must be 256 or 128");
+    PVR_REQUIRE(bm == 256 || bm == 224 || bm == 128, "conv_pp256: pixel tile must be 256, 224 or 128");
     p.M = (int)M; p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb; p.out_bytes = (unsigned)ob; p.res_bytes = (unsigned)rb;
     p.act = act; p.out_f32 = out_f32;
     p.n_tiles = (cout + 255) / 256;
     const int rmode = !res ? 0 : (res_f32 ? 2 : 1);
+    if (bm == 224) return launch_pp_bm<224>(p, rmode, dtype, stream);
     return bm == 256 ? launch_pp_bm<256>(p, rmode, dtype, stream) : launch_pp_bm<128>(p, rmode, dtype, stream);
 }
 

@@ -171,14 +171,15 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
     ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
     persistent = ((n * ho * wo + 255) // 256) * ((cout + 255) // 256) >= 384
     before = _lib.lib().pvr_debug_pp_persistent_launches()
-    for algo in (1, 2):                                            # 256- and 128-pixel tiles
+    for algo in (1, 2, 3):                                         # 256-, 128- and 224-pixel tiles
         conv_algo(algo)
         for rep in range(4):
             out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
             torch.cuda.synchronize()
             assert torch.isfinite(out.float()).all()
             assert torch.equal(out, ref), (algo, rep, int((out != ref).sum()))
-    assert _lib.lib().pvr_debug_pp_persistent_launches() == before + (4 if persistent else 0)
+    persistent224 = ((n * ho * wo + 223) // 224) * ((cout + 255) // 256) >= 384
+    assert _lib.lib().pvr_debug_pp_persistent_launches() == before + (4 if persistent else 0) + (4 if persistent224 else 0)
 
 
 EXPAND_CASES = [
