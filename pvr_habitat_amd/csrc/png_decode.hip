@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const unsigned char *_
             }
         }
     }
-    if (bad) status[i] = PNG_BAD_FILTER;
+    if (bad && c == 0) status[i] = PNG_BAD_FILTER;      // (every chain of the file saw the same filter bytes: one writer)
 }
 
 }  // namespace pvr

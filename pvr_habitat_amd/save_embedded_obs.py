@@ -62,7 +62,7 @@ def embed_rows(embed_fn, obs, n_frames, batch):
     return np.concatenate(out) if out else np.zeros((0, 0), np.float32)
 
 
-def _load_png_trajectories(data_path, t0, t1, workers, gpu=False, listing=None):
+def _load_png_trajectories(data_path, t0, t1, workers, gpu=False, listing=None, device=None):
     """Decode trajectories t0 .. t1-1 (stopping at the first missing one): a list of (goal, meta dict, frames (L,H,W,3) uint8 or None,
     file names).  All frames of the group are decoded in ONE call: on the GPU (gpu=True: png_gpu.decode_files, the host only reads
     file bytes and the frames never leave HBM; goal and frames are uint8 CUDA tensors then), or by the worker processes
@@ -91,8 +91,11 @@ def _load_png_trajectories(data_path, t0, t1, workers, gpu=False, listing=None):
         goal_names.append(goal_path)
     if gpu and group:
         from . import png_gpu
-        with torch.cuda.stream(_png_stream()):                 # (this runs in the read-ahead thread: keep it off the encoder's stream)
-            dec = png_gpu.decode_files(goal_names + all_names, threads=max(1, min(16, workers)))      # returns after its stream has drained
+        # this runs in the read-ahead thread: the current device is per THREAD (a rank's GPU is not device 0), and the decode stays off
+        # the encoder's stream
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            with torch.cuda.stream(_png_stream()):
+                dec = png_gpu.decode_files(goal_names + all_names, threads=max(1, min(16, workers)))      # returns after its stream has drained
         for i, g in enumerate(group):
             g[0] = dec[i]
         group[0].append(dec)                                   # (the whole group in one tensor: goals first, then every frame in order)
@@ -110,13 +113,14 @@ def _load_png_trajectories(data_path, t0, t1, workers, gpu=False, listing=None):
     return group, len(group) < t1 - t0                          # (trajectories, "the scene ends inside this group")
 
 
-_PNG_STREAM = []
+_PNG_STREAM = {}
 
 
 def _png_stream():
-    if not _PNG_STREAM:
-        _PNG_STREAM.append(torch.cuda.Stream())
-    return _PNG_STREAM[0]
+    dev = torch.cuda.current_device()
+    if dev not in _PNG_STREAM:
+        _PNG_STREAM[dev] = torch.cuda.Stream(device=dev)
+    return _PNG_STREAM[dev]
 
 
 def _t(a):
@@ -150,13 +154,14 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     G = 16 if gpu_decode else 4                                 # trajectories decoded per call (<= 8000 / 2000 frames of 12 KB in flight)
     t = t_lo
     listing = frozenset(os.listdir(data_path)) if os.path.isdir(data_path) else frozenset()
+    device = torch.cuda.current_device() if gpu_decode else None
     with ThreadPoolExecutor(max_workers=1) as ahead:
-        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode, listing) if t_hi > t_lo else None
+        nxt = ahead.submit(_load_png_trajectories, data_path, t_lo, min(t_lo + G, t_hi), workers, gpu_decode, listing, device) if t_hi > t_lo else None
         g0 = t_lo
         while nxt is not None:
             group, ended = nxt.result()
             g0 += G
-            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode, listing) if (not ended and g0 < t_hi) else None
+            nxt = ahead.submit(_load_png_trajectories, data_path, g0, min(g0 + G, t_hi), workers, gpu_decode, listing, device) if (not ended and g0 < t_hi) else None
             emb = None
             if group and len(group[0]) == 5 and isinstance(model, EmbeddingNet):
                 # frames decoded on the GPU: the whole group goes through the encoder in one pipelined pass (two lanes, D2H overlapped)
