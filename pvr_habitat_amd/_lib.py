@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpvr_hip.so')
+LIB_PATH = os.environ.get('PVR_LIB') or os.path.join(_HERE, 'lib', 'libpvr_hip.so')      # PVR_LIB: e.g. the host-ASan build (`make asan`)
 
 PVR_BF16, PVR_F16, PVR_F32 = 0, 1, 2
 ARCH_RESNET50, ARCH_RESNET50_L4, ARCH_RESNET50_L3 = 0, 1, 2
