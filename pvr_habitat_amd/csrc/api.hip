@@ -1,6 +1,7 @@
 // C-ABI glue: error state, version, single-operator entry points (include/pvr_hip.h).
 #include <stdarg.h>
 #include "common.h"
+#include <dlfcn.h>
 
 namespace pvr {
 
@@ -15,6 +16,30 @@ void set_error(const char *fmt, ...) {
     g_err = buf;
 }
 const std::string &last_error() { return g_err; }
+
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)();
+struct Roctx {
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    Roctx() {
+        const char *e = getenv("PVR_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+                pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char *name) { if (roctx().push) roctx().push(name); }
+void trace_pop() { if (roctx().pop) roctx().pop(); }
 
 pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t, int crop_pos = 0);
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);

@@ -13,6 +13,14 @@ constexpr size_t PVR_ZERO_BYTES = 16384;   // size of an encoder's zero page (>=
 
 // ---- error plumbing (thread-local message, integer status across the ABI) -------------------
 void set_error(const char *fmt, ...);
+// Optional roctx ranges around the C-ABI entry points (PVR_ROCTX=1; librocprofiler-sdk-roctx / libroctx64 is dlopen'ed on first use, so the
+// library has no link-time dependency on a profiler).  `rocprofv3 --marker-trace --kernel-trace` then groups the launches per call.
+void trace_push(const char *name);
+void trace_pop();
+struct TraceScope {
+    explicit TraceScope(const char *name) { trace_push(name); }
+    ~TraceScope() { trace_pop(); }
+};
 const std::string &last_error();
 
 #define PVR_HIP_TRY(expr)                                                                      \

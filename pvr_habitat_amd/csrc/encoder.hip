@@ -782,6 +782,7 @@ extern "C" {
 pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
                                int64_t out_stride, void *hip_stream) {
     PVR_REQUIRE(enc, "pvr_encoder_forward: null encoder");
+    TraceScope trace("pvr_encoder_forward");
     if (enc->finalized && !enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, 0); if (s) return s; }
     if (enc->finalized && enc->vit) { pvr_status s = vit_use_lane(enc, 0); if (s) return s; }
     if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
@@ -791,6 +792,7 @@ pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t 
 pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
                                     int64_t out_stride, void *hip_stream) {
     PVR_REQUIRE(enc, "pvr_encoder_forward_lane: null encoder");
+    TraceScope trace(lane == 0 ? "pvr_encoder_forward_lane 0" : "pvr_encoder_forward_lane 1+");
     PVR_REQUIRE(lane >= 0 && lane < PVR_MAX_LANES, "pvr_encoder_forward_lane: lane must be 0..%d", PVR_MAX_LANES - 1);
     if (!enc->finalized) { set_error("encoder not finalized"); return PVR_ERR_STATE; }
     if (enc->vit) { pvr_status s = vit_use_lane(enc, lane); if (s) return s; }

@@ -367,6 +367,7 @@ extern "C" int64_t pvr_png_scratch_bytes(int32_t n, int32_t h, int32_t w) {
 extern "C" pvr_status pvr_png_decode(const uint8_t *files_dev, const int64_t *offsets_dev, int32_t n, int32_t h, int32_t w, uint8_t *out_dev,
                                      uint8_t *scratch_dev, int64_t scratch_bytes, int32_t *status_dev, void *hip_stream) {
     PVR_REQUIRE(files_dev && offsets_dev && out_dev && scratch_dev && status_dev, "pvr_png_decode: null argument");
+    pvr::TraceScope trace("pvr_png_decode");
     PVR_REQUIRE(n > 0 && h > 0 && w > 0 && (int64_t)h * w <= (1 << 26), "pvr_png_decode: n=%d h=%d w=%d", n, h, w);
     PVR_REQUIRE(scratch_bytes >= pvr_png_scratch_bytes(n, h, w), "pvr_png_decode: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
                 (long long)pvr_png_scratch_bytes(n, h, w));

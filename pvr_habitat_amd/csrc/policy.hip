@@ -806,6 +806,7 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
                               float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
+    TraceScope trace("pvr_policy_forward");
     ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
@@ -827,6 +828,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
                                const int64_t *actions, int32_t T, int32_t B, float *grads, float *stats_out, float *logits_out,
                                void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done && actions && grads, "pvr_policy_backward: null argument");
+    TraceScope trace("pvr_policy_backward");
     ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
@@ -900,6 +902,7 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
                            const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
                            float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    TraceScope trace("pvr_policy_step");
     ScratchScope scratch_scope(pol);
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
