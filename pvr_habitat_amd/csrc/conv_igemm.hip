@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || BM == 64) ? 3 : 2) void conv_i
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));   // v_rcp_f32 (1 ulp): an IEEE division here cost 15 % of the FC1 launch
             } else if (p.act == 3) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
             }
             if (p.out_f32) {
                 float *op = (float *)p.out + o + (p.nk_split ? (size_t)blockIdx.y * p.M * p.Cout : 0);

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));   // v_rcp_f32 (1 ulp): an IEEE division here cost 15 % of the FC1 launch
             } else if (p.act == 3) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
             }
             // byte offsets go into voffset (soffset stays 0): see store_b128_imm in bottleneck_chain.hip
             const int oo = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_o : OOB;

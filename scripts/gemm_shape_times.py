@@ -24,5 +24,5 @@ def run(n, t, cin, cout, act, res, out_f32, reps=30):
     print('M=%6d K=%4d N=%4d act=%d res=%d f32out=%d: %7.1f us  %6.1f TFLOP/s  %4d tiles (%.2f per CU), %5.2f us per tile-round, K loop alone %5.2f us'
           % (n * t, cin, cout, act, res, out_f32, us, fl / us / 1e6, tiles, tiles / 256, us / -(-tiles // 256), cin / 64 * 2810 / 2100), flush=True)
 for args in [(256, 197, 768, 2304, 0, 0, 0), (256, 197, 768, 3072, 2, 0, 0), (256, 197, 768, 3072, 0, 0, 0), (256, 197, 3072, 768, 0, 2, 1), (256, 197, 768, 768, 0, 2, 1),
-             (256, 197, 3072, 768, 0, 0, 0), (256, 197, 768, 3072, 0, 0, 1), (256, 196, 768, 3072, 2, 0, 0), (256, 200, 768, 3072, 2, 0, 0)]:
+             (256, 197, 3072, 768, 0, 0, 0), (256, 197, 768, 3072, 0, 0, 1), (256, 196, 768, 3072, 2, 0, 0), (256, 200, 768, 3072, 2, 0, 0), (256, 197, 768, 3072, 3, 0, 0)]:
     run(*args)
