@@ -18,6 +18,15 @@ struct ConvFP {
 
 constexpr int CONV_TPW = 8;      // 16-pixel tiles per wave of the few-channel forward kernel
 
+// (float)x / 255.0f for x = 0 .. 255, bit for bit (the reference divides: models.py:163), without the ~10-instruction IEEE division
+// sequence: one multiply by 1/255 and one Newton step through two FMAs give the correctly rounded quotient for all 256 inputs
+// (checked exhaustively; the multiply alone is off by an ulp for 126 of them).
+__device__ __forceinline__ float div255(float x) {
+    const float inv = 1.0f / 255.0f;
+    const float q = x * inv;
+    return __fmaf_rn(__fmaf_rn(-q, 255.0f, x), inv, q);
+}
+
 // forward: wave = 16 output pixels x 32 channels
 template <int CIN>
 static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
@@ -34,9 +43,36 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) wv[tap][j] = p.W[((j * 16 + fr) * 9 + tap) * CP + fq];
     }
+    // CIN == 3: the nine input bytes of the wave's NEXT tile are requested before the current tile's MFMAs (the kernel is a chain of
+    // byte gathers: 9 loads -> 18 MFMAs -> stores per tile, 8 tiles per wave)
+    uint8_t xnext[CIN == 3 ? 9 : 1];
+    auto gather3 = [&](long long tile_, uint8_t (&dst)[CIN == 3 ? 9 : 1]) {
+        if constexpr (CIN == 3) {
+            const long long px_ = tile_ * 16 + fr;
+            const bool pk = px_ < npix;
+            const long long q_ = pk ? px_ : 0;
+            const int ox_ = (int)(q_ % p.So), oy_ = (int)((q_ / p.So) % p.So), f_ = (int)(q_ / ((long long)p.So * p.So));
+            const int n_ = f_ / p.nf, fi_ = f_ % p.nf;
+            const uint8_t *x = (const uint8_t *)p.in;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = 2 * oy_ + tap / 3 - 1, ix = 2 * ox_ + tap % 3 - 1;
+                const bool in = pk && (unsigned)iy < (unsigned)p.Sin && (unsigned)ix < (unsigned)p.Sin && fq < 3;
+                dst[tap] = x[(((size_t)n_ * p.Sin + (in ? ix : 0)) * p.Sin + (in ? iy : 0)) * (3 * p.nf) + 3 * fi_ + (in ? fq : 0)];
+            }
+        }
+    };
+    const long long tile0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+    if constexpr (CIN == 3) gather3(tile0, xnext);
     for (int tt = 0; tt < TPW; ++tt) {
-    const long long tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + tt;
+    const long long tile = tile0 + tt;
     if (tile * 16 >= npix) return;
+    uint8_t xcur[CIN == 3 ? 9 : 1];
+    if constexpr (CIN == 3) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) xcur[tap] = xnext[tap];
+        if (tt + 1 < TPW) gather3(tile + 1, xnext);
+    }
     const long long pix = tile * 16 + fr;                 // B-operand column of this lane
     const bool pok = pix < npix;
     const long long pp = pok ? pix : 0;
@@ -52,10 +88,7 @@ static __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(ConvFP p) {
             // (clamped address + select instead of a branch around the load: hipcc waits for every load inside a branch on its own,
             //  nine serial memory latencies per tile; unconditional loads are issued back to back)
             const bool in = ok && fq < 3;
-            const int n = f / p.nf, fi = f % p.nf;
-            const uint8_t *x = (const uint8_t *)p.in;
-            const uint8_t xv = x[(((size_t)n * p.Sin + (in ? ix : 0)) * p.Sin + (in ? iy : 0)) * (3 * p.nf) + 3 * fi + (in ? fq : 0)];
-            const float a = in ? (float)xv / 255.0f : 0.f;
+            const float a = in ? div255((float)xcur[tap]) : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = mfma_f32(wv[tap][j], a, acc[j]);
         } else if constexpr (CIN == 4) {
@@ -153,7 +186,7 @@ static __global__ __launch_bounds__(256) void conv_s2_wgrad_kernel(ConvWP p) {
             float v;
             if constexpr (CIN == 3) {
                 const int n = cf / p.nf, fi = cf % p.nf;
-                v = (float)((const uint8_t *)p.in)[(((size_t)n * p.Sin + cx) * p.Sin + cy) * (3 * p.nf) + 3 * fi + cc] / 255.0f;
+                v = div255((float)((const uint8_t *)p.in)[(((size_t)n * p.Sin + cx) * p.Sin + cy) * (3 * p.nf) + 3 * fi + cc]);
             } else {
                 v = ((const float *)p.in)[(((size_t)cf * p.Sin + cy) * p.Sin + cx) * 32 + cc];
             }
