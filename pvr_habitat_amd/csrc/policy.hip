@@ -40,16 +40,18 @@ struct pvr_policy {
     hipStream_t lane_a = nullptr, lane_b = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join_a = nullptr, ev_join_b = nullptr, ev_chunk[8] = {nullptr};
     int pipeline = 1;
-    // persistent recurrence (lstm_fwd_seq_kernel, PVR_POLICY_PERSIST=1): one launch per (layer, chunk) instead of one per step.
-    // Bit-identical, but measured SLOWER than per-step launches on MI355X / ROCm 7.2 (scripts/bc_graph_ab.py: 154-164 vs 178
-    // steps/s): the per-step grid hand-off (sc1 stores + drain, agent-scope counter, poll, 64 KB of sc1 loads of h per block)
-    // costs ~13 us against ~11 us for a launch, so it stays off until the hand-off is cheaper.
+    // persistent recurrence (lstm_fwd_seq_kernel): one launch per layer (or per (layer, chunk)) instead of one per step; bit-identical.
+    // PVR_POLICY_PERSIST=1 = round 1's hand-off (sc1 stores + drain, 256 atomic adds on one agent-scope counter, a block-wide poll):
+    // ~13 us per step against ~10 us for a launch (155 vs 208 steps/s).  =2 (round 2, default): the data is its own flag - Hs[t] is
+    // pre-filled with 0xFFFFFFFF words, a consumer wave re-reads its slice of h_{t-1} until no word is that pattern; no atomics, no
+    // drain, no block-wide poll: ~5 us per step, 208 -> 219 steps/s with one launch per layer for the whole sequence (two persistent
+    // kernels side by side on the two lanes measured slower: 182-194).
     // chunked layer wavefront (default): the two recurrences share launches - layer 0 at step t and layer 1 one chunk (T/4 steps)
     // behind run as the two blockIdx.y jobs of one launch, forward and BPTT, with the hoisted projections done per chunk.  Same
     // per-(layer, step) arithmetic as every other mode (bit-identical); (NCH+1)/(2 NCH) of the dependent launches.
     int chunkwave = 1;
     unsigned *seq_counters = nullptr;       // 16 slots of 16 bytes, zeroed before each launch that uses one
-    int persist = 0;
+    int persist = 2;                        // 0 per-step launches, 1 persistent with the counter hand-off, 2 persistent with the data-as-flag hand-off
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
@@ -307,8 +309,10 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         if (pol->persist && H == 1024 && B <= 64 && t1 - t0 > 1) {
             // one persistent launch for the whole step range (grid-wide hand-off per step inside the kernel)
             unsigned *ctr = pol->seq_counters + 4 * ((l * 4 + (t0 * 4 / (T > 0 ? T : 1))) & 15);
-            (void)hipMemsetAsync(ctr, 0, 16, s_);
             LstmSeqP q;
+            q.data_flag = pol->persist == 2;
+            if (q.data_flag) (void)hipMemsetAsync(pol->Hs[l] + (size_t)t0 * B * H, 0xFF, (size_t)(t1 - t0) * B * H * sizeof(float), s_);
+            else (void)hipMemsetAsync(ctr, 0, 16, s_);
             q.G = pol->G[l];
             q.h_init = t0 == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t0 - 1) * B * H;
             q.c_init = t0 == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t0 - 1) * B * H;
@@ -346,7 +350,17 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         f.B = B; f.H = H;
         return f;
     };
-    if (pol->chunkwave && !pol->persist && NCH > 1) {
+    // persistent recurrence with the data-as-flag hand-off (default, PVR_POLICY_PERSIST=2): ONE launch per layer for the whole sequence
+    // (not inside a hipGraph: replayed nodes run with weaker cache maintenance between them than stream launches - the 0xFF pre-fill of a
+    //  memset node was not visible to the other XCDs' sc1 loads in time, which then took the PREVIOUS iteration's h for data; measured
+    //  as a 1e-3 drift with PVR_POLICY_GRAPH=1 on the conv model, scripts/debug_bc_modes.py)
+    const bool use_persist = pol->persist == 2 && !pol->use_graph && H == 1024 && B <= 64 && T > 1;
+    if (use_persist) {
+        fwd_steps(0, 0, T, st);
+        TRY(gemm(pol->Hs[0], P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1], N, 4 * H, H, false, false, 0, st));
+        fwd_steps(1, 0, T, st);
+        PVR_LAUNCH_CHECK();
+    } else if (pol->chunkwave && !pol->persist && NCH > 1) {
         for (int c = 0; c <= NCH; ++c) {
             if (c >= 1) {                                       // input projection of layer 1 for the chunk layer 0 has just finished
                 const int t0 = (c - 1) * CH, t1 = c * CH < T ? c * CH : T;
@@ -737,7 +751,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     A_(in_done, N); A_(in_act, N);
     if (const char *e = getenv("PVR_POLICY_GRAPH")) p->use_graph = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
-    if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e) != 0;
+    if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e);      // 1: counter hand-off, 2: data-as-flag hand-off
     if (const char *e = getenv("PVR_POLICY_CHUNKWAVE")) p->chunkwave = atoi(e) != 0;
     A_(seq_counters, 64);
     if (!s && p->pipeline) {

@@ -407,6 +407,8 @@ struct LstmSeqP {
     float *Hs, *Cs;                    // layer bases [T][B][H]
     unsigned *counter;                 // zeroed before the launch
     int t0, t1, B, H;
+    int data_flag;                     // 1: no counter - Hs[t0 .. t1) is pre-filled with 0xFFFFFFFF words and a consumer re-reads its slice of
+                                       // h_{t-1} until none of its words is that pattern (the data is its own flag: no atomics, no drain, no block-wide poll)
 };
 
 static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
@@ -435,7 +437,7 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
     const size_t hbytes = (size_t)B * H * 4;
     for (int t = p.t0; t < p.t1; ++t) {
         const int s = t - p.t0;
-        if (s > 0) {
+        if (s > 0 && !p.data_flag) {
             if (tid == 0 && !dead_s) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk * (unsigned)s) {
@@ -468,6 +470,26 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)                                  // sc1 loads: h_{t-1} was published by other CUs in this launch
                 hv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff, c * 64, 16));
+            if (p.data_flag && s > 0) {
+                // every word of this lane's slice must have been written (0xFFFFFFFF = the pre-fill; a stored h is never that NaN
+                // pattern); the wave re-reads until all of its lanes see data.  Bounded like the counter poll.
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned m = 0xffffffffu;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, hv[c]);
+                        const bool written = (w[0] != 0xffffffffu) & (w[1] != 0xffffffffu) & (w[2] != 0xffffffffu) & (w[3] != 0xffffffffu);
+                        m &= written ? 0xffffffffu : 0u;
+                    }
+                    if (__all(m != 0u || !bok)) break;
+                    if (++spins > (1u << 20)) { dead_s = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        hv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff, c * 64, 16));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -501,10 +523,12 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), rs_o, ((b0 + tid) * H + u0) * 4, 0, 16);
             }
         }
-        // publish h_t: the storing wave drains its write-through stores, then one lane signals
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) (void)__hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // publish h_t: the storing wave drains its write-through stores, then one lane signals (data_flag: the stores are the signal)
+        if (!p.data_flag) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) (void)__hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -202,7 +202,7 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch):
     T, B, O, A, S = 24, 20, 256, 3, 3
     obs, done, act = synth.bc_batches(6, T, B, O, A, S)
     finals = {}
-    for persist, pipe in (('0', '1'), ('1', '1'), ('1', '0')):
+    for persist, pipe in (('0', '1'), ('1', '1'), ('1', '0'), ('2', '1'), ('2', '0')):      # 2: data-as-flag hand-off
         monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
         monkeypatch.setenv('PVR_POLICY_PIPELINE', pipe)
         m, _ = _model(6, O, A, True, T, B)
@@ -213,7 +213,7 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch):
             opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
         finals[(persist, pipe)] = m._flat.clone()
         assert torch.isfinite(finals[(persist, pipe)]).all()
-    assert torch.equal(finals[('0', '1')], finals[('1', '1')]) and torch.equal(finals[('0', '1')], finals[('1', '0')])
+    assert all(torch.equal(finals[('0', '1')], v) for v in finals.values())
 
 
 @pytest.mark.parametrize('conv', [False, True])
