@@ -69,7 +69,22 @@ typedef struct pvr_policy_bn {
  * world_size <= 1 or fn == NULL restores single-rank behaviour. */
 typedef int32_t (*pvr_allreduce_fn)(void *buf_dev, int64_t count, void *hip_stream, void *user);
 #define PVR_ERR_COMM 5
+#define PVR_ERR_TIMEOUT 6
 pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int32_t sync_bn, pvr_allreduce_fn fn, void *user);
+
+/* Health of the handle's persistent launches.  The forward recurrence (models.py:66-73) may run as ONE launch per layer whose
+ * blocks hand h_t to each other inside the kernel; it is only chosen when the whole grid fits the GPU at once (occupancy x CU count,
+ * checked at create), its waits are bounded, and a wait that runs out stores into a pinned status word (and poisons that call's
+ * outputs with NaN).  pvr_policy_status returns PVR_ERR_TIMEOUT once for such an event (message via pvr_last_error) and the handle
+ * falls back to per-step launches; pvr_policy_forward / _backward / _backward_dlogits / _step perform the same check on entry, so a
+ * time-out never goes unnoticed.  It does not synchronise: call it after the stream has been synchronised to learn about the
+ * launches just enqueued.  (The reference has no counterpart: nn.LSTM cannot time out.)
+ * pvr_policy_recurrence_mode: 0 per-step launches, 1 / 2 persistent (counter / data-as-flag hand-off) - what the next forward will use. */
+pvr_status pvr_policy_status(pvr_policy *pol);
+int32_t pvr_policy_recurrence_mode(const pvr_policy *pol);
+/* test hook: block `block` (>= 0) of every following persistent launch exits at once, so its peers' waits run out and the failure
+ * path above can be exercised on a healthy GPU (tests/test_gpu_policy.py); -1 restores normal launches */
+pvr_status pvr_policy_debug_drop_block(pvr_policy *pol, int32_t block);
 
 /* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32 (uint8 (T,B,64,64,3n) when conv_frames = n > 0), done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
  * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82), h_out/c_out

@@ -51,6 +51,8 @@ def make_parser():
                         help='encoder storage/MFMA input type (default: $PVR_DTYPE or bf16)')
     parser.add_argument('--embed_batch', type=int, default=256, help='frames per encoder launch (the reference '
                         'pushes batch_size x n_frames = 64 per forward, save_embedded_obs.py:151-153)')
+    parser.add_argument('--embed_block', type=int, default=0, help='observation rows a rank reads, embeds and appends to its shard file at a '
+                        'time (bounds host memory for scenes of millions of frames); 0 = about 1 GiB of frames')
     parser.add_argument('--num_actions', type=int, default=3, help='size of the policy head when no simulator is attached (the reference '
                         'reads env.gym_env.action_space.n, main_bc_2.py:77; Habitat ImageNav without STOP has 3 actions, gym_wrappers.py:173). '
                         'The data is checked against it - it is never derived from the data')

@@ -111,8 +111,9 @@ def train(flags, obs, action, reward, done, save_path, to_env, stats=None, env=N
             for k in stat_keys:
                 stats[to_env][k].append(ev[k])
             stats[to_env]['frames'].append(frames)
-            stats[to_env]['training_loss'].append(float(loss))
+            stats[to_env]['training_loss'].append(float(loss))              # (synchronises)
             stats[to_env]['gradient_norm'].append(float(gradient_norm))
+            actor_model.check_status()                                      # a persistent launch that gave up raises here, not as a silent NaN
             print('  ', 'frames', frames, 'training loss', float(loss), 'gradient norm', float(gradient_norm))
             if not flags.disable_save:
                 pickle.dump(stats, open(save_path + '.pickle', 'wb'), protocol=pickle.HIGHEST_PROTOCOL)
@@ -122,6 +123,10 @@ def train(flags, obs, action, reward, done, save_path, to_env, stats=None, env=N
                             'actor_model_optimizer_state_dict': optimizer.state_dict(),
                             'scheduler_state_dict': sched_sd,
                             'flags': {k: v for k, v in vars(flags).items() if k != 'device'}}, save_path + '.tar')
+    torch.cuda.synchronize()
+    actor_model.check_status()
+    actor_model.close()                                         # library handles are freed here, not at garbage-collection time
+    test_model.close()
     if env is not None:
         env.close()
     return stats

@@ -52,6 +52,12 @@ struct pvr_policy {
     int chunkwave = 1;
     unsigned *seq_counters = nullptr;       // 16 slots of 16 bytes, zeroed before each launch that uses one
     int persist = 2;                        // 0 per-step launches, 1 persistent with the counter hand-off, 2 persistent with the data-as-flag hand-off
+    // A persistent launch is only chosen when its whole grid can be resident at once (persist_fits: occupancy x CU count >= H/4 blocks,
+    // checked at create); its bounded spins report through `status_host` (one pinned, GPU-visible word) instead of only poisoning h:
+    // every entry point looks at the word on the way in (sticky: the error surfaces at the next call, or at pvr_policy_status after the
+    // caller's own sync), returns PVR_ERR_TIMEOUT once, and the handle then stays on per-step launches (persist_tripped).
+    int persist_fits = 0, persist_tripped = 0, debug_drop_block = -1;
+    unsigned *status_host = nullptr, *status_dev = nullptr;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
@@ -305,38 +311,10 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
     TRY(gemm(x0, P + pol->o_fc1w, P + pol->o_fc1b, nullptr, pol->a1, N, H, O, false, false, 1, st));
     TRY(gemm(pol->a1, P + pol->o_fc2w, P + pol->o_fc2b, nullptr, pol->a2, N, H, H, false, false, 1, st));
     // LSTM, two layers.  Input projections are hoisted out of the recurrence (one GEMM over all steps of a chunk).
-    auto fwd_steps = [&](int l, int t0, int t1, hipStream_t s_) {
-        if (pol->persist && H == 1024 && B <= 64 && t1 - t0 > 1) {
-            // one persistent launch for the whole step range (grid-wide hand-off per step inside the kernel)
-            unsigned *ctr = pol->seq_counters + 4 * ((l * 4 + (t0 * 4 / (T > 0 ? T : 1))) & 15);
-            LstmSeqP q;
-            q.data_flag = pol->persist == 2;
-            if (q.data_flag) (void)hipMemsetAsync(pol->Hs[l] + (size_t)t0 * B * H, 0xFF, (size_t)(t1 - t0) * B * H * sizeof(float), s_);
-            else (void)hipMemsetAsync(ctr, 0, 16, s_);
-            q.G = pol->G[l];
-            q.h_init = t0 == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t0 - 1) * B * H;
-            q.c_init = t0 == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t0 - 1) * B * H;
-            q.nd = pol->nd; q.W = P + pol->o_whh[l]; q.bhh = P + pol->o_bhh[l];
-            q.Hs = pol->Hs[l]; q.Cs = pol->Cs[l]; q.counter = ctr; q.t0 = t0; q.t1 = t1; q.B = B; q.H = H;
-            hipLaunchKernelGGL(lstm_fwd_seq_kernel, dim3(H / 4), dim3(256), 0, s_, q);
-            return;
-        }
-        for (int t = t0; t < t1; ++t) {
-            LstmFwdP f;
-            f.G = pol->G[l] + (size_t)t * B * 4 * H;
-            f.h_prev = t == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t - 1) * B * H;
-            f.c_prev = t == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t - 1) * B * H;
-            f.nd = pol->nd + (size_t)t * B;
-            f.W = P + pol->o_whh[l];
-            f.bhh = P + pol->o_bhh[l];
-            f.h_out = pol->Hs[l] + (size_t)t * B * H;
-            f.c_out = pol->Cs[l] + (size_t)t * B * H;
-            f.B = B; f.H = H;
-            hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, s_, f);
-        }
-    };
-    TRY(gemm(pol->a2, P + pol->o_wih[0], P + pol->o_bih[0], nullptr, pol->G[0], N, 4 * H, H, false, false, 0, st));
-    const int NCH = (pol->pipeline || pol->chunkwave) && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
+    // effective hand-off mode of this call: none when the grid cannot be co-resident or a spin has run out on this handle before;
+    // the data-as-flag form never inside a hipGraph (capture or replay: see below)
+    const int persist = (!pol->persist_fits || pol->persist_tripped) ? 0 : (pol->persist == 2 && pol->use_graph) ? 0 : pol->persist;
+    hipError_t fill_err = hipSuccess;
     auto fwd_job = [&](int l, int t) {
         LstmFwdP f;
         f.G = pol->G[l] + (size_t)t * B * 4 * H;
@@ -350,17 +328,44 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
         f.B = B; f.H = H;
         return f;
     };
+    auto fwd_steps = [&](int l, int t0, int t1, hipStream_t s_) {
+        if (persist && H == 1024 && B <= 64 && t1 - t0 > 1) {
+            // one persistent launch for the whole step range (grid-wide hand-off per step inside the kernel)
+            unsigned *ctr = pol->seq_counters + 4 * ((l * 4 + (t0 * 4 / (T > 0 ? T : 1))) & 15);
+            LstmSeqP q;
+            q.data_flag = persist == 2;
+            q.status = pol->status_dev;
+            q.drop_block = pol->debug_drop_block;
+            const hipError_t me = q.data_flag ? hipMemsetAsync(pol->Hs[l] + (size_t)t0 * B * H, 0xFF, (size_t)(t1 - t0) * B * H * sizeof(float), s_)
+                                              : hipMemsetAsync(ctr, 0, 16, s_);
+            if (me != hipSuccess) {                              // without the pre-fill the hand-off has no meaning: per-step launches instead
+                fill_err = me;
+                for (int t = t0; t < t1; ++t) { LstmFwdP f = fwd_job(l, t); hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, s_, f); }
+                return;
+            }
+            q.G = pol->G[l];
+            q.h_init = t0 == 0 ? h0 + (size_t)l * B * H : pol->Hs[l] + (size_t)(t0 - 1) * B * H;
+            q.c_init = t0 == 0 ? c0 + (size_t)l * B * H : pol->Cs[l] + (size_t)(t0 - 1) * B * H;
+            q.nd = pol->nd; q.W = P + pol->o_whh[l]; q.bhh = P + pol->o_bhh[l];
+            q.Hs = pol->Hs[l]; q.Cs = pol->Cs[l]; q.counter = ctr; q.t0 = t0; q.t1 = t1; q.B = B; q.H = H;
+            hipLaunchKernelGGL(lstm_fwd_seq_kernel, dim3(H / 4), dim3(256), 0, s_, q);
+            return;
+        }
+        for (int t = t0; t < t1; ++t) { LstmFwdP f = fwd_job(l, t); hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 4), dim3(256), 0, s_, f); }
+    };
+    TRY(gemm(pol->a2, P + pol->o_wih[0], P + pol->o_bih[0], nullptr, pol->G[0], N, 4 * H, H, false, false, 0, st));
+    const int NCH = (pol->pipeline || pol->chunkwave) && T >= 8 ? 4 : 1, CH = (T + NCH - 1) / NCH;
     // persistent recurrence with the data-as-flag hand-off (default, PVR_POLICY_PERSIST=2): ONE launch per layer for the whole sequence
     // (not inside a hipGraph: replayed nodes run with weaker cache maintenance between them than stream launches - the 0xFF pre-fill of a
     //  memset node was not visible to the other XCDs' sc1 loads in time, which then took the PREVIOUS iteration's h for data; measured
     //  as a 1e-3 drift with PVR_POLICY_GRAPH=1 on the conv model, scripts/debug_bc_modes.py)
-    const bool use_persist = pol->persist == 2 && !pol->use_graph && H == 1024 && B <= 64 && T > 1;
+    const bool use_persist = persist == 2 && H == 1024 && B <= 64 && T > 1;
     if (use_persist) {
         fwd_steps(0, 0, T, st);
         TRY(gemm(pol->Hs[0], P + pol->o_wih[1], P + pol->o_bih[1], nullptr, pol->G[1], N, 4 * H, H, false, false, 0, st));
         fwd_steps(1, 0, T, st);
         PVR_LAUNCH_CHECK();
-    } else if (pol->chunkwave && !pol->persist && NCH > 1) {
+    } else if (pol->chunkwave && !persist && NCH > 1) {
         for (int c = 0; c <= NCH; ++c) {
             if (c >= 1) {                                       // input projection of layer 1 for the chunk layer 0 has just finished
                 const int t0 = (c - 1) * CH, t1 = c * CH < T ? c * CH : T;
@@ -416,6 +421,11 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
     hp.action = pol->action; hp.target = target; hp.N = N; hp.H = H; hp.A = d.num_actions;
     hipLaunchKernelGGL(heads_kernel, dim3((N + 3) / 4), dim3(256), 0, st, hp);
     PVR_LAUNCH_CHECK();
+    if (fill_err != hipSuccess) {
+        // the recurrence ran through per-step launches (results are valid); the failed memset is still an error of this call
+        set_error("policy: hipMemsetAsync of the persistent recurrence's hand-off words failed: %s", hipGetErrorString(fill_err));
+        return PVR_ERR_HIP;
+    }
     return PVR_OK;
 }
 
@@ -754,6 +764,21 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e);      // 1: counter hand-off, 2: data-as-flag hand-off
     if (const char *e = getenv("PVR_POLICY_CHUNKWAVE")) p->chunkwave = atoi(e) != 0;
     A_(seq_counters, 64);
+    if (!s) {
+        // status word of the persistent recurrence: pinned host memory the GPU writes with a system-scope store
+        hipError_t he = hipHostMalloc((void **)&p->status_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (he == hipSuccess) { memset(p->status_host, 0, 64); he = hipHostGetDevicePointer((void **)&p->status_dev, p->status_host, 0); }
+        if (he != hipSuccess) { set_error("policy: status word allocation failed: %s", hipGetErrorString(he)); s = PVR_ERR_HIP; }
+    }
+    if (!s) {
+        // co-residency of the persistent grid (H/4 blocks of 256 threads, all of which spin on each other): blocks per CU x CUs
+        int dev = 0, cus = 0, per_cu = 0;
+        hipError_t he = hipGetDevice(&dev);
+        if (he == hipSuccess) he = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_fwd_seq_kernel, 256, 0);
+        p->persist_fits = he == hipSuccess && (long long)per_cu * cus >= desc->hidden / 4;
+        (void)hipGetLastError();
+    }
     if (!s && p->pipeline) {
         hipError_t he = hipStreamCreateWithFlags(&p->lane_a, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->lane_b, hipStreamNonBlocking);
@@ -780,6 +805,7 @@ void pvr_policy_destroy(pvr_policy *p) {
     for (hipEvent_t ev : {p->ev_fork, p->ev_join_a, p->ev_join_b}) if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < 8; ++i) if (p->ev_chunk[i]) (void)hipEventDestroy(p->ev_chunk[i]);
     drop_graph(p);
+    if (p->status_host) (void)hipHostFree(p->status_host);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
     for (hipEvent_t ev : p->ev_ready) if (ev) (void)hipEventDestroy(ev);
@@ -805,6 +831,30 @@ pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int
     return PVR_OK;
 }
 
+// The persistent recurrence's spin ran out in an earlier launch of this handle: report it once, stay on per-step launches afterwards.
+pvr_status pvr_policy_status(pvr_policy *pol) {
+    PVR_REQUIRE(pol, "pvr_policy_status: null policy");
+    const unsigned w = pol->status_host ? __atomic_load_n(pol->status_host, __ATOMIC_ACQUIRE) : 0u;
+    if (!w) return PVR_OK;
+    __atomic_store_n(pol->status_host, 0u, __ATOMIC_RELEASE);
+    pol->persist_tripped = 1;
+    set_error("policy: the persistent LSTM recurrence gave up waiting for a peer block (status 0x%x): the hidden states, logits and - after "
+              "a training step - the parameters of that call are NaN.  Its grid was not co-resident (another process or stream holding "
+              "CUs?); this handle uses per-step launches from now on (PVR_POLICY_PERSIST=0 selects them from the start)", w);
+    return PVR_ERR_TIMEOUT;
+}
+
+pvr_status pvr_policy_debug_drop_block(pvr_policy *pol, int32_t block) {
+    PVR_REQUIRE(pol, "pvr_policy_debug_drop_block: null policy");
+    pol->debug_drop_block = block;
+    return PVR_OK;
+}
+
+int32_t pvr_policy_recurrence_mode(const pvr_policy *pol) {
+    if (!pol) return -1;
+    return (!pol->persist_fits || pol->persist_tripped) ? 0 : (pol->persist == 2 && pol->use_graph) ? 0 : pol->persist;
+}
+
 int64_t pvr_policy_param_count(const pvr_policy *p) { return p ? p->n_total : 0; }
 int64_t pvr_policy_trainable_count(const pvr_policy *p) { return p ? p->n_train : 0; }
 
@@ -822,6 +872,7 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
     PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
     TraceScope trace("pvr_policy_forward");
     ScratchScope scratch_scope(pol);
+    TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, H = pol->d.hidden, A = pol->d.num_actions;
@@ -844,6 +895,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
     PVR_REQUIRE(pol && params && obs && done && actions && grads, "pvr_policy_backward: null argument");
     TraceScope trace("pvr_policy_backward");
     ScratchScope scratch_scope(pol);
+    TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;
@@ -868,6 +920,7 @@ pvr_status pvr_policy_backward_dlogits(pvr_policy *pol, const float *params, con
                                        float *grads, void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && dlogits && grads, "pvr_policy_backward_dlogits: null argument");
     ScratchScope scratch_scope(pol);
+    TRY(pvr_policy_status(pol));
     if (pol->fwd_T != T || pol->fwd_B != B) {
         set_error("pvr_policy_backward_dlogits: needs the activations of a training-mode pvr_policy_forward with T=%d, B=%d (last: %d, %d)", T, B,
                   pol->fwd_T, pol->fwd_B);
@@ -918,6 +971,7 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
     PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
     TraceScope trace("pvr_policy_step");
     ScratchScope scratch_scope(pol);
+    TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
     PVR_REQUIRE(T > 0 && T <= pol->d.max_t && B > 0 && B <= pol->d.max_b, "T=%d B=%d outside the workspace (%d,%d)", T, B, pol->d.max_t, pol->d.max_b);
     hipStream_t st = (hipStream_t)hip_stream;
     const int N = T * B, A = pol->d.num_actions;

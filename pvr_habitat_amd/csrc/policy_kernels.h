@@ -409,7 +409,12 @@ struct LstmSeqP {
     int t0, t1, B, H;
     int data_flag;                     // 1: no counter - Hs[t0 .. t1) is pre-filled with 0xFFFFFFFF words and a consumer re-reads its slice of
                                        // h_{t-1} until none of its words is that pattern (the data is its own flag: no atomics, no drain, no block-wide poll)
+    int drop_block;                    // -1; test hook (pvr_policy_debug_drop_block): this block leaves at once, so its peers' waits run out
+    unsigned *status;                  // host-visible (pinned, fine-grained) status word: a wave whose bounded spin runs out stores LSTM_SEQ_TIMEOUT
+                                       // there (a plain system-scope store: PCIe atomics offer no OR); pvr_policy_forward / _step / _status turn it into PVR_ERR_TIMEOUT (policy.hip)
 };
+constexpr unsigned LSTM_SEQ_TIMEOUT = 1u;
+constexpr unsigned LSTM_SEQ_SPINS = 1u << 20;   // ~1-2 s of re-reads: far beyond any scheduling delay of a co-resident grid
 
 static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
     __shared__ float part[4][16][17];
@@ -418,6 +423,7 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int u0 = blockIdx.x * 4, H = p.H, B = p.B;
+    if ((int)blockIdx.x == p.drop_block) return;
     if (tid == 0) dead_s = 0;
     __syncthreads();
     const float *wrow = p.W + (size_t)((fr >> 2) * H + u0 + (fr & 3)) * H;
@@ -435,6 +441,7 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
     float creg[4] = {0.f, 0.f, 0.f, 0.f};           // cell state of (batch row b0 + tb, unit u0 + tj) per 16-row batch group
     const unsigned nblk = gridDim.x;
     const size_t hbytes = (size_t)B * H * 4;
+    bool dead = false;                               // this wave's spin ran out once (wave-uniform)
     for (int t = p.t0; t < p.t1; ++t) {
         const int s = t - p.t0;
         if (s > 0 && !p.data_flag) {
@@ -442,7 +449,11 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk * (unsigned)s) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) { dead_s = 1; break; }     // bounded: never hang the GPU on a lost block
+                    if (++spins > 4 * LSTM_SEQ_SPINS) {                  // bounded: never hang the GPU on a lost block
+                        dead_s = 1;
+                        __hip_atomic_store(p.status, LSTM_SEQ_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
             }
             __syncthreads();
@@ -470,9 +481,10 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)                                  // sc1 loads: h_{t-1} was published by other CUs in this launch
                 hv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, hoff, c * 64, 16));
-            if (p.data_flag && s > 0) {
-                // every word of this lane's slice must have been written (0xFFFFFFFF = the pre-fill; a stored h is never that NaN
-                // pattern); the wave re-reads until all of its lanes see data.  Bounded like the counter poll.
+            if (p.data_flag && s > 0 && !dead) {
+                // every word of this lane's slice must have been written (0xFFFFFFFF = the pre-fill; a stored h is never that
+                // pattern: the store below canonicalises NaNs); the wave re-reads until all of its lanes see data.  Bounded like the
+                // counter poll; a wave that ran out once never waits again (`dead`), so a broken launch drains in ~one timeout.
                 unsigned spins = 0;
                 for (;;) {
                     unsigned m = 0xffffffffu;
@@ -483,7 +495,11 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
                         m &= written ? 0xffffffffu : 0u;
                     }
                     if (__all(m != 0u || !bok)) break;
-                    if (++spins > (1u << 20)) { dead_s = 1; break; }
+                    if (++spins > LSTM_SEQ_SPINS) {
+                        dead = true; dead_s = 1;
+                        if (lane == 0) __hip_atomic_store(p.status, LSTM_SEQ_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                     for (int c = 0; c < 16; ++c)
@@ -514,7 +530,8 @@ static __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqP p) {
                 float *g = Gt + (size_t)tbi * 4 * H + u0 + tj;
                 g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
                 p.Cs[((size_t)t * B + tbi) * H + u0 + tj] = c;
-                hstage[tb][tj] = dead_s ? __builtin_nanf("") : h;
+                // (h != h: an input NaN may carry any payload, 0xFFFFFFFF included - the stored word must never look like the pre-fill)
+                hstage[tb][tj] = (dead_s || h != h) ? __builtin_nanf("") : h;
             }
             __syncthreads();
             if (tid < 16 && b0 + tid < B) {                              // one 16-byte write-through store per batch row

@@ -199,6 +199,11 @@ class HipResNet50(_Node):
             _lib.lib().pvr_encoder_destroy(self._handle)
             self._handle = None
 
+    def close(self):
+        """Free the library handle (folded weights, workspaces) NOW, at a point the caller chooses, instead of whenever the garbage
+        collector finds the object.  The module stays usable: the next call re-folds and re-uploads from the host tensors."""
+        self._release()
+
     def __del__(self):
         try:
             self._release()
@@ -319,6 +324,10 @@ class UberModel(nn.Module):
         self.training = models[0].training
         self.out_size = sum(m.out_size for m in models)
 
+    def close(self):
+        for m in self.models:
+            m.close()
+
     def to(self, device):
         return self
 
@@ -378,6 +387,9 @@ class FiveCrop(nn.Module):
         self.model = [model]                                   # plain list: not a sub-module (as UberModel.models)
         self.training = model.training
         self.out_size = 5 * model.out_size
+
+    def close(self):
+        self.model[0].close()
 
     def to(self, device):
         return self
@@ -512,6 +524,12 @@ class EmbeddingNet(nn.Module):
     def _forward(self, observation_u8):
         return self.embedding(observation_u8)
 
+    def close(self):
+        """free every library handle under this embedding now (HipResNet50.close); the module stays usable"""
+        for m in self.modules():
+            if m is not self and hasattr(m, 'close'):
+                m.close()
+
     def embed_device(self, observation):
         """uint8 (N,H,W,3) -> cuda fp32 (N, out_size); no host sync (for streaming callers)."""
         _lib.require_gpu()
@@ -538,6 +556,7 @@ def _checked(host_out, model):
 
 
 _STREAM_CACHE = {}
+_REGISTER_MIN_BYTES = 64 << 20      # stream_embed page-locks a pageable source in place only from this size up (see there)
 
 
 def _streams(dev_index=None):
@@ -577,7 +596,10 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     calling `net` batch by batch; this is the "embeddings streamed to host" path of BASELINE config 5 and what save_embedded_obs
     uses for big scenes.  Returns np.float32 (N, out_size) (no squeeze)."""
     _lib.require_gpu()
-    x = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames_u8))
+    # a strided view (e.g. the channel slice obs[..., 3:6] of a (N,H,W,6) scene) is taken as it is: the staging threads gather it
+    # into pinned memory batch by batch, overlapped with the GPU, instead of one np.ascontiguousarray pass over the scene up front
+    x = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.from_numpy(frames_u8 if all(st >= 0 for st in frames_u8.strides)
+                                                                               else np.ascontiguousarray(frames_u8))
     assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3
     n, osz = x.shape[0], net.out_size
     res = torch.empty((n, osz), dtype=torch.float32, pin_memory=True) if out is None else out
@@ -595,12 +617,17 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     device_src = x.is_cuda                                  # frames already in HBM (PNG source decoded on the GPU): no upload at all
     pinned_src = device_src or x.is_pinned()                 # caller already holds page-locked frames: no staging copy
     registered = None
-    if not pinned_src and stage_threads != 0 and os.environ.get('PVR_STREAM_REGISTER', '1') == '1' and x.is_contiguous() and x.numel() > 0:
-        # page-lock the caller's array IN PLACE for the duration of the call (hipHostRegister): the frames then go straight from the
-        # caller's memory to the GPU by DMA - no staging copy at all (measured: 72 k frames/s vs 16-26 k through a pinned staging ring
-        # and 44 k through the driver's own staged copy of pageable memory)
+    if (not pinned_src and stage_threads != 0 and os.environ.get('PVR_STREAM_REGISTER', '0') == '1' and x.is_contiguous()
+            and x.numel() >= _REGISTER_MIN_BYTES):
+        # OPT-IN (PVR_STREAM_REGISTER=1): page-lock the caller's array IN PLACE for the duration of the call (hipHostRegister), so the
+        # frames go straight from the caller's memory to the GPU by DMA - no staging copy (measured: 72 k frames/s vs 16-26 k through
+        # the pinned staging ring and 44 k through the driver's own staged copy of pageable memory).  Round 2 did this by default for any
+        # pageable source, i.e. it locked and unlocked pages of the glibc heap that the package does not own, next to unrelated objects
+        # (ADVICE round 2); now it needs the opt-in AND a buffer of >= 64 MiB, which glibc serves by a private mmap (above
+        # M_MMAP_THRESHOLD_MAX), so the locked pages belong to this array alone.  Callers that want the full rate by default hold
+        # their frames in pinned memory (torch.empty(..., pin_memory=True)), as bench.py's headline PCIe leg does.
         try:
-            if torch.cuda.cudart().cudaHostRegister(x.data_ptr(), x.numel(), 0) == 0:
+            if int(torch.cuda.cudart().cudaHostRegister(x.data_ptr(), x.numel(), 0)) == 0:
                 registered = x.data_ptr()
                 pinned_src = True
         except Exception:
@@ -662,7 +689,10 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
             pool.shutdown()
         if registered is not None:
             torch.cuda.synchronize()
-            torch.cuda.cudart().cudaHostUnregister(registered)
+            rc = int(torch.cuda.cudart().cudaHostUnregister(registered))
+            if rc != 0:
+                import warnings
+                warnings.warn('stream_embed: hipHostUnregister(%#x) returned %d - the source array stays page-locked' % (registered, rc))
     _checked(res.numpy(), model)
     return res.numpy() if out is None else res
 

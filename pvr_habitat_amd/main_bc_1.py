@@ -26,7 +26,7 @@ def embed_scene(embedding_model, obs_u8, batch_size):
         obs_u8 = np.repeat(obs_u8, 3, -1)
     n_frames = max(obs_u8.shape[3] // 3, 1)
     if hasattr(getattr(embedding_model, 'embedding', None), 'forward_into'):
-        return np.concatenate([stream_embed(embedding_model, np.ascontiguousarray(obs_u8[..., 3 * f:3 * f + 3]), 256)
+        return np.concatenate([stream_embed(embedding_model, obs_u8[..., 3 * f:3 * f + 3], 256)
                                for f in range(n_frames)], axis=-1)
     return embed_rows(embedding_model, obs_u8, n_frames, batch_size)
 

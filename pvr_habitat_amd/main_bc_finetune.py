@@ -113,8 +113,9 @@ def run(flags, make_env=None):
             for k in stat_keys:
                 stats[to_env][k].append(ev[k])
             stats[to_env]['frames'].append(frames)
-            stats[to_env]['training_loss'].append(float(loss))
+            stats[to_env]['training_loss'].append(float(loss))              # (synchronises)
             stats[to_env]['gradient_norm'].append(float(gradient_norm))
+            actor_model.check_status()
             if rank == 0:
                 print('  ', 'frames', frames, 'training loss', float(loss), 'gradient norm', float(gradient_norm))
                 if not flags.disable_save:
@@ -123,6 +124,11 @@ def run(flags, make_env=None):
                                 'actor_model_optimizer_state_dict': optimizer.state_dict(),
                                 'scheduler_state_dict': {'last_epoch': optimizer.last_epoch},
                                 'flags': {k: v for k, v in vars(flags).items() if k != 'device'}}, save_path + '.tar')
+    if flags.device.type == 'cuda':
+        torch.cuda.synchronize()
+    actor_model.check_status()
+    actor_model.close()                                         # library handles are freed here, not at garbage-collection time
+    test_model.close()
     if env is not None:
         env.close()
     return stats

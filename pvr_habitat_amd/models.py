@@ -71,6 +71,12 @@ def _plib():
         L.pvr_policy_apply_adam.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, f32, vp, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
+        L.pvr_policy_status.restype = C.c_int
+        L.pvr_policy_status.argtypes = [vp]
+        L.pvr_policy_recurrence_mode.restype = i32
+        L.pvr_policy_recurrence_mode.argtypes = [vp]
+        L.pvr_policy_debug_drop_block.restype = C.c_int
+        L.pvr_policy_debug_drop_block.argtypes = [vp, i32]
         L.pvr_op_gemm_f32.restype = C.c_int
         L.pvr_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L._policy_bound = True
@@ -229,11 +235,34 @@ class PolicyNet(nn.Module):
             self._handle = None
         self._dp_key = None                              # (a new handle has no collective installed)
 
+    def close(self):
+        """Free the library handle (workspace, streams) NOW, at a point the caller chooses - after its own synchronisation - instead of
+        whenever the garbage collector finds the object.  The module stays usable: the next forward / step builds a new handle."""
+        self._release()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
         try:
             self._release()
         except Exception:
             pass
+
+    def check_status(self):
+        """Raise if a persistent launch of this policy gave up waiting (pvr_policy_status: PVR_ERR_TIMEOUT, once per event).  Does not
+        synchronise: call it after a sync of your own (bc_loop does when it reads the loss) to learn about the steps just run; every
+        forward / step performs the same check on entry, so the event also surfaces at the next call."""
+        if self._handle is not None:
+            _lib.check(_plib().pvr_policy_status(self._handle))
+
+    def recurrence_mode(self):
+        """0 per-step launches, 1 / 2 persistent forward recurrence (counter / data-as-flag hand-off) - what the next forward uses"""
+        return int(_plib().pvr_policy_recurrence_mode(self._handle)) if self._handle is not None else -1
 
     def _ensure(self, T, B):
         _lib.require_gpu()

@@ -136,12 +136,15 @@ def count_png_trajectories(data_path, n_trajectories=-1):
     return t
 
 
-def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None, gpu_decode=None):
+def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=256, decode_workers=None, t_range=None, gpu_decode=None,
+                               row_sink=None):
     """PNG layout of save_opt_trajectories_png.py:44-58.  The reference decodes and embeds one frame per forward (:69-77);
     here the frames of four trajectories are decoded in one call and embedded together (same rows, same order), and the next group
     is decoded while this one is on the encoder (keeping the GPU fed from the PNG source).  With an encoder on a GPU
     the files are decoded ON the GPU (csrc/png_decode.hip; PVR_PNG_GPU=0 or gpu_decode=False selects the host decoders);
-    decode_workers: host decoder processes (default min(32, cores); <= 1 decodes in this process) / file-reader threads."""
+    decode_workers: host decoder processes (default min(32, cores); <= 1 decodes in this process) / file-reader threads.
+    row_sink: called with every trajectory's finished (L, 2*O) rows in order instead of keeping them (run(): the rank's shard file),
+    so the host never holds more than the group in flight; data['obs'] is then empty."""
     from concurrent.futures import ThreadPoolExecutor
     print('loading %s ...' % data_path)
     data = dict(obs=[], action=[], reward=[], done=[], true_state=[], png=[])
@@ -151,6 +154,18 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     if gpu_decode is None:
         gpu_decode = model is not None and torch.cuda.is_available() and os.environ.get('PVR_PNG_GPU', '1') != '0'
     t_lo, t_hi = t_range if t_range is not None else (0, n_trajectories)     # a rank's shard: trajectories [t_lo, t_hi)
+
+    def join(e, g):                                             # rows = [frame | goal of its trajectory] (:73-77)
+        rows = np.empty((len(e),) + e.shape[1:-1] + (e.shape[-1] + g.shape[-1],), e.dtype)
+        rows[..., :e.shape[-1]] = e
+        rows[..., e.shape[-1]:] = g
+        return rows
+
+    def keep(eg):
+        if row_sink is not None and model is not None:
+            row_sink(join(*eg))
+        else:
+            data['obs'].append(eg)
     G = 16 if gpu_decode else 4                                 # trajectories decoded per call (<= 8000 / 2000 frames of 12 KB in flight)
     t = t_lo
     listing = frozenset(os.listdir(data_path)) if os.path.isdir(data_path) else frozenset()
@@ -176,7 +191,7 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
                 if frames is None:
                     continue
                 if emb is not None:
-                    data['obs'].append((emb[lo:lo + len(names)], emb[gi]))      # (frame rows, goal row): joined once, at the end
+                    keep((emb[lo:lo + len(names)], emb[gi]))                    # (frame rows, goal row): joined once, at the end
                     lo += len(names)
                 elif model is not None:
                     if torch.is_tensor(frames):                 # decoded on the side stream: tell the allocator who reads them
@@ -184,9 +199,9 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
                     g = np.asarray(model(_t(goal)[None, :])).reshape(-1,)
                     e = np.concatenate([np.asarray(model(_t(frames[i:i + batch]))).reshape(min(batch, len(frames) - i), -1)
                                         for i in range(0, len(frames), batch)])
-                    data['obs'].append((e, g))
+                    keep((e, g))
                 else:
-                    data['obs'].append((frames, goal))
+                    keep((frames, goal))
                 data['png'] += names
     n_trajectories = t - t_lo
     if data['obs']:                                             # rows = [frame | goal of its trajectory] (:73-77), written once
@@ -205,6 +220,109 @@ def read_habitat_data_from_png(data_path, model=None, n_trajectories=-1, batch=2
     n_samples = len(data['reward'])
     print('  ', '%d trajectories for a total of %d samples' % (n_trajectories, n_samples))
     return data
+
+
+class ShardWriter(object):
+    """One rank's output while a run is in progress ("per-shard output files make a crashed 8-GPU run resumable"):
+        <base>.rank<r>.obs.f32   raw float32 rows, appended block by block as they come off the encoder (never all in RAM)
+        <base>.rank<r>.pickle    written LAST, through a rename: {'_shard': {...what this shard covers...}, action, reward, done,
+                                 true_state[, png]} - its existence means the shard is complete
+    A relaunch finds the pickle, compares `_shard` with what it would compute itself (rank, world size, source, embedding, row or
+    trajectory range) and skips the work: only ranks that did not finish run again."""
+
+    def __init__(self, save_name, rank):
+        self.meta_path, self.obs_path = shard_name(save_name, rank), shard_name(save_name, rank)[:-len('.pickle')] + '.obs.f32'
+        for q in (self.meta_path, self.obs_path):               # leftovers of an interrupted attempt at this shard
+            if os.path.isfile(q):
+                os.remove(q)
+        self.f, self.rows, self.width = open(self.obs_path, 'wb'), 0, None
+
+    def append(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.shape[0] == 0:
+            return
+        assert rows.ndim == 2 and (self.width is None or rows.shape[1] == self.width), rows.shape
+        self.width = rows.shape[1]
+        self.f.write(memoryview(rows).cast('B'))
+        self.rows += rows.shape[0]
+
+    def finish(self, small, cover):
+        self.f.flush()
+        os.fsync(self.f.fileno())
+        self.f.close()
+        meta = dict(small, _shard=dict(cover, rows=self.rows, width=self.width or 0))
+        with open(self.meta_path + '.tmp', 'wb') as handle:
+            pickle.dump(meta, handle, protocol=pickle.HIGHEST_PROTOCOL)
+            handle.flush()
+            os.fsync(handle.fileno())
+        os.replace(self.meta_path + '.tmp', self.meta_path)
+
+
+def load_complete_shard(save_name, rank, cover):
+    """the shard's small arrays if <base>.rank<r>.pickle exists, covers exactly `cover` and its row file has the size it states"""
+    path = shard_name(save_name, rank)
+    if not os.path.isfile(path):
+        return None
+    try:
+        with open(path, 'rb') as handle:
+            meta = pickle.load(handle)
+        sh = meta['_shard']
+        ok = all(sh.get(k) == v for k, v in cover.items()) and \
+            os.path.getsize(path[:-len('.pickle')] + '.obs.f32') == 4 * sh['rows'] * sh['width']
+    except Exception:
+        return None
+    return meta if ok else None
+
+
+def stitch_shards(save_name, world, keys, copy_bytes=256 << 20):
+    """Rank 0, after the barrier: the reference's single output pickle (save_embedded_obs.py:165-172) from the shard files, in rank
+    order (= the reference's row order), without ever holding the embeddings in RAM: the (N, D) float32 matrix is assembled in a
+    file-backed np.memmap by bounded copies from the shards' row files and pickled from there (protocol 5 writes an array's
+    buffer to the file as it is, no intermediate copy).  Round 2 np.concatenate'd every shard in memory: 125 GB for BASELINE
+    config 5 (1 M frames x 31 310 floats)."""
+    metas = []
+    for r in range(world):
+        with open(shard_name(save_name, r), 'rb') as handle:
+            metas.append(pickle.load(handle))
+    live = [(r, q) for r, q in enumerate(metas) if q['_shard']['rows'] > 0]
+    n = sum(q['_shard']['rows'] for _, q in live)
+    assert n > 0, 'no data found'
+    widths = set(q['_shard']['width'] for _, q in live)
+    assert len(widths) == 1, 'shards disagree on the embedding width: %s' % sorted(widths)
+    width = widths.pop()
+    obs_file = lambda r: shard_name(save_name, r)[:-len('.pickle')] + '.obs.f32'
+    if len(live) == 1:
+        tmp, obs = None, np.memmap(obs_file(live[0][0]), np.float32, 'r+', shape=(n, width))        # nothing to copy
+    else:
+        tmp = save_name + '.obs.tmp'
+        obs = np.memmap(tmp, np.float32, 'w+', shape=(n, width))
+        step, row = max(1, copy_bytes // (4 * width)), 0
+        for r, q in live:
+            src = np.memmap(obs_file(r), np.float32, 'r', shape=(q['_shard']['rows'], width))
+            for a in range(0, src.shape[0], step):
+                obs[row + a:row + min(a + step, src.shape[0])] = src[a:a + step]
+            row += src.shape[0]
+            del src
+        obs.flush()
+    small = [q for _, q in live]
+    data = {'obs': np.asarray(obs)}
+    for k in keys[1:]:
+        data[k] = sum((list(q[k]) for q in small), []) if k == 'png' else np.concatenate([q[k] for q in small])
+    assert len(data['reward']) == n, 'data length does not match'
+    print('  ', 'total number of samples', n)
+    with open(save_name + '.tmp', 'wb') as handle:
+        pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
+    os.replace(save_name + '.tmp', save_name)
+    del data, obs
+    for q in ([tmp] if tmp else []) + [f for r in range(world) for f in (shard_name(save_name, r), obs_file(r))]:
+        if os.path.isfile(q):
+            os.remove(q)
+
+
+def _block_rows(flags, row_bytes, batch):
+    """observation rows embedded per block (bounds the host memory of a rank): --embed_block, else about 1 GiB of frames"""
+    blk = int(getattr(flags, 'embed_block', 0) or 0)
+    return max(1, blk) if blk > 0 else max(batch, min(8192, (1 << 30) // max(1, row_bytes)))
 
 
 def run(flags):
@@ -228,54 +346,71 @@ def run(flags):
     print('=== Loading trajectories ===')
     batch = getattr(flags, 'embed_batch', 256)
     keys = ('obs', 'action', 'reward', 'done', 'true_state')
+    cover = dict(rank=rank, world=world, source=flags.source, embedding=flags.embedding_name, crops=int(getattr(flags, 'crops', 1)),
+                 run_id=int(flags.run_id) if flags.embedding_name == 'random' else None)
     if flags.source == 'png':
         # the goal frame is per trajectory, so the png source shards on trajectory boundaries: rank r takes trajectories [t_lo, t_hi)
         png_dir = os.path.join(flags.data_path, flags.env)
-        t_range = None
-        if world > 1:
-            t_range = shard_bounds(count_png_trajectories(png_dir, flags.n_trajectories), rank, world)
-        data = read_habitat_data_from_png(png_dir, embedding_model, flags.n_trajectories, batch, t_range=t_range)
         keys = keys + ('png',)          # (the reference dumps this dict as it is, 'png' file list included: save_embedded_obs.py:53,78,171-172)
-        data = {k: data[k] for k in keys}
-    else:
-        data = read_habitat_data_from_pickle(os.path.join(flags.data_path, flags.env), flags.n_trajectories)
-        print('  ', 'passing observations through embedding model')
-        n_samples = data['obs'].shape[0]
-        n_frames = max(data['obs'].shape[3] // 3, 1)
-        lo, hi = shard_bounds(n_samples, rank, world)
-        if hasattr(getattr(embedding_model, 'embedding', None), 'forward_into'):
-            # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU
-            # test), so the per-batch split/stack/concat of save_embedded_obs.py:151-156 is reproduced by streaming
-            # each 3-channel frame plane through the overlapped H2D/compute/D2H path and concatenating on features
-            from .embeddings import stream_embed
-            shard = data['obs'][lo:hi]
-            mine = np.concatenate([stream_embed(embedding_model, np.ascontiguousarray(shard[..., 3 * f:3 * f + 3]), batch)
-                                   for f in range(n_frames)], axis=-1) if hi > lo else np.zeros((0, 0), np.float32)
+        t_range = shard_bounds(count_png_trajectories(png_dir, flags.n_trajectories), rank, world) if world > 1 else None
+        cover['range'] = tuple(t_range) if t_range is not None else (0, int(flags.n_trajectories))
+        if load_complete_shard(save_name, rank, cover) is None:
+            writer = ShardWriter(save_name, rank)
+            data = read_habitat_data_from_png(png_dir, embedding_model, flags.n_trajectories, batch, t_range=t_range, row_sink=writer.append)
+            writer.finish({k: data[k] for k in keys[1:]}, cover)
         else:
-            mine = embed_rows(embedding_model, data['obs'][lo:hi], n_frames, max(1, batch // n_frames))
-        data = dict(obs=np.array(mine), action=data['action'][lo:hi], reward=data['reward'][lo:hi],
-                    done=data['done'][lo:hi], true_state=data['true_state'][lo:hi])
+            print('  ', 'rank %d: shard %s is complete, nothing to embed' % (rank, os.path.basename(shard_name(save_name, rank))))
+    else:
+        # (the reference reads the whole scene whatever --n_trajectories says: save_embedded_obs.py:142-145 passes no count)
+        from .scene_pickle import scene_index, scene_rows
+        scene = os.path.join(flags.data_path, flags.env) + '.pickle'
+        print('loading %s ...' % scene[:-len('.pickle')])
+        lengths, frame_shape, small = scene_index(scene)        # pass 1: trajectory lengths + the small arrays; no frame is kept
+        small = {k: np.concatenate(v) for k, v in small.items()}
+        n_samples = int(sum(lengths))
+        print('  ', '%d trajectories for a total of %d samples' % (len(lengths), n_samples))
+        print('  ', 'avg. return is', small['reward'].sum() / max(1, len(lengths)))
+        lo, hi = shard_bounds(n_samples, rank, world)
+        cover['range'] = (int(lo), int(hi))
+        if load_complete_shard(save_name, rank, cover) is None:
+            print('  ', 'passing observations through embedding model')
+            writer = ShardWriter(save_name, rank)
+            n_frames = max(frame_shape[2] // 3, 1) if frame_shape else 1
+            hip = hasattr(getattr(embedding_model, 'embedding', None), 'forward_into')
+            block = _block_rows(flags, int(np.prod(frame_shape)) if frame_shape else 1, batch)
+            pending, n_pending = [], [0]
+
+            def flush():
+                if not pending:
+                    return
+                obs = pending[0] if len(pending) == 1 else np.concatenate(pending)
+                del pending[:]
+                n_pending[0] = 0
+                if hip:
+                    # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU test), so
+                    # the per-batch split/stack/concat of save_embedded_obs.py:151-156 is reproduced by streaming each 3-channel
+                    # frame plane through the overlapped H2D/compute/D2H path and concatenating on features
+                    writer.append(np.concatenate([stream_embed(embedding_model, obs[..., 3 * f:3 * f + 3], batch) for f in range(n_frames)], axis=-1))
+                else:
+                    writer.append(embed_rows(embedding_model, obs, n_frames, max(1, batch // n_frames)))
+
+            def take(rows):                                    # rows: a view of one trajectory's buffer - keep a copy, embed per block
+                pending.append(np.array(rows))
+                n_pending[0] += len(rows)
+                if n_pending[0] >= block:
+                    flush()
+            if hi > lo:
+                scene_rows(scene, lo, hi, take)                 # pass 2: only this rank's rows are kept, one block at a time
+            flush()
+            writer.finish({k: small[k][lo:hi] for k in keys[1:]}, cover)
+        else:
+            print('  ', 'rank %d: shard %s is complete, nothing to embed' % (rank, os.path.basename(shard_name(save_name, rank))))
+    # every rank has written its own shard files; rank 0 stitches them in rank order (= the reference's row order): nothing but a
+    # barrier crosses ranks, and no rank ever holds another rank's rows (cfg 5: 125 GB of embeddings)
     if world > 1:
-        # every rank writes its own shard file; rank 0 stitches them in rank order (= the reference's row order): nothing but a
-        # barrier crosses ranks, and no rank ever holds another rank's rows in a collective buffer (cfg 5: 125 GB of embeddings)
-        with open(shard_name(save_name, rank), 'wb') as handle:
-            pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
         dist.barrier()
-        if rank != 0:
-            return
-        parts = []
-        for r in range(world):
-            with open(shard_name(save_name, r), 'rb') as handle:
-                parts.append(pickle.load(handle))
-        parts = [q for q in parts if len(q['reward']) > 0] or parts[:1]
-        data = {k: (sum((list(q[k]) for q in parts), []) if k == 'png' else np.concatenate([q[k] for q in parts])) for k in keys}
-    n_samples = len(data['reward'])
-    assert n_samples > 0, 'no data found'
-    print('  ', 'total number of samples', n_samples)
-    with open(save_name, 'wb') as handle:
-        pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
-    for r in range(world if world > 1 else 0):
-        os.remove(shard_name(save_name, r))
+    if rank == 0:
+        stitch_shards(save_name, world, keys)
 
 
 def shard_name(save_name, rank):

@@ -4,6 +4,7 @@ import os
 import pickle
 import subprocess
 import sys
+import time
 import numpy as np
 import pytest
 import torch
@@ -229,3 +230,133 @@ def test_native_file_reader(tmp_path):
             assert buf[off[i]:off[i + 1]].numpy().tobytes() == bytes([i]) * (i * 13 % 97) + b'x'
     with pytest.raises(Exception, match='missing.bin'):
         png_gpu.read_files(paths + [str(tmp_path / 'missing.bin')], 4)
+
+
+def _scene(rng, lens, hw=8, c=6):
+    trajs = [rng.integers(0, 255, (L, hw, hw, c), dtype=np.uint8) for L in lens]
+    return dict(obs=trajs, action=[rng.integers(0, 3, len(t)) for t in trajs], reward=[np.zeros(len(t)) for t in trajs],
+                done=[np.zeros(len(t), bool) for t in trajs], true_state=[np.zeros((len(t), 12)) for t in trajs])
+
+
+@pytest.mark.parametrize('protocol', [3, 4, 5])
+def test_scene_pickle_reads_row_ranges_without_holding_the_scene(tmp_path, protocol):
+    """scene_pickle: the per-scene pickle of save_opt_trajectories.py:100-106 read as (index pass, row-range pass) - same rows as
+    np.concatenate(data['obs'])[lo:hi] of the reference's loader (save_embedded_obs.py:29-47), with a peak of a few trajectories
+    instead of the whole file (what lets each of 8 ranks read only its slice of a 1 M-frame scene)."""
+    import tracemalloc
+    from pvr_habitat_amd import scene_pickle as SP
+    rng = np.random.default_rng(3)
+    raw = _scene(rng, (5, 9, 3, 7))
+    raw['obs'][2] = np.asfortranarray(raw['obs'][2])            # a non-contiguous block takes numpy's other pickle path
+    p = str(tmp_path / 's.pickle')
+    pickle.dump(raw, open(p, 'wb'), protocol=protocol)
+    rows = np.concatenate(raw['obs'])
+    lengths, frame_shape, small = SP.scene_index(p)
+    assert lengths == [5, 9, 3, 7] and frame_shape == (8, 8, 6)
+    for k in ('action', 'reward', 'done', 'true_state'):
+        np.testing.assert_array_equal(np.concatenate(small[k]), np.concatenate(raw[k]))
+    for lo, hi in ((0, 24), (3, 17), (14, 14), (20, 24), (5, 6), (0, 0)):
+        got = []
+        assert SP.scene_rows(p, lo, hi, lambda b: got.append(np.array(b))) == hi - lo
+        np.testing.assert_array_equal(np.concatenate(got) if got else rows[:0], rows[lo:hi])
+    big = _scene(rng, (150,) * 24, hw=64, c=6)                  # 24 x 3.7 MB of frames
+    p = str(tmp_path / 'big.pickle')
+    pickle.dump(big, open(p, 'wb'), protocol=protocol)
+    del big
+    tracemalloc.start()
+    SP.scene_index(p)
+    assert SP.scene_rows(p, 1000, 1400, lambda b: None) == 400
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < 0.25 * os.path.getsize(p), (peak, os.path.getsize(p))
+
+
+def test_stitch_shards_streams_rows_from_disk(tmp_path):
+    """Rank 0's stitch (save_embedded_obs.stitch_shards): shard row files -> the reference's single pickle through a file-backed
+    memmap; peak Python-side memory stays far below the size of the embedding matrix (round 2 concatenated every shard in RAM)."""
+    import tracemalloc
+    from pvr_habitat_amd import save_embedded_obs as S
+    save = str(tmp_path / 'scene_fake.pickle')
+    rng = np.random.default_rng(0)
+    parts = [rng.standard_normal((n, 2048)).astype(np.float32) for n in (3000, 0, 2500, 1700)]      # 59 MB in all; one empty rank
+    for r, rows in enumerate(parts):
+        w = S.ShardWriter(save, r)
+        for a in range(0, len(rows), 700):
+            w.append(rows[a:a + 700])
+        n = len(rows)
+        w.finish(dict(action=np.full(n, r), reward=np.zeros(n), done=np.zeros(n, bool), true_state=np.zeros((n, 12))), dict(rank=r, world=4))
+    want = np.concatenate(parts)
+    del parts
+    tracemalloc.start()
+    S.stitch_shards(save, 4, ('obs', 'action', 'reward', 'done', 'true_state'), copy_bytes=4 << 20)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < 0.25 * want.nbytes, (peak, want.nbytes)
+    out = pickle.load(open(save, 'rb'))
+    assert type(out['obs']) is np.ndarray and out['obs'].dtype == np.float32
+    np.testing.assert_array_equal(out['obs'], want)
+    np.testing.assert_array_equal(out['action'], np.concatenate([np.full(n, r) for r, n in enumerate((3000, 0, 2500, 1700))]))
+    assert sorted(os.listdir(tmp_path)) == ['scene_fake.pickle']
+
+
+_RESUME_WORKER = r'''
+import os, sys, pickle, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', rank=rank, world_size=int(os.environ['WORLD_SIZE']))
+import pvr_habitat_amd.save_embedded_obs as S
+calls = os.path.join(sys.argv[1], 'calls.rank%%d' %% rank)
+class Fake:                                    # stand-in embedder: deterministic function of the frame bytes; counts its calls on disk
+    out_size = 4
+    def __init__(self, *a, **k): pass
+    def state_dict(self): return {}
+    def __call__(self, t):
+        n = int(open(calls).read()) if os.path.isfile(calls) else 0
+        open(calls, 'w').write(str(n + 1))
+        if rank == 1 and os.environ.get('DIE_AT') and n + 1 >= int(os.environ['DIE_AT']):
+            os._exit(17)                       # the rank dies in the middle of its shard
+        x = t.numpy().astype(np.float32).reshape(t.shape[0], -1)
+        return np.stack([x.sum(1), x[:, 0], x[:, -1], x.mean(1)], 1).squeeze()
+S.EmbeddingNet = Fake
+flags = S.make_parser().parse_args(['--data_path', sys.argv[1], '--env', 'scene', '--embedding_name', 'fake', '--source', 'pickle',
+                                    '--embed_batch', '4', '--embed_block', '6'])
+S.run(flags)
+dist.barrier()
+'''
+
+
+def test_save_embedded_obs_resumes_after_a_rank_died(tmp_path):
+    """SURVEY section 5 / save_embedded_obs.py:97-101: rank 1 is killed in the middle of its shard (rank 0 is then stopped by the
+    launcher, as torch.distributed.run does).  The relaunch finds rank 0's finished shard and does NOT embed it again, rank 1
+    starts its shard over, and the stitched file equals a single-process run."""
+    rng = np.random.default_rng(5)
+    raw = _scene(rng, (11, 14, 9, 12))
+    pickle.dump(raw, open(tmp_path / 'scene.pickle', 'wb'))
+    script = tmp_path / 'worker.py'
+    script.write_text(_RESUME_WORKER % dict(root=ROOT))
+
+    def launch(port, **extra):
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **extra)
+            procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env))
+        return procs
+    p0, p1 = launch(29771, DIE_AT='3')
+    assert p1.wait(timeout=120) == 17
+    deadline = time.time() + 60
+    while not os.path.isfile(tmp_path / 'scene_fake.rank0.pickle') and time.time() < deadline:
+        time.sleep(0.1)                                         # rank 0 finishes its shard, then waits at the barrier for a dead peer
+    p0.kill()
+    p0.wait()
+    assert os.path.isfile(tmp_path / 'scene_fake.rank0.pickle') and not os.path.isfile(tmp_path / 'scene_fake.rank1.pickle')
+    assert not os.path.isfile(tmp_path / 'scene_fake.pickle')
+    calls0 = int(open(tmp_path / 'calls.rank0').read())
+    assert all(p.wait(timeout=120) == 0 for p in launch(29773))
+    assert int(open(tmp_path / 'calls.rank0').read()) == calls0          # rank 0 skipped its finished shard
+    out = pickle.load(open(tmp_path / 'scene_fake.pickle', 'rb'))
+    x = np.concatenate(raw['obs']).astype(np.float32)
+    want = np.concatenate([np.stack([f.reshape(len(f), -1).sum(1), f.reshape(len(f), -1)[:, 0], f.reshape(len(f), -1)[:, -1],
+                                     f.reshape(len(f), -1).mean(1)], 1) for f in (x[..., :3], x[..., 3:])], axis=1)
+    np.testing.assert_array_equal(out['obs'], want)
+    np.testing.assert_array_equal(out['action'], np.concatenate(raw['action']))
+    assert not [f for f in os.listdir(tmp_path) if '.rank' in f and not f.startswith('calls')]

@@ -216,20 +216,86 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch):
     assert all(torch.equal(finals[('0', '1')], v) for v in finals.values())
 
 
-@pytest.mark.parametrize('conv', [False, True])
-def test_policy_step_graph_replay_equals_eager_launches(monkeypatch, conv):
+def test_persistent_recurrence_timeout_reaches_the_host(monkeypatch):
+    """A wait of the persistent recurrence that runs out must not stay a silent NaN (missing item 2): with one block of the
+    grid removed (pvr_policy_debug_drop_block) every peer's bounded spin expires; the launch drains in about one timeout, the pinned
+    status word makes pvr_policy_status fail with PVR_ERR_TIMEOUT exactly once, the handle falls back to per-step launches, and those
+    reproduce the healthy persistent result bit for bit.  The same event also surfaces at the NEXT entry point (sticky check)."""
+    import time
+    from pvr_habitat_amd.models import _plib
+    monkeypatch.setenv('PVR_POLICY_PERSIST', '2')
+    T, B, O, A = 6, 4, 64, 3
+    obs, done, _ = synth.bc_batches(21, T, B, O, A, 1)
+    inp = dict(obs=torch.from_numpy(obs[0]), done=torch.from_numpy(done[0]))
+    for how in ('status', 'next_call'):
+        m, _ = _model(21, O, A, False, T, B)
+        m.eval()
+        good, _ = m(inp, m.initial_state(B))
+        torch.cuda.synchronize()
+        m.check_status()
+        assert m.recurrence_mode() == 2
+        _lib.check(_plib().pvr_policy_debug_drop_block(m._handle, 5))
+        t0 = time.time()
+        bad, _ = m(inp, m.initial_state(B))
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 60, 'a broken launch must drain in about one timeout'
+        assert not torch.isfinite(bad['policy_logits']).all()               # poisoned, never plausible numbers
+        _lib.check(_plib().pvr_policy_debug_drop_block(m._handle, -1))
+        with pytest.raises(RuntimeError, match='gave up waiting'):
+            if how == 'status':
+                m.check_status()
+            else:
+                m(inp, m.initial_state(B))
+        assert m.recurrence_mode() == 0
+        m.check_status()                                                    # reported once
+        again, _ = m(inp, m.initial_state(B))
+        torch.cuda.synchronize()
+        m.check_status()
+        assert torch.equal(again['policy_logits'], good['policy_logits']) and torch.equal(again['action'], good['action'])
+        m.close()
+
+
+def test_nan_observation_does_not_stall_the_data_as_flag_handoff(monkeypatch):
+    """An all-ones NaN (0xFFFFFFFF, the pre-fill pattern of the data-as-flag hand-off) in the input must propagate as an ordinary NaN:
+    h words are canonicalised before they are published, so no consumer mistakes them for "not written yet" (ADVICE round 2)."""
+    import time
+    monkeypatch.setenv('PVR_POLICY_PERSIST', '2')
+    T, B, O, A = 6, 4, 64, 3
+    obs, done, _ = synth.bc_batches(22, T, B, O, A, 1)
+    x = torch.from_numpy(obs[0]).clone()
+    x.view(torch.int32)[0, 1, :] = -1                                       # 0xFFFFFFFF
+    m, _ = _model(22, O, A, False, T, B)
+    m.eval()
+    t0 = time.time()
+    out, _ = m(dict(obs=x, done=torch.from_numpy(done[0])), m.initial_state(B))
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5
+    m.check_status()                                                        # no timeout
+    lg = out['policy_logits']
+    assert torch.isnan(lg[:, 1]).all() and torch.isfinite(lg[:, 0]).all() and torch.isfinite(lg[:, 2:]).all()
+    m.close()
+
+
+@pytest.mark.parametrize('conv,T,persist', [(False, 12, None), (True, 12, None), (False, 12, '2'), (False, 6, '2'), (True, 6, '2')])
+def test_policy_step_graph_replay_equals_eager_launches(monkeypatch, conv, T, persist):
     """pvr_policy_step replays a captured hipGraph from the third iteration on (eager, capture, replay...): parameters,
     optimizer state, BN buffers and per-step statistics must be bit-identical to eager launches (PVR_POLICY_GRAPH=0),
     also when the shape changes in between (re-capture) and when lr changes every step (device-side scalar)."""
     from pvr_habitat_amd.models import HipRMSprop
-    T, B, O, A, S = 12, 8, 256, 3, 6
+    B, O, A, S = 8, 256, 3, 6
     obs, done, act = synth.bc_conv_batches(5, T, B, S, A) if conv else synth.bc_batches(5, T, B, O, A, S)
+    if persist is not None:
+        # the data-as-flag hand-off must stay out of captured graphs whatever branch forward_core takes (T < 8: one launch per layer;
+        # T >= 8: chunked) - ADVICE round 2: it used to reach the capture through fwd_steps and drifted by 1e-3
+        monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
     results = []
     for graph in ("0", "1"):
         monkeypatch.setenv('PVR_POLICY_GRAPH', graph)
         m, _ = _model(5, O, A, True, T, B, conv)
         opt = HipRMSprop(m, max_epochs=50)
         m.train()
+        m._ensure(T, B)
+        assert m.recurrence_mode() != 2 if graph == "1" else (persist is None or m.recurrence_mode() == int(persist))
         stats = []
         for s in range(S):
             opt.scheduler_step()
