@@ -45,11 +45,22 @@ static void build_resnet50(pvr_encoder *e) {
     const int nblk[4] = {3, 4, 6, 3};
     e->resid32 = e->desc.dtype == PVR_F16 && arch != PVR_ARCH_RESNET50;
     if (const char *f = getenv("PVR_RESID32")) if (atoi(f) == 0) e->resid32 = false;
+    // Round 3: the fp32 residual stream alone left *_l3 at 9.75e-4 of a 1e-3 bound, and CPU emulation over three weight seeds
+    // (scripts/emulate_l3_rounding.py) puts that plan at 8.6e-4 ... 1.01e-3: one seed from red.  What gives real margin is the LAST
+    // trunk stage entirely in fp32 (fp32 weights, fp32 operands: conv_f32.hip, the kernels of the PVR_F32 mode) with the fp32
+    // residual stream starting at layer2: 5.6e-4 ... 6.4e-4 on the same seeds for *_l3, 6.3e-4 ... 6.7e-4 for *_l4 (16-bit weights alone cost ~6e-4
+    // at layer3, whatever the activations do).  That stage is 36 % (layer3) / 20 % (layer4) of the trunk's FLOPs at the f32-MFMA
+    // rate: the parity mode of the compressed PVRs pays for its margin in throughput (DESIGN.md section 2 has the numbers);
+    // PVR_TAIL_F32=0 restores round 2's plan, bf16 (the throughput mode) never uses either.
+    e->tail32 = e->resid32;
+    if (const char *f = getenv("PVR_TAIL_F32")) if (atoi(f) == 0) e->tail32 = false;
+    const int r32_from = e->tail32 ? 1 : 2;             // fp32 residual stream from layer2 on (emulated: *_l3 5.6e-4 ... 6.4e-4, *_l4 6.3e-4 ... 6.7e-4)
     int hw = 56, inpl = 64, x = B_X0, x32 = B_NONE;
     for (int li = 0; li < stages; ++li) {
         const int planes = 64 << li;
         const bool nested = (arch == PVR_ARCH_RESNET50_L4 && li == 3) || (arch == PVR_ARCH_RESNET50_L3 && li == 2);
-        const bool r32 = e->resid32 && li >= 2;
+        const bool r32 = e->resid32 && li >= r32_from;
+        const bool f32stage = e->tail32 && li == stages - 1;
         for (int bi = 0; bi < nblk[li]; ++bi) {
             char pfx[64];
             if (nested) snprintf(pfx, sizeof pfx, "layer%d.0.%d", li + 1, bi);
@@ -59,6 +70,28 @@ static void build_resnet50(pvr_encoder *e) {
             const int ohw = hw / stride;
             const int y = x == B_X0 ? B_X1 : B_X0;
             const bool last = (li == stages - 1 && bi == nblk[li] - 1);
+            char tn[16]; snprintf(tn, sizeof tn, "layer%d", li + 1);
+            if (f32stage) {
+                // every tensor of the block is fp32 (the 16-bit ping-pong buffers are large enough: the stage's activations are
+                // 1/4 ... 1/16 of layer1's elements); the block reads the fp32 stream directly
+                const size_t first = e->ops.size();
+                const int y32 = x32 == B_Y0 ? B_Y1 : B_Y0;
+                add_conv(e, p + ".conv1", p + ".bn1", x32, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
+                add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_T2, B_NONE, hw, hw, planes, planes, planes, planes, 3, stride, 1);
+                int res32 = x32;
+                if (bi == 0) {
+                    add_conv(e, p + ".downsample.0", p + ".downsample.1", x32, B_DS, B_NONE, hw, hw, inpl, inpl, planes * 4, planes * 4, 1, stride, 0, 1);
+                    res32 = B_DS;
+                }
+                add_conv(e, p + ".conv3", p + ".bn3", B_T2, y32, res32, ohw, ohw, planes, planes, planes * 4, planes * 4, 1, 1, 1, 1 | 2);
+                for (size_t i = first; i < e->ops.size(); ++i) e->ops[i].f32op = true;
+                if (bi == nblk[li] - 1) {
+                    e->ops.back().tap = tn;
+                    e->taps[tn] = {y32, {ohw, ohw, planes * 4, 1}};
+                }
+                x32 = y32; hw = ohw; inpl = planes * 4;
+                continue;
+            }
             add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
             add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_T2, B_NONE, hw, hw, planes, planes, planes, planes, 3, stride, 1);
             int res = r32 ? x32 : x;
@@ -67,11 +100,12 @@ static void build_resnet50(pvr_encoder *e) {
                          planes * 4, 1, stride, 0, r32 ? 1 : 0);
                 res = B_DS;
             }
-            char tn[16]; snprintf(tn, sizeof tn, "layer%d", li + 1);
             if (r32) {
                 const int y32 = x32 == B_Y0 ? B_Y1 : B_Y0;
                 add_conv(e, p + ".conv3", p + ".bn3", B_T2, y32, res, ohw, ohw, planes, planes, planes * 4, planes * 4, 1, 1, 1, 1 | 2);
-                if (!last) add_cast(e, y32, y, ohw, planes * 4);        // the head reads the fp32 stream itself
+                // the 16-bit copy feeds the next block's convolutions - unless that block is fp32 (it reads the stream itself), as the head does
+                const bool next_f32 = e->tail32 && li == stages - 2 && bi == nblk[li] - 1;
+                if (!last && !next_f32) add_cast(e, y32, y, ohw, planes * 4);
                 if (bi == nblk[li] - 1) {
                     e->ops.back().tap = tn;
                     e->taps[tn] = {y32, {ohw, ohw, planes * 4, 1}};
@@ -306,14 +340,19 @@ static pvr_status build_schedules(pvr_encoder *e) {
     for (int i = 0; i < n;) {
         ConvOp &op = e->ops[i];
         if (ends_with(op.conv, ".conv1") && conv1_done) { conv1_done = false; ++i; continue; }
-        int c3 = -1;
-        if (ends_with(op.conv, ".conv2") && op.k == 3 && op.cin == op.cout && op.cin_real == op.cin && op.cout_real == op.cout) {
-            c3 = i + 1;
-            if (c3 < n && ends_with(e->ops[c3].conv, ".downsample.0")) ++c3;
-            if (!(c3 < n && ends_with(e->ops[c3].conv, ".conv3") && e->ops[c3].cout == 4 * op.cout && e->ops[c3].relu &&
-                  !e->ops[c3].out_f32 && e->ops[c3].res_buf != B_NONE && chain_supported(op.cout, 0)))
-                c3 = -1;
-        }
+        // index of the conv3 that closes the chain starting at conv2 `j`, or -1 when that bottleneck does not run as a chain
+        auto chain_end = [&](int j) -> int {
+            if (j < 0 || j >= n) return -1;
+            const ConvOp &o2 = e->ops[j];
+            if (!(ends_with(o2.conv, ".conv2") && o2.k == 3 && o2.cin == o2.cout && o2.cin_real == o2.cin && o2.cout_real == o2.cout) || o2.f32op) return -1;
+            int c = j + 1;
+            if (c < n && ends_with(e->ops[c].conv, ".downsample.0")) ++c;
+            if (!(c < n && ends_with(e->ops[c].conv, ".conv3") && e->ops[c].cout == 4 * o2.cout && e->ops[c].relu &&
+                  !e->ops[c].out_f32 && e->ops[c].res_buf != B_NONE && chain_supported(o2.cout, 0)))
+                return -1;
+            return c;
+        };
+        const int c3 = chain_end(i);
         if (c3 < 0) {
             Launch l; l.conv2 = i;
             e->sched_fused.push_back(l);
@@ -335,9 +374,13 @@ static pvr_status build_schedules(pvr_encoder *e) {
         }
         if (l.ds < 0)
             for (int d = i + 1; d < c3; ++d) { Launch l2; l2.conv2 = d; e->sched_fused.push_back(l2); }   // the downsample runs first
+        // the next block's conv1 rides in this chain only if that block is a chain itself: the chain leaves t1' in the OTHER of the two
+        // t1 buffers (it reads one while it writes the next), which only a following chain knows to read (l.t1_in); a plain conv2 launch
+        // reads its own in_buf.  (Round 3: with the fp32 residual stream of the compressed PVRs' parity plan starting at layer2, layer1's
+        // last chain is followed by plain launches.)
         if (nx < n && ends_with(e->ops[nx].conv, ".conv1") && e->ops[nx].k == 1 && e->ops[nx].stride == 1 && e->ops[nx].relu &&
             e->ops[nx].cin == 4 * op.cout && e->ops[nx].in_buf == e->ops[c3].out_buf && e->ops[nx].cout_real == e->ops[nx].cout &&
-            chain_supported(op.cout, e->ops[nx].cout)) {
+            chain_supported(op.cout, e->ops[nx].cout) && chain_end(nx + 1) >= 0) {
             l.next1 = nx;
             l.t1_out = cur_t1 == B_T1 ? B_T2 : B_T1;
             cur_t1 = l.t1_out;

@@ -81,6 +81,7 @@ struct pvr_encoder {
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
     bool low_latency = false;                       // pvr_encoder_set_low_latency: split-K plan for forwards of <= 4 frames
     float *d_smallk[PVR_MAX_LANES] = {nullptr};     // its fp32 partial planes, per lane (allocated on first use)
+    bool tail32 = false;                            // round 3: + the last trunk stage entirely in fp32 (conv_f32.hip), fp32 stream one stage earlier
     bool resid32 = false;                           // compressed PVRs, f16: fp32 residual stream from layer3 on + fp32 compression head
     bool finalized = false;
     int out_size = 0;

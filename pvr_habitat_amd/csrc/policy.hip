@@ -57,6 +57,13 @@ struct pvr_policy {
     // every entry point looks at the word on the way in (sticky: the error surfaces at the next call, or at pvr_policy_status after the
     // caller's own sync), returns PVR_ERR_TIMEOUT once, and the handle then stays on per-step launches (persist_tripped).
     int persist_fits = 0, persist_tripped = 0, debug_drop_block = -1;
+    // persistent BPTT (lstm_bwd_seq_kernel, round 3; OPT-IN, PVR_POLICY_PERSIST_BWD=1): both layers' recurrences of one chunk wave in
+    // ONE launch (2 x 256 blocks), two in-kernel hand-offs per step.  dGx = hand-off copy of the gate gradients (pre-filled per launch),
+    // Px = armed ring of partials.  Bit-identical to the launches (tests) but SLOWER on MI355X: a cross-XCD hand-off costs ~3.5 us, two
+    // per step plus the arithmetic come to ~14.5 us against 11.7 us for the wavefronted pair of launches (212 vs 233 steps/s) - a BPTT
+    // step needs two grid-wide exchanges where the forward step needs one (profiles/experiments/r03_bc_persistent_bptt.txt).
+    int persist_bwd = 0, persist_bwd_fits = 0;
+    float *dGx[2] = {nullptr, nullptr}, *Px[2] = {nullptr, nullptr};
     unsigned *status_host = nullptr, *status_dev = nullptr;
     float *logits = nullptr, *baseline = nullptr, *dlogits = nullptr, *loss_row = nullptr, *stats = nullptr, *partial = nullptr;
     long long *action = nullptr;
@@ -503,9 +510,28 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         c.B = B; c.H = H;
         return c;
     };
-    if (pol->chunkwave && NCH > 1) {
+    // persistent BPTT: the chunk waves below, each as ONE launch (both layers' step ranges as the two jobs of lstm_bwd_seq_kernel)
+    const bool bwd_persist = pol->persist_bwd && pol->persist_bwd_fits && pol->dGx[0] && !pol->persist_tripped && !pol->use_graph &&
+                             pol->persist == 2 && pol->chunkwave && H == 1024 && B <= 64 && T > 1;
+    if (pol->chunkwave && (NCH > 1 || bwd_persist)) {
         // chunk index c descending; launch pair s: layer 1 at the s-th step (from the top) of chunk c, layer 0 at the s-th of chunk c+1
         for (int c = NCH - 1; c >= -1; --c) {
+            if (bwd_persist) {
+                LstmBwdSeqP q = {};
+                q.nd = pol->nd; q.T = T; q.B = B; q.H = H; q.drop_block = pol->debug_drop_block; q.status = pol->status_dev;
+                const float *dh_of[2] = {dh0, dh1};
+                for (int l = 0; l < 2; ++l) {
+                    const int cc = l == 1 ? c : c + 1;              // layer 1 works on chunk c, layer 0 on the chunk behind it
+                    LstmBwdJob &jb = q.j[l];
+                    jb.t_lo = cc * CH; jb.t_hi = (cc + 1) * CH < T ? (cc + 1) * CH : T;
+                    jb.active = cc >= 0 && cc < NCH && jb.t_hi > jb.t_lo;
+                    if (!jb.active) continue;
+                    jb.G = pol->G[l]; jb.dGx = pol->dGx[l]; jb.Px = pol->Px[l]; jb.W = P + pol->o_whh[l]; jb.dh_ext = dh_of[l];
+                    jb.Cs = pol->Cs[l]; jb.c0 = pol->zeros; jb.dc_carry = scr_dc[l];
+                    PVR_HIP_TRY(hipMemsetAsync(pol->dGx[l] + (size_t)jb.t_lo * B * 4 * H, 0xFF, (size_t)(jb.t_hi - jb.t_lo) * B * 4 * H * sizeof(float), st));
+                }
+                if (q.j[0].active || q.j[1].active) hipLaunchKernelGGL(lstm_bwd_seq_kernel, dim3(256, 2), dim3(256), 0, st, q);
+            } else
             for (int s_ = 0; s_ < CH; ++s_) {
                 const int hi1 = (c + 1) * CH < T ? (c + 1) * CH : T, hi0 = (c + 2) * CH < T ? (c + 2) * CH : T;
                 const int ta = hi1 - 1 - s_, tb = hi0 - 1 - s_;          // layer 1 step, layer 0 step
@@ -582,13 +608,33 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     TRY(gemm(dz2, pol->a1, nullptr, nullptr, Gd + pol->o_fc2w, H, H, N, true, true, 0, st));
     TRY(colsum(dz2, Gd + pol->o_fc2b, nullptr, N, H, st));
     TRY(gemm(dz2, P + pol->o_fc2w, nullptr, pol->a1, dz1, N, H, H, false, true, 0, st));      // masked by a1 > 0
+    const bool need_dobs = d.conv_frames > 0;
+    // PolicyNet with BatchNorm: the affine gradients come out of the fc1 weight-gradient GEMM itself (bn_fold_grads_kernel), without
+    // the [N][O] product dz1 W1 (PVR_POLICY_BN_FOLD=0: round 2's path through da0)
+    static const bool bn_fold_on = [] { const char *e = getenv("PVR_POLICY_BN_FOLD"); return !e || atoi(e) != 0; }();
+    const bool bn_fold = d.batch_norm && !need_dobs && bn_fold_on && O % 128 == 0 && H % 64 == 0;
+    if (bn_fold) {
+        float *xhat = pol->da0;                                                    // (free: nothing needs d(loss)/d(a0) on this path)
+        hipLaunchKernelGGL(bn_xhat_kernel, dim3(blocks_for((size_t)N * O / 4)), dim3(256), 0, st, obs, pol->bn_mean, pol->bn_invstd, xhat, (size_t)N * O / 4, O);
+        TRY(gemm(dz1, xhat, nullptr, nullptr, Gd + pol->o_fc1w, H, O, N, true, true, 0, st));         // S = dz1^T xhat
+        TRY(colsum(dz1, Gd + pol->o_fc1b, nullptr, N, H, st));
+        constexpr int RPG = 64;
+        const int G = (H + RPG - 1) / RPG;
+        float *part;
+        TRY(col_scratch((size_t)2 * G * O, &part));
+        hipLaunchKernelGGL(bn_fold_grads_kernel, dim3(O / 128, G), dim3(256), 0, st, Gd + pol->o_fc1w, P + pol->o_fc1w, Gd + pol->o_fc1b, P + pol->o_bnw,
+                           P + pol->o_bnb, part, H, O, RPG);
+        hipLaunchKernelGGL(colfinal_kernel<1>, dim3((O + 255) / 256), dim3(256), 0, st, part, Gd + pol->o_bnw, Gd + pol->o_bnb, G, O);
+        PVR_LAUNCH_CHECK();
+        TRY(dp_bucket(pol, Gd, b_fc, b_l0 - b_fc, 2, st));
+    } else {
     TRY(gemm(dz1, x0, nullptr, nullptr, Gd + pol->o_fc1w, H, O, N, true, true, 0, st));
     TRY(colsum(dz1, Gd + pol->o_fc1b, nullptr, N, H, st));
     TRY(dp_bucket(pol, Gd, b_fc, b_l0 - b_fc, 2, st));
-    const bool need_dobs = d.conv_frames > 0;
-    if (d.batch_norm || need_dobs) TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
+    }
+    if (!bn_fold && (d.batch_norm || need_dobs)) TRY(gemm(dz1, P + pol->o_fc1w, nullptr, nullptr, pol->da0, N, O, H, false, true, 0, st));
     const float *dfeat = pol->da0;
-    if (d.batch_norm) {
+    if (d.batch_norm && !bn_fold) {
         ColP c = {};
         c.X = obs; c.dY = pol->da0; c.mean_in = pol->bn_mean; c.invstd_in = pol->bn_invstd;
         c.out0 = Gd + pol->o_bnw; c.out1 = Gd + pol->o_bnb; c.R = N; c.C = O;
@@ -777,7 +823,21 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
         if (he == hipSuccess) he = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_fwd_seq_kernel, 256, 0);
         p->persist_fits = he == hipSuccess && (long long)per_cu * cus >= desc->hidden / 4;
+        int per_cu_b = 0;
+        if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, lstm_bwd_seq_kernel, 256, 0);
+        p->persist_bwd_fits = he == hipSuccess && (long long)per_cu_b * cus >= 2 * 256 && desc->hidden == 1024;
         (void)hipGetLastError();
+    }
+    if (const char *e = getenv("PVR_POLICY_PERSIST_BWD")) p->persist_bwd = atoi(e) != 0;
+    if (!s && p->persist_bwd && p->persist_bwd_fits && p->persist == 2) {
+        for (int l = 0; l < 2 && !s; ++l) {
+            const size_t px = (size_t)2 * 16 * B * desc->hidden;
+            if (hipMalloc((void **)&p->dGx[l], N * 4 * desc->hidden * sizeof(float)) != hipSuccess ||
+                hipMalloc((void **)&p->Px[l], px * sizeof(float)) != hipSuccess ||
+                hipMemset(p->Px[l], 0xFF, px * sizeof(float)) != hipSuccess) {              // the ring starts fully armed
+                set_error("policy: allocation of the persistent-BPTT hand-off buffers failed"); s = PVR_ERR_HIP;
+            }
+        }
     }
     if (!s && p->pipeline) {
         hipError_t he = hipStreamCreateWithFlags(&p->lane_a, hipStreamNonBlocking);
@@ -806,6 +866,7 @@ void pvr_policy_destroy(pvr_policy *p) {
     for (int i = 0; i < 8; ++i) if (p->ev_chunk[i]) (void)hipEventDestroy(p->ev_chunk[i]);
     drop_graph(p);
     if (p->status_host) (void)hipHostFree(p->status_host);
+    for (int l = 0; l < 2; ++l) { if (p->dGx[l]) (void)hipFree(p->dGx[l]); if (p->Px[l]) (void)hipFree(p->Px[l]); }
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
     for (hipEvent_t ev : p->ev_ready) if (ev) (void)hipEventDestroy(ev);

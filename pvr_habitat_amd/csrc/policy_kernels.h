@@ -133,7 +133,7 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu) v = v < 0.f ? 0.f : v;                      // (not fmaxf: torch's ReLU hands a NaN on, fmaxf(NaN, 0) = 0 would hide it)
                 if (p.mask && p.mask[(size_t)m * p.ldc + n] <= 0.f) v = 0.f;
                 p.C[(size_t)m * p.ldc + n] = v;
             }
@@ -147,7 +147,7 @@ static __global__ __launch_bounds__(256) void splitk_sum_kernel(const float *__r
         float v = 0.f;
         for (int s_ = 0; s_ < S; ++s_) v += part[(size_t)s_ * n + i];
         if (bias) v += bias[i % N];
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu) v = v < 0.f ? 0.f : v;
         if (mask && mask[i] <= 0.f) v = 0.f;
         out[i] = v;
     }
@@ -278,6 +278,55 @@ static __global__ __launch_bounds__(256) void colfinal_kernel(const float *__res
     for (int g = 0; g < G; ++g) { t0 += part[(size_t)g * C + c]; if (TWO) t1 += part[(size_t)(G + g) * C + c]; }
     out0[c] = t0;
     if (TWO) out1[c] = t1; else if (out1) out1[c] = t0;
+}
+
+// BatchNorm1d affine gradients without d(loss)/d(a0) (PolicyNet: nothing below the BatchNorm needs a gradient, so the [N][O] product
+// dz1 W1 - 13.4 GFLOP at obs 4096, more than 6 % of the iteration - only ever fed two column sums).  With a0 = gamma * xhat + beta:
+//     S      = dz1^T xhat                       (the fc1 weight-gradient GEMM, on xhat instead of a0: same cost)
+//     dW1    = gamma * S + beta * db1^T         (db1 = column sums of dz1 = the fc1 bias gradient)
+//     dgamma = sum_j W1[j][c] * S[j][c]         dbeta = sum_j W1[j][c] * db1[j]
+// (sum_r (dz1 W1)[r][c] xhat[r][c] = sum_j W1[j][c] sum_r dz1[r][j] xhat[r][c]; no division by gamma anywhere.)
+// bn_xhat_kernel writes xhat; bn_fold_grads_kernel turns S into dW1 in place and emits the per-row-group partials of the two sums
+// (row groups summed in ascending order by colfinal_kernel<1>: fixed order).
+static __global__ __launch_bounds__(256) void bn_xhat_kernel(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                      float *__restrict__ xhat, size_t total4, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % (size_t)C);
+        const f32x4 xv = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), is = *reinterpret_cast<const f32x4 *>(invstd + c);
+        reinterpret_cast<f32x4 *>(xhat)[i] = (xv - mu) * is;
+    }
+}
+// grid (C / 128, G row groups of rpg rows); S_dW [R][C] in: S, out: dW1
+static __global__ __launch_bounds__(256) void bn_fold_grads_kernel(float *__restrict__ S_dW, const float *__restrict__ W1, const float *__restrict__ db1,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ part,
+                                                            int R, int C, int rpg) {
+    __shared__ f32x4 s0[8][33], s1[8][33];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cq) * 4, g = blockIdx.y;
+    const bool ok = c < C;
+    const int r0 = g * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c), be = *reinterpret_cast<const f32x4 *>(beta + c);
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(S_dW + (size_t)r * C + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(W1 + (size_t)r * C + c);
+            const float d = db1[r];
+            a0 += wv * sv;
+            a1 += wv * d;
+            *reinterpret_cast<f32x4 *>(S_dW + (size_t)r * C + c) = ga * sv + be * d;
+        }
+    }
+    s0[rl][cq] = a0; s1[rl][cq] = a1;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0 += s0[i][cq]; t1 += s1[i][cq]; }
+        *reinterpret_cast<f32x4 *>(part + (size_t)g * C + c) = t0;
+        *reinterpret_cast<f32x4 *>(part + (size_t)(gridDim.y + g) * C + c) = t1;
+    }
 }
 
 // y = (x - mean) * invstd * gamma + beta  (training: batch stats; eval: running stats, invstd computed here)
@@ -626,6 +675,26 @@ static __global__ __launch_bounds__(256) void lstm_bwd_rec2_kernel(LstmRec2P pp)
     lstm_bwd_rec_body(pp.j[blockIdx.y]);
 }
 
+// Gate gradients of one (batch row, unit) at one step - the arithmetic of autograd's LSTM cell backward, written ONCE for the per-step
+// kernel and the persistent one: contraction is switched off and the fused multiply-adds are spelled out, so both kernels (and every
+// future one) round identically whatever code surrounds the inlined body (hipcc contracts a*b+c opportunistically per context: the
+// first persistent build differed from the launches in the last bit of a handful of products).
+struct CellGrad { float d0, d1, d2, d3, dc; };
+static __device__ __forceinline__ CellGrad lstm_cell_grad(float ig, float fg, float gg, float og, float ct, float cprev, float ndt, float dh, float dc_in) {
+#pragma clang fp contract(off)
+    const float tc = tanhf(ct);
+    const float cm = ndt * cprev;
+    const float dog = dh * tc * og * (1.f - og);
+    const float dcc = __builtin_fmaf(dh * og, __builtin_fmaf(-tc, tc, 1.f), dc_in);
+    CellGrad r;
+    r.d0 = dcc * gg * ig * (1.f - ig);
+    r.d1 = dcc * cm * fg * (1.f - fg);
+    r.d2 = dcc * ig * __builtin_fmaf(-gg, gg, 1.f);
+    r.d3 = dog;
+    r.dc = ndt * dcc * fg;
+    return r;
+}
+
 struct LstmCellBP {
     const float *partial, *nd_next, *dh_ext;      // [16][B][H] (nullptr at t = T-1), [B], [B][H]
     float *dc_carry, *G;                          // [B][H] in/out, [B][4H] gates in / dG out
@@ -643,20 +712,16 @@ static __device__ __forceinline__ void lstm_bwd_cell_body(const LstmCellBP &p) {
         float s = 0.f;
 #pragma unroll
         for (int kg = 0; kg < 16; ++kg) s += p.partial[((size_t)kg * p.B + bi) * H + u];
-        dh += p.nd_next[bi] * s;
+        dh = __builtin_fmaf(p.nd_next[bi], s, dh);
         dc_in = p.dc_carry[i];
     }
     float *g = p.G + (size_t)bi * 4 * H + u;
-    const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
-    const float tc = tanhf(p.c_t[i]);
-    const float cm = p.nd[bi] * p.c_prev[i];
-    const float dog = dh * tc * og * (1.f - og);
-    const float dc = dh * og * (1.f - tc * tc) + dc_in;
-    g[0] = dc * gg * ig * (1.f - ig);
-    g[H] = dc * cm * fg * (1.f - fg);
-    g[2 * H] = dc * ig * (1.f - gg * gg);
-    g[3 * H] = dog;
-    p.dc_carry[i] = p.nd[bi] * dc * fg;
+    const CellGrad r = lstm_cell_grad(g[0], g[H], g[2 * H], g[3 * H], p.c_t[i], p.c_prev[i], p.nd[bi], dh, dc_in);
+    g[0] = r.d0;
+    g[H] = r.d1;
+    g[2 * H] = r.d2;
+    g[3 * H] = r.d3;
+    p.dc_carry[i] = r.dc;
 }
 
 static __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(LstmCellBP p) { lstm_bwd_cell_body(p); }
@@ -664,6 +729,215 @@ struct LstmCellB2P { LstmCellBP j[2]; int active[2]; };
 static __global__ __launch_bounds__(256) void lstm_bwd_cell2_kernel(LstmCellB2P pp) {
     if (!pp.active[blockIdx.y]) return;
     lstm_bwd_cell_body(pp.j[blockIdx.y]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent BPTT (round 3): ONE launch runs steps t_hi-1 ... t_lo of up to two independent jobs (blockIdx.y: layer 1 on one chunk of
+// the sequence, layer 0 on the chunk behind it - the chunked layer wavefront of the per-step launches, 2 x 256 blocks, co-resident).
+// Per job the 256 blocks keep the 2-D partition of lstm_bwd_rec_kernel (kg = 16 k-groups x ug = 16 unit-groups; the block's 256 x 64
+// slab of W_hh stays in registers for the whole range) and a step is two grid-wide hand-offs inside the kernel instead of two
+// launches (~11 us per wavefronted pair of launches before):
+//   phase 1  partial[kg][b][u0..u0+63] = sum_{k in group kg} dG[t+1][b][k] W_hh[k][u]    (same MFMA chain / LDS reduce as the launch)
+//   phase 2  the block ALSO owns the cell update of units u0 + 4 kg .. +3 (all batch rows): dh = dh_ext + nd[t+1] * sum_kg partial
+//            (fixed kg order), gate gradients, dc carry in a register
+// Same arithmetic per element as lstm_bwd_rec_kernel + lstm_bwd_cell_kernel: bit-identical.  Hand-offs use the data-as-flag scheme of
+// lstm_fwd_seq_kernel (sc1 write-through stores, sc1 polling loads, 0xFFFFFFFF = "not written yet", NaNs canonicalised on publish):
+//   * dG[t] goes to G in place (plain stores: the weight-gradient GEMMs of later launches read it) AND to dGx[t], a hand-off copy whose
+//     range [t_lo, t_hi) the host pre-fills before the launch; phase 1 of step t polls dGx[t+1] (16 consumers per word: no re-arming);
+//     the first step of a launch reads G[t+1], which an earlier launch finished;
+//   * the partials live in a two-slot ring Px[t & 1]; every word has exactly ONE consumer, which re-arms it (stores 0xFFFFFFFF) right
+//     after reading.  vmcnt retires vector-memory operations in issue order, so by the time the consumer has USED the polling loads of
+//     step t-1 (issued after the re-arming stores of step t) those stores have completed; dG[t-1] is published after that, and the
+//     producer's next write to the slot (step t-2) causally follows that publication: a re-arm never lands on top of new data.
+//     The ring is fully armed whenever no launch is in flight (armed at create; every word written is consumed).
+// Bounded spins, status word and NaN poisoning as in the forward kernel.
+// ---------------------------------------------------------------------------------------------------------
+struct LstmBwdJob {
+    float *G;                  // [T][B][4H]: activated gates in, dG out (in place)
+    float *dGx;                // [T][B][4H]: hand-off copy of dG
+    float *Px;                 // [2][16][B][H]: ring of the partial products of phase 1
+    const float *W;            // [4H][H]
+    const float *dh_ext;       // [T][B][H]: d(loss)/d(h_t) arriving from above
+    const float *Cs, *c0;      // [T][B][H] cell states, [B][H] state before t = 0 (zeros)
+    float *dc_carry;           // [B][H]: carry across launches (read unless the range starts at T-1, written at the end)
+    int t_lo, t_hi, active;
+};
+struct LstmBwdSeqP {
+    LstmBwdJob j[2];
+    const float *nd;           // [T][B]
+    int T, B, H, drop_block;
+    unsigned *status;
+};
+
+static __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmBwdSeqP pp) {
+    const LstmBwdJob &p = pp.j[blockIdx.y];
+    if (!p.active || (int)blockIdx.x == pp.drop_block) return;
+    __shared__ float part[4][4][16][17];
+    __shared__ __attribute__((aligned(16))) float gstage[64][4][4];        // [batch row][gate][unit]
+    __shared__ int dead_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int H = pp.H, K = 4 * pp.H, B = pp.B, T = pp.T;
+    const int kg = blockIdx.x >> 4, ug = blockIdx.x & 15;
+    const int u0 = ug * (H / 16), kbeg = kg * (K / 16) + wave * (K / 64);         // 64 units, 256 k per block, 64 k per wave
+    if (tid == 0) dead_s = 0;
+    __syncthreads();
+    // the wave's 64 x 64 weight slab, for the whole range: lane (fr, fq) holds W[kbeg + 16 c + 4 fq + e1][u0 + 4 fr .. + 3]
+    f32x4 w[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) w[c][e1] = *reinterpret_cast<const f32x4 *>(p.W + (size_t)(kbeg + c * 16 + fq * 4 + e1) * H + u0 + fr * 4);
+    // cell ownership: thread (cb, cj) updates unit cu of batch row cb at every step
+    const int cb = tid >> 2, cj = tid & 3, cu = u0 + kg * 4 + cj;
+    const bool cok = cb < B;
+    float dc = (cok && p.t_hi - 1 < T - 1) ? p.dc_carry[(size_t)cb * H + cu] : 0.f;
+    bool dead = false;                                                            // this wave's spin ran out once (wave-uniform)
+    const unsigned ARM = 0xffffffffu;
+    for (int t = p.t_hi - 1; t >= p.t_lo; --t) {
+        const bool has_next = t < T - 1;
+        // operands of the cell update: plain loads of data earlier launches finished.  vmcnt is ONE in-order queue: a polling load issued
+        // behind them cannot return before they have, so they are requested right after phase 1's poll has succeeded (they then travel
+        // under the MFMA chain and the second hand-off), not in front of it (an HBM miss per step on the critical path, measured)
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cprev = 0.f, ndt = 0.f, dhe = 0.f, ndn = 0.f;
+        float *gp = p.G + ((size_t)t * B + (cok ? cb : 0)) * K + cu;
+        auto fetch_cell = [&]() {
+            if (cok) {
+                ig = gp[0]; fg = gp[H]; gg = gp[2 * H]; og = gp[3 * H];
+                ct = p.Cs[((size_t)t * B + cb) * H + cu];
+                cprev = t == 0 ? p.c0[(size_t)cb * H + cu] : p.Cs[((size_t)(t - 1) * B + cb) * H + cu];
+                ndt = pp.nd[(size_t)t * B + cb];
+                dhe = p.dh_ext[((size_t)t * B + cb) * H + cu];
+                if (has_next) ndn = pp.nd[(size_t)(t + 1) * B + cb];
+            }
+        };
+        if (!has_next) fetch_cell();
+        float s = 0.f;
+        if (has_next) {
+            const bool polled = t + 1 < p.t_hi;                                   // produced inside this launch: hand-off copy, sc1
+            const float *src = (polled ? p.dGx : p.G) + (size_t)(t + 1) * B * K;
+            const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (unsigned)((size_t)B * K * 4), 0x00020000);
+            float *slot = p.Px + (size_t)(t & 1) * 16 * B * H;
+            const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(slot, 0, (unsigned)((size_t)16 * B * H * 4), 0x00020000);
+            // ---- phase 1 ----
+            for (int b0 = 0; b0 < B; b0 += 16) {
+                const int b = b0 + fr;
+                const bool bok = b < B;
+                const int goff = ((bok ? b : 0) * K + kbeg + fq * 4) * 4;
+                f32x4 a[4];
+                if (polled) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, goff, c * 64, 16));
+                    if (!dead) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            bool written = true;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const u32x4 q = __builtin_bit_cast(u32x4, a[c]);
+                                written = written & (q[0] != ARM) & (q[1] != ARM) & (q[2] != ARM) & (q[3] != ARM);
+                            }
+                            if (__all(written || !bok)) break;
+                            if (++spins > LSTM_SEQ_SPINS) {
+                                dead = true; dead_s = 1;
+                                if (lane == 0) __hip_atomic_store(pp.status, LSTM_SEQ_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, goff, c * 64, 16));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, goff, c * 64, 0));
+                }
+                if (b0 == 0) fetch_cell();
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float bmask = bok ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a[c] *= bmask;
+#pragma unroll
+                    for (int e1 = 0; e1 < 4; ++e1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = mfma_f32(a[c][e1], w[c][e1][e], acc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[wave][e][fq * 4 + r][fr] = acc[e][r];
+                __syncthreads();
+                // 16 batch rows x 64 units; thread: row bb = tid >> 4, four consecutive units 4 jq .. + 3 -> one 16-byte store
+                {
+                    const int bb = tid >> 4, jq = tid & 15;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = (part[0][e][bb][jq] + part[1][e][bb][jq]) + (part[2][e][bb][jq] + part[3][e][bb][jq]);
+                        v[e] = (dead_s || x != x) ? __builtin_nanf("") : x;
+                    }
+                    if (b0 + bb < B)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_p, ((kg * B + b0 + bb) * H + u0 + jq * 4) * 4, 0, 16);
+                }
+                __syncthreads();
+            }
+            // ---- phase 2: the 16 partials of (cb, cu), summed in kg order; every word is re-armed by its one reader ----
+            float pv[16];
+            const int poff = ((cok ? cb : 0) * H + cu) * 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_p, poff, q * B * H * 4, 16));
+            if (!dead) {
+                unsigned spins = 0;
+                for (;;) {
+                    bool written = true;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) written = written & (__builtin_bit_cast(unsigned, pv[q]) != ARM);
+                    if (__all(written || !cok)) break;
+                    if (++spins > LSTM_SEQ_SPINS) {
+                        dead = true; dead_s = 1;
+                        if (lane == 0) __hip_atomic_store(pp.status, LSTM_SEQ_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_p, poff, q * B * H * 4, 16));
+                }
+            }
+            if (cok) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) __builtin_amdgcn_raw_buffer_store_b32(ARM, rs_p, poff + q * B * H * 4, 0, 16);      // (offset in voffset: soffset stays 0 for stores)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += pv[q];
+            }
+        }
+        // ---- cell update (lstm_cell_grad: the per-step kernel's arithmetic, element for element) ----
+        if (cok) {
+            const float dh = has_next ? __builtin_fmaf(ndn, s, dhe) : dhe;
+            const CellGrad r = lstm_cell_grad(ig, fg, gg, og, ct, cprev, ndt, dh, has_next ? dc : 0.f);
+            dc = r.dc;
+            gp[0] = r.d0; gp[H] = r.d1; gp[2 * H] = r.d2; gp[3 * H] = r.d3;
+            const bool bad = dead_s != 0;
+            gstage[cb][0][cj] = (bad || r.d0 != r.d0) ? __builtin_nanf("") : r.d0;
+            gstage[cb][1][cj] = (bad || r.d1 != r.d1) ? __builtin_nanf("") : r.d1;
+            gstage[cb][2][cj] = (bad || r.d2 != r.d2) ? __builtin_nanf("") : r.d2;
+            gstage[cb][3][cj] = (bad || r.d3 != r.d3) ? __builtin_nanf("") : r.d3;
+        }
+        // No drain is needed for the re-arming stores: vmcnt retires in issue order, and the NEXT step's polling loads - issued after
+        // them - have returned before that step's dG is published, which is what the producer's next write to the slot (two steps on)
+        // causally follows.  (The slot re-armed at the launch's last step is next written by a later launch: kernel boundary.)
+        __syncthreads();
+        if (t > p.t_lo && tid < 4 * B) {                                           // (nobody in this launch reads dGx[t_lo])
+            const int pb = tid >> 2, pg = tid & 3;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&gstage[pb][pg][0]);
+            const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.dGx + (size_t)t * B * K, 0, (unsigned)((size_t)B * K * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, (pb * K + pg * H + u0 + kg * 4) * 4, 0, 16);
+        }
+        __syncthreads();                                                           // gstage / part are reused by the next step
+    }
+    if (cok) p.dc_carry[(size_t)cb * H + cu] = dc;
 }
 
 // Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh

@@ -153,6 +153,7 @@ class _PolicyFunction(torch.autograd.Function):
 
 class PolicyNet(nn.Module):
     _conv_frames = 0
+    _stats_groups = {}              # id(gradient process group) -> the SyncBN statistics group over the same ranks (one per process)
 
     def __init__(self, observation_shape, num_actions, batch_norm=False, max_unroll=100, max_batch=32):
         super(PolicyNet, self).__init__()
@@ -353,7 +354,16 @@ class PolicyNet(nn.Module):
         if getattr(self, '_dp_key', None) == key:
             return world
         if world > 1:
-            self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda')       # (the ctypes thunk must stay alive while installed)
+            stats_group = None
+            if sync:
+                # SyncBN statistics travel on their own process group (own RCCL communicator / stream): see make_allreduce_fn.  new_group
+                # is itself a collective over the default group - every rank reaches this line at its first data-parallel step.
+                cache = PolicyNet._stats_groups
+                if id(group) not in cache:
+                    ranks = dist.get_process_group_ranks(group) if group is not None else None
+                    cache[id(group)] = dist.new_group(ranks=ranks)
+                stats_group = cache[id(group)]
+            self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda', stats_group)       # (the ctypes thunk must stay alive while installed)
             _lib.check(_plib().pvr_policy_set_data_parallel(self._handle, world, int(sync), self._dp_cb, None))
         else:
             _lib.check(_plib().pvr_policy_set_data_parallel(self._handle, 1, 0, ALLREDUCE_FN(), None))
@@ -394,13 +404,17 @@ class _DevMem(object):
         self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
 
 
-def make_allreduce_fn(group=None, device='cuda'):
+def make_allreduce_fn(group=None, device='cuda', stats_group=None):
     """The collective libpvr_hip.so calls for data-parallel training (pvr_allreduce_fn, include/pvr_policy.h): an in-place SUM
     all-reduce of `count` floats at `buf`, enqueued on the HIP stream the library names - its communication stream for the
     gradient buckets, the compute stream for SyncBN statistics.  torch.distributed under backend "nccl" is RCCL over xGMI;
     "gloo" (CPU tests, or ranks sharing one GPU) works too.  ctypes would print and swallow an exception raised inside the
     callback, so it is caught here, kept in `errors`, and turned into a non-zero status: the library entry point then fails
     with PVR_ERR_COMM and the caller re-raises the original exception.
+    stats_group: a second process group over the same ranks for the collectives the library issues on its COMPUTE stream (SyncBN
+    statistics: 2 x obs_size floats that the very next kernel needs).  A torch process group owns one RCCL stream per device, so on a
+    single group such a 2 KB all-reduce queues behind the 33 MB gradient bucket enqueued just before it and the compute stream waits
+    for the whole transfer it was meant to overlap with; its own group = its own communicator and stream.
     Returns (ctypes thunk - keep it alive while installed -, errors list)."""
     import torch.distributed as dist
     errors, streams = [], {}
@@ -411,7 +425,7 @@ def make_allreduce_fn(group=None, device='cuda'):
                 t = torch.as_tensor(_DevMem(buf, count), device='cuda')
                 sp = int(stream or 0)
                 if sp == torch.cuda.current_stream().cuda_stream:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=stats_group if stats_group is not None else group)
                 else:
                     if sp not in streams:
                         streams[sp] = torch.cuda.ExternalStream(sp)

@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) per kernel, with the gfx950 corrections
 of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB; FETCH_SIZE reports 1/2 of the bytes of
 wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact for 16 B/lane stores.
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv>"""
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json [plan.json from bench.py --dump-plan [label]]]"""
 import csv, sys, collections, json
 
 def load(path, name):
@@ -25,10 +25,15 @@ for k in sorted(f, key=lambda k: -f[k][2]):
                      avg_us=round(dur * 1e6, 1), hbm_TBps=round((fetch + write) / dur / 1e12, 2)))
 for r in rows[:14]:
     print(json.dumps(r))
-conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain'))]
+conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain', 'conv_expand'))]
 tot_b = sum((r['fetch_MB'] + r['write_MB']) * r['launches'] for r in conv); tot_n = sum(r['launches'] for r in conv)
 print('conv family: avg HBM traffic per launch = %.1f MB over %d launches' % (tot_b / tot_n, tot_n))
 if len(sys.argv) > 3:
-    json.dump({'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel (all instantiations)', 'launches': tot_n, 'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
-               'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]},
-              open(sys.argv[3], 'w'), indent=1)
+    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel (all instantiations)', 'launches': tot_n,
+           'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
+           'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]}
+    if len(sys.argv) > 4:                                  # the launch plan these counters belong to (bench.py refuses them for any other plan)
+        out['plan_launches'] = json.load(open(sys.argv[4]))['plan_launches']
+    if len(sys.argv) > 5:
+        out['captured'] = sys.argv[5]
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)

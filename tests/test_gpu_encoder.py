@@ -274,30 +274,40 @@ def test_resnet50_stagewise_parity(dt, tol):
 
 @pytest.mark.parametrize('variant,osz', [('conv3', 2156), ('conv4', 2058)])
 def test_compressed_variants(variant, osz):
+    """No averaging at the end of the compressed PVRs (moco.py:29-113): the trunk's storage rounding reaches the output element by
+    element, and 16-bit weights alone cost ~6e-4 at layer3.  The f16 parity plan of these variants therefore keeps the residual
+    stream in fp32 from layer2 on and runs the LAST trunk stage and the compression head entirely in fp32 (encoder.hip
+    build_resnet50, conv_f32.hip).  Bound: 8e-4 on THREE weight seeds (north star: 1e-3), i.e. real margin - round 2's plan
+    (fp32 residual from layer3 only, PVR_TAIL_F32=0) measured 9.75e-4 on one seed and emulates to 1.01e-3 on another."""
     from oracle import encoder_oracle as eo
     from pvr_habitat_amd.embeddings import HipResNet50
     torch.set_num_threads(8)
-    sd = synth.resnet50_state_dict(2, variant)
-    fr = synth.smooth_frames(22, 2, 128, 128)
-    ref = eo.embed(sd, fr, variant)
-    m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
-    out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
-    assert out.shape == (2, osz)
-    l2, mx = _relerr(out, ref)
-    print('\n[%s f16] rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
-    # no averaging at the end of the compressed variants, so the trunk's storage rounding reaches the output element by element
-    # (all-f16 plan: 1.09e-3 / 9.6e-4).  The f16 plan of these variants keeps the residual stream in fp32 from layer3 on and runs
-    # the compression head in fp32 (encoder.hip::build_resnet50, PVR_RESID32): 9.8e-4 / 8.0e-4 measured, inside the north-star 1e-3
-    assert l2 < 1e-3 and mx < 2e-3
-    m0 = None
-    os.environ['PVR_RESID32'] = '0'                                    # A/B: the all-16-bit plan is measurably further away
-    try:
-        m0 = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
-        l2_16, _ = _relerr(m0(torch.from_numpy(fr).cuda()).cpu().numpy(), ref)
-    finally:
-        del os.environ['PVR_RESID32']
-    print('[%s f16, all-16-bit plan] rel-L2 %.2e' % (variant, l2_16))
-    assert l2 < l2_16
+    worst = 0.0
+    for seed in (2, 3, 4):
+        sd = synth.resnet50_state_dict(seed, variant)
+        fr = synth.smooth_frames(20 + seed, 2, 128, 128)
+        ref = eo.embed(sd, fr, variant)
+        m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
+        out = m(torch.from_numpy(fr).cuda()).cpu().numpy()
+        m.close()
+        assert out.shape == (2, osz)
+        l2, mx = _relerr(out, ref)
+        print('\n[%s f16, seed %d] rel-L2 %.2e max-norm %.2e' % (variant, seed, l2, mx))
+        assert l2 < 8e-4 and mx < 2e-3, (seed, l2, mx)
+        worst = max(worst, l2)
+        if seed == 2:
+            # A/B: round 2's plans are measurably further away (all 16-bit: 1.09e-3; fp32 residual from layer3 only: 9.75e-4 on conv3)
+            for env, val in (('PVR_TAIL_F32', '0'), ('PVR_RESID32', '0')):
+                os.environ[env] = val
+                try:
+                    m0 = HipResNet50(sd, variant, compute_dtype='f16', max_batch=4)
+                    l2_old, _ = _relerr(m0(torch.from_numpy(fr).cuda()).cpu().numpy(), ref)
+                    m0.close()
+                finally:
+                    del os.environ[env]
+                print('[%s f16, %s=%s] rel-L2 %.2e' % (variant, env, val, l2_old))
+                assert l2 < l2_old < 1.3e-3
+    print('[%s f16] worst of three seeds %.2e' % (variant, worst))
 
 
 def test_f16_activation_range(monkeypatch):

@@ -194,26 +194,33 @@ def test_policy_step_is_deterministic_and_single_step_eval():
     assert acts == [int(a) for a in ref['action'].flatten()]
 
 
-def test_persistent_forward_recurrence_is_bit_identical(monkeypatch):
-    """PVR_POLICY_PERSIST=1: one launch per (layer, chunk) with a grid-wide hand-off of h_t per step (write-through stores,
-    agent-scope counter, sc1 loads) instead of one launch per step; same arithmetic order, so parameters after three updates
-    must be bit-identical, with and without the two-lane layer pipeline, and B > 16 (two batch groups per block)."""
+@pytest.mark.parametrize('T,B', [(24, 20), (26, 5), (6, 16)])
+def test_persistent_forward_recurrence_is_bit_identical(monkeypatch, T, B):
+    """PVR_POLICY_PERSIST=1 / 2: one launch per (layer, chunk) / per layer with a grid-wide hand-off of h_t per step inside the kernel
+    instead of one launch per step; PVR_POLICY_PERSIST_BWD (round 3): the BPTT of both layers as ONE persistent launch per chunk wave
+    (lstm_bwd_seq_kernel: two in-kernel hand-offs per step).  Same arithmetic order everywhere, so parameters after three updates must
+    be bit-identical across all modes, with and without the two-lane layer pipeline, for B > 16 (two batch groups per block), a
+    ragged last chunk (T = 26) and T < 8 (a single chunk)."""
     from pvr_habitat_amd.models import HipRMSprop
-    T, B, O, A, S = 24, 20, 256, 3, 3
+    O, A, S = 256, 3, 3
     obs, done, act = synth.bc_batches(6, T, B, O, A, S)
     finals = {}
-    for persist, pipe in (('0', '1'), ('1', '1'), ('1', '0'), ('2', '1'), ('2', '0')):      # 2: data-as-flag hand-off
+    for persist, pipe, bwd in (('0', '1', '0'), ('1', '1', '0'), ('1', '0', '0'), ('2', '1', '0'), ('2', '0', '0'), ('2', '1', '1'), ('2', '0', '1')):
         monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
         monkeypatch.setenv('PVR_POLICY_PIPELINE', pipe)
+        monkeypatch.setenv('PVR_POLICY_PERSIST_BWD', bwd)
         m, _ = _model(6, O, A, True, T, B)
         opt = HipRMSprop(m, max_epochs=50)
         m.train()
         for s in range(S):
             opt.scheduler_step()
             opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
-        finals[(persist, pipe)] = m._flat.clone()
-        assert torch.isfinite(finals[(persist, pipe)]).all()
-    assert all(torch.equal(finals[('0', '1')], v) for v in finals.values())
+        finals[(persist, pipe, bwd)] = m._flat.clone()
+        torch.cuda.synchronize()
+        m.check_status()
+        assert torch.isfinite(finals[(persist, pipe, bwd)]).all()
+        m.close()
+    assert all(torch.equal(finals[('0', '1', '0')], v) for v in finals.values())
 
 
 def test_persistent_recurrence_timeout_reaches_the_host(monkeypatch):
