@@ -149,6 +149,18 @@ static pvr_status scratch_grow(float **buf, size_t *have, size_t need) {
     return PVR_OK;
 }
 
+template <bool ATR, bool BTR, int BM, int BN>
+static pvr_status launch_gemm(const GemmP &g, dim3 gd, hipStream_t st) {
+    constexpr size_t lds = gemm_f32_lds<BM, BN, ATR, BTR>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<ATR, BTR, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<ATR, BTR, BM, BN>), gd, dim3(256), lds, st, g);
+    return PVR_OK;
+}
+
 pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
                 bool a_km, bool b_kn, int relu, hipStream_t st) {
     GemmP g;
@@ -157,10 +169,17 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
     g.a_kstride = 0; g.b_kstride = 0; g.c_stride = 0;
     PVR_REQUIRE(((a_km && b_kn) || K % 4 == 0) && (!a_km || M % 4 == 0) && (!b_kn || N % 4 == 0),
                 "gemm_f32: contiguous dims must be multiples of 4 (M=%d N=%d K=%d)", M, N, K);
-    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+    // tile choice (the result never depends on it): PVR_GEMM_TILE = 0 64x64 (round 1/2), 1 128x64, 2 64x128, 3 128x128; default: see below
+    static const int forced = [] { const char *e = getenv("PVR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+    // measured per shape (profiles/experiments/r03_gemm_f32_tile_shapes.txt): 64x64 everywhere except the two 4 M-output weight-gradient
+    // products (dW_hh / dW_ih: 4096 x 1024, dW_fc1: 1024 x 4096; K = T*B), where 64x128 is 3-4 % faster
+    int tile = forced >= 0 && forced <= 3 ? forced : (a_km && b_kn && (long long)M * N >= (4ll << 20) && N % 128 == 0) ? 2 : 0;
+    const int BMs[4] = {64, 128, 64, 128}, BNs[4] = {64, 64, 128, 128};
+    const int BM = BMs[tile], BN = BNs[tile];
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     // too few output tiles for the chip and a long K: split K over blockIdx.y into fp32 partial products, summed in slice order
     int S = 1;
-    if (grid < 192 && K >= 2048 && K % 128 == 0) S = 4;
+    if (((M + 63) / 64) * ((N + 63) / 64) < 192 && K >= 2048 && K % 128 == 0) S = 4;
     float *splitk_buf = nullptr;
     if (S > 1) {
         const size_t need = (size_t)S * M * N;
@@ -174,10 +193,22 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
         g.C = splitk_buf; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
     }
     const dim3 gd(grid, S);
-    if (!a_km && !b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), gd, dim3(256), 0, st, g);
-    else if (!a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), gd, dim3(256), 0, st, g);
-    else if (a_km && b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), gd, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), gd, dim3(256), 0, st, g);
+    pvr_status ls = PVR_OK;
+#define PVR_GEMM_CASE(T_, BM_, BN_)                                                                                     \
+    case T_:                                                                                                            \
+        if (!a_km && !b_kn) ls = launch_gemm<false, false, BM_, BN_>(g, gd, st);                                        \
+        else if (!a_km && b_kn) ls = launch_gemm<false, true, BM_, BN_>(g, gd, st);                                     \
+        else if (a_km && b_kn) ls = launch_gemm<true, true, BM_, BN_>(g, gd, st);                                       \
+        else ls = launch_gemm<true, false, BM_, BN_>(g, gd, st);                                                        \
+        break;
+    switch (tile) {
+        PVR_GEMM_CASE(0, 64, 64)
+        PVR_GEMM_CASE(1, 128, 64)
+        PVR_GEMM_CASE(2, 64, 128)
+        PVR_GEMM_CASE(3, 128, 128)
+    }
+#undef PVR_GEMM_CASE
+    if (ls) return ls;
     if (S > 1) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st,

@@ -31,13 +31,18 @@ struct GemmP {
     long long a_kstride, b_kstride, c_stride;
 };
 
-template <bool ATR, bool BTR>
+// BM x BN in {64, 128}: the wave grid stays 2 x 2, a wave owns (BM/2) x (BN/2) outputs = (BM/32) x (BN/32) MFMA tiles.  Every output
+// is the same ascending-k fma chain whatever the tile (the choice never changes a result), so the host picks per shape
+// (policy.hip gemm(): tile quantisation on 256 CUs against operand re-reads; PVR_GEMM_TILE forces one).
+template <bool ATR, bool BTR, int BM = 64, int BN = 64>
 static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
-    constexpr int BM = 64, BN = 64, BK = 32;
-    constexpr int LDN = 36;        // [rows][k] stride (floats) of a k-contiguous operand tile
-    constexpr int LDT = 80;        // [k][rows] stride of a row-contiguous operand tile (== 16 mod 32: conflict-free)
-    constexpr int TILE = 2560;     // max(64*36, 32*80)
-    __shared__ __attribute__((aligned(16))) float sm[2][2][TILE];
+    constexpr int BK = 32;
+    constexpr int LDN = 36;                 // [rows][k] stride (floats) of a k-contiguous operand tile
+    constexpr int LDTA = BM + 16, LDTB = BN + 16;   // [k][rows] stride of a row-contiguous operand tile (== 16 mod 32: conflict-free)
+    constexpr int TA = ATR ? BK * LDTA : BM * LDN, TB = BTR ? BK * LDTB : BN * LDN;
+    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;      // float4 loads per thread and K tile
+    constexpr int TM = BM / 32, TN = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];       // [2 stages][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = (p.N + BN - 1) / BN;
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
@@ -45,92 +50,95 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     const int nk = (p.K + BK - 1) / BK;
     p.A += (long long)blockIdx.y * p.a_kstride; p.B += (long long)blockIdx.y * p.b_kstride; p.C += (long long)blockIdx.y * p.c_stride;
 
-    f32x4 ra[2], rb[2];
-#define PVR_G_LOAD(kt_)                                                                                   \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
-            const int idx = tid + 256 * i;                                                                \
-            if (!ATR) {                                                                                   \
-                const int gm = m0 + (idx >> 3), gk = (kt_) * BK + (idx & 7) * 4;                          \
-                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gm * p.lda + gk) \
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
-            } else {                                                                                      \
-                const int gk = (kt_) * BK + (idx >> 4), gm = m0 + (idx & 15) * 4;                         \
-                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gk * p.lda + gm) \
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
-            }                                                                                             \
-            if (!BTR) {                                                                                   \
-                const int gn = n0 + (idx >> 3), gk = (kt_) * BK + (idx & 7) * 4;                          \
-                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gn * p.ldb + gk) \
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
-            } else {                                                                                      \
-                const int gk = (kt_) * BK + (idx >> 4), gn = n0 + (idx & 15) * 4;                         \
-                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gk * p.ldb + gn) \
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};                               \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-#define PVR_G_STORE(buf_)                                                                                 \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
-            const int idx = tid + 256 * i;                                                                \
-            float *da = !ATR ? &sm[buf_][0][(idx >> 3) * LDN + (idx & 7) * 4] : &sm[buf_][0][(idx >> 4) * LDT + (idx & 15) * 4]; \
-            float *db = !BTR ? &sm[buf_][1][(idx >> 3) * LDN + (idx & 7) * 4] : &sm[buf_][1][(idx >> 4) * LDT + (idx & 15) * 4]; \
-            *reinterpret_cast<f32x4 *>(da) = ra[i];                                                       \
-            *reinterpret_cast<f32x4 *>(db) = rb[i];                                                       \
-        }                                                                                                 \
-    }
+    f32x4 ra[NA], rb[NB];
+    auto g_load = [&](int kt_) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i;
+            if (!ATR) {
+                const int gm = m0 + (idx >> 3), gk = kt_ * BK + (idx & 7) * 4;
+                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gm * p.lda + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int gk = kt_ * BK + idx / (BM / 4), gm = m0 + (idx % (BM / 4)) * 4;
+                ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (size_t)gk * p.lda + gm) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            if (!BTR) {
+                const int gn = n0 + (idx >> 3), gk = kt_ * BK + (idx & 7) * 4;
+                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gn * p.ldb + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int gk = kt_ * BK + idx / (BN / 4), gn = n0 + (idx % (BN / 4)) * 4;
+                rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const f32x4 *>(p.B + (size_t)gk * p.ldb + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto g_store = [&](int buf_) {
+        float *sa = gsm + buf_ * (TA + TB), *sb = sa + TA;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i;
+            float *da = !ATR ? &sa[(idx >> 3) * LDN + (idx & 7) * 4] : &sa[(idx / (BM / 4)) * LDTA + (idx % (BM / 4)) * 4];
+            *reinterpret_cast<f32x4 *>(da) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            float *db = !BTR ? &sb[(idx >> 3) * LDN + (idx & 7) * 4] : &sb[(idx / (BN / 4)) * LDTB + (idx % (BN / 4)) * 4];
+            *reinterpret_cast<f32x4 *>(db) = rb[i];
+        }
+    };
 
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-    f32x4 acc[2][2];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    PVR_G_LOAD(0);
-    PVR_G_STORE(0);
+    g_load(0);
+    g_store(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) PVR_G_LOAD(kt + 1);
-        const float *As = sm[cur][0], *Bs = sm[cur][1];
+        if (more) g_load(kt + 1);
+        const float *As = gsm + cur * (TA + TB), *Bs = As + TA;
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             const int k = ks * 4 + fq;
-            float a[2], b[2];
+            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 32 + i * 16 + fr;
-                a[i] = !ATR ? As[row * LDN + k] : As[k * LDT + row];
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / 2) + i * 16 + fr;
+                a[i] = !ATR ? As[row * LDN + k] : As[k * LDTA + row];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 32 + j * 16 + fr;
-                b[j] = !BTR ? Bs[row * LDN + k] : Bs[k * LDT + row];
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + fr;
+                b[j] = !BTR ? Bs[row * LDN + k] : Bs[k * LDTB + row];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32(a[i], b[j], acc[i][j]);
         }
-        if (more) PVR_G_STORE(cur ^ 1);
+        if (more) g_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-#undef PVR_G_LOAD
-#undef PVR_G_STORE
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 32 + j * 16 + fr;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fr;
         if (n >= p.N) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
+                const int m = m0 + wm * (BM / 2) + i * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bv;
                 if (p.relu) v = v < 0.f ? 0.f : v;                      // (not fmaxf: torch's ReLU hands a NaN on, fmaxf(NaN, 0) = 0 would hide it)
@@ -138,6 +146,9 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 p.C[(size_t)m * p.ldc + n] = v;
             }
     }
+}
+template <int BM, int BN, bool ATR, bool BTR> constexpr size_t gemm_f32_lds() {
+    return (size_t)2 * ((ATR ? 32 * (BM + 16) : BM * 36) + (BTR ? 32 * (BN + 16) : BN * 36)) * sizeof(float);
 }
 
 // out = sum over the split-K slices (ascending), then the epilogue the GEMM kernel would have applied

@@ -23,12 +23,19 @@ def imread(path):
         from PIL import Image
         if not os.path.isfile(path):
             return None
-        return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[..., ::-1])
+        try:
+            return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[..., ::-1])
+        except Exception as e:                                  # an undecodable file is an error that names the file
+            raise ValueError('cannot decode %s: %s' % (path, e))
 
 
 def decode_many(paths):
     """stack of the decoded frames of `paths` (all the same size): (n,H,W,3) uint8"""
-    return np.stack([imread(p) for p in paths])
+    frames = [imread(p) for p in paths]
+    for p, f in zip(paths, frames):
+        if f is None:                                           # (cv2.imread's answer to a missing or undecodable file)
+            raise ValueError('cannot decode %s' % p)
+    return np.stack(frames)
 
 
 def _send(f, obj):

@@ -1,15 +1,26 @@
 #!/bin/bash
-# Round-2 profile capture on the GPU box: kernel stats (1 and 2 batches in flight), HBM traffic (two separate PMC passes),
+# Profile capture (rounds 2-3) on the GPU box: kernel stats (1 and 2 batches in flight), HBM traffic (two separate PMC passes),
 # SQ counters of the final kernel set.  Outputs under gpurun_out/$1; summaries are copied into profiles/ by hand afterwards.
 set -u
 OUT=gpurun_out/${1:-r02_prof}; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 FAST="--no-cpu-baseline --no-bc --no-vit --no-pcie --no-f16 --no-png"
-rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s1 -- python3 bench.py --steps 8 --warmup 2 --lanes 1 $FAST > $OUT/bench_lanes1.json 2> $OUT/s1.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s1 -- python3 bench.py --steps 8 --warmup 2 --lanes 1 --dump-plan $OUT/plan.json $FAST > $OUT/bench_lanes1.json 2> $OUT/s1.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o s2 -- python3 bench.py --steps 8 --warmup 2 --lanes 2 $FAST > $OUT/bench_lanes2.json 2> $OUT/s2.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 scripts/fwd_only.py conv5 8 > $OUT/f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python3 scripts/fwd_only.py conv5 8 > $OUT/w.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY -d $OUT/sq1 -o q1 -- python3 scripts/fwd_only.py conv5 6 > $OUT/q1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/sq2 -o q2 -- python3 scripts/fwd_only.py conv5 6 > $OUT/q2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES -d $OUT/sq3 -o q3 -- python3 scripts/fwd_only.py conv5 6 > $OUT/q3.log 2>&1
-ls -R $OUT | head -40
+rocprofv3 --kernel-trace --stats -d $OUT/bc -o bc -- python3 scripts/bc_only.py 30 > $OUT/bc.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/ft -o ft -- python3 scripts/bc_only.py 20 conv > $OUT/ft.log 2>&1
+# summaries (rocprofv3 7.2 writes rocpd sqlite databases)
+P=$OUT/summary; mkdir -p $P
+python3 scripts/rocpd_summary.py stats $(ls $OUT/stats1/*/*.db $OUT/stats1/*.db 2>/dev/null | head -1) $P/kernel_stats_lanes1.csv > /dev/null
+python3 scripts/rocpd_summary.py stats $(ls $OUT/stats2/*/*.db $OUT/stats2/*.db 2>/dev/null | head -1) $P/kernel_stats_lanes2.csv > /dev/null
+python3 scripts/rocpd_summary.py stats $(ls $OUT/bc/*/*.db $OUT/bc/*.db 2>/dev/null | head -1) $P/bc_kernel_stats.csv > /dev/null
+python3 scripts/rocpd_summary.py stats $(ls $OUT/ft/*/*.db $OUT/ft/*.db 2>/dev/null | head -1) $P/finetune_kernel_stats.csv > /dev/null
+python3 scripts/rocpd_summary.py pmc $(ls $OUT/fetch/*/*.db $OUT/fetch/*.db 2>/dev/null | head -1) $(ls $OUT/write/*/*.db $OUT/write/*.db 2>/dev/null | head -1) $P/pmc_conv_traffic.json $P/pmc_hbm_traffic_per_kernel.txt $OUT/plan.json "${2:-round 3 build}" > /dev/null
+python3 scripts/rocpd_summary.py sq $P/sq_counters_conv.txt $(ls $OUT/sq1/*/*.db $OUT/sq1/*.db 2>/dev/null | head -1) $(ls $OUT/sq2/*/*.db $OUT/sq2/*.db 2>/dev/null | head -1) $(ls $OUT/sq3/*/*.db $OUT/sq3/*.db 2>/dev/null | head -1) > /dev/null
+find $OUT -name "*.db" -size +20M -delete            # the databases stay on the box side of the 64 MiB merge limit; the summaries travel
+ls -la $P

@@ -2,7 +2,7 @@
   rocpd_summary.py stats <results.db> <out.csv>                      per-kernel calls / total / average duration (= --stats)
   rocpd_summary.py sq <out.txt> <pass1.db> [<pass2.db> ...]          SQ counters per kernel from separate --pmc passes: MFMA-busy,
                                                                      wait / active fractions, LDS conflicts, instruction mix
-  rocpd_summary.py pmc <fetch.db> <write.db> <out.json> [<out.txt>]  HBM bytes per launch from two separate --pmc passes
+  rocpd_summary.py pmc <fetch.db> <write.db> <out.json> [<out.txt> [<plan.json> [<label>]]]  HBM bytes per launch from two separate --pmc passes
                                                                      (FETCH_SIZE, WRITE_SIZE), gfx950 corrections of
                                                                      /opt/skills/guides/MI355X_MICROARCH.md: KiB units,
                                                                      FETCH_SIZE x2 for wide (16 B/lane) coalesced reads."""
@@ -29,7 +29,7 @@ def load(db, counter):
     return agg
 
 
-def pmc(fdb, wdb, out_json, out_txt=None):
+def pmc(fdb, wdb, out_json, out_txt=None, plan_json=None, label=None):
     f, w = load(fdb, 'FETCH_SIZE'), load(wdb, 'WRITE_SIZE')
     rows = []
     for k in sorted(f, key=lambda k: -f[k][2]):
@@ -45,10 +45,14 @@ def pmc(fdb, wdb, out_json, out_txt=None):
     print('\n'.join(lines))
     if out_txt:
         open(out_txt, 'w').write('\n'.join(lines) + '\n')
-    json.dump({'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel (all instantiations)', 'launches': tot_n,
-               'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
-               'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]},
-              open(out_json, 'w'), indent=1)
+    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel (all instantiations)', 'launches': tot_n,
+           'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
+           'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]}
+    if plan_json:                                           # the launch plan these counters belong to (bench.py --dump-plan): bench.py withholds them for any other plan
+        out['plan_launches'] = json.load(open(plan_json))['plan_launches']
+    if label:
+        out['captured'] = label
+    json.dump(out, open(out_json, 'w'), indent=1)
 
 
 def sq(out_txt, *dbs):

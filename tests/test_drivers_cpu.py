@@ -360,3 +360,54 @@ def test_save_embedded_obs_resumes_after_a_rank_died(tmp_path):
     np.testing.assert_array_equal(out['obs'], want)
     np.testing.assert_array_equal(out['action'], np.concatenate(raw['action']))
     assert not [f for f in os.listdir(tmp_path) if '.rank' in f and not f.startswith('calls')]
+
+
+class _FakeNet(object):
+    """stand-in embedder for the host-logic tests: a deterministic function of the frame bytes"""
+    out_size = 4
+
+    def __init__(self, *a, **k):
+        pass
+
+    def state_dict(self):
+        return {}
+
+    def __call__(self, t):
+        x = t.numpy().astype(np.float32).reshape(t.shape[0], -1)
+        return np.stack([x.sum(1), x[:, 0], x[:, -1], x.mean(1)], 1).squeeze()
+
+
+def test_pickle_source_ignores_n_trajectories_like_the_reference(tmp_path, monkeypatch):
+    """save_embedded_obs.py:142-145 calls read_habitat_data_from_pickle WITHOUT the trajectory count: the pickle source always embeds
+    the whole scene, whatever --n_trajectories says (the build used to pass the flag on)."""
+    import pvr_habitat_amd.save_embedded_obs as S
+    monkeypatch.setattr(S, 'EmbeddingNet', _FakeNet)
+    raw = _scene(np.random.default_rng(2), (4, 6, 5))
+    pickle.dump(raw, open(tmp_path / 'scene.pickle', 'wb'))
+    S.run(S.make_parser().parse_args(['--data_path', str(tmp_path), '--env', 'scene', '--embedding_name', 'fake', '--source', 'pickle',
+                                      '--n_trajectories', '1', '--embed_batch', '4', '--embed_block', '3']))
+    out = pickle.load(open(tmp_path / 'scene_fake.pickle', 'rb'))
+    assert out['obs'].shape == (15, 8) and len(out['action']) == 15
+    np.testing.assert_array_equal(out['action'], np.concatenate(raw['action']))
+    assert sorted(f for f in os.listdir(tmp_path) if 'scene' in f) == ['scene.pickle', 'scene_fake.pickle']        # shard files are gone
+
+
+def test_png_source_fails_loudly_on_an_undecodable_frame(tmp_path, monkeypatch):
+    """Deliberate difference: where the reference's `except: break` (save_embedded_obs.py:69-79) silently ends a
+    trajectory at a frame that does not decode - leaving obs shorter than action / reward / done, which main_bc_2.py:118 then rejects
+    with 'data length does not match' - this build stops at the frame and names the file."""
+    from PIL import Image
+    import pvr_habitat_amd.save_embedded_obs as S
+    monkeypatch.setattr(S, 'EmbeddingNet', _FakeNet)
+    d = tmp_path / 'scene'
+    d.mkdir()
+    rng = np.random.default_rng(4)
+    for t in range(2):
+        pickle.dump(dict(action=np.zeros(3, int), reward=np.zeros(3), done=np.zeros(3, bool), true_state=np.zeros((3, 12))), open(d / ('%d.pickle' % t), 'wb'))
+        Image.fromarray(rng.integers(0, 255, (8, 8, 3), dtype=np.uint8)).save(d / ('%d_goal.png' % t))
+        for s_ in range(3):
+            Image.fromarray(rng.integers(0, 255, (8, 8, 3), dtype=np.uint8)).save(d / ('%d_%d.png' % (t, s_)))
+    (d / '1_1.png').write_bytes(b'\x89PNG\r\n\x1a\n' + b'garbage' * 10)
+    with pytest.raises(Exception, match='1_1.png'):
+        S.run(S.make_parser().parse_args(['--data_path', str(tmp_path), '--env', 'scene', '--embedding_name', 'fake', '--source', 'png', '--embed_batch', '4']))
+    assert not os.path.isfile(tmp_path / 'scene_fake.pickle')
