@@ -177,6 +177,134 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ 
     }
 }
 
+// Round 3 form of the fused stem (stem_pool_kernel above stays as the A/B, PVR_STEM_LDS=0).  rocprofv3 / SQ counters of the round-2 kernel:
+// 199 us per 256 frames, 1.6 TB/s, MFMA 27 % busy - a latency chain: each wave walked 9 tiles, every tile waited for 7 global 16-byte
+// loads (a 27.8 KB working set per image and block, re-read 8.8 x through L2) with one tile of prefetch and two waves per SIMD.
+// Here the 15 image rows a block needs per image are CONTIGUOUS in the zero-bordered image (rows 2*cr0 .. 2*cr0 + 14, 1856 B each), so
+// they are copied to LDS once by LDS-DMA (32 wave instructions of 1 KB, double-buffered across the block's images: the rows of image
+// n + 2 are requested when image n's MFMA phase has ended, i.e. a full image period before they are read) and the MFMA fragments
+// become ds_read_b128 (lanes px + g share / neighbour 16-byte pieces: conflict-free).  512 threads: seven waves own one 16-column tile
+// each for the five conv rows, pooling runs over all 512 threads.  LDS: conv tile 70 KB + 2 x 32 KB of rows = 134 KB, one block per CU.  Same fragments, same MFMA order, same
+// rounding points as stem_kernel + maxpool_kernel: bit-identical (test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool).
+// Rows above the image (cr0 = -1 for the first row pair) have a negative source offset: the buffer range check returns zeros; the conv
+// rows they would feed are outside the image and never pooled, as before.
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
+                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
+    constexpr int ROWB = PW * 8;                                     // bytes of one image row (4 channels x 16 bit)
+    constexpr int CT = 5 * OW * 128;                                 // conv tile [5][112] pixels x 128 B
+    constexpr int INB = 32768;                                       // one input-row buffer (15 rows = 27 840 B, copied as 32 x 1 KB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [conv tile | rows buffer 0 | rows buffer 1]
+    const int pr0 = blockIdx.x * 2;                                  // pooled rows pr0, pr0+1
+    const int cr0 = 2 * pr0 - 1;                                     // first conv row held (may be -1: above the image)
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    V8 wf[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+            wf[i][s] = *reinterpret_cast<const V8 *>(wgt + (size_t)(i * 16 + px) * STEM_K + s * 32 + g * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + g * 4);
+    const int n0 = blockIdx.y * ipb, n1 = n0 + ipb < nimg ? n0 + ipb : nimg;
+    // rows of image n_ -> buffer b_: wave w issues instructions 4 w .. 4 w + 3 of the flat 32 KB copy
+    auto stage_rows = [&](int n_, int b_) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(img) + (size_t)n_ * PH * PW * 4, 0, (unsigned)(PH * ROWB), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int flat = (wave * 4 + k) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + CT + b_ * INB + flat), 16,
+                                                     2 * cr0 * ROWB + flat + lane * 16, 0, 0, 0);
+        }
+    };
+    if (n0 < n1) stage_rows(n0, 0);
+    if (n0 + 1 < n1) stage_rows(n0 + 1, 1);
+    for (int n = n0; n < n1; ++n) {
+        const int b = (n - n0) & 1;
+        // the rows of image n have arrived (everything this wave has in flight - the next image's rows and the last pooling stores
+        // included - is older than one image period); DMA data is read one barrier after the barrier that follows the wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char *rows = smem + CT + b * INB;
+        // Wave w < 7 owns column tile w (16 conv columns) for all five conv rows: lr is a compile-time index, so every fragment address
+        // is one base register + an immediate and the two fragment sets alternate without register copies (the round-2 loop spent
+        // ~30 VALU instructions per tile on t / 7, t % 7 and v_mov: the kernel is VALU-bound, 78 M wave instructions per launch against
+        // 7 M MFMAs - profiles/r03_sq_counters_conv.txt).  Lane (px, g), filter row s: pixels 2 (wo0 + px) + 2 g, + 1 of LDS row 2 lr + s.
+        if (wave < 7) {
+            const int wo0 = wave * 16, col = wo0 + px;
+            const char *fb = rows + (2 * (wo0 + px) + 2 * g) * 8;
+            V8 xa[7], xb[7];
+#pragma unroll
+            for (int s = 0; s < 7; ++s) xa[s] = *reinterpret_cast<const V8 *>(fb + s * ROWB);
+#pragma unroll
+            for (int lr = 0; lr < 5; ++lr) {
+                V8 (&xc)[7] = (lr & 1) ? xb : xa;
+                V8 (&xnx)[7] = (lr & 1) ? xa : xb;
+                if (lr + 1 < 5) {
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) xnx[s] = *reinterpret_cast<const V8 *>(fb + (2 * (lr + 1) + s) * ROWB);
+                }
+                const int ho = cr0 + lr;
+                if (ho < 0 || ho >= OW) continue;                        // rows outside the image are never pooled (wave-uniform)
+                f32x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma16<F16>(wf[i][s], xc[s], acc[i]);
+                char *prow = smem + ((size_t)lr * OW + col) * 128;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ushort4 r;
+                    r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
+                    r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
+                    r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
+                    r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
+                    const int c16 = i * 2 + (g >> 1);                    // 16-byte chunk of channels 16i+4g .. +3
+                    *reinterpret_cast<ushort4 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
+                }
+            }
+        }
+        __syncthreads();                                                 // conv tile complete; every wave has finished with rows buffer b
+        if (n + 2 < n1) stage_rows(n + 2, b);                            // (travels under the pooling phase and the next image's MFMAs)
+        // pooling: 2 rows x 56 cols x 8 channel-chunks = 896 outputs of 16 B.  The inputs are post-ReLU, i.e. non-negative, and for
+        // non-negative bf16 / f16 values the numeric order IS the order of their bit patterns read as unsigned integers: the maximum is
+        // four packed v_pk_max_u16 per tap instead of 8 unpack-convert-fmax chains (sign bit masked first: a -0 would read as 0x8000).
+        // The selected element is one of the inputs, bit for bit, as with fmaxf.
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        for (int o = tid; o < 2 * PO * 8; o += 512) {
+            const int k = o & 7, pc = (o >> 3) % PO, pr = o / (8 * PO);
+            unsigned mx[4] = {0u, 0u, 0u, 0u};               // (scalars: hipcc mis-folds a bit_cast of a vector ELEMENT lvalue to element 0)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int lr = 2 * pr + dy, ho = cr0 + lr;
+                if (ho < 0 || ho >= OW) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int col = 2 * pc - 1 + dx;
+                    if (col < 0 || col >= OW) continue;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + ((size_t)lr * OW + col) * 128 + ((k ^ (col & 7)) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w = v[e] & 0x7fff7fffu;
+                        mx[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, mx[e]), __builtin_bit_cast(us2, w)));
+                    }
+                }
+            }
+            *reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pc) * STEM_CO + k * 8) = u32x4{mx[0], mx[1], mx[2], mx[3]};
+        }
+        // (the conv tile is rewritten only after the barriers at the top of the next image)
+    }
+}
+
 // maxpool 3x3 stride 2 pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are post-ReLU but the
 // kernel is general: out-of-range taps are skipped (-inf padding as torch does).
 template <bool F16>
@@ -301,6 +429,24 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
 pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias, void *out, int n, int crop, int dtype,
                             hipStream_t stream) {
     PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);
+    static const bool use_lds = [] { const char *e = getenv("PVR_STEM_LDS"); return !e || atoi(e) != 0; }();
+    const int ipb = n <= 8 ? 1 : STEM_IPB;        // a handful of frames (online embedding): one image per block, 28 n blocks instead of 28 n / 4
+    dim3 grid(28, (n + ipb - 1) / ipb);
+    if (use_lds) {
+        const size_t lds = 5 * 112 * 128 + 2 * 32768;
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr2_done = true;
+        }
+        if (dtype == PVR_F16)
+            hipLaunchKernelGGL(stem_pool_lds_kernel<true>, grid, dim3(512), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+        else
+            hipLaunchKernelGGL(stem_pool_lds_kernel<false>, grid, dim3(512), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+        PVR_LAUNCH_CHECK();
+        return PVR_OK;
+    }
     const size_t lds = 5 * 112 * 128;
     static bool attr_done = false;
     if (!attr_done) {
@@ -308,8 +454,6 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    const int ipb = n <= 8 ? 1 : STEM_IPB;        // a handful of frames (online embedding): one image per block, 28 n blocks instead of 28 n / 4
-    dim3 grid(28, (n + ipb - 1) / ipb);
     if (dtype == PVR_F16)
         hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
     else

@@ -235,6 +235,29 @@ def test_maxpool_avgpool(dt):
     assert (o[:, :20] == 0).all() and (o[:, 2068:] == 0).all()
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('n', [3, 9, 12])
+def test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool(dt, n):
+    """conv1 + bn1 + relu + maxpool as ONE kernel whose image rows are staged in LDS by LDS-DMA (stem_pool_lds_kernel, round 3) against
+    the plain stem kernel (global fragment loads, conv1 activation in HBM) followed by max_pool2d: same fragments, same MFMA order,
+    same rounding points -> every pooled value identical.  n = 3: one image per block (online path), 9 / 12: four images per block
+    with and without a ragged last group (double-buffered row staging across the block's images)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    m = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=n)
+    d = torch.from_numpy(synth.smooth_frames(40 + n, n, 256, 256)).cuda()
+    for rep in range(3):
+        m.debug_stop_after('stem'); m(d)
+        stem = m.tap('stem', n * 112 * 112 * 64).view(n, 112, 112, 64).clone()
+        m.debug_stop_after('pool'); m(d)
+        pool = m.tap('pool', n * 56 * 56 * 64).view(n, 56, 56, 64)
+        ref = F.max_pool2d(stem.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+        assert torch.isfinite(pool).all() and float(pool.abs().max()) > 0
+        assert torch.equal(pool, ref), (rep, int((pool != ref).sum()))
+    m.debug_stop_after('')
+    m.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # whole encoder
 # ------------------------------------------------------------------------------------------------
