@@ -116,7 +116,7 @@ pvr_status pvr_op_conv2d(const void *in, const void *wgt, const float *bias, con
 }
 
 pvr_status pvr_debug_set_conv_algo(int32_t algo) {
-    PVR_REQUIRE(algo >= -1 && algo <= 3, "pvr_debug_set_conv_algo: algo must be -1 (auto), 0 (conv_igemm), 1 / 2 / 3 (conv_pp256 with 256- / 128- / 224-pixel tiles)");
+    PVR_REQUIRE(algo >= -1 && algo <= 4, "pvr_debug_set_conv_algo: algo must be -1 (auto), 0 (conv_igemm), 1 / 2 / 3 (conv_pp256 with 256- / 128- / 224-pixel tiles), 4 (conv_w4)");
     set_conv_algo(algo);
     return PVR_OK;
 }

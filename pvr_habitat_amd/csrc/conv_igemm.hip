@@ -28,6 +28,8 @@ pvr_status launch_conv3x3_halo(const void *in, const void *wgt, const float *bia
                                int dtype, hipStream_t stream);
 // conv_pp256.hip
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
+pvr_status launch_conv_w4(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
+                          int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, hipStream_t stream);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
                              int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream);
 
@@ -486,6 +488,9 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         const bool better224 = use224 && ((tiles224 + 255) / 256) * 224 < ((tiles + 255) / 256) * 256;
         const int bm = algo == 1 ? 256 : algo == 2 ? 128 : algo == 3 ? 224
                      : (algo == -1 && deep) ? (tiles >= 160 ? (better224 ? 224 : 256) : (tiles128 >= 160 ? 128 : 0)) : 0;
+        // algo 4 (round 3): the four-wave 128 x 128-per-wave kernel (conv_w4.hip) wherever it accepts the shape
+        if (ok && algo == 4)
+            return launch_conv_w4(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, stream);
         if (ok && bm)
             return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, bm, stream);
     }

@@ -180,6 +180,14 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
             assert torch.equal(out, ref), (algo, rep, int((out != ref).sum()))
     persistent224 = ((n * ho * wo + 223) // 224) * ((cout + 255) // 256) >= 384
     assert _lib.lib().pvr_debug_pp_persistent_launches() == before + (4 if persistent else 0) + (4 if persistent224 else 0)
+    # round 3: the four-wave kernel (conv_w4.hip: 112 x 128 outputs per wave, accumulators in a fixed AccVGPR block, four 32-deep LDS
+    # stages, hand-counted LDS-DMA waits): same K order, same epilogue -> the same bits, on every repeat
+    conv_algo(4)
+    for rep in range(6):
+        out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(out, ref), ('w4', rep, int((out != ref).sum()))
 
 
 EXPAND_CASES = [
