@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
         for (int i = 0; i < HOPS; ++i) {
             const int o = i * 4 + wave, sl = o / (HROWS / 8), rb = o % (HROWS / 8);
-            const int r = rb * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            const int r = rb * 8 + (lane >> 3), c = (lane & 7) ^ (r & 6);         // halo swizzle: see the tap reads below
             const int vo = (r < HR && hbase + r >= 0) ? ((hbase + r) * CM + sl * 64 + c * 8) * 2 : OOB;   // past the tensor: range miss -> zeros
             ch_dma16(rs_in, smem + sl * HSL + rb * 1024, vo, 0);
         }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int r = h_row[j] + shift;
-                const int a = csl * HSL + r * 128 + ((fq ^ ((r >> 1) & 7)) << 4);
+                const int a = csl * HSL + r * 128 + ((fq ^ (r & 6)) << 4);
                 xo[j] = ((h_mask[j] >> tp) & 1) ? a : ZERO_OFF;
             }
             const char *ring = smem + RING_OFF + (kt & 1) * SLICE - BM * 128;     // (b_rd carries the per-tap form's BM*128 base)
