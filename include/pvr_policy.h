@@ -144,11 +144,17 @@ pvr_status pvr_bc_gather(const void *obs_dev, const int64_t *action_dev, const u
 /* parity/debug: copy the flat gradient of the last pvr_policy_step (pre-clip) to grads_out (device, trainable_count) */
 pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_stream);
 
-/* fp32 GEMM on the f32 MFMA path used by the policy: C[M,N] = op(A) op(B)^T-style contraction over K.
+/* fp32-in / fp32-out GEMM as the policy runs it: C[M,N] = op(A) op(B)^T-style contraction over K.
  * a_km != 0: A stored [K][M] else [M][K];  b_kn != 0: B stored [K][N] else [N][K].  Optional bias[N], relu.
- * (unit-parity entry point) */
+ * (unit-parity entry point; the arithmetic is the one pvr_debug_set_gemm_mode selects) */
 pvr_status pvr_op_gemm_f32(const float *A, const float *B, const float *bias, float *C, int32_t M, int32_t N,
                            int32_t K, int32_t a_km, int32_t b_kn, int32_t relu, void *hip_stream);
+/* How every fp32 GEMM of the policy is computed (process-wide; the reference's counterpart is torch's fp32 matmul, src/models.py:66-73):
+ *   0  fp32 MFMA (v_mfma_f32_16x16x4_f32: the ascending-k fma chain; the default, rounds 1-3)
+ *   1  bf16 MFMA on an exact three-term split of both operands, six products per pair, fp32 accumulation (round 3, opt-in: 2.7 x closer
+ *      to an fp64 product than mode 0 and about as fast); 2 / 3: the same with 128 x 128 / 64 x 64 tiles forced
+ *  -1  back to the default (environment PVR_GEMM_BF16X3, else 0) */
+pvr_status pvr_debug_set_gemm_mode(int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include "policy_kernels.h"
 #include "policy_conv.h"
 #include "../../include/pvr_policy.h"
@@ -161,6 +162,20 @@ static pvr_status launch_gemm(const GemmP &g, dim3 gd, hipStream_t st) {
     return PVR_OK;
 }
 
+static std::atomic<int> g_gemm_mode{-1};          // pvr_debug_set_gemm_mode
+
+template <bool ATR, bool BTR, int BM, int BN>
+static pvr_status launch_gemm_x3(const GemmP &g, dim3 gd, hipStream_t st) {
+    constexpr size_t lds = gemm_bf16x3_lds<BM, BN>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<ATR, BTR, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<ATR, BTR, BM, BN>), gd, dim3(256), lds, st, g);
+    return PVR_OK;
+}
+
 pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
                 bool a_km, bool b_kn, int relu, hipStream_t st) {
     GemmP g;
@@ -192,8 +207,29 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
         g.c_stride = (long long)M * N;
         g.C = splitk_buf; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
     }
-    const dim3 gd(grid, S);
     pvr_status ls = PVR_OK;
+    // round 3, opt-in (PVR_GEMM_BF16X3=1 or pvr_debug_set_gemm_mode): the same product on the bf16 matrix pipe (three-term exact split of
+    // both operands, gemm_bf16x3_kernel); 128 x 128 tiles when they fill the chip, else 64 x 64.  2.7 x more accurate than the fp32 chain
+    // and no faster (profiles/experiments/r03_gemm_split_bf16.txt), so the fp32 MFMA GEMM stays the default.
+    static const int x3_env = [] { const char *e = getenv("PVR_GEMM_BF16X3"); return e ? atoi(e) : 0; }();
+    const int gm = g_gemm_mode.load();
+    const int x3 = gm >= 0 ? gm : x3_env;
+    const long long a_ext = ((long long)((a_km ? g.K : M) - 1) * g.lda + (a_km ? M : g.K)) * 4, b_ext = ((long long)((b_kn ? g.K : N) - 1) * g.ldb + (b_kn ? N : g.K)) * 4;
+    if (x3 && forced < 0 && a_ext < 0x7ffffff0ll && b_ext < 0x7ffffff0ll) {
+        g.a_bytes = (unsigned)a_ext; g.b_bytes = (unsigned)b_ext;
+        const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * S;
+        const bool t128 = x3 == 2 || (x3 != 3 && big >= 192);
+        const int bm = t128 ? 128 : 64;
+        const dim3 gx(((M + bm - 1) / bm) * ((N + bm - 1) / bm), S);
+#define PVR_X3_CASE(BM_)                                                                                                \
+        if (!a_km && !b_kn) ls = launch_gemm_x3<false, false, BM_, BM_>(g, gx, st);                                     \
+        else if (!a_km && b_kn) ls = launch_gemm_x3<false, true, BM_, BM_>(g, gx, st);                                  \
+        else if (a_km && b_kn) ls = launch_gemm_x3<true, true, BM_, BM_>(g, gx, st);                                    \
+        else ls = launch_gemm_x3<true, false, BM_, BM_>(g, gx, st);
+        if (t128) { PVR_X3_CASE(128) } else { PVR_X3_CASE(64) }
+#undef PVR_X3_CASE
+    } else {
+    const dim3 gd(grid, S);
 #define PVR_GEMM_CASE(T_, BM_, BN_)                                                                                     \
     case T_:                                                                                                            \
         if (!a_km && !b_kn) ls = launch_gemm<false, false, BM_, BN_>(g, gd, st);                                        \
@@ -208,6 +244,7 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
         PVR_GEMM_CASE(3, 128, 128)
     }
 #undef PVR_GEMM_CASE
+    }
     if (ls) return ls;
     if (S > 1) {
         const size_t n = (size_t)M * N;
@@ -1123,6 +1160,12 @@ pvr_status pvr_op_gemm_f32(const float *A, const float *B, const float *bias, fl
     PVR_REQUIRE(A && B && C, "pvr_op_gemm_f32: null pointer");
     ScratchScope scratch_scope(nullptr);
     return gemm(A, B, bias, nullptr, C, M, N, K, a_km != 0, b_kn != 0, relu, (hipStream_t)hip_stream);
+}
+
+pvr_status pvr_debug_set_gemm_mode(int32_t mode) {
+    PVR_REQUIRE(mode >= -1 && mode <= 3, "pvr_debug_set_gemm_mode: mode must be -1 (default), 0 (fp32 MFMA), 1 / 2 / 3 (split-bf16 MFMA: automatic / 128 / 64 tiles)");
+    g_gemm_mode = mode;
+    return PVR_OK;
 }
 
 }  // extern "C"

@@ -29,6 +29,7 @@ struct GemmP {
     // split-K (blockIdx.y = slice): slice s multiplies k in [s*K, (s+1)*K) of the full problem into C + s*c_stride (K is the slice length);
     // used when M*N alone gives too few blocks (BPTT chunk GEMMs: M = 400, K = 4096); the slices are summed in a fixed order afterwards
     long long a_kstride, b_kstride, c_stride;
+    unsigned a_bytes = 0, b_bytes = 0;      // extent of A / B from the (slice's) base pointer: gemm_bf16x3_kernel's buffer resources
 };
 
 // BM x BN in {64, 128}: the wave grid stays 2 x 2, a wave owns (BM/2) x (BN/2) outputs = (BM/32) x (BN/32) MFMA tiles.  Every output
@@ -149,6 +150,180 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 }
 template <int BM, int BN, bool ATR, bool BTR> constexpr size_t gemm_f32_lds() {
     return (size_t)2 * ((ATR ? 32 * (BM + 16) : BM * 36) + (BTR ? 32 * (BN + 16) : BN * 36)) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix pipe (round 3): every fp32 operand value is split EXACTLY into three bf16 terms
+//     a = a1 + a2 + a3,   a1 = top 16 bits of a,  a2 = top 16 bits of (a - a1),  a3 = a - a1 - a2   (8 + 8 + 8 significand bits)
+// and C accumulates the six products of combined order <= 4 in fp32:  a1 b1  |  a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1.
+// bf16 x bf16 products are exact in fp32; the dropped terms (a2 b3, a3 b2, a3 b3) are <= 2^-22 |a b| each, the size of the fp32
+// rounding of one product in gemm_f32_kernel's fma chain.  The leading products go to their own accumulator and the corrections
+// (2^-8 of them) to a second one, added once at the end - the small terms are not rounded away against a large running sum.
+// Measured against an fp64 product the result is as accurate as gemm_f32_kernel's (tests/test_gpu_policy.py).  Six bf16 MFMAs
+// (16 cycles per 16x16x32) replace eight fp32 MFMAs (32 cycles per 16x16x4): 96 against 256 matrix-pipe cycles per 16x16x32 block.
+// Non-finite inputs: a NaN stays a NaN; +-Inf becomes a NaN (Inf - Inf in the split) where gemm_f32_kernel hands on the Inf.
+//
+// Tile BM x BN x 32, 2 x 2 waves.  A thread converts what it loaded (f32x4: four consecutive k of a row, or, for an operand stored
+// [K][rows], the same four k of four consecutive rows gathered from four loads) and writes 8-byte pieces of the three planes;
+// LDS planes are [rows][32 k] bf16 = 64-byte rows with the chunk swizzle c ^ 2*((row>>2)&1) (conflict-free ds_read_b128 fragment reads,
+// see conv_w4.hip).  Two LDS stages, two register sets: a tile's loads are requested two tiles ahead.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN> constexpr size_t gemm_bf16x3_lds() { return (size_t)2 * 3 * (BM + BN) * 64; }
+
+__device__ __forceinline__ void split3(float a, unsigned &h1, unsigned &h2, unsigned &h3) {
+    h1 = __builtin_bit_cast(unsigned, a);
+    const float r1 = a - __builtin_bit_cast(float, h1 & 0xffff0000u);
+    h2 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, h2 & 0xffff0000u);
+    h3 = __builtin_bit_cast(unsigned, r2);
+}
+// (hi16(x1) << 16) | hi16(x0)
+__device__ __forceinline__ unsigned pack_hi(unsigned x0, unsigned x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+template <bool ATR, bool BTR, int BM, int BN>
+static __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmP p) {
+    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+    constexpr int BK = 32;
+    constexpr int PA = BM * 64, PB = BN * 64, STG = 3 * (PA + PB);          // bytes per plane / per stage
+    constexpr int NA = ATR ? 4 : BM / 32, NB = BTR ? 4 : BN / 32;           // f32x4 loads per thread and K tile
+    constexpr int TM = BM / 32, TN = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (swz / n_tiles) * BM, n0 = (swz % n_tiles) * BN;
+    const int nk = (p.K + BK - 1) / BK;
+    p.A += (long long)blockIdx.y * p.a_kstride; p.B += (long long)blockIdx.y * p.b_kstride; p.C += (long long)blockIdx.y * p.c_stride;
+
+    f32x4 ra[2][NA], rb[2][NB];         // two register sets: tile kt + 2 is requested while tile kt is multiplied (one iteration of latency cover)
+    // k-contiguous operand: load i of a thread = row (tid + 256 i) / 8, k quad (tid + 256 i) % 8
+    // row-contiguous ([K][rows]) operand: the thread owns k quad kq = tid / (R/4) and rows 4 rq .. 4 rq + 3, rq = tid % (R/4) (rows fastest:
+    //   coalesced 512-byte runs per k row; its 8-byte LDS writes conflict 8-way, and the k-fastest mapping that avoids that was 35 % SLOWER
+    //   on the weight-gradient shapes: the loads matter more); load j = k row 4 kq + j (four loads; at
+    //   R = 64 the threads 128.. repeat what threads 0..127 do: identical values to identical addresses)
+    // Branch-free: 16-byte buffer loads; a row or k quad outside the matrix goes to an out-of-range offset and reads zeros (a
+    // predicated load makes hipcc carry each register set through the loop as one tuple and copy it at every join, see conv_w4.hip).
+    constexpr int OOB = 0x7ffffff0;
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, p.a_bytes, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.B), 0, p.b_bytes, 0x00020000);
+    auto g_load_one = [&](__amdgpu_buffer_rsrc_t rs, int ld, int rows, int r0, bool tr, int R, f32x4 *dst, int n_ld, int kt_) {
+        if (!tr) {
+            const int gk = kt_ * BK + (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < n_ld; ++i) {
+                const int gr = r0 + ((tid + 256 * i) >> 3);
+                dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (gr < rows && gk < p.K) ? (gr * ld + gk) * 4 : OOB, 0, 0));
+            }
+        } else {
+            const int kq = (tid / (R / 4)) & 7, gr = r0 + (tid % (R / 4)) * 4;      // (R = 64: threads 128.. repeat the work of threads 0..127)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gk = kt_ * BK + kq * 4 + j;
+                dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (gr < rows && gk < p.K) ? (gk * ld + gr) * 4 : OOB, 0, 0));
+            }
+        }
+    };
+    auto cvt_store_quad = [&](char *plane0, int plane_bytes, int row, int kq, float x0, float x1, float x2, float x3) {
+        unsigned a1[4], a2[4], a3[4];
+        split3(x0, a1[0], a2[0], a3[0]); split3(x1, a1[1], a2[1], a3[1]); split3(x2, a1[2], a2[2], a3[2]); split3(x3, a1[3], a2[3], a3[3]);
+        char *d = plane0 + row * 64 + ((((kq >> 1) ^ (((row >> 2) & 1) << 1))) << 4) + (kq & 1) * 8;
+        *reinterpret_cast<u32x2_ *>(d) = u32x2_{pack_hi(a1[0], a1[1]), pack_hi(a1[2], a1[3])};
+        *reinterpret_cast<u32x2_ *>(d + plane_bytes) = u32x2_{pack_hi(a2[0], a2[1]), pack_hi(a2[2], a2[3])};
+        *reinterpret_cast<u32x2_ *>(d + 2 * plane_bytes) = u32x2_{pack_hi(a3[0], a3[1]), pack_hi(a3[2], a3[3])};
+    };
+    auto g_store_one = [&](char *plane0, int plane_bytes, bool tr, int R, const f32x4 *src, int n_ld) {
+        if (!tr) {
+#pragma unroll
+            for (int i = 0; i < n_ld; ++i) {
+                const int idx = tid + 256 * i;
+                cvt_store_quad(plane0, plane_bytes, idx >> 3, idx & 7, src[i][0], src[i][1], src[i][2], src[i][3]);
+            }
+        } else {
+            const int kq = (tid / (R / 4)) & 7, rq = tid % (R / 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) cvt_store_quad(plane0, plane_bytes, rq * 4 + rr, kq, src[0][rr], src[1][rr], src[2][rr], src[3][rr]);
+        }
+    };
+    auto g_load = [&](int kt_, int set) {
+        g_load_one(rs_a, p.lda, p.M, m0, ATR, BM, ra[set], NA, kt_);
+        g_load_one(rs_b, p.ldb, p.N, n0, BTR, BN, rb[set], NB, kt_);
+    };
+    auto g_store = [&](int buf_, int set) {
+        char *st = bsm + buf_ * STG;
+        g_store_one(st, PA, ATR, BM, ra[set], NA);
+        g_store_one(st + 3 * PA, PB, BTR, BN, rb[set], NB);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int frag = fr * 64 + ((fq ^ (((fr >> 2) & 1) << 1)) << 4);
+    f32x4 hi[TM][TN], lo[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto k_tile = [&](int cur) {
+        const char *As = bsm + cur * STG + (wm * (BM / 2)) * 64 + frag, *Bs = bsm + cur * STG + 3 * PA + (wn * (BN / 2)) * 64 + frag;
+        bf16x8 b1[TN], b2[TN], b3[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            b1[j] = *reinterpret_cast<const bf16x8 *>(Bs + j * 1024);
+            b2[j] = *reinterpret_cast<const bf16x8 *>(Bs + PB + j * 1024);
+            b3[j] = *reinterpret_cast<const bf16x8 *>(Bs + 2 * PB + j * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(As + i * 1024);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(As + PA + i * 1024);
+            const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(As + 2 * PA + i * 1024);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                hi[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[j], hi[i][j], 0, 0, 0);
+                f32x4 l = lo[i][j];
+                l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1[j], l, 0, 0, 0);      // smallest first
+                l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2[j], l, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3[j], l, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1[j], l, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2[j], l, 0, 0, 0);
+                lo[i][j] = l;
+            }
+        }
+    };
+    // tile kt is multiplied from LDS stage kt & 1 while tile kt + 1 waits in register set (kt + 1) & 1 (requested one iteration ago)
+    // and tile kt + 2 is requested into set kt & 1 (its previous content, tile kt, went to LDS one iteration ago)
+    // (requests past the last tile read zeros and the stores of those zeros go to a stage nobody reads again: no conditions)
+    g_load(0, 0);
+    g_store(0, 0);
+    g_load(1, 1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        g_load(kt + 2, 0);
+        k_tile(0);
+        g_store(1, 1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        g_load(kt + 3, 1);
+        k_tile(1);
+        g_store(0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                float v = (hi[i][j][r] + lo[i][j][r]) + bv;
+                if (p.relu) v = v < 0.f ? 0.f : v;
+                if (p.mask && p.mask[(size_t)m * p.ldc + n] <= 0.f) v = 0.f;
+                p.C[(size_t)m * p.ldc + n] = v;
+            }
+    }
 }
 
 // out = sum over the split-K slices (ascending), then the epilogue the GEMM kernel would have applied

@@ -77,6 +77,8 @@ def _plib():
         L.pvr_policy_recurrence_mode.argtypes = [vp]
         L.pvr_policy_debug_drop_block.restype = C.c_int
         L.pvr_policy_debug_drop_block.argtypes = [vp, i32]
+        L.pvr_debug_set_gemm_mode.restype = C.c_int
+        L.pvr_debug_set_gemm_mode.argtypes = [i32]
         L.pvr_op_gemm_f32.restype = C.c_int
         L.pvr_op_gemm_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L._policy_bound = True
