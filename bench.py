@@ -544,7 +544,7 @@ def main():
     chunk = args.chunk if args.chunk else args.batch
     cap = 128
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
-    conv_ms, conv_fl, other_ms = 0.0, 0.0, 0.0
+    conv_ms, conv_fl, other_ms, bound_ms = 0.0, 0.0, 0.0, 0.0
     plan_names = [nm for nm in model.op_names()]
     if args.dump_plan and rank == 0:
         json.dump({'plan_launches': plan_names, 'dtype': args.dtype, 'chunk': chunk}, open(args.dump_plan, 'w'))
@@ -560,7 +560,10 @@ def main():
                 conv_ms += op_ms[i]; conv_fl += op_fl[i]
                 if args.dtype != 'f32' and i - 3 < len(plan_names):
                     g = grp.setdefault(plan_names[i - 3].split('.')[0], [0.0, 0.0, 0.0])
-                    g[0] += op_ms[i]; g[1] += op_fl[i]; g[2] += conv_algorithmic_bytes(chunk, [plan_names[i - 3]])
+                    ab = conv_algorithmic_bytes(chunk, [plan_names[i - 3]])
+                    g[0] += op_ms[i]; g[1] += op_fl[i]; g[2] += ab
+                    # this launch's own lower bound: its FLOPs on the matrix pipe or its algorithmic bytes through HBM, whichever is longer
+                    bound_ms += max(op_fl[i] / (PEAK_BF16_TFLOPS * 1e12), ab / 8e12) * 1e3
             else:
                 other_ms += op_ms[i]
     # every stage against BOTH roofs: layer1 / layer2 (fused tails, 16-bit NHWC activations) sit on the HBM roof,
@@ -620,6 +623,10 @@ def main():
                              'frac': round(traffic * n_conv / (el / args.steps) / 8e12, 4),
                              'note': 'conv-launch HBM bytes per batch (committed PMC passes) / step time of THIS run'},
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3),
+                         # both roofs at once (extra to the contract's single-roof frac): sum over the conv launches of max(FLOPs / MFMA peak,
+                         # algorithmic bytes / 8 TB/s) against the sum of their measured durations - layer1 / layer2 launches are bounded by HBM
+                         'two_roof': None if bound_ms == 0.0 else {'bound_ms_per_chunk': round(bound_ms / reps, 3), 'frac': round(bound_ms / conv_ms, 4),
+                                                                  'note': 'per launch max(flops / %.0f TFLOP/s, algorithmic bytes / 8 TB/s), summed, / measured conv_ms_per_chunk' % PEAK_BF16_TFLOPS},
                          'stages': stages},
         }
         # parity of what was timed: the same model handle / dtype vs the fp32 CPU oracle (north-star tolerance 1e-3 relative fp32)
