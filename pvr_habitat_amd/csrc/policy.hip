@@ -36,6 +36,8 @@ struct pvr_policy {
     float *G[2] = {nullptr, nullptr}, *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};
     float *hprev = nullptr, *nd = nullptr, *zeros = nullptr, *dc_carry = nullptr, *rec_partial = nullptr;
     float *hprev1 = nullptr, *dc_carry1 = nullptr, *rec_partial1 = nullptr;   // layer-1 copies: the two layers run concurrently
+    float *whhT[2] = {nullptr, nullptr};    // W_hh^T [H][4H] of both layers, refreshed at the start of every backward pass (lstm_bwd_step2_kernel)
+    int bwd_fused = 0;                       // PVR_POLICY_BWD_FUSED=1: one launch per BPTT step (correct, SLOWER: profiles/experiments/r03_bc_fused_bptt_step.txt)
     // layer pipeline: the recurrences of the two LSTM layers are chains of ~6 us launches; layer 1 of time chunk c only needs
     // layer 0 of chunk c (forward; mirrored in BPTT), so the two chains run on two streams, a quarter of the sequence apart
     hipStream_t lane_a = nullptr, lane_b = nullptr;
@@ -526,8 +528,34 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     PVR_LAUNCH_CHECK();
     // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
     float *scr_dc[2] = {pol->dc_carry, pol->dc_carry1}, *scr_rec[2] = {pol->rec_partial, pol->rec_partial1}, *scr_hp[2] = {pol->hprev, pol->hprev1};
+    // opt-in, one launch per step (round 3): W_hh^T of both layers first, then lstm_bwd_step2_kernel per (wavefronted) step
+    const bool fused = pol->bwd_fused && H % 16 == 0 && (4 * H) % 512 == 0;
+    if (fused)
+        for (int l = 0; l < 2; ++l)
+            hipLaunchKernelGGL(transpose_kernel, dim3(H / 32, 4 * H / 32), dim3(256), 0, st, P + pol->o_whh[l], pol->whhT[l], 4 * H, H);
+    auto step_job = [&](int l, int t, const float *dh_ext_) {
+        const bool has_next = t < T - 1;
+        LstmStepP c;
+        c.dG_next = has_next ? pol->G[l] + (size_t)(t + 1) * B * 4 * H : nullptr;
+        c.WT = pol->whhT[l];
+        c.nd_next = has_next ? pol->nd + (size_t)(t + 1) * B : nullptr;
+        c.dh_ext = dh_ext_ + (size_t)t * B * H;
+        c.dc_carry = scr_dc[l];
+        c.G = pol->G[l] + (size_t)t * B * 4 * H;
+        c.c_t = pol->Cs[l] + (size_t)t * B * H;
+        c.c_prev = t == 0 ? pol->zeros : pol->Cs[l] + (size_t)(t - 1) * B * H;
+        c.nd = pol->nd + (size_t)t * B;
+        c.B = B; c.H = H;
+        return c;
+    };
     auto bwd_steps = [&](int l, int t_hi, int t_lo, const float *dh_ext_, hipStream_t s_) {          // t = t_hi-1 ... t_lo
         for (int t = t_hi - 1; t >= t_lo; --t) {
+            if (fused) {
+                LstmStep2P q = {};
+                q.active[0] = 1; q.j[0] = step_job(l, t, dh_ext_);
+                hipLaunchKernelGGL(lstm_bwd_step2_kernel, dim3(H / 16, 1), dim3(256), 0, s_, q);
+                continue;
+            }
             const bool has_next = t < T - 1;
             if (has_next) {
                 LstmRecP r;
@@ -605,6 +633,14 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                 const int ta = hi1 - 1 - s_, tb = hi0 - 1 - s_;          // layer 1 step, layer 0 step
                 const bool a1 = c >= 0 && ta >= c * CH && ta >= 0, a0 = c + 1 < NCH && tb >= (c + 1) * CH && tb >= 0;
                 if (!a1 && !a0) continue;
+                if (fused) {
+                    LstmStep2P q = {};
+                    q.active[0] = a0; q.active[1] = a1;
+                    if (a0) q.j[0] = step_job(0, tb, dh0);
+                    if (a1) q.j[1] = step_job(1, ta, dh1);
+                    hipLaunchKernelGGL(lstm_bwd_step2_kernel, dim3(H / 16, 2), dim3(256), 0, st, q);
+                    continue;
+                }
                 LstmRec2P r = {};
                 r.active[0] = a0 && tb < T - 1; r.active[1] = a1 && ta < T - 1;
                 if (r.active[0]) r.j[0] = rec_job(0, tb);
@@ -857,6 +893,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); }
     A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H); A_(rec_partial, 16 * B * H);
     A_(hprev1, N * H); A_(dc_carry1, B * H); A_(rec_partial1, 16 * B * H);
+    A_(whhT[0], (size_t)4 * H * H); A_(whhT[1], (size_t)4 * H * H);
     A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
     A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
     if (desc->conv_frames > 0) {
@@ -877,6 +914,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e);      // 1: counter hand-off, 2: data-as-flag hand-off
     if (const char *e = getenv("PVR_POLICY_CHUNKWAVE")) p->chunkwave = atoi(e) != 0;
+    if (const char *e = getenv("PVR_POLICY_BWD_FUSED")) p->bwd_fused = atoi(e) != 0;
     A_(seq_counters, 64);
     if (!s) {
         // status word of the persistent recurrence: pinned host memory the GPU writes with a system-scope store
@@ -927,7 +965,7 @@ void pvr_policy_destroy(pvr_policy *p) {
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
                     p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
-                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act, p->hprev1, p->dc_carry1, p->rec_partial1, p->seq_counters};
+                    p->cpartial, p->cgpacked, p->bpartial, p->in_obs, p->in_done, p->in_act, p->hprev1, p->dc_carry1, p->rec_partial1, p->seq_counters, p->whhT[0], p->whhT[1]};
     if (p->lane_a) (void)hipStreamDestroy(p->lane_a);
     if (p->lane_b) (void)hipStreamDestroy(p->lane_b);
     for (hipEvent_t ev : {p->ev_fork, p->ev_join_a, p->ev_join_b}) if (ev) (void)hipEventDestroy(ev);

@@ -918,6 +918,90 @@ static __global__ __launch_bounds__(256) void lstm_bwd_cell2_kernel(LstmCellB2P 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// BPTT step as ONE launch (round 3, opt-in PVR_POLICY_BWD_FUSED=1: correct and 2.5 x SLOWER per step than the two launches it replaces -
+// 128 blocks stream W_hh^T with 16 loads in flight per wave and every block re-reads all of dG[t+1]; the two-launch form's rec kernel
+// already runs at the ~7 us it takes to stream 32 MB of W_hh from the Infinity Cache, so only the 4.8 us cell launch was ever to be
+// had): the recurrent product and the cell update of a (layer, timestep) in the same kernel.
+// The two-launch form above splits the product over 16 k-groups x 16 unit-groups, so the cell update has to wait for a grid-wide
+// reduction - a second dependent launch per step (6.9 + 4.8 us per wavefronted pair, 124 pairs per iteration).  Here a block owns 16
+// units for ALL 4096 gate rows: its four waves take a quarter of k each, their tiles are summed in LDS in a fixed order, and each of
+// the 256 threads then finishes one (batch row, unit) of the cell update.  64 blocks per layer, both layers of the chunk wavefront
+// as blockIdx.y.  The weights are read from a TRANSPOSED copy W_hh^T [H][4H] (made once per backward pass): a lane streams 16 bytes
+// of its unit's row per four MFMAs; dG[t+1] (256 KB, shared by every block) comes from L2.
+// Arithmetic per element: the MFMA chain over one quarter of k per wave, ((w0 + w1) + (w2 + w3)), then lstm_cell_grad - a different
+// summation ORDER from the two-launch form (16 k-groups), same fp32 accuracy; deterministic.
+// MFMA roles: A[i = batch][k] = dG[t+1], B[k][j = unit] = W_hh^T[u0 + j][k]; lane (fr, fq) holds k0 + 4 fq .. + 3 of both.
+// ---------------------------------------------------------------------------------------------------------
+struct LstmStepP {
+    const float *dG_next, *WT;                    // [B][4H] (nullptr at t = T-1), W_hh^T [H][4H]
+    const float *nd_next, *dh_ext;                // [B], [B][H]
+    float *dc_carry, *G;                          // [B][H] in/out, [B][4H] gates in / dG out
+    const float *c_t, *c_prev, *nd;
+    int B, H;
+};
+
+static __device__ __forceinline__ void lstm_bwd_step_body(const LstmStepP &p) {
+    __shared__ float part[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int H = p.H, K = 4 * p.H;
+    const int u0 = blockIdx.x * 16;
+    const int kq = K / 4;                                             // k per wave
+    const float *wrow = p.WT + (size_t)(u0 + fr) * K + wave * kq + fq * 4;
+    for (int b0 = 0; b0 < p.B; b0 += 16) {
+        float s = 0.f;
+        if (p.dG_next) {
+            const int b = b0 + fr;
+            const bool bok = b < p.B;
+            const float bmask = bok ? 1.f : 0.f;
+            const float *drow = p.dG_next + (size_t)(bok ? b : 0) * K + wave * kq + fq * 4;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            // 16-k chunks, eight at a time: all 16 loads of a group are in flight before its 32 MFMAs
+            for (int c0 = 0; c0 < kq; c0 += 128) {
+                f32x4 a[8], w[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    a[c] = *reinterpret_cast<const f32x4 *>(drow + c0 + c * 16);
+                    w[c] = *reinterpret_cast<const f32x4 *>(wrow + c0 + c * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    a[c] *= bmask;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma_f32(a[c][e], w[c][e], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];      // D: row = batch 4 fq + r, col = unit fr
+            __syncthreads();
+            s = (part[0][tid >> 4][tid & 15] + part[1][tid >> 4][tid & 15]) + (part[2][tid >> 4][tid & 15] + part[3][tid >> 4][tid & 15]);
+        }
+        const int bi = b0 + (tid >> 4), u = u0 + (tid & 15);
+        if (bi < p.B) {
+            const size_t i = (size_t)bi * H + u;
+            float dh = p.dh_ext[i], dc_in = 0.f;
+            if (p.dG_next) {
+                dh = __builtin_fmaf(p.nd_next[bi], s, dh);
+                dc_in = p.dc_carry[i];
+            }
+            float *g = p.G + (size_t)bi * 4 * H + u;
+            const CellGrad r = lstm_cell_grad(g[0], g[H], g[2 * H], g[3 * H], p.c_t[i], p.c_prev[i], p.nd[bi], dh, dc_in);
+            g[0] = r.d0;
+            g[H] = r.d1;
+            g[2 * H] = r.d2;
+            g[3 * H] = r.d3;
+            p.dc_carry[i] = r.dc;
+        }
+        if (b0 + 16 < p.B) __syncthreads();                            // part is rewritten by the next batch tile
+    }
+}
+struct LstmStep2P { LstmStepP j[2]; int active[2]; };
+static __global__ __launch_bounds__(256) void lstm_bwd_step2_kernel(LstmStep2P pp) {      // chunked layer wavefront (blockIdx.y = job)
+    if (!pp.active[blockIdx.y]) return;
+    lstm_bwd_step_body(pp.j[blockIdx.y]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Persistent BPTT (round 3): ONE launch runs steps t_hi-1 ... t_lo of up to two independent jobs (blockIdx.y: layer 1 on one chunk of
 // the sequence, layer 0 on the chunk behind it - the chunked layer wavefront of the per-step launches, 2 x 256 blocks, co-resident).
 // Per job the 256 blocks keep the 2-D partition of lstm_bwd_rec_kernel (kg = 16 k-groups x ug = 16 unit-groups; the block's 256 x 64

@@ -238,22 +238,31 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch, T, B):
     O, A, S = 256, 3, 3
     obs, done, act = synth.bc_batches(6, T, B, O, A, S)
     finals = {}
-    for persist, pipe, bwd in (('0', '1', '0'), ('1', '1', '0'), ('1', '0', '0'), ('2', '1', '0'), ('2', '0', '0'), ('2', '1', '1'), ('2', '0', '1')):
+    # fused = 1 (opt-in PVR_POLICY_BWD_FUSED): one launch per BPTT step (lstm_bwd_step2_kernel); fused = 0 (default): the two-launch form,
+    # whose summation order the persistent BPTT (bwd = 1) shares.  Bit-identity holds WITHIN each group; the two groups differ by fp32 regrouping only.
+    cases = [(p_, q_, '0', '1') for p_, q_ in (('0', '1'), ('1', '1'), ('1', '0'), ('2', '1'), ('2', '0'))] + \
+            [('0', '1', '0', '0'), ('2', '1', '1', '0'), ('2', '0', '1', '0')]
+    for persist, pipe, bwd, fused in cases:
         monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
         monkeypatch.setenv('PVR_POLICY_PIPELINE', pipe)
         monkeypatch.setenv('PVR_POLICY_PERSIST_BWD', bwd)
+        monkeypatch.setenv('PVR_POLICY_BWD_FUSED', fused)
         m, _ = _model(6, O, A, True, T, B)
         opt = HipRMSprop(m, max_epochs=50)
         m.train()
         for s in range(S):
             opt.scheduler_step()
             opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
-        finals[(persist, pipe, bwd)] = m._flat.clone()
+        finals[(persist, pipe, bwd, fused)] = m._flat.clone()
         torch.cuda.synchronize()
         m.check_status()
-        assert torch.isfinite(finals[(persist, pipe, bwd)]).all()
+        assert torch.isfinite(finals[(persist, pipe, bwd, fused)]).all()
         m.close()
-    assert all(torch.equal(finals[('0', '1', '0')], v) for v in finals.values())
+    for fused in ('1', '0'):
+        grp = [v for k, v in finals.items() if k[3] == fused]
+        assert all(torch.equal(grp[0], v) for v in grp), 'modes with fused = %s differ' % fused
+    a, b = finals[('0', '1', '0', '1')], finals[('0', '1', '0', '0')]
+    assert float((a - b).abs().max()) <= 2e-6 + 1e-4 * float(b.abs().max()), float((a - b).abs().max())
 
 
 def test_persistent_recurrence_timeout_reaches_the_host(monkeypatch):
