@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ 
 // rounding points as stem_kernel + maxpool_kernel: bit-identical (test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool).
 // Rows above the image (cr0 = -1 for the first row pair) have a negative source offset: the buffer range check returns zeros; the conv
 // rows they would feed are outside the image and never pooled, as before.
+#ifdef STEM_STAMP
+__device__ long long stem_stamps[8][64][5];
+#define ST_T(i_) { if (blockIdx.x == 13 && blockIdx.y == 1 && lane == 0 && n - n0 < 64) stem_stamps[wave][n - n0][i_] = __builtin_amdgcn_s_memtime(); }
+#else
+#define ST_T(i_)
+#endif
 template <bool F16>
 __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
                                                                const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb) {
@@ -223,15 +229,21 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
     };
     if (n0 < n1) stage_rows(n0, 0);
     if (n0 + 1 < n1) stage_rows(n0 + 1, 1);
+    // LDS-DMA data may be read one barrier after the barrier that follows the s_waitcnt.  Per image that costs nothing extra here: the
+    // rows of image n + 1 are waited for at the END of image n's MFMA phase (they were requested a whole image earlier), in front of
+    // the barrier that phase ends with anyway, and the barrier at the top of the next image - needed so that nobody rewrites the conv
+    // tile while another wave still pools from it - is the second one.  (Until round 3's last build the wait and two extra barriers sat
+    // at the top of every image: s_memtime stamps, scripts/stem_stamps.hip, priced them at 1400 of the 11 000 cycles per image.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     for (int n = n0; n < n1; ++n) {
         const int b = (n - n0) & 1;
-        // the rows of image n have arrived (everything this wave has in flight - the next image's rows and the last pooling stores
-        // included - is older than one image period); DMA data is read one barrier after the barrier that follows the wait
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ST_T(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        ST_T(1);
+        ST_T(2);
         const char *rows = smem + CT + b * INB;
         // Wave w < 7 owns column tile w (16 conv columns) for all five conv rows: lr is a compile-time index, so every fragment address
         // is one base register + an immediate and the two fragment sets alternate without register copies (the round-2 loop spent
@@ -273,7 +285,10 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
                 }
             }
         }
+        ST_T(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the rows of image n + 1 (and this wave's older pooling stores) have landed
         __syncthreads();                                                 // conv tile complete; every wave has finished with rows buffer b
+        ST_T(4);
         if (n + 2 < n1) stage_rows(n + 2, b);                            // (travels under the pooling phase and the next image's MFMAs)
         // pooling: 2 rows x 56 cols x 8 channel-chunks = 896 outputs of 16 B.  The inputs are post-ReLU, i.e. non-negative, and for
         // non-negative bf16 / f16 values the numeric order IS the order of their bit patterns read as unsigned integers: the maximum is
@@ -430,7 +445,13 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
                             hipStream_t stream) {
     PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);
     static const bool use_lds = [] { const char *e = getenv("PVR_STEM_LDS"); return !e || atoi(e) != 0; }();
-    const int ipb = n <= 8 ? 1 : STEM_IPB;        // a handful of frames (online embedding): one image per block, 28 n blocks instead of 28 n / 4
+    // images per block: a handful of frames (online embedding) -> one image per block (28 n blocks); else as many as it takes for the
+    // 28 x ceil(n / ipb) blocks to fit the chip in ONE round (n = 256 on 256 CUs: 9 block rows of 29 images = 252 blocks), never fewer
+    // than STEM_IPB: a block's prologue (weights, first rows) costs about what 0.7 images do
+    static const int cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    const int yb = cus / 28 > 0 ? cus / 28 : 1;
+    const int ipb_fit = (n + yb - 1) / yb;
+    const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB && use_lds ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
     if (use_lds) {
         const size_t lds = 5 * 112 * 128 + 2 * 32768;
