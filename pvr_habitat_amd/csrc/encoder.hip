@@ -735,8 +735,22 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if ((s = clip_rn50_chunk(enc, fr, nb, h, w, out + (size_t)f0 * out_stride, out_stride, st))) return s;
             continue;
         }
+        // frames that need no resize (the bench configuration: 256 x 256 frames, Resize(256) is the identity): the fused stem reads the
+        // uint8 frames itself - no preprocess launch, no padded 16-bit image in HBM
+        int fused_u8 = 0;
+        if (enc->stop_after.empty() && enc->desc.crop == 224 && enc->crop_pos >= 0 && enc->crop_pos <= 4) {
+            int rn = 1, top = 0, left = 0;
+            preprocess_geometry(h, w, enc->desc.resize, enc->desc.crop, enc->crop_pos, &rn, &top, &left);
+            if (!rn && stem_pool_u8_ok(h, w, top, left)) {
+                if ((s = mark())) return s;                  // (launch index of the preprocess stays: pvr_encoder_profile)
+                if ((s = launch_stem_pool_u8(fr, nb, h, w, top, left, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], dt, st))) return s;
+                fused_u8 = 1;
+            }
+        }
+        if (!fused_u8) {
         if ((s = launch_preprocess(fr, nb, h, w, enc->desc.resize, enc->desc.crop, enc->d_img, dt, st, enc->crop_pos))) return s;
         if ((s = mark())) return s;
+        }
         enc->last_n = nb;
         if (enc->stop_after == "pre") return PVR_OK;
         if (enc->stop_after == "stem") {             // debug tap of the un-pooled conv1 output: unfused kernel
@@ -744,7 +758,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             return PVR_OK;
         }
         // conv1 + bn1 + relu + maxpool fused: the 112x112x64 activation stays in LDS
-        if ((s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st))) return s;
+        if (!fused_u8 && (s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st))) return s;
         if ((s = mark())) return s;
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;

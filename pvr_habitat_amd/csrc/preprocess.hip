@@ -74,6 +74,19 @@ void resized_size(int h, int w, int size, int *rh, int *rw) {
     if (w <= h) { *rw = ns; *rh = nl; } else { *rh = ns; *rw = nl; }
 }
 
+// the geometry launch_preprocess applies (for callers that fuse the no-resize case into their own kernel: stem_pool_lds_kernel<., true>)
+void preprocess_geometry(int h, int w, int resize, int crop, int crop_pos, int *resize_needed, int *top, int *left) {
+    int rh, rw;
+    resized_size(h, w, resize, &rh, &rw);
+    *resize_needed = (rh != h || rw != w) || rh < crop || rw < crop;
+    *top = (int)nearbyint((rh - crop) / 2.0);
+    *left = (int)nearbyint((rw - crop) / 2.0);
+    if (crop_pos > 0) {
+        *top = (crop_pos == 3 || crop_pos == 4) ? rh - crop : 0;
+        *left = (crop_pos == 2 || crop_pos == 4) ? rw - crop : 0;
+    }
+}
+
 // crop_pos: 0 centre (the reference's CenterCrop), 1 top-left, 2 top-right, 3 bottom-left, 4 bottom-right of the resized frame
 // (the four corner crops of torchvision FiveCrop; build-defined 5-crop extension of BASELINE config 5)
 pvr_status launch_preprocess(const uint8_t *frames, int n, int h, int w, int resize, int crop, void *out,

@@ -194,15 +194,22 @@ __device__ long long stem_stamps[8][64][5];
 #else
 #define ST_T(i_)
 #endif
-template <bool F16>
+// U8 (round 3, last build): the kernel reads the uint8 frames itself - no preprocess launch, no padded 16-bit image in HBM (110 MB
+// written and 234 MB read per 256 frames).  Valid when the reference's Resize is the identity (frame edge == resize) - the bench
+// configuration: the crop window's rows, 672 B each, are DMA'd RAW into one of three small LDS buffers three images ahead and
+// converted (x - 128 exactly, 4th channel 1, zero border: what preprocess_kernel writes) into the two row buffers by all 512 threads
+// at the start of the previous image's pooling phase.  u8s: the frames, geometry in U8Geo.
+struct U8Geo { const uint8_t *src; int pitch, img_bytes, off0; };     // bytes per source row, bytes per frame, byte offset of the crop's first pixel
+template <bool F16, bool U8 = false>
 __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
-                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb) {
+                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb, U8Geo u8g = U8Geo{}) {
     typedef typename HT<F16>::V8 V8;
     constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
     constexpr int ROWB = PW * 8;                                     // bytes of one image row (4 channels x 16 bit)
     constexpr int CT = 5 * OW * 128;                                 // conv tile [5][112] pixels x 128 B
-    constexpr int INB = 32768;                                       // one input-row buffer (15 rows = 27 840 B, copied as 32 x 1 KB)
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [conv tile | rows buffer 0 | rows buffer 1]
+    constexpr int INB = U8 ? 28672 : 32768;                          // one input-row buffer (15 rows = 27 840 B, copied as 32 x 1 KB)
+    constexpr int RAWROW = 224 * 3, RAWB = 10240, RAW0 = CT + 2 * INB; // U8: raw crop rows [15][672] uint8 (10 x 1 KB of DMA), three buffers
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [conv tile | rows buffer 0 | rows buffer 1 (| raw 0 | raw 1 | raw 2)]
     const int pr0 = blockIdx.x * 2;                                  // pooled rows pr0, pr0+1
     const int cr0 = 2 * pr0 - 1;                                     // first conv row held (may be -1: above the image)
     const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, g = lane >> 4;
@@ -227,8 +234,56 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
                                                      2 * cr0 * ROWB + flat + lane * 16, 0, 0, 0);
         }
     };
-    if (n0 < n1) stage_rows(n0, 0);
-    if (n0 + 1 < n1) stage_rows(n0 + 1, 1);
+    // U8: raw rows of image n_ -> raw buffer (n_ - n0) % 3: 630 sixteen-byte chunks [row r][42], instruction i = chunks 64 i .. 64 i + 63
+    auto stage_raw = [&](int n_) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(u8g.src) + (size_t)n_ * u8g.img_bytes, 0, (unsigned)u8g.img_bytes, 0x00020000);
+        char *rb = smem + RAW0 + ((n_ - n0) % 3) * RAWB;
+        for (int i = wave; i < 10; i += 8) {
+            const int q = i * 64 + lane, r = q / 42, c = q % 42;
+            const int yi = 2 * cr0 - 3 + r;                               // crop row of padded row 2 cr0 + r
+            const bool ok = q < 630 && yi >= 0 && yi < 224;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(rb + i * 1024), 16,
+                                                     ok ? u8g.off0 + yi * u8g.pitch + c * 16 : 0x7ffffff0, 0, 0, 0);
+        }
+    };
+    // U8: raw buffer of image n_ -> rows buffer zb_ (what preprocess_kernel would have written for these 15 padded rows)
+    auto convert_rows = [&](int n_, int zb_) {
+        const char *rb = smem + RAW0 + ((n_ - n0) % 3) * RAWB;
+        char *zb = smem + CT + zb_ * INB;
+        // groups of four crop pixels = three aligned dwords of raw bytes -> four padded pixels of 8 bytes (v_cvt_f32_ubyte0..3: one
+        // instruction per byte; byte-wise LDS reads made the first build of this path as slow as the preprocess launch it replaces)
+        for (int i = tid; i < 15 * 56; i += 512) {
+            const int r = i / 56, k = i - r * 56, yi = 2 * cr0 - 3 + r;
+            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 w = u32x3{0u, 0u, 0u};
+            const bool ok = yi >= 0 && yi < 224;
+            if (ok) w = *reinterpret_cast<const u32x3 *>(rb + r * RAWROW + k * 12);
+            const float one = ok ? 1.0f : 0.f, off = ok ? 128.f : 0.f;
+            float f[12];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                f[4 * d] = (float)(w[d] & 0xffu); f[4 * d + 1] = (float)((w[d] >> 8) & 0xffu);
+                f[4 * d + 2] = (float)((w[d] >> 16) & 0xffu); f[4 * d + 3] = (float)(w[d] >> 24);
+            }
+            char *dst = zb + r * ROWB + (4 * k + 3) * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ushort4 o;
+                o.x = to_h<F16>(f[3 * q] - off); o.y = to_h<F16>(f[3 * q + 1] - off); o.z = to_h<F16>(f[3 * q + 2] - off); o.w = to_h<F16>(one);
+                *reinterpret_cast<ushort4 *>(dst + q * 8) = o;
+            }
+        }
+        if (tid < 15 * 8) {                                           // the zero border: padded columns 0..2 and 227..231 of every row
+            const int r = tid >> 3, e = tid & 7, pc = e < 3 ? e : 224 + e;
+            *reinterpret_cast<ushort4 *>(zb + r * ROWB + pc * 8) = make_ushort4(0, 0, 0, 0);
+        }
+    };
+    if constexpr (U8) {
+        for (int k = 0; k < 3; ++k) if (n0 + k < n1) stage_raw(n0 + k);
+    } else {
+        if (n0 < n1) stage_rows(n0, 0);
+        if (n0 + 1 < n1) stage_rows(n0 + 1, 1);
+    }
     // LDS-DMA data may be read one barrier after the barrier that follows the s_waitcnt.  Per image that costs nothing extra here: the
     // rows of image n + 1 are waited for at the END of image n's MFMA phase (they were requested a whole image earlier), in front of
     // the barrier that phase ends with anyway, and the barrier at the top of the next image - needed so that nobody rewrites the conv
@@ -237,9 +292,15 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (U8) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (n0 < n1) convert_rows(n0, 0);
+    }
     for (int n = n0; n < n1; ++n) {
         const int b = (n - n0) & 1;
         ST_T(0);
+        if constexpr (U8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // convert_rows' LDS stores (previous pooling phase / prologue)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         ST_T(1);
@@ -289,7 +350,14 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the rows of image n + 1 (and this wave's older pooling stores) have landed
         __syncthreads();                                                 // conv tile complete; every wave has finished with rows buffer b
         ST_T(4);
-        if (n + 2 < n1) stage_rows(n + 2, b);                            // (travels under the pooling phase and the next image's MFMAs)
+        if constexpr (U8) {
+            // raw rows of image n + 3 into the buffer image n's came from (converted one pooling phase ago); image n + 1's raw rows -
+            // waited for before the barrier that ended image n - 1, two barriers back - become the rows buffer MFMA(n - 1) is done with
+            if (n + 3 < n1) stage_raw(n + 3);
+            if (n + 1 < n1) convert_rows(n + 1, 1 - b);
+        } else {
+            if (n + 2 < n1) stage_rows(n + 2, b);                        // (travels under the pooling phase and the next image's MFMAs)
+        }
         // pooling: 2 rows x 56 cols x 8 channel-chunks = 896 outputs of 16 B.  The inputs are post-ReLU, i.e. non-negative, and for
         // non-negative bf16 / f16 values the numeric order IS the order of their bit patterns read as unsigned integers: the maximum is
         // four packed v_pk_max_u16 per tap instead of 8 unpack-convert-fmax chains (sign bit masked first: a -0 would read as 0x8000).
@@ -437,6 +505,39 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
         hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
     else
         hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, crop);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// Fused form for frames that need no resize: uint8 NHWC frames [n][h][w][3] in, pooled stem output out; (top, left) = crop origin.
+// stem_pool_u8_ok: the geometry fits the kernel's 16-byte row DMA (and PVR_STEM_U8 / PVR_STEM_LDS are not 0).
+bool stem_pool_u8_ok(int h, int w, int top, int left) {
+    const char *e = getenv("PVR_STEM_U8"), *l = getenv("PVR_STEM_LDS");          // (read per call: the A/B test flips it inside one process)
+    const bool enabled = (!e || atoi(e) != 0) && (!l || atoi(l) != 0);
+    return enabled && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 && top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w &&
+           (long long)h * w * 3 < 0x7ffffff0ll;
+}
+pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int top, int left, const void *wgt, const float *bias, void *out,
+                               int dtype, hipStream_t stream) {
+    PVR_REQUIRE(stem_pool_u8_ok(h, w, top, left), "stem (uint8 form): geometry h=%d w=%d top=%d left=%d not supported", h, w, top, left);
+    static const int cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    const int yb = cus / 28 > 0 ? cus / 28 : 1;
+    const int ipb_fit = (n + yb - 1) / yb;
+    const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB ? ipb_fit : STEM_IPB);
+    dim3 grid(28, (n + ipb - 1) / ipb);
+    const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    U8Geo g;
+    g.src = frames; g.pitch = w * 3; g.img_bytes = h * w * 3; g.off0 = (top * w + left) * 3;
+    if (dtype == PVR_F16)
+        hipLaunchKernelGGL((stem_pool_lds_kernel<true, true>), grid, dim3(512), lds, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
+    else
+        hipLaunchKernelGGL((stem_pool_lds_kernel<false, true>), grid, dim3(512), lds, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }

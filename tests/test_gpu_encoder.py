@@ -266,6 +266,29 @@ def test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool(dt, n):
     m.close()
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_stem_reading_uint8_frames_is_bit_identical_to_preprocess_then_stem(monkeypatch, dt):
+    """Frames that need no resize (256 x 256: Resize(256) is the identity) skip the preprocess launch: stem_pool_lds_kernel<., true>
+    DMAs the crop window's raw uint8 rows into LDS and converts them itself.  Same values into the same MFMAs: the embeddings must be
+    bit-identical to PVR_STEM_U8=0 (preprocess_kernel -> padded 16-bit image -> stem), for 1 ... 70 images per launch (one image per block,
+    a single block row, ragged last block row, three-deep raw-row pipeline longer than the block's image list) and for every 5-crop window."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    m = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=70)
+    for n in (1, 2, 3, 9, 10, 31, 70):
+        d = torch.from_numpy(synth.frames(70 + n, n, 256, 256)).cuda()
+        for pos in ((0,) if n not in (3, 31) else (0, 1, 2, 3, 4)):
+            m.set_crop(pos)
+            outs = []
+            for u8 in ('1', '0'):
+                monkeypatch.setenv('PVR_STEM_U8', u8)
+                outs.append(m(d).clone())
+            assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+            assert torch.equal(outs[0], outs[1]), (n, pos, int((outs[0] != outs[1]).sum()))
+    m.set_crop(0)
+    m.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # whole encoder
 # ------------------------------------------------------------------------------------------------
