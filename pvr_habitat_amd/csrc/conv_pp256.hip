@@ -147,8 +147,13 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     const int nk = p.KH * p.KW * cpt;
     int xs_tap = 0, xs_kh = 0, xs_kw = 0, xs_cs = 0;   // filter position of the next X tile to stage (wave-uniform)
 
+#ifdef PP_KNOCK
+#define PP_KNOCK_ PP_KNOCK
+#else
+#define PP_KNOCK_ 0            // timing experiments (scripts/pp256_stamps.hip -DPP_KNOCK=bits): 1 no RAW wait in phase 3, 2 no LDS-DMA in the K loop, 4 no fragment reads
+#endif
 #define PP_STAGE_X(h_, buf_)                                                                                     \
-    {                                                                                                            \
+    if constexpr (!(PP_KNOCK_ & 2)) {                                                                            \
         const int tap_off = ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;                                     \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                         \
             const int vo = ((a_mask[h_][i] >> xs_tap) & 1) ? a_off[h_][i] + tap_off : OOB;                        \
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #define PP_ADVANCE_X()                                                                                           \
     { if (++xs_cs == cpt) { xs_cs = 0; ++xs_tap; if (++xs_kw == p.KW) { xs_kw = 0; ++xs_kh; } } }
 #define PP_STAGE_W(h_, kt_, buf_)                                                                                \
-    {                                                                                                            \
+    if constexpr (!(PP_KNOCK_ & 2)) {                                                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, PP_LDS_PTR((buf_) * BUF + WOFF + (h_) * HALF + (i * 8 + wave) * 1024), 16, \
                                                      b_off[h_][i], (kt_) * 128, 0, 0);                           \
@@ -229,10 +234,12 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     PP_T(sti++);                                                                                                 \
     PP_T(sti++);
 #define PP_READ_X(dst_, j0_, B_)                                                                                 \
+    if constexpr (!(PP_KNOCK_ & 4))                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
         _Pragma("unroll") for (int j = 0; j < ((j0_) == 0 ? 4 : T1); ++j)                                        \
             dst_[j][ks] = *reinterpret_cast<const V8 *>(smem + xrd[B_][ks] + ((j0_) + j) * 2048);
 #define PP_READ_W(i0_, B_)                                                                                       \
+    if constexpr (!(PP_KNOCK_ & 4))                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
             wf[i][ks] = *reinterpret_cast<const V8 *>(smem + wrd[B_][ks] + ((i0_) + i) * 2048);
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             _Pragma("unroll") for (int j = 0; j < ((j0_) == 0 ? 4 : T1); ++j)                                    \
                 acc[(i0_) + i][(j0_) + j] = mfma16<F16>(wf[i][ks], x_[j][ks], acc[(i0_) + i][(j0_) + j]);
 
+#define PP_KNOCK_WAIT() { if constexpr (!(PP_KNOCK_ & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     // one K tile; B_ is a literal so that every LDS address is base register + immediate
 #define PP_TILE(kt_, B_)                                                                                         \
     {                                                                                                            \
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         PP_FEED_DONE(); PP_MATH(2, x1, 4); PP_MATH_DONE();                                                       \
         if (next2) {                                                                                             \
             PP_STAGE_X(1, B_); PP_ADVANCE_X();                                                                   \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                     \
+            PP_KNOCK_WAIT();                                                                                     \
         } else {                                                                                                 \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
         }                                                                                                        \
