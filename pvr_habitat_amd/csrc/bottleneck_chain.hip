@@ -58,8 +58,11 @@ __device__ unsigned long long chain_stamps[8192][12];
 #define CH_T(i_)
 #endif
 
+#ifndef CH_KNOCK
+#define CH_KNOCK 0      // timing experiments (scripts/chain_stamps.hip -DCH_KNOCK=bits): 1 no y / t1' stores, 2 residual refill loads go out of range (zeros, no traffic)
+#endif
 __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
+    if constexpr (!(CH_KNOCK & 1)) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
 }
 
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         if constexpr (!DS) {                                                                                            \
             _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                              \
                 _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                          \
-                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), d * 128, 0)); \
+                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : Y_OFF(j), d * 128, 0)); \
         }                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                               \
             w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));            \
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         if (!DS && g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, Y_OFF(j), (g + RD) * 128, 0));
+                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : Y_OFF(j), (g + RD) * 128, 0));
         }
         if (g == 1) CH_T(8);
         __syncthreads();                          // y group visible; every wave is done with this W3 group
