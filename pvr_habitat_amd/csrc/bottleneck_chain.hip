@@ -59,7 +59,8 @@ __device__ unsigned long long chain_stamps[8192][12];
 #endif
 
 #ifndef CH_KNOCK
-#define CH_KNOCK 0      // timing experiments (scripts/chain_stamps.hip -DCH_KNOCK=bits): 1 no y / t1' stores, 2 residual refill loads go out of range (zeros, no traffic)
+#define CH_KNOCK 0      // timing experiments (scripts/chain_stamps.hip -DCH_KNOCK=bits): 1 no y / t1' stores, 2 residual loads out of range (zeros, no traffic);
+                        // phase A of the halo form: 4 no W2 ring stores, 8 no W2 loads, 16 no per-step barrier, 32 no fragment reads
 #endif
 __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
     if constexpr (!(CH_KNOCK & 1)) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             if (kt + RL < nk) {                   // register stage kt % RL held slice kt, which reached LDS during step kt - 1
 #pragma unroll
                 for (int i = 0; i < B_CH; ++i)
-                    w2r[kt % RL][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, b_off[i], (kt + RL) * (BK * 2), 0));
+                    w2r[kt % RL][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (CH_KNOCK & 8) ? OOB : b_off[i], (kt + RL) * (BK * 2), 0));
             }
             const int tp = kt / KS, csl = kt % KS, shift = (tp / 3) * p.W + tp % 3;
             int xo[TM];
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             for (int ks = 0; ks < 2; ++ks) {
                 V8 xa[TM], wb[TN];
 #pragma unroll
-                for (int j = 0; j < TM; ++j) xa[j] = *reinterpret_cast<const V8 *>(smem + (xo[j] ^ (ks * 64)));
+                for (int j = 0; j < TM; ++j) if constexpr (!(CH_KNOCK & 32)) xa[j] = *reinterpret_cast<const V8 *>(smem + (xo[j] ^ (ks * 64)));
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const V8 *>(ring + b_rd[ks][i]);
+                for (int i = 0; i < TN; ++i) if constexpr (!(CH_KNOCK & 32)) wb[i] = *reinterpret_cast<const V8 *>(ring + b_rd[ks][i]);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             if (kt + 1 < nk) {
 #pragma unroll
                 for (int i = 0; i < B_CH; ++i)
-                    *reinterpret_cast<u32x4 *>(smem + RING_OFF + ((kt + 1) & 1) * SLICE + lds_st + i * 32 * 128) = w2r[(kt + 1) % RL][i];
+                    if constexpr (!(CH_KNOCK & 4)) *reinterpret_cast<u32x4 *>(smem + RING_OFF + ((kt + 1) & 1) * SLICE + lds_st + i * 32 * 128) = w2r[(kt + 1) % RL][i];
             }
-            __syncthreads();                      // slice kt + 1 visible; every wave is done with stage kt & 1 (and, at the end, the halo)
+            if constexpr (!(CH_KNOCK & 16)) __syncthreads();                      // slice kt + 1 visible; every wave is done with stage kt & 1 (and, at the end, the halo)
         }
     } else {
     PVR_LOAD_SLICE(0);
