@@ -286,6 +286,17 @@ def test_stem_reading_uint8_frames_is_bit_identical_to_preprocess_then_stem(monk
             assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
             assert torch.equal(outs[0], outs[1]), (n, pos, int((outs[0] != outs[1]).sum()))
     m.set_crop(0)
+    # non-square frames whose shorter edge already is 256 (Resize(256) still the identity): centre and corner crops off-centre in one axis
+    for hh, ww in ((256, 320), (288, 256)):
+        d = torch.from_numpy(synth.frames(7, 5, hh, ww)).cuda()
+        for pos in (0, 2, 3):
+            m.set_crop(pos)
+            outs = []
+            for u8 in ('1', '0'):
+                monkeypatch.setenv('PVR_STEM_U8', u8)
+                outs.append(m(d).clone())
+            assert torch.equal(outs[0], outs[1]), (hh, ww, pos, int((outs[0] != outs[1]).sum()))
+    m.set_crop(0)
     m.close()
 
 
