@@ -741,7 +741,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if (enc->stop_after.empty() && enc->desc.crop == 224 && enc->crop_pos >= 0 && enc->crop_pos <= 4) {
             int rn = 1, top = 0, left = 0;
             preprocess_geometry(h, w, enc->desc.resize, enc->desc.crop, enc->crop_pos, &rn, &top, &left);
-            if (!rn && stem_pool_u8_ok(h, w, top, left)) {
+            if (!rn && stem_pool_u8_ok(fr, h, w, top, left)) {
                 if ((s = mark())) return s;                  // (launch index of the preprocess stays: pvr_encoder_profile)
                 if ((s = launch_stem_pool_u8(fr, nb, h, w, top, left, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], dt, st))) return s;
                 fused_u8 = 1;

@@ -12,7 +12,7 @@ pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, i
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
 pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
-bool stem_pool_u8_ok(int, int, int, int);
+bool stem_pool_u8_ok(const void *, int, int, int, int);
 pvr_status launch_stem_pool_u8(const uint8_t *, int, int, int, int, int, const void *, const float *, void *, int, hipStream_t);
 void preprocess_geometry(int h, int w, int resize, int crop, int crop_pos, int *resize_needed, int *top, int *left);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);

@@ -511,15 +511,15 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
 
 // Fused form for frames that need no resize: uint8 NHWC frames [n][h][w][3] in, pooled stem output out; (top, left) = crop origin.
 // stem_pool_u8_ok: the geometry fits the kernel's 16-byte row DMA (and PVR_STEM_U8 / PVR_STEM_LDS are not 0).
-bool stem_pool_u8_ok(int h, int w, int top, int left) {
+bool stem_pool_u8_ok(const void *frames, int h, int w, int top, int left) {
     const char *e = getenv("PVR_STEM_U8"), *l = getenv("PVR_STEM_LDS");          // (read per call: the A/B test flips it inside one process)
     const bool enabled = (!e || atoi(e) != 0) && (!l || atoi(l) != 0);
-    return enabled && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 && top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w &&
+    return enabled && ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&      // (16-byte row DMA: every source chunk aligned) top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w &&
            (long long)h * w * 3 < 0x7ffffff0ll;
 }
 pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int top, int left, const void *wgt, const float *bias, void *out,
                                int dtype, hipStream_t stream) {
-    PVR_REQUIRE(stem_pool_u8_ok(h, w, top, left), "stem (uint8 form): geometry h=%d w=%d top=%d left=%d not supported", h, w, top, left);
+    PVR_REQUIRE(stem_pool_u8_ok(frames, h, w, top, left), "stem (uint8 form): geometry h=%d w=%d top=%d left=%d not supported", h, w, top, left);
     static const int cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
     const int yb = cus / 28 > 0 ? cus / 28 : 1;
     const int ipb_fit = (n + yb - 1) / yb;

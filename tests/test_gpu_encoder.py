@@ -297,6 +297,15 @@ def test_stem_reading_uint8_frames_is_bit_identical_to_preprocess_then_stem(monk
                 outs.append(m(d).clone())
             assert torch.equal(outs[0], outs[1]), (hh, ww, pos, int((outs[0] != outs[1]).sum()))
     m.set_crop(0)
+    # frames that do not start on a 16-byte boundary cannot use the 16-byte row DMA: the library takes the preprocess path by itself
+    monkeypatch.setenv('PVR_STEM_U8', '1')
+    src = torch.from_numpy(synth.frames(9, 3, 256, 256)).cuda()
+    buf = torch.zeros(src.numel() + 32, dtype=torch.uint8, device='cuda')
+    off = 3 + (-buf.data_ptr()) % 16                                    # data_ptr + off = 3 (mod 16)
+    view = buf[off:off + src.numel()].view(3, 256, 256, 3)
+    view.copy_(src)
+    assert view.data_ptr() % 16 == 3 and view.is_contiguous()
+    assert torch.equal(m(view), m(src))
     m.close()
 
 
