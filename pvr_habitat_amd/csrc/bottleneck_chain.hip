@@ -22,21 +22,10 @@
 //     the W3 group; only the W1' slice lives beside them.
 //   * phase-B weights and the next group's residual are prefetched into registers one group ahead; plain loads, so
 //     hipcc's counted vmcnt keeps them in flight across the barriers.
-#include "common.h"
+#include "chain_params.h"
 
 namespace pvr {
 
-struct ChainP {
-    const u16 *in, *w2, *w3, *w1n, *res;
-    const float *b2, *b3, *b1n;
-    u16 *y, *t1n;
-    int N, H, W, Ho, Wo, stride, M;
-    unsigned in_bytes, w2_bytes, w3_bytes, w1n_bytes, y_bytes, t1n_bytes;
-    // DS form (block 0 of layer1): the identity branch is a 1x1 stride-1 convolution of the block input x (64 channels); it is
-    // accumulated into conv3's fp32 accumulators (a K extension of 64) instead of being read back as a 16-bit residual tensor
-    const u16 *xds = nullptr, *wds = nullptr;      // x [M][64]; Wd [4Cm][64] with W3's row permutation; b3 then holds b3 + bd
-    unsigned xds_bytes = 0, wds_bytes = 0;
-};
 
 // 16-byte buffer store with a compile-time byte offset.  The offset goes into the instruction's immediate field
 // (voffset + constant, soffset = 0), NEVER into soffset: with an SGPR soffset hipcc (ROCm 7.2) omits the wait states
@@ -658,6 +647,13 @@ static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream
     return PVR_ERR_INVALID;
 }
 
+// PVR_CHAIN_WAVE=0 keeps the stride-1 Cm = 64 tails on the block form above (A/B runs; both forms are bit-identical)
+static bool chain_wave_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PVR_CHAIN_WAVE"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 bool chain_ds_supported(int cm, int cmn, int cin, int stride) { return cm == 64 && cmn == 64 && cin == 64 && stride == 1; }
 bool chain_supported(int cm, int cmn) { return (cm == 64 && (cmn == 0 || cmn == 64 || cmn == 128)) || (cm == 128 && (cmn == 0 || cmn == 128)); }
 
@@ -683,6 +679,7 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
     p.xds = (const u16 *)xds; p.wds = (const u16 *)wdsp;
     p.xds_bytes = xds ? (unsigned)(M * 64 * 2) : 0; p.wds_bytes = xds ? (unsigned)(4 * cm * 64 * 2) : 0;
     p.w2_bytes = (unsigned)(cm * 9 * cm * 2); p.w3_bytes = (unsigned)(4 * cm * cm * 2); p.w1n_bytes = (unsigned)(cmn * 4 * cm * 2);
+    if (chain_wave_enabled() && chain_wave_supported(cm, cmn, stride, xds != nullptr)) return launch_chain_wave(p, cmn, dtype, stream);
     return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
 }
 
