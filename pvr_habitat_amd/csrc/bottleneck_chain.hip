@@ -647,12 +647,13 @@ static pvr_status launch_chain_dt(ChainP &p, int cm, int cmn, hipStream_t stream
     return PVR_ERR_INVALID;
 }
 
-// PVR_CHAIN_WAVE=0 keeps the stride-1 Cm = 64 tails on the block form above (A/B runs; both forms are bit-identical)
+// PVR_CHAIN_WAVE=0 keeps the stride-1 Cm = 64 tails on the block form above (A/B runs; both forms are bit-identical); read per plan
 static bool chain_wave_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PVR_CHAIN_WAVE"); v = e ? atoi(e) : 1; }
-    return v != 0;
+    const char *e = getenv("PVR_CHAIN_WAVE");
+    return !e || atoi(e) != 0;
 }
+
+bool chain_uses_wave_form(int cm, int cmn, int stride, bool ds) { return chain_wave_enabled() && chain_wave_supported(cm, cmn, stride, ds); }
 
 bool chain_ds_supported(int cm, int cmn, int cin, int stride) { return cm == 64 && cmn == 64 && cin == 64 && stride == 1; }
 bool chain_supported(int cm, int cmn) { return (cm == 64 && (cmn == 0 || cmn == 64 || cmn == 128)) || (cm == 128 && (cmn == 0 || cmn == 128)); }
@@ -662,7 +663,10 @@ int chain_row_source(int row) { return (row & ~31) + 8 * ((row >> 2) & 3) + 4 * 
 
 pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
                                    void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
-                                   int stride, int dtype, hipStream_t stream, const void *xds, const void *wdsp) {
+                                   int stride, int dtype, hipStream_t stream, const void *xds, const void *wdsp, const void *w3pb, const void *wdspb,
+                                   int wave, int in_blk, int out_blk) {
+    // wave: run the wave form (chain_wave.hip; the plan decided with chain_uses_wave_form); w3pb / wdspb: blocked copies of w3p / wdsp for
+    // it; in_blk / out_blk: blocked activations between two wave-form launches
     // xds != null: `res` is unused; the identity branch is Wd . x (x = xds: [pixels][64], wdsp: [4Cm][64] row-permuted) and b3 = b3 + bd
     PVR_REQUIRE(chain_supported(cm, cmn), "bottleneck chain: unsupported widths Cm=%d next=%d", cm, cmn);
     PVR_REQUIRE(t1 && w2 && b2 && w3p && b3 && (res || xds) && y && (cmn == 0 || (w1np && b1n && t1n)), "bottleneck chain: null argument");
@@ -679,7 +683,12 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
     p.xds = (const u16 *)xds; p.wds = (const u16 *)wdsp;
     p.xds_bytes = xds ? (unsigned)(M * 64 * 2) : 0; p.wds_bytes = xds ? (unsigned)(4 * cm * 64 * 2) : 0;
     p.w2_bytes = (unsigned)(cm * 9 * cm * 2); p.w3_bytes = (unsigned)(4 * cm * cm * 2); p.w1n_bytes = (unsigned)(cmn * 4 * cm * 2);
-    if (chain_wave_enabled() && chain_wave_supported(cm, cmn, stride, xds != nullptr)) return launch_chain_wave(p, cmn, dtype, stream);
+    if (wave) {
+        PVR_REQUIRE(chain_wave_supported(cm, cmn, stride, xds != nullptr), "bottleneck chain: no wave form for Cm=%d next=%d stride=%d", cm, cmn, stride);
+        p.w3b = (const u16 *)w3pb; p.wdsb = (const u16 *)wdspb; p.in_blk = in_blk; p.out_blk = out_blk;
+        return launch_chain_wave(p, cmn, dtype, stream);
+    }
+    PVR_REQUIRE(!in_blk && !out_blk, "bottleneck chain: the blocked layout is the wave form's");
     return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
 }
 

@@ -14,10 +14,25 @@ struct ChainP {
     // accumulated into conv3's fp32 accumulators (a K extension of 64) instead of being read back as a 16-bit residual tensor
     const u16 *xds = nullptr, *wds = nullptr;      // x [M][64]; Wd [4Cm][64] with W3's row permutation; b3 then holds b3 + bd
     unsigned xds_bytes = 0, wds_bytes = 0;
+    // wave form: t1 + residual (in) / y + t1' (out) in the blocked layout [pixel >> 4][channel >> 3][pixel & 15][8] (chain_wave.hip)
+    int in_blk = 0, out_blk = 0;
+    // ... and the row-permuted W3 / Wd in that layout ([row >> 4][channel >> 3][row & 15][8]) for the instances that read them from L2
+    const u16 *w3b = nullptr, *wdsb = nullptr;
 };
+
+bool chain_supported(int cm, int cmn);
+bool chain_ds_supported(int cm, int cmn, int cin, int stride);
+bool chain_uses_wave_form(int cm, int cmn, int stride, bool ds);   // PVR_CHAIN_WAVE (default 1) and an instance exists; read when a plan is built
+int chain_row_source(int row);
+pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
+                                   void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
+                                   int stride, int dtype, hipStream_t stream, const void *xds = nullptr, const void *wdsp = nullptr,
+                                   const void *w3pb = nullptr, const void *wdspb = nullptr, int wave = 0, int in_blk = 0, int out_blk = 0);
+
 
 // chain_wave.hip: the barrier-free form (stride-1 blocks with Cm = 64)
 bool chain_wave_supported(int cm, int cmn, int stride, bool ds);
+bool chain_wave_blocked_ok(int cmn_first, int h, int w);
 pvr_status launch_chain_wave(ChainP &p, int cmn, int dtype, hipStream_t stream);
 
 }  // namespace pvr

@@ -16,22 +16,26 @@
 //     accumulators to MFMA operands in registers (bias + ReLU + 16-bit rounding in between, as the unfused launches round them);
 //     nothing is written to LDS after the prologue and no wave ever waits for another.
 //   * All weights of the block stay in LDS for the whole launch (W2 72 KB, W3 32 KB, W1' 32 KB, biases): one 512-thread block per CU,
-//     persistent, every wave walks its own list of 32-pixel tiles.  (Cmn = 128: W1' is 64 KB, so W3's fragments are read from L2 in
-//     MFMA layout instead; DS: Wd's fragments likewise.)
-//   * conv2's pixel fragments are 16-byte global loads in operand layout (a lane reads channels 8q..8q+7 of pixel m + tap shift;
-//     taps outside the image read past the buffer: the range check returns zeros).  The nine taps re-read each line from L1 / L2;
-//     HBM sees t1 once.  Loads run XD K-steps ahead of their MFMAs through a register ring and the next tile's first steps and
-//     residual half-groups are requested before the current tile's stores are issued (loads and stores share one in-order vmcnt queue).
+//     persistent, every wave walks its own list of 32-pixel tiles.  (Cmn = 128: W1' is 64 KB, so W3's pieces are read from L2
+//     instead; DS: Wd's likewise.)
+//   * Memory lane layouts.  The MFMA fragment layout (lane = 16 * chunk + pixel) makes a quarter wave - the unit the texture-address
+//     path works in - touch 16 pixel rows x 16 B of an NHWC tensor: measured 4x slower through the TA than 4 rows x 64 B
+//     (profiles/experiments/r04_chain_wave.txt).  Two answers, both used:
+//       - NHWC tensors (the launch's boundary with other kernels): lane l moves pixel l >> 2, 16-byte chunk l & 3 of a 64-byte piece;
+//         ds_bpermute (the LDS crossbar, no LDS memory) turns a loaded register into a fragment and a result into a store register.
+//       - BLOCKED tensors between two launches of this form ("P16C8": [pixel >> 4][channel >> 3][pixel & 15][8 channels], i.e. every
+//         (16 pixels x 8 channels) fragment column is 256 contiguous bytes): the fragment layout IS the coalesced layout - loads,
+//         stores and the residual need no permutation and a wave instruction moves 1 KB of contiguous memory.
+//   * conv2's pixels.  NHWC input: 16-byte pieces per K-step, XD steps ahead of their MFMAs through a register ring.  Blocked input
+//     (HALO): the tile's whole halo - the ten 16-pixel blocks around it, 20 KB - is loaded ONCE, one full phase ahead, and the nine
+//     taps' fragments are made from those registers by DPP row shifts (pixel m + s of a 16-lane row = lane + (s & 15) of block
+//     k or k + 1): no load is issued while conv2 runs, none ever waits behind a store, and t1 crosses the TA once instead of nine times.
 //
-// Eight independent waves per CU, each with ~25 KB of loads and stores in flight, keep HBM busy while other waves compute; MFMA work
-// is ~25 % of the launch's HBM time, so the launch is a stream with arithmetic underneath.  Numerics: the same rounding points and the
-// same K order per accumulator as bottleneck_chain.hip and the unfused launches - bit-identical outputs
-// (tests/test_gpu_encoder.py::test_fused_bottleneck_chain_is_bit_identical, ::test_chain_wave_equals_block_form).
+// Numerics: the same rounding points and the same K order per accumulator as bottleneck_chain.hip and the unfused launches -
+// bit-identical outputs (tests/test_gpu_encoder.py::test_fused_bottleneck_chain_is_bit_identical, scripts/chain_wave_bench.hip).
 #include "chain_params.h"
 
 namespace pvr {
-
-int chain_row_source(int row);
 
 __device__ __forceinline__ int cw_row_source(int row) { return (row & ~31) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3); }
 
@@ -45,21 +49,50 @@ __device__ __forceinline__ void cw_store(u32x4 v, __amdgpu_buffer_rsrc_t rs, int
     else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
 }
 
+typedef float cw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 cw_f16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two 16-bit values (round to nearest even, as to_h): one v_cvt_pk instruction instead of two conversions + a pack
+template <bool F16> __device__ __forceinline__ unsigned cw_pack2(float a, float b) {
+    const cw_f32x2 v = {a, b};
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cw_f16x2));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cw_bf16x2));
+}
+
+__device__ __forceinline__ u32x4 cw_perm(int addr, u32x4 v) {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[e]);
+    return r;
+}
+
+// lane fr of every 16-lane row <- lane fr + d of `lo` where that stays inside the row, else lane fr + d - 16 of `hi` (DPP row shifts)
+__device__ __forceinline__ unsigned cw_row_shift(unsigned lo, unsigned hi, int d) {
+#define CW_SH(D_) case D_: { const int a_ = __builtin_amdgcn_update_dpp(0, (int)lo, 0x100 + D_, 0xf, 0xf, true); \
+                             return (unsigned)__builtin_amdgcn_update_dpp(a_, (int)hi, 0x110 + (16 - D_), 0xf, 0xf, false); }
+    switch (d) {
+        CW_SH(1) CW_SH(2) CW_SH(3) CW_SH(4) CW_SH(5) CW_SH(6) CW_SH(7) CW_SH(8) CW_SH(9) CW_SH(10) CW_SH(11) CW_SH(12) CW_SH(13) CW_SH(14) CW_SH(15)
+        default: return lo;
+    }
+#undef CW_SH
+}
+
 struct CwTile {
-    int xb[2];      // byte offset of (pixel, 16-byte chunk lc) in t1 (128-byte rows); also x's offset in the DS form
-    int mk[2];      // 9-bit "tap inside the image" mask of the pixel (0 for pixels past M)
-    int yo[2];      // byte offset of (pixel, 16-byte chunk lc) in y / the residual tensor (512-byte rows)
+    int xb[2];      // conv2 input: byte offset of the lane's piece at the centre tap (NHWC: (pixel lp, chunk lc); blocked ring: pixel index m0 + 16 j + fr)
+    int mk[2];      // 9-bit "tap inside the image" mask of the pixel the lane loads (NHWC) / owns in the fragment (blocked)
+    int yi[2];      // residual: byte offset of the lane's 16 bytes of half-group 0
+    int yo[2];      // y: likewise for the store
+    int to[2];      // t1': likewise (tile pair 0)
+    int hb;         // HALO: byte offset of the lane's 16 bytes of halo block 0, K half 0
 };
 
-// Addresses of a wave's 32-pixel tile in the MEMORY lane layout: lane l handles pixel lp = l >> 2 of a 16-pixel MFMA tile and the
-// 16-byte chunk lc = l & 3 of a 64-byte piece of its row.  A quarter wave (the unit the texture-address path works in) then touches
-// 4 rows x 64 B instead of the 16 rows x 16 B of the MFMA fragment layout (lane = 16 * chunk + pixel): 4x fewer row touches per
-// wave instruction.  cw_perm_in / cw_perm_out (ds_bpermute: the LDS crossbar, no LDS memory) move a loaded register into fragment
-// layout and a result register back.
-__device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lp, int lc, int M, int H, int W) {
+template <int CMN, bool INB, bool OUTB>
+__device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lane, int M, int H, int W) {
+    const int fr = lane & 15, fq = lane >> 4, lp = lane >> 2, lc = lane & 3;
+    a.hb = ((m0 >> 4) - 4) * 2048 + fq * 256 + fr * 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = m0 + 16 * j + lp;
+        const int m = m0 + 16 * j + (INB ? fr : lp);       // the pixel whose taps this lane masks
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         const int wo = mm % W, ho = (mm / W) % H;
@@ -72,34 +105,35 @@ __device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lp, int lc, int 
         int mask = 0;
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * 3)) : 0;
-        a.xb[j] = m * 128 + lc * 16;
         a.mk[j] = mask;
-        a.yo[j] = m * 512 + lc * 16;
+        a.xb[j] = INB ? m : m * 128 + lc * 16;
+        const int blk = (m0 >> 4) + j;                     // (m0 is a multiple of 32: pixel tile j is block blk of a blocked tensor)
+        a.yi[j] = INB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
+        a.yo[j] = OUTB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
+        a.to[j] = OUTB ? blk * (CMN * 32) + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * (CMN * 2) + lc * 16;
     }
 }
 
-__device__ __forceinline__ u32x4 cw_perm(int addr, u32x4 v) {
-    u32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[e]);
-    return r;
-}
-
-// XD: conv2 K-steps of pixel pieces in flight (8 VGPRs each); RD: residual half-groups in flight (8 VGPRs each);
+// INB / OUTB: t1 + residual / y + t1' in the blocked layout; HALO (with INB, W = 56): conv2's pixels from halo registers
+// XD: conv2 K-steps of pixel pieces in flight (ring forms; 8 VGPRs each); RD: residual half-groups in flight (8 VGPRs each);
 // WD: half-groups of W3 / Wd pieces in flight when they come from L2 (16 VGPRs each)
-template <int CMN, bool F16, bool DS, bool W3G, int XD, int RD, int WD, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
+template <int CMN, bool F16, bool DS, bool W3G, bool INB, bool OUTB, bool HALO, int XD, int RD, int WD>
+__global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
     typedef typename HT<F16>::V8 V8;
+    constexpr int WW = 56, HB = 10;                        // HALO: image width (the launcher checks), 16-pixel blocks m0 / 16 - 4 .. + 5 cover m0 - 57 .. m0 + 88
     constexpr int NH = 8, NK = 18;                         // half-groups of 32 couts; conv2 K-steps of 32 channels (9 taps x 2)
     constexpr int TN1 = CMN / 16;
     constexpr int W2L = 0, W3L = 73728, W1L = W3G ? 73728 : 73728 + 32768;
     constexpr int B2L = W1L + CMN * 512, B3L = B2L + 256, B1L = B3L + 1024;
     constexpr int OOB = 0x7ffffff0;
+    constexpr int YH = INB ? 1024 : 64, YHO = OUTB ? 1024 : 64;     // byte step of a half-group (32 channels) in the residual / in y
     static_assert(XD >= 1 && XD <= NK && RD >= 1 && RD <= NH && NH % RD == 0 && WD >= 1 && WD <= NH, "prefetch depths (the residual ring must close over a tile)");
+    static_assert(!HALO || INB, "the halo form reads the blocked layout");
+    static_assert(!(DS && INB), "the DS instance reads NHWC inputs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int lp = lane >> 2, lc = lane & 3;               // memory lane layout: pixel (row) of the 16-row tile, 16-byte chunk of the 64-byte piece
+    const int lp = lane >> 2, lc = lane & 3;               // NHWC memory lane layout: pixel (row) of the 16-row tile, 16-byte chunk of the 64-byte piece
     const int pin = (fr * 4 + fq) * 4;                     // ds_bpermute source of fragment lane (fr, fq): memory lane 4 fr + fq
     const int pout = (lc * 16 + lp) * 4;                   // ... and of memory lane (lp, lc): fragment lane 16 lc + lp
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
@@ -107,38 +141,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
     const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
     const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1n), 0, p.w1n_bytes, 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DS ? p.xds : p.res), 0, DS ? p.xds_bytes : p.y_bytes, 0x00020000);
-    const auto rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DS ? p.wds : p.w3), 0, DS ? p.wds_bytes : p.w3_bytes, 0x00020000);
+    const auto rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DS ? p.wdsb : p.w3b), 0, DS ? p.wds_bytes : p.w3_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
 
     // ---- prologue: the block's weights and biases -> LDS ([rows][64] 16-bit tiles, 128-byte rows, chunk ^= (row >> 1) & 7) -------
-    constexpr int NT = NW * 64;
 #pragma unroll
-    for (int q = 0; q < (4608 + NT - 1) / NT; ++q) {        // W2: 9 taps x 64 rows x 8 chunks; LDS row r holds cout cw_row_source(r)
-        const int idx = tid + NT * q, tap = idx >> 9, r = (idx >> 3) & 63, c = idx & 7;
-        if (idx < 4608) {
-            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (cw_row_source(r) * 576 + tap * 64 + c * 8) * 2, 0, 0));
-            *reinterpret_cast<u32x4 *>(smem + W2L + tap * 8192 + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
-        }
+    for (int q = 0; q < 9; ++q) {                          // W2: 9 taps x 64 rows x 8 chunks; LDS row r holds cout cw_row_source(r)
+        const int r = tid >> 3, c = tid & 7;
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (cw_row_source(r) * 576 + c * 8) * 2, q * 128, 0));
+        *reinterpret_cast<u32x4 *>(smem + W2L + q * 8192 + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
     }
     if constexpr (!W3G) {                                  // W3 (rows already permuted by the host): [256][64]
 #pragma unroll
-        for (int q = 0; q < (2048 + NT - 1) / NT; ++q) {
-            const int idx = tid + NT * q, r = idx >> 3, c = idx & 7;
-            if (idx < 2048) {
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, idx * 16, 0, 0));
-                *reinterpret_cast<u32x4 *>(smem + W3L + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 512 * q, r = idx >> 3, c = idx & 7;
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, idx * 16, 0, 0));
+            *reinterpret_cast<u32x4 *>(smem + W3L + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
         }
     }
     if constexpr (CMN > 0) {                               // W1' (rows permuted): [CMN][256] -> four K groups of [CMN][64]
 #pragma unroll
-        for (int q = 0; q < (CMN * 32 + NT - 1) / NT; ++q) {
-            const int idx = tid + NT * q, r = idx >> 5, c32 = idx & 31;
-            if (idx < CMN * 32) {
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, idx * 16, 0, 0));
-                *reinterpret_cast<u32x4 *>(smem + W1L + (c32 >> 3) * (CMN * 128) + r * 128 + (((c32 & 7) ^ ((r >> 1) & 7)) << 4)) = v;
-            }
+        for (int q = 0; q < CMN * 32 / 512; ++q) {
+            const int idx = tid + 512 * q, r = idx >> 5, c32 = idx & 31;
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, idx * 16, 0, 0));
+            *reinterpret_cast<u32x4 *>(smem + W1L + (c32 >> 3) * (CMN * 128) + r * 128 + (((c32 & 7) ^ ((r >> 1) & 7)) << 4)) = v;
         }
     }
     if (tid < 64) *reinterpret_cast<float *>(smem + B2L + tid * 4) = p.b2[tid];
@@ -146,10 +173,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
     if constexpr (CMN > 0) { if (tid < CMN) *reinterpret_cast<float *>(smem + B1L + tid * 4) = p.b1n[tid]; }
     __syncthreads();                                       // the only barrier of the kernel
 
-    // ---- this wave's tiles: chunk = NW x 32 consecutive pixels; an XCD's blocks walk a contiguous run of chunks side by
+    // ---- this wave's tiles: chunk = 256 consecutive pixels (8 waves x 32); an XCD's blocks walk a contiguous run of chunks side by
     // side, so the rows two neighbouring tiles both read meet in that XCD's L2
-    constexpr int CH = NW * 32;                            // pixels per chunk
-    const int nch = (p.M + CH - 1) / CH, cx = (nch + 7) >> 3, L = gridDim.x >> 3;
+    const int nch = (p.M + 255) >> 8, cx = (nch + 7) >> 3, L = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7, c_end = min((xcd + 1) * cx, nch);
     int chunk = xcd * cx + (blockIdx.x >> 3);
     if (chunk >= c_end) return;
@@ -159,37 +185,67 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
     const int Wb = p.W * 128;
 
     CwTile cur, nxt;
-    cw_setup(cur, chunk * CH + wave * 32, lp, lc, p.M, p.H, p.W);
+    cw_setup<CMN, INB, OUTB>(cur, chunk * 256 + wave * 32, lane, p.M, p.H, p.W);
 
-    u32x4 xr[XD][2];                                       // conv2 pixel pieces (memory layout), K-steps kt .. kt + XD - 1
+    u32x4 xr[HALO ? 1 : XD][2];                            // ring forms: conv2 pixel pieces, K-steps kt .. kt + XD - 1
+    u32x4 xh[HALO ? HB : 1][2];                            // HALO: fragments of the ten 16-pixel blocks around the tile, K halves 0 / 1
     u32x4 rres[DS ? 1 : RD][2];                            // residual pieces, half-groups h .. h + RD - 1
     V8 xd[2][2];                                           // DS: the block input's fragments (K steps 0 / 1) of the wave's two pixel tiles
     u32x4 wg[(W3G || DS) ? WD : 1][2][2];                  // W3 (W3G) or Wd (DS) pieces from L2: [half-group ring][cout tile][K step]
+    // conv2 pixel pieces of K-step kt_ (tap kt_ / 2, channels 32 (kt_ & 1) ..) of tile A_ -> ring slot
 #define CW_ISSUE_X(slot_, kt_, A_)                                                                                      \
     {                                                                                                                   \
-        const int tp_ = (kt_) >> 1, sh_ = (tp_ / 3 - 1) * Wb + (tp_ % 3 - 1) * 128 + ((kt_) & 1) * 64;                 \
+        const int tp_ = (kt_) >> 1;                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
-            int vo_ = ((A_.mk[j] >> tp_) & 1) ? A_.xb[j] + sh_ : OOB;                                                   \
+            int vo_;                                                                                                    \
+            if constexpr (INB) {                           /* blocked: pixel pm's 16 bytes of chunk 4 ks + fq */        \
+                const int pm_ = A_.xb[j] + (tp_ / 3 - 1) * p.W + (tp_ % 3 - 1);                                         \
+                vo_ = (pm_ >> 4) * 2048 + (pm_ & 15) * 16 + (((kt_) & 1) * 4 + fq) * 256;                               \
+            } else vo_ = A_.xb[j] + (tp_ / 3 - 1) * Wb + (tp_ % 3 - 1) * 128 + ((kt_) & 1) * 64;                        \
+            vo_ = ((A_.mk[j] >> tp_) & 1) ? vo_ : OOB;                                                                  \
             if constexpr (CW_KNOCK & 4) vo_ = OOB;                                                                      \
             xr[slot_][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo_, 0, 0));          \
+        }                                                                                                               \
+    }
+    // HALO: the whole halo of a tile in one burst (no load is issued during conv2); blocks before / past the tensor read zeros
+#define CW_ISSUE_HALO(A_)                                                                                               \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < HB; ++k)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+                xh[k][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (CW_KNOCK & 4) ? OOB : A_.hb + k * 2048 + ks * 1024, 0, 0)); \
+    }
+    // HALO: fragment of K-step kt_ for pixel tile j_: pixel 16 j + fr at tap (kh, kw) is pixel 64 + 16 j + (kh - 1) W + (kw - 1) + fr of
+    // the halo, i.e. lane fr + d of block k0 (d = that offset & 15, k0 = offset >> 4) or, past the row's end, lane fr + d - 16 of block
+    // k0 + 1; then zero where the tap falls outside the pixel's image
+#define CW_FRAG(dst_, kt_, j_)                                                                                          \
+    {                                                                                                                   \
+        const int tp_ = (kt_) >> 1, ks_ = (kt_) & 1, o_ = 64 + 16 * (j_) + (tp_ / 3 - 1) * WW + tp_ % 3 - 1, k0_ = o_ >> 4, d_ = o_ & 15; \
+        const bool in_ = (cur.mk[j_] >> tp_) & 1;                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                 \
+            const unsigned v_ = cw_row_shift(xh[k0_][ks_][e], xh[k0_ + 1 < HB ? k0_ + 1 : k0_][ks_][e], d_);            \
+            dst_[e] = in_ ? v_ : 0u;                                                                                    \
         }                                                                                                               \
     }
 #define CW_ISSUE_RES(slot_, h_, A_)                                                                                     \
     {                                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
-            rres[slot_][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CW_KNOCK & 2) ? OOB : A_.yo[j], (h_) * 64, 0)); \
+            rres[slot_][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CW_KNOCK & 2) ? OOB : A_.yi[j], (h_) * YH, 0)); \
     }
-    // weight rows 32 h + 16 t + lp, channels 32 ks + 8 lc .. (128-byte rows: W3 [256][64] / Wd [256][64], both row-permuted)
+    // W3 (W3G) / Wd (DS) from L2, row-permuted [256][64] in the blocked layout [row >> 4][chunk][row & 15][8]: the fragment of rows
+    // 32 h + 16 t + fr, channels 32 ks + 8 fq .. is 1 KB of contiguous memory
 #define CW_ISSUE_WG(slot_, h_)                                                                                          \
     {                                                                                                                   \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                   \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
-                wg[slot_][t][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, wg_off + t * 2048 + ks * 64, (h_) * 4096, 0)); \
+                wg[slot_][t][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, wg_off + t * 2048 + ks * 1024, (h_) * 4096, 0)); \
     }
-    const int wg_off = lp * 128 + lc * 16;
+    const int wg_off = fq * 256 + fr * 16;
 
+    if constexpr (HALO) CW_ISSUE_HALO(cur)
+    else {
 #pragma unroll
-    for (int k = 0; k < XD; ++k) CW_ISSUE_X(k, k, cur);
+        for (int k = 0; k < XD; ++k) CW_ISSUE_X(k, k, cur);
+    }
     if constexpr (!DS) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) CW_ISSUE_RES(d, d, cur);
@@ -201,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
         // (the weights in LDS are loop-invariant: without this hipcc hoists all 2 KB of a lane's fragment reads out of the tile loop - into scratch)
         asm volatile("" : "+v"(lb0), "+v"(lb1));
 
-        // DS: the block input x at the wave's own pixels (the centre-tap pattern on the 64-channel tensor x); used from half-group 0 on
+        // DS: the block input x at the wave's own pixels (NHWC, 64 channels); requested here, used from half-group 0 on
         u32x4 xdr[2][2];
         if constexpr (DS) {
 #pragma unroll
@@ -211,22 +267,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
                     xdr[ks][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, cur.xb[j], ks * 64, 0));
         }
 
-        // ---- conv2 3x3: 32 pixels x 64 couts, K = 9 taps x 64 channels; weights from LDS, pixels from the register ring ----------
+        // ---- conv2 3x3: 32 pixels x 64 couts, K = 9 taps x 64 channels; weights from LDS -------------------------------------------
         f32x4 acc2[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 xc[2], xn[2];                                // fragments of the current / next K-step
+        if constexpr (HALO) { CW_FRAG(xc[0], 0, 0); CW_FRAG(xc[1], 0, 1); }
+        else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xc[j] = cw_perm(pin, xr[0][j]);
-        if (XD < NK) CW_ISSUE_X(0, XD, cur);
+            for (int j = 0; j < 2; ++j) xc[j] = INB ? xr[0][j] : cw_perm(pin, xr[0][j]);
+            if (XD < NK) CW_ISSUE_X(0, XD, cur);
+        }
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
-            if (kt + 1 < NK) {                             // the next step's pieces -> fragment layout while this step's MFMAs run
+            if (kt + 1 < NK) {                             // the next step's fragments while this step's MFMAs run
+                if constexpr (HALO) { CW_FRAG(xn[0], kt + 1, 0); CW_FRAG(xn[1], kt + 1, 1); }
+                else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xn[j] = cw_perm(pin, xr[(kt + 1) % XD][j]);
-                if (kt + 1 + XD < NK) CW_ISSUE_X((kt + 1) % XD, kt + 1 + XD, cur);
+                    for (int j = 0; j < 2; ++j) xn[j] = INB ? xr[(kt + 1) % XD][j] : cw_perm(pin, xr[(kt + 1) % XD][j]);
+                    if (kt + 1 + XD < NK) CW_ISSUE_X((kt + 1) % XD, kt + 1 + XD, cur);
+                }
             }
             const char *wbase = smem + W2L + (kt >> 1) * 8192 + ((kt & 1) ? lb1 : lb0);
             V8 wb[4];
@@ -253,15 +315,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                    o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
                 t2[q][j] = o;
             }
         }
 
-        // ---- the next tile's addresses and its first conv2 pieces: requested before this tile's stores are issued -----------------
-        cw_setup(nxt, more ? chunk_n * CH + wave * 32 : p.M, lp, lc, p.M, p.H, p.W);
+        // ---- the next tile's addresses and its conv2 pixels: requested before this tile's stores are issued -----------------------
+        cw_setup<CMN, INB, OUTB>(nxt, more ? chunk_n * 256 + wave * 32 : ((p.M + 31) & ~31), lane, p.M, p.H, p.W);
+        if (!more) nxt.hb = OOB;
+        if constexpr (HALO) CW_ISSUE_HALO(nxt)
+        else {
 #pragma unroll
-        for (int k = 0; k < XD; ++k) CW_ISSUE_X(k, k, nxt);
+            for (int k = 0; k < XD; ++k) CW_ISSUE_X(k, k, nxt);
+        }
         if constexpr (W3G || DS) {
 #pragma unroll
             for (int d = 0; d < WD; ++d) CW_ISSUE_WG(d, d);
@@ -287,7 +353,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
             u32x4 rp[2], wp[2][2];
             if constexpr (!DS) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) rp[j] = cw_perm(pin, rres[h % RD][j]);
+                for (int j = 0; j < 2; ++j) rp[j] = INB ? rres[h % RD][j] : cw_perm(pin, rres[h % RD][j]);
                 if (h + RD < NH) CW_ISSUE_RES(h % RD, h + RD, cur)
                 else CW_ISSUE_RES(h % RD, h + RD - NH, nxt)
             }
@@ -295,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) wp[t][ks] = cw_perm(pin, wg[h % WD][t][ks]);
+                    for (int ks = 0; ks < 2; ++ks) wp[t][ks] = wg[h % WD][t][ks];
                 if (h + WD < NH) CW_ISSUE_WG(h % WD, h + WD);
             }
             f32x4 acc3[2][2];
@@ -324,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc3[t][j] = mfma16<F16>(__builtin_bit_cast(V8, wp[t][ks]), xd[ks][j], acc3[t][j]);
             }
-            // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane = conv1''s B fragment of K step h; stored through the memory layout
+            // y = relu(acc3 + b3 + residual): 8 consecutive couts per lane = conv1''s B fragment of K step h
             const float4 bA = *reinterpret_cast<const float4 *>(smem + B3L + (32 * h + 8 * fq) * 4);
             const float4 bB = *reinterpret_cast<const float4 *>(smem + B3L + (32 * h + 8 * fq + 4) * 4);
             u32x4 o[2];
@@ -335,19 +401,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
                 if constexpr (DS) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        o[j][e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                        o[j][e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
                 } else {
                     const u32x4 r = rp[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
                         const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
-                        o[j][e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                        o[j][e] = cw_pack2<F16>(v0, v1);
                     }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cw_store(cw_perm(pout, o[j]), rs_y, cur.yo[j], h * 64, p.stride == 77);
+            for (int j = 0; j < 2; ++j) cw_store(OUTB ? o[j] : cw_perm(pout, o[j]), rs_y, cur.yo[j], h * YHO, p.stride == 77);
             if constexpr (CMN > 0) {
 #pragma unroll
                 for (int i = 0; i < TN1; ++i) {
@@ -372,10 +438,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
-                    // byte offset of (pixel, chunk lc) in t1': yo = m * 512 + lc * 16  ->  m * 2 CMN + lc * 16
-                    const int to = ((cur.yo[j] - lc * 16) >> 9) * (CMN * 2) + lc * 16;
-                    cw_store(cw_perm(pout, o), rs_t, to, q * 64, p.stride == 77);
+                        o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
+                    cw_store(OUTB ? o : cw_perm(pout, o), rs_t, cur.to[j], q * (OUTB ? 1024 : 64), p.stride == 77);
                 }
             }
         }
@@ -384,6 +448,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_wave_kernel(ChainP p) {
         chunk = chunk_n;
     }
 #undef CW_ISSUE_X
+#undef CW_ISSUE_HALO
+#undef CW_FRAG
 #undef CW_ISSUE_RES
 #undef CW_ISSUE_WG
 }
@@ -398,46 +464,68 @@ static int cw_num_cus() {
     return v;
 }
 
-template <int CMN, bool F16, bool DS, bool W3G, int XD, int RD, int WD, int NW = 8>
+template <int CMN, bool F16, bool DS, bool W3G, bool INB, bool OUTB, bool HALO, int XD, int RD, int WD>
 static pvr_status launch_cw_one(ChainP &p, hipStream_t stream) {
     const size_t lds = (size_t)(W3G ? 73728 : 73728 + 32768) + (size_t)CMN * 512 + 256 + 1024 + 512;
-    PVR_HIP_TRY(hipFuncSetAttribute((const void *)chain_wave_kernel<CMN, F16, DS, W3G, XD, RD, WD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int nch = (p.M + NW * 32 - 1) / (NW * 32);
+    PVR_HIP_TRY(hipFuncSetAttribute((const void *)chain_wave_kernel<CMN, F16, DS, W3G, INB, OUTB, HALO, XD, RD, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nch = (p.M + 255) / 256;
     int grid = cw_num_cus() & ~7;                          // one persistent block per CU; a multiple of 8 (blocks b and b + 8 share an XCD)
     if (grid < 8) grid = 8;
     const int need = ((nch + 7) / 8) * 8;                  // small launches: one chunk per block
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((chain_wave_kernel<CMN, F16, DS, W3G, XD, RD, WD, NW>), dim3(grid), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((chain_wave_kernel<CMN, F16, DS, W3G, INB, OUTB, HALO, XD, RD, WD>), dim3(grid), dim3(512), lds, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }
 
-// PVR_CHAIN_WAVE_NW=12: twelve waves per CU (three per SIMD, <= 168 VGPRs) instead of eight (A/B runs)
-static int cw_nw() {
+// PVR_CHAIN_WAVE_HALO=0: blocked inputs through the per-K-step load ring instead of the halo registers (A/B runs)
+static int cw_halo() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("PVR_CHAIN_WAVE_NW"); v = e ? atoi(e) : 8; }
+    if (v < 0) { const char *e = getenv("PVR_CHAIN_WAVE_HALO"); v = e ? atoi(e) : 1; }
     return v;
 }
 
 template <bool F16>
 static pvr_status launch_cw_dt(ChainP &p, int cmn, hipStream_t stream) {
-    if (p.xds) {
-        if (cmn == 64) return launch_cw_one<64, F16, true, false, 4, 1, 1>(p, stream);
-    } else {
-        if (cmn == 64) return cw_nw() == 12 ? launch_cw_one<64, F16, false, false, 4, 4, 1, 12>(p, stream) : launch_cw_one<64, F16, false, false, 4, 4, 1>(p, stream);
-        if (cmn == 128) return launch_cw_one<128, F16, false, true, 2, 2, 1>(p, stream);
-        if (cmn == 0) return cw_nw() == 12 ? launch_cw_one<0, F16, false, false, 4, 4, 1, 12>(p, stream) : launch_cw_one<0, F16, false, false, 4, 4, 1>(p, stream);
+    const bool ib = p.in_blk, ob = p.out_blk, halo = ib && p.W == 56 && cw_halo();
+    if (p.xds) {                                           // layer1 block 0: NHWC inputs (x from the stem, t1 from conv1's own launch)
+        if (cmn == 64 && !ib) return ob ? launch_cw_one<64, F16, true, false, false, true, false, 4, 1, 2>(p, stream)
+                                        : launch_cw_one<64, F16, true, false, false, false, false, 4, 1, 2>(p, stream);
+    } else if (cmn == 64) {
+        if (ib && ob) return halo ? launch_cw_one<64, F16, false, false, true, true, true, 1, 4, 1>(p, stream)
+                                  : launch_cw_one<64, F16, false, false, true, true, false, 4, 4, 1>(p, stream);
+        if (!ib && !ob) return launch_cw_one<64, F16, false, false, false, false, false, 4, 4, 1>(p, stream);
+        if (!ib && ob) return launch_cw_one<64, F16, false, false, false, true, false, 4, 4, 1>(p, stream);
+        return halo ? launch_cw_one<64, F16, false, false, true, false, true, 1, 4, 1>(p, stream)
+                    : launch_cw_one<64, F16, false, false, true, false, false, 4, 4, 1>(p, stream);
+    } else if (cmn == 128 && !ob) {                        // layer1's last block: t1' feeds layer2's block form (NHWC)
+        return ib ? launch_cw_one<128, F16, false, true, true, false, false, 3, 4, 2>(p, stream)
+                  : launch_cw_one<128, F16, false, true, false, false, false, 3, 4, 2>(p, stream);
+    } else if (cmn == 0 && !ob) {
+        if (ib) return halo ? launch_cw_one<0, F16, false, false, true, false, true, 1, 4, 1>(p, stream)
+                            : launch_cw_one<0, F16, false, false, true, false, false, 4, 4, 1>(p, stream);
+        return launch_cw_one<0, F16, false, false, false, false, false, 4, 4, 1>(p, stream);
     }
-    set_error("bottleneck chain (wave form): no instance for next Cm=%d%s", cmn, p.xds ? " with downsample" : "");
+    set_error("bottleneck chain (wave form): no instance for next Cm=%d%s, blocked in/out %d/%d", cmn, p.xds ? " with downsample" : "", (int)ib, (int)ob);
     return PVR_ERR_INVALID;
 }
 
+// Cmn = 128 (layer1's last block, t1' for layer2): the instance exists and is bit-identical, but inside the forward it is slower than the
+// block form (0.299 vs 0.279 ms: W3 from L2, NHWC stores through the crossbar, 224 VGPRs); PVR_CHAIN_WAVE_128=1 selects it for A/B runs
 bool chain_wave_supported(int cm, int cmn, int stride, bool ds) {
-    return cm == 64 && stride == 1 && (ds ? cmn == 64 : (cmn == 0 || cmn == 64 || cmn == 128));
+    if (cm != 64 || stride != 1) return false;
+    if (ds) return cmn == 64;
+    if (cmn == 128) { const char *e = getenv("PVR_CHAIN_WAVE_128"); return e && atoi(e) != 0; }
+    return cmn == 0 || cmn == 64;
 }
+
+// can the tensors between two consecutive wave-form launches (y = the next residual, t1' = the next conv2 input) use the blocked layout?
+bool chain_wave_blocked_ok(int cmn_first, int h, int w) { return cmn_first == 64 && (h * w) % 32 == 0; }
 
 pvr_status launch_chain_wave(ChainP &p, int cmn, int dtype, hipStream_t stream) {
     PVR_REQUIRE((int64_t)(p.M + 64) * 512 < 0x7ffffff0ll, "bottleneck chain (wave form): operand larger than 2 GiB (use a smaller chunk)");
+    PVR_REQUIRE(p.xds ? p.wdsb != nullptr : (cmn != 128 || p.w3b != nullptr), "bottleneck chain (wave form): the blocked copy of W3 / Wd is missing");
+    PVR_REQUIRE(!(p.in_blk || p.out_blk) || p.M % 32 == 0, "bottleneck chain (wave form): the blocked layout needs a multiple of 32 pixels");
     return dtype == PVR_F16 ? launch_cw_dt<true>(p, cmn, stream) : launch_cw_dt<false>(p, cmn, stream);
 }
 

@@ -409,8 +409,33 @@ static pvr_status build_schedules(pvr_encoder *e) {
             for (int r = 0; r < o.cout; ++r) memcpy(&hp[(size_t)r * K], &o.h_w[(size_t)chain_row_source(r) * K], K * 2);
             pvr_status s = enc_upload(&o.d_wp, hp);
             if (s) return s;
+            if (which != 1) {                        // W3 / Wd once more, in the blocked layout the wave form reads its L2-resident pieces in
+                std::vector<u16> hb(hp.size());
+                for (int r = 0; r < o.cout; ++r)
+                    for (size_t c = 0; c < K; ++c) hb[(((size_t)(r >> 4) * (K / 8) + (c >> 3)) * 16 + (r & 15)) * 8 + (c & 7)] = hp[(size_t)r * K + c];
+                if ((s = enc_upload(&o.d_wpb, hb))) return s;
+            }
         }
         i = c3 + 1;
+    }
+    // Two consecutive wave-form tails hand y (the second one's residual) and t1' (its conv2 input) over in the blocked layout
+    // (chain_wave.hip): only when nothing else reads those two buffers in between - no tap, no other launch - and the geometry allows it.
+    for (Launch &l : e->sched_fused)
+        if (l.conv3 >= 0) {
+            const ConvOp &c2 = e->ops[l.conv2];
+            l.wave = chain_uses_wave_form(c2.cout, l.next1 >= 0 ? e->ops[l.next1].cout : 0, c2.stride, l.ds >= 0);
+        }
+    for (size_t a = 0; a + 1 < e->sched_fused.size(); ++a) {
+        Launch &A = e->sched_fused[a], &B = e->sched_fused[a + 1];
+        if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0) continue;
+        const ConvOp &a2 = e->ops[A.conv2], &a3 = e->ops[A.conv3], &b2 = e->ops[B.conv2], &b3 = e->ops[B.conv3];
+        const int a_cmn = e->ops[A.next1].cout;
+        if (!A.wave || !B.wave) continue;
+        if (B.t1_in != A.t1_out || b3.res_buf != a3.out_buf || !a3.tap.empty() || b2.h != a2.h || b2.w != a2.w) continue;
+        if (!chain_wave_blocked_ok(a_cmn, a2.h, a2.w)) continue;
+        const char *env = getenv("PVR_CHAIN_BLOCKED");
+        if (env && atoi(env) == 0) continue;
+        A.out_blk = 1; B.in_blk = 1;
     }
     return PVR_OK;
 }
@@ -775,7 +800,8 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 s = launch_bottleneck_chain(enc->d_buf[l.t1_in], c2.d_w, c2.d_b, op.d_wp, cd ? op.d_bsum : op.d_b, res, enc->d_buf[op.out_buf],
                                             c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
                                             c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st,
-                                            cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr);
+                                            cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr, op.d_wpb, cd ? cd->d_wpb : nullptr,
+                                            l.wave, l.in_blk, l.out_blk);
             } else if (op.kind == 2) {
                 s = launch_f32_to_h((const float *)enc->d_buf[op.in_buf], enc->d_buf[op.out_buf], (size_t)nb * op.h * op.w * op.cin, dt, st);
             } else if (op.f32op) {
@@ -988,7 +1014,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

@@ -5,6 +5,7 @@
 #include <vector>
 #include <cmath>
 #include "common.h"
+#include "chain_params.h"
 
 namespace pvr {
 
@@ -48,6 +49,7 @@ struct ConvOp {
     bool f32op = false;            // convolution on fp32 buffers with fp32 weights on the f32-input MFMA (conv_f32.hip) inside a 16-bit plan
     u16 *d_w = nullptr;
     u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
+    u16 *d_wpb = nullptr;          // ... and that copy in the blocked layout [row >> 4][cin >> 3][row & 15][8] (chain_wave.hip reads W3 / Wd pieces from L2)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
@@ -63,14 +65,9 @@ struct Launch {
     int conv2 = -1, conv3 = -1, next1 = -1;   // chain members (indices into ops); conv3 < 0: single launch of ops[conv2]
     int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
+    int wave = 0;                             // chain: the wave form runs it (chain_wave.hip)
+    int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip)
 };
-
-bool chain_supported(int cm, int cmn);
-bool chain_ds_supported(int cm, int cmn, int cin, int stride);
-int chain_row_source(int row);
-pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
-                                   void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
-                                   int stride, int dtype, hipStream_t stream, const void *xds = nullptr, const void *wdsp = nullptr);
 
 }  // namespace pvr
 

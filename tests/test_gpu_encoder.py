@@ -753,6 +753,29 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch)
     assert torch.equal(fused, again)
 
 
+@pytest.mark.parametrize('variant,dtype,n,ds', [('conv5', 'bf16', 3, '1'), ('conv5', 'f16', 5, '0'), ('conv3', 'f16', 2, '1'), ('conv5', 'bf16', 1, '1')])
+def test_chain_wave_equals_block_form(variant, dtype, n, ds, monkeypatch):
+    """chain_wave.hip (layer1's stride-1 tails: wave-owned pixels, weights resident in LDS, no barrier) computes what
+    bottleneck_chain.hip's block form computes, bit for bit - same rounding points, same K order per accumulator - whether its
+    launches hand y and t1' over in the blocked layout (default) or in NHWC (PVR_CHAIN_BLOCKED=0), with the downsample inside the
+    first tail (ds=1) or as its own launch.  The form is chosen when the plan is built, so every setting gets its own encoder."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(8, variant)
+    fr = torch.from_numpy(synth.smooth_frames(70 + n, n, 160, 200)).cuda()
+    monkeypatch.setenv('PVR_CHAIN_DS', ds)
+    outs = {}
+    for key, wave, blocked in (('block', '0', '1'), ('wave', '1', '1'), ('wave_nhwc', '1', '0')):
+        monkeypatch.setenv('PVR_CHAIN_WAVE', wave)
+        monkeypatch.setenv('PVR_CHAIN_BLOCKED', blocked)
+        m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
+        outs[key] = m(fr).clone()
+        assert torch.equal(outs[key], m(fr))
+        m.close()
+    assert torch.isfinite(outs['block']).all() and float(outs['block'].abs().max()) > 0
+    assert torch.equal(outs['wave'], outs['block']), float((outs['wave'] - outs['block']).abs().max())
+    assert torch.equal(outs['wave_nhwc'], outs['block']), float((outs['wave_nhwc'] - outs['block']).abs().max())
+
+
 @pytest.mark.parametrize('dtype,n', [('bf16', 3), ('f16', 5), ('f16', 1)])
 def test_downsample_inside_the_chain(dtype, n):
     """layer1.0: the downsample convolution is accumulated in fp32 inside the fused tail's conv3 (K extension by the block input's 64
