@@ -21,8 +21,9 @@
 //   * Memory lane layouts.  The MFMA fragment layout (lane = 16 * chunk + pixel) makes a quarter wave - the unit the texture-address
 //     path works in - touch 16 pixel rows x 16 B of an NHWC tensor: measured 4x slower through the TA than 4 rows x 64 B
 //     (profiles/experiments/r04_chain_wave.txt).  Two answers, both used:
-//       - NHWC tensors (the launch's boundary with other kernels): lane l moves pixel l >> 2, 16-byte chunk l & 3 of a 64-byte piece;
-//         ds_bpermute (the LDS crossbar, no LDS memory) turns a loaded register into a fragment and a result into a store register.
+//       - NHWC tensors (the launch's boundary with other kernels): lane l moves pixel l >> 2 and one 16-byte chunk of a 64-byte piece;
+//         a write + a read of a wave-private 1 KB LDS slot turn a loaded register into a fragment and a result into a store register
+//         (cw_m2f / cw_f2m; ds_bpermute, tried first, costs ~5x the LDS time).
 //       - BLOCKED tensors between two launches of this form ("P16C8": [pixel >> 4][channel >> 3][pixel & 15][8 channels], i.e. every
 //         (16 pixels x 8 channels) fragment column is 256 contiguous bytes): the fragment layout IS the coalesced layout - loads,
 //         stores and the residual need no permutation and a wave instruction moves 1 KB of contiguous memory.
@@ -59,11 +60,19 @@ template <bool F16> __device__ __forceinline__ unsigned cw_pack2(float a, float 
     else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cw_bf16x2));
 }
 
-__device__ __forceinline__ u32x4 cw_perm(int addr, u32x4 v) {
-    u32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[e]);
-    return r;
+// NHWC <-> fragment layout of one 1 KB piece (16 pixels x 64 B) through a wave-private LDS slot: the memory layout's lane l = 4 r + q holds
+// row r, 16-byte position q; the fragment layout's lane (fr, fq) wants row fr, chunk fq.  The slot is the memory image with the chunks of
+// row r XOR-ed by (r >> 1) & 3 - lane l therefore carries chunk q ^ ((r >> 1) & 3), which its global address accounts for - so that both
+// the contiguous side and the strided side are bank-conflict free.  A write + a read cost ~12 LDS cycles; four ds_bpermute_b32, the first
+// form of this kernel, ~64 (they made every NHWC side of a launch ~45 us slower than its blocked side).  DS operations of one wave execute
+// in order, so a slot needs no wait between its write and its read, nor between two uses.
+__device__ __forceinline__ u32x4 cw_m2f(char *slot, int lane, int foff, u32x4 v) {
+    *reinterpret_cast<u32x4 *>(slot + lane * 16) = v;
+    return *reinterpret_cast<const u32x4 *>(slot + foff);
+}
+__device__ __forceinline__ u32x4 cw_f2m(char *slot, int lane, int foff, u32x4 v) {
+    *reinterpret_cast<u32x4 *>(slot + foff) = v;
+    return *reinterpret_cast<const u32x4 *>(slot + lane * 16);
 }
 
 // lane fr of every 16-lane row <- lane fr + d of `lo` where that stays inside the row, else lane fr + d - 16 of `hi` (DPP row shifts)
@@ -84,11 +93,12 @@ struct CwTile {
     int yo[2];      // y: likewise for the store
     int to[2];      // t1': likewise (tile pair 0)
     int hb;         // HALO: byte offset of the lane's 16 bytes of halo block 0, K half 0
+    int xs[2];      // DS: byte offset of the lane's piece of the block input x (always NHWC: the stem writes it)
 };
 
 template <int CMN, bool INB, bool OUTB>
 __device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lane, int M, int H, int W) {
-    const int fr = lane & 15, fq = lane >> 4, lp = lane >> 2, lc = lane & 3;
+    const int fr = lane & 15, fq = lane >> 4, lp = lane >> 2, lc = (lane & 3) ^ ((lane >> 3) & 3);   // NHWC lanes: row lp, chunk lc (cw_m2f)
     a.hb = ((m0 >> 4) - 4) * 2048 + fq * 256 + fr * 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -107,6 +117,7 @@ __device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lane, int M, int
         for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * 3)) : 0;
         a.mk[j] = mask;
         a.xb[j] = INB ? m : m * 128 + lc * 16;
+        a.xs[j] = (m0 + 16 * j + lp) * 128 + lc * 16;
         const int blk = (m0 >> 4) + j;                     // (m0 is a multiple of 32: pixel tile j is block blk of a blocked tensor)
         a.yi[j] = INB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
         a.yo[j] = OUTB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
@@ -124,18 +135,16 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
     constexpr int NH = 8, NK = 18;                         // half-groups of 32 couts; conv2 K-steps of 32 channels (9 taps x 2)
     constexpr int TN1 = CMN / 16;
     constexpr int W2L = 0, W3L = 73728, W1L = W3G ? 73728 : 73728 + 32768;
-    constexpr int B2L = W1L + CMN * 512, B3L = B2L + 256, B1L = B3L + 1024;
+    constexpr int B2L = W1L + CMN * 512, B3L = B2L + 256, B1L = B3L + 1024, SCR = B1L + 512;   // SCR: 2 KB of layout-conversion slots per wave
     constexpr int OOB = 0x7ffffff0;
     constexpr int YH = INB ? 1024 : 64, YHO = OUTB ? 1024 : 64;     // byte step of a half-group (32 channels) in the residual / in y
     static_assert(XD >= 1 && XD <= NK && RD >= 1 && RD <= NH && NH % RD == 0 && WD >= 1 && WD <= NH, "prefetch depths (the residual ring must close over a tile)");
     static_assert(!HALO || INB, "the halo form reads the blocked layout");
-    static_assert(!(DS && INB), "the DS instance reads NHWC inputs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int lp = lane >> 2, lc = lane & 3;               // NHWC memory lane layout: pixel (row) of the 16-row tile, 16-byte chunk of the 64-byte piece
-    const int pin = (fr * 4 + fq) * 4;                     // ds_bpermute source of fragment lane (fr, fq): memory lane 4 fr + fq
-    const int pout = (lc * 16 + lp) * 4;                   // ... and of memory lane (lp, lc): fragment lane 16 lc + lp
+    const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) << 4);   // fragment lane's 16 bytes inside a conversion slot (cw_m2f / cw_f2m)
+    char *const slot0 = smem + SCR + wave * 2048, *const slot1 = slot0 + 1024;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
     const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    xdr[ks][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, cur.xb[j], ks * 64, 0));
+                    xdr[ks][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, cur.xs[j], ks * 64, 0));
         }
 
         // ---- conv2 3x3: 32 pixels x 64 couts, K = 9 taps x 64 channels; weights from LDS -------------------------------------------
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
         if constexpr (HALO) { CW_FRAG(xc[0], 0, 0); CW_FRAG(xc[1], 0, 1); }
         else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xc[j] = INB ? xr[0][j] : cw_perm(pin, xr[0][j]);
+            for (int j = 0; j < 2; ++j) xc[j] = INB ? xr[0][j] : cw_m2f(j ? slot1 : slot0, lane, foff, xr[0][j]);
             if (XD < NK) CW_ISSUE_X(0, XD, cur);
         }
 #pragma unroll
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
                 if constexpr (HALO) { CW_FRAG(xn[0], kt + 1, 0); CW_FRAG(xn[1], kt + 1, 1); }
                 else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) xn[j] = INB ? xr[(kt + 1) % XD][j] : cw_perm(pin, xr[(kt + 1) % XD][j]);
+                    for (int j = 0; j < 2; ++j) xn[j] = INB ? xr[(kt + 1) % XD][j] : cw_m2f(j ? slot1 : slot0, lane, foff, xr[(kt + 1) % XD][j]);
                     if (kt + 1 + XD < NK) CW_ISSUE_X((kt + 1) % XD, kt + 1 + XD, cur);
                 }
             }
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xd[ks][j] = __builtin_bit_cast(V8, cw_perm(pin, xdr[ks][j]));
+                for (int j = 0; j < 2; ++j) xd[ks][j] = __builtin_bit_cast(V8, cw_m2f(j ? slot1 : slot0, lane, foff, xdr[ks][j]));
         }
 
         // ---- conv3 (+ residual / + Wd . x) and conv1', one 32-cout half-group at a time --------------------------------------------
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
             u32x4 rp[2], wp[2][2];
             if constexpr (!DS) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) rp[j] = INB ? rres[h % RD][j] : cw_perm(pin, rres[h % RD][j]);
+                for (int j = 0; j < 2; ++j) rp[j] = INB ? rres[h % RD][j] : cw_m2f(j ? slot1 : slot0, lane, foff, rres[h % RD][j]);
                 if (h + RD < NH) CW_ISSUE_RES(h % RD, h + RD, cur)
                 else CW_ISSUE_RES(h % RD, h + RD - NH, nxt)
             }
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cw_store(OUTB ? o[j] : cw_perm(pout, o[j]), rs_y, cur.yo[j], h * YHO, p.stride == 77);
+            for (int j = 0; j < 2; ++j) cw_store(OUTB ? o[j] : cw_f2m(j ? slot1 : slot0, lane, foff, o[j]), rs_y, cur.yo[j], h * YHO, p.stride == 77);
             if constexpr (CMN > 0) {
 #pragma unroll
                 for (int i = 0; i < TN1; ++i) {
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
-                    cw_store(OUTB ? o : cw_perm(pout, o), rs_t, cur.to[j], q * (OUTB ? 1024 : 64), p.stride == 77);
+                    cw_store(OUTB ? o : cw_f2m(j ? slot1 : slot0, lane, foff, o), rs_t, cur.to[j], q * (OUTB ? 1024 : 64), p.stride == 77);
                 }
             }
         }
@@ -466,7 +475,7 @@ static int cw_num_cus() {
 
 template <int CMN, bool F16, bool DS, bool W3G, bool INB, bool OUTB, bool HALO, int XD, int RD, int WD>
 static pvr_status launch_cw_one(ChainP &p, hipStream_t stream) {
-    const size_t lds = (size_t)(W3G ? 73728 : 73728 + 32768) + (size_t)CMN * 512 + 256 + 1024 + 512;
+    const size_t lds = (size_t)(W3G ? 73728 : 73728 + 32768) + (size_t)CMN * 512 + 256 + 1024 + 512 + 8 * 2048;
     PVR_HIP_TRY(hipFuncSetAttribute((const void *)chain_wave_kernel<CMN, F16, DS, W3G, INB, OUTB, HALO, XD, RD, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nch = (p.M + 255) / 256;
     int grid = cw_num_cus() & ~7;                          // one persistent block per CU; a multiple of 8 (blocks b and b + 8 share an XCD)
@@ -488,7 +497,8 @@ static int cw_halo() {
 template <bool F16>
 static pvr_status launch_cw_dt(ChainP &p, int cmn, hipStream_t stream) {
     const bool ib = p.in_blk, ob = p.out_blk, halo = ib && p.W == 56 && cw_halo();
-    if (p.xds) {                                           // layer1 block 0: NHWC inputs (x from the stem, t1 from conv1's own launch)
+    if (p.xds) {                                           // layer1 block 0: x (from the stem) is NHWC; t1 is blocked when conv1's launch wrote it so
+        if (cmn == 64 && halo && ob) return launch_cw_one<64, F16, true, false, true, true, true, 1, 1, 2>(p, stream);
         if (cmn == 64 && !ib) return ob ? launch_cw_one<64, F16, true, false, false, true, false, 4, 1, 2>(p, stream)
                                         : launch_cw_one<64, F16, true, false, false, false, false, 4, 1, 2>(p, stream);
     } else if (cmn == 64) {
@@ -510,12 +520,13 @@ static pvr_status launch_cw_dt(ChainP &p, int cmn, hipStream_t stream) {
     return PVR_ERR_INVALID;
 }
 
-// Cmn = 128 (layer1's last block, t1' for layer2): the instance exists and is bit-identical, but inside the forward it is slower than the
-// block form (0.299 vs 0.279 ms: W3 from L2, NHWC stores through the crossbar, 224 VGPRs); PVR_CHAIN_WAVE_128=1 selects it for A/B runs
+// Cmn = 128 (layer1's last block, t1' for layer2): as a launch of its own this instance is no faster than the block form (0.299 vs 0.279 ms
+// inside the forward: W3 from L2, NHWC outputs, 228 VGPRs), but it takes its inputs in the blocked layout, which is what lets the tail in
+// front of it run all-blocked (0.205 instead of 0.238 ms; with NHWC outputs that one takes 0.261).  PVR_CHAIN_WAVE_128=0 for the A/B.
 bool chain_wave_supported(int cm, int cmn, int stride, bool ds) {
     if (cm != 64 || stride != 1) return false;
     if (ds) return cmn == 64;
-    if (cmn == 128) { const char *e = getenv("PVR_CHAIN_WAVE_128"); return e && atoi(e) != 0; }
+    if (cmn == 128) { const char *e = getenv("PVR_CHAIN_WAVE_128"); return !e || atoi(e) != 0; }
     return cmn == 0 || cmn == 64;
 }
 

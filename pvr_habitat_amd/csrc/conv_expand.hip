@@ -29,6 +29,7 @@ struct ExpP {
     int M, K, Cout, CoutPad, n_tiles, n_mgroups, m_tiles, act;
     int H, W, Ho, Wo;              // STRIDE 2: input / output geometry (output pixel (n,ho,wo) reads input pixel (n,2ho,2wo))
     unsigned in_bytes, w_bytes, out_bytes;
+    int out_blk;                   // output in the blocked layout [pixel >> 4][cout >> 3][pixel & 15][8] (chain_wave.hip reads layer1.0's t1 so)
 };
 
 // KS = K / 64 slices; BN couts per block (KS * BN * 128 B of weights stay in LDS: 64 KB); BM = 64 pixels per tile
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                     if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                                  \
                     o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);                              \
                 }                                                                                                  \
-                const int vo = (m < p.M && cbase[bp] >= 0) ? (m * p.Cout + cbase[bp]) * 2 : OOB;                   \
+                int vo = (m * p.Cout + cbase[bp]) * 2;                                                             \
+                if (p.out_blk) vo = ((m >> 4) * (p.Cout >> 3) + (cbase[bp] >> 3)) * 256 + (m & 15) * 16;           \
+                vo = (m < p.M && cbase[bp] >= 0) ? vo : OOB;                                                       \
                 __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, 0);                                       \
             }                                                                                                      \
         mt = mtn; ac[0] = an[0]; ac[1] = an[1];                                                                    \
@@ -266,8 +269,9 @@ long long conv_expand_launches() { return g_expand_launches; }
 
 // M = output pixels (n * ho * wo); h, w = input height / width (used for stride 2)
 pvr_status launch_conv_expand(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                              int cout, int stride, int relu, int dtype, hipStream_t stream) {
+                              int cout, int stride, int relu, int dtype, hipStream_t stream, int out_blk) {
     ExpP p;
+    p.out_blk = out_blk;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.res = (const u16 *)res; p.bias = bias; p.out = (u16 *)out;
     p.H = h; p.W = w; p.Ho = h / stride; p.Wo = w / stride;
     const int64_t M = (int64_t)n * p.Ho * p.Wo;

@@ -19,10 +19,10 @@
 
 namespace pvr {
 
-// conv3x3_halo.hip
+// conv_expand.hip / conv3x3_halo.hip
 bool conv_expand_supported(int64_t M, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32, bool has_res);
 pvr_status launch_conv_expand(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                              int cout, int stride, int relu, int dtype, hipStream_t stream);
+                              int cout, int stride, int relu, int dtype, hipStream_t stream, int out_blk);
 bool conv3x3_halo_supported(int64_t M, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32, int64_t in_bytes);
 pvr_status launch_conv3x3_halo(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int c, int relu,
                                int dtype, hipStream_t stream);
@@ -468,7 +468,7 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         return launch_conv3x3_halo(in, wgt, bias, res, out, n, h, w, cin, relu, dtype, stream);
     if (conv_algo() == -1 && kh == 1 && kw == 1 && (stride == 1 || stride == 2) &&
         conv_expand_supported((int64_t)n * (h / stride) * (w / stride), h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, res != nullptr))
-        return launch_conv_expand(in, wgt, bias, res, out, n, h, w, cin, cout, stride, relu, dtype, stream);
+        return launch_conv_expand(in, wgt, bias, res, out, n, h, w, cin, cout, stride, relu, dtype, stream, 0);
     {
         const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
         const int64_t M = (int64_t)n * ho * wo, K = (int64_t)kh * kw * cin;

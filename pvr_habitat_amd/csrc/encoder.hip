@@ -436,6 +436,16 @@ static pvr_status build_schedules(pvr_encoder *e) {
         const char *env = getenv("PVR_CHAIN_BLOCKED");
         if (env && atoi(env) == 0) continue;
         A.out_blk = 1; B.in_blk = 1;
+        // ... and when A is layer1's first tail (downsample inside), its conv2 input t1 can arrive blocked too: from conv1's own launch,
+        // which directly precedes it (conv_expand.hip writes either layout; whether THAT kernel runs is known per forward: batch size)
+        if (A.ds >= 0 && a > 0 && a2.w == 56) {
+            Launch &C = e->sched_fused[a - 1];
+            if (C.conv3 < 0 && C.conv2 >= 0) {
+                const ConvOp &c1 = e->ops[C.conv2];
+                if (c1.kind == 0 && !c1.f32op && c1.k == 1 && c1.stride == 1 && c1.out_buf == A.t1_in && c1.tap.empty() && c1.res_buf == B_NONE && !c1.out_f32 &&
+                    c1.ksplit <= 1) { C.out_blk = 1; A.in_blk = 1; }
+            }
+        }
     }
     return PVR_OK;
 }
@@ -787,7 +797,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
-        bool stopped = false;
+        bool stopped = false, t1_blocked = false;   // t1_blocked: the conv1 launch in front of layer1's first tail wrote t1 in the blocked layout
         int launch_idx = 0;                          // debug: stop_after = "#k" ends the forward after conv launch k of the plan
         const int stop_idx = enc->stop_after.size() > 1 && enc->stop_after[0] == '#' ? atoi(enc->stop_after.c_str() + 1) : -1;
         for (const Launch &l : (enc->fuse ? enc->sched_fused : enc->sched_plain)) {
@@ -801,7 +811,8 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                             c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
                                             c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st,
                                             cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr, op.d_wpb, cd ? cd->d_wpb : nullptr,
-                                            l.wave, l.in_blk, l.out_blk);
+                                            l.wave, cd ? (l.in_blk && t1_blocked) : l.in_blk, l.out_blk);
+                t1_blocked = false;
             } else if (op.kind == 2) {
                 s = launch_f32_to_h((const float *)enc->d_buf[op.in_buf], enc->d_buf[op.out_buf], (size_t)nb * op.h * op.w * op.cin, dt, st);
             } else if (op.f32op) {
@@ -815,6 +826,11 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             } else if (op.ksplit > 1) {
                 s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, (float *)enc->d_buf[op.ks_buf],
                                        op.ksplit, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
+            } else if (l.out_blk && conv_algo() == -1 &&
+                       conv_expand_supported((int64_t)nb * op.h * op.w, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, op.relu, 0, false)) {
+                // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
+                s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);
+                t1_blocked = true;
             } else {
                 s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h, op.w,
                                 op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);

@@ -25,6 +25,11 @@ pvr_status launch_conv_splitk(const void *, const void *, const float *, const v
 pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
                        int, int, int, int, int, int, int, int, hipStream_t);
 
+// conv_expand.hip: persistent weight-stationary 1x1 convolutions (out_blk: blocked output layout for chain_wave.hip)
+bool conv_expand_supported(int64_t M, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32, bool has_res);
+pvr_status launch_conv_expand(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
+                              int cout, int stride, int relu, int dtype, hipStream_t stream, int out_blk = 0);
+
 // conv_pp256.hip: 256x256-tile ping-pong kernel for deep-K convolutions / linear layers
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,

@@ -107,12 +107,14 @@ int main(int argc, char **argv) {
     rc |= run_case(3, 64, false, PVR_BF16, 2, false, true);
     rc |= run_case(3, 64, false, PVR_BF16, 2, true, false);
     rc |= run_case(3, 64, true, PVR_BF16, 2, false, true);
+    rc |= run_case(3, 64, true, PVR_F16, 2, true, true);
     rc |= run_case(5, 128, false, PVR_BF16, 2, true, false);
     rc |= run_case(1, 0, false, PVR_F16, 2, true, false);
     rc |= run_case(n, 64, false, PVR_BF16, reps);
     rc |= run_case(n, 64, false, PVR_BF16, reps, true, true);
     rc |= run_case(n, 64, true, PVR_BF16, reps);
     rc |= run_case(n, 64, true, PVR_BF16, reps, false, true);
+    rc |= run_case(n, 64, true, PVR_BF16, reps, true, true);
     rc |= run_case(n, 128, false, PVR_BF16, reps);
     rc |= run_case(n, 128, false, PVR_BF16, reps, true, false);
     rc |= run_case(n, 0, false, PVR_BF16, reps, true, false);

@@ -753,21 +753,25 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch)
     assert torch.equal(fused, again)
 
 
-@pytest.mark.parametrize('variant,dtype,n,ds', [('conv5', 'bf16', 3, '1'), ('conv5', 'f16', 5, '0'), ('conv3', 'f16', 2, '1'), ('conv5', 'bf16', 1, '1')])
-def test_chain_wave_equals_block_form(variant, dtype, n, ds, monkeypatch):
+@pytest.mark.parametrize('variant,dtype,n,ds,w128', [('conv5', 'bf16', 3, '1', '0'), ('conv5', 'f16', 5, '0', '1'), ('conv3', 'f16', 2, '1', '0'), ('conv5', 'bf16', 1, '1', '1'),
+                                                     ('conv5', 'bf16', 40, '1', '0')])
+def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
     """chain_wave.hip (layer1's stride-1 tails: wave-owned pixels, weights resident in LDS, no barrier) computes what
     bottleneck_chain.hip's block form computes, bit for bit - same rounding points, same K order per accumulator - whether its
     launches hand y and t1' over in the blocked layout (default) or in NHWC (PVR_CHAIN_BLOCKED=0), with the downsample inside the
-    first tail (ds=1) or as its own launch.  The form is chosen when the plan is built, so every setting gets its own encoder."""
+    first tail (ds=1) or as its own launch, with layer1's last tail (Cmn = 128) on the wave form too (w128=1; off by default: slower).
+    n = 40: enough pixel tiles for conv_expand to run layer1.0.conv1, which then hands t1 over in the blocked layout as well.
+    The form is chosen when the plan is built, so every setting gets its own encoder."""
     from pvr_habitat_amd.embeddings import HipResNet50
     sd = synth.resnet50_state_dict(8, variant)
     fr = torch.from_numpy(synth.smooth_frames(70 + n, n, 160, 200)).cuda()
     monkeypatch.setenv('PVR_CHAIN_DS', ds)
+    monkeypatch.setenv('PVR_CHAIN_WAVE_128', w128)
     outs = {}
     for key, wave, blocked in (('block', '0', '1'), ('wave', '1', '1'), ('wave_nhwc', '1', '0')):
         monkeypatch.setenv('PVR_CHAIN_WAVE', wave)
         monkeypatch.setenv('PVR_CHAIN_BLOCKED', blocked)
-        m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
+        m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=max(8, n))
         outs[key] = m(fr).clone()
         assert torch.equal(outs[key], m(fr))
         m.close()
