@@ -189,9 +189,16 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     // lane's 8 consecutive couts of a 64-cout group start at wn*32 + fq*8; pixel of tile j is wm*64 + 16j + fr
     // byte offset of (pixel, group 0) in res / y and of the pixel row in t1': tile j adds 16 rows.  Rows past M lie past the end of
     // the buffers (num_records = M rows): the hardware range check drops those stores and returns zeros for those loads
-    const int y_off0 = ((m0 + wm * 64 + fr) * C4 + wn * 32 + fq * 8) * 2;
+    // y / the residual in the BLOCKED layout ([pixel >> 4][cout >> 3][pixel & 15][8], chain_params.h: between two fused tails of a
+    // layer): the lane's 8 couts of pixel tile j are 16 contiguous bytes of a 256-byte run, a wave instruction covers 2 x 512 contiguous
+    // bytes instead of 16 x 64-byte pieces (a quarter wave touches 2 lines instead of 16)
+    const int y_nhwc = ((m0 + wm * 64 + fr) * C4 + wn * 32 + fq * 8) * 2;
+    const int y_blkd = ((m0 >> 4) + wm * 4) * (C4 * 32) + (wn * 4 + fq) * 256 + fr * 16;
+    const int y_off0 = p.y_blk ? y_blkd : y_nhwc, y_js = p.y_blk ? C4 * 32 : 16 * C4 * 2, y_gs = p.y_blk ? 2048 : 128;
+    const int r_off0 = p.res_blk ? y_blkd : y_nhwc, r_js = p.res_blk ? C4 * 32 : 16 * C4 * 2, r_gs = p.res_blk ? 2048 : 128;
     const int t_off0 = ((m0 + wm * 64 + fr) * CMN + wn * (CMN / 2) + fq * 8) * 2;
-#define Y_OFF(j_) (y_off0 + (j_) * (16 * C4 * 2))
+#define Y_OFF(j_) (y_off0 + (j_) * y_js)
+#define R_OFF(j_) (r_off0 + (j_) * r_js)
 #define T_OFF(j_) (t_off0 + (j_) * (16 * CMN * 2))
     // W3 group / W1' slice staging: thread q = tid + 256 i moves chunk (q & 7) of row r; r advances by 32 per i (the swizzle term
     // (r >> 1) & 7 does not change), so every offset is ONE per-thread base + a compile-time constant (keeps the arrays out of VGPRs)
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         if constexpr (!DS) {                                                                                            \
             _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                              \
                 _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                          \
-                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : Y_OFF(j), d * 128, 0)); \
+                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), d * r_gs, 0)); \
         }                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                               \
             w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));            \
@@ -471,13 +478,13 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                     o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
                 }
             }
-            store_b128_imm(o, rs_y, Y_OFF(j), g * 128);
+            store_b128_imm(o, rs_y, Y_OFF(j) + g * y_gs, 0);
             if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
         if (!DS && g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : Y_OFF(j), (g + RD) * 128, 0));
+                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), (g + RD) * r_gs, 0));
         }
         if (g == 1) CH_T(8);
         __syncthreads();                          // y group visible; every wave is done with this W3 group
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #undef W1_G
 #undef W1_L
 #undef Y_OFF
+#undef R_OFF
 #undef T_OFF
 #ifdef CHAIN_STAMP
     CH_T(5);
@@ -688,7 +696,8 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
         p.w3b = (const u16 *)w3pb; p.wdsb = (const u16 *)wdspb; p.in_blk = in_blk; p.out_blk = out_blk;
         return launch_chain_wave(p, cmn, dtype, stream);
     }
-    PVR_REQUIRE(!in_blk && !out_blk, "bottleneck chain: the blocked layout is the wave form's");
+    PVR_REQUIRE(!(in_blk || out_blk) || M % 16 == 0, "bottleneck chain: the blocked layout needs a multiple of 16 pixels");
+    p.res_blk = xds ? 0 : in_blk; p.y_blk = out_blk;           // block form: only y / the residual travel blocked (t1 and t1' stay NHWC)
     return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
 }
 

@@ -16,6 +16,7 @@ struct ChainP {
     unsigned xds_bytes = 0, wds_bytes = 0;
     // wave form: t1 + residual (in) / y + t1' (out) in the blocked layout [pixel >> 4][channel >> 3][pixel & 15][8] (chain_wave.hip)
     int in_blk = 0, out_blk = 0;
+    int res_blk = 0, y_blk = 0;                    // block form: the residual / y in that layout (t1 and t1' stay NHWC)
     // ... and the row-permuted W3 / Wd in that layout ([row >> 4][channel >> 3][row & 15][8]) for the instances that read them from L2
     const u16 *w3b = nullptr, *wdsb = nullptr;
 };

@@ -70,9 +70,16 @@ __device__ __forceinline__ u32x4 cw_m2f(char *slot, int lane, int foff, u32x4 v)
     *reinterpret_cast<u32x4 *>(slot + lane * 16) = v;
     return *reinterpret_cast<const u32x4 *>(slot + foff);
 }
-__device__ __forceinline__ u32x4 cw_f2m(char *slot, int lane, int foff, u32x4 v) {
-    *reinterpret_cast<u32x4 *>(slot + foff) = v;
-    return *reinterpret_cast<const u32x4 *>(slot + lane * 16);
+// Two consecutive 32-channel fragments (64 channels = 128 B per pixel) of a 16-pixel tile -> two registers of FULL 128-byte lines: lane l
+// gets rows (l >> 3) and (l >> 3) + 8, chunk (l & 7) ^ (l >> 3).  Slot image: [16 rows][128 B], chunk c of row r at position c ^ (r & 7).
+// (Stores of 16 x 64-byte pieces - half lines, the second half arriving a microsecond later - made an NHWC output side ~45 us slower than
+// a blocked one at layer1's size; full lines take the same number of instructions.)
+__device__ __forceinline__ void cw_f2m_pair(char *slot, int lane, u32x4 even, u32x4 odd, u32x4 &lo, u32x4 &hi) {
+    const int fr = lane & 15, fq = lane >> 4, base = fr * 128, sw = fr & 7;
+    *reinterpret_cast<u32x4 *>(slot + base + ((fq ^ sw) << 4)) = even;
+    *reinterpret_cast<u32x4 *>(slot + base + (((4 + fq) ^ sw) << 4)) = odd;
+    lo = *reinterpret_cast<const u32x4 *>(slot + lane * 16);
+    hi = *reinterpret_cast<const u32x4 *>(slot + 1024 + lane * 16);
 }
 
 // lane fr of every 16-lane row <- lane fr + d of `lo` where that stays inside the row, else lane fr + d - 16 of `hi` (DPP row shifts)
@@ -120,8 +127,9 @@ __device__ __forceinline__ void cw_setup(CwTile &a, int m0, int lane, int M, int
         a.xs[j] = (m0 + 16 * j + lp) * 128 + lc * 16;
         const int blk = (m0 >> 4) + j;                     // (m0 is a multiple of 32: pixel tile j is block blk of a blocked tensor)
         a.yi[j] = INB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
-        a.yo[j] = OUTB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * 512 + lc * 16;
-        a.to[j] = OUTB ? blk * (CMN * 32) + fq * 256 + fr * 16 : (m0 + 16 * j + lp) * (CMN * 2) + lc * 16;
+        // NHWC outputs leave as FULL 128-byte lines (cw_f2m_pair): lane l stores rows (l >> 3) and (l >> 3) + 8, chunk (l & 7) ^ (l >> 3) of a 64-channel group
+        a.yo[j] = OUTB ? blk * 8192 + fq * 256 + fr * 16 : (m0 + 16 * j + (lane >> 3)) * 512 + (((lane & 7) ^ (lane >> 3)) << 4);
+        a.to[j] = OUTB ? blk * (CMN * 32) + fq * 256 + fr * 16 : (m0 + 16 * j + (lane >> 3)) * (CMN * 2) + (((lane & 7) ^ (lane >> 3)) << 4);
     }
 }
 
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
     constexpr int W2L = 0, W3L = 73728, W1L = W3G ? 73728 : 73728 + 32768;
     constexpr int B2L = W1L + CMN * 512, B3L = B2L + 256, B1L = B3L + 1024, SCR = B1L + 512;   // SCR: 2 KB of layout-conversion slots per wave
     constexpr int OOB = 0x7ffffff0;
-    constexpr int YH = INB ? 1024 : 64, YHO = OUTB ? 1024 : 64;     // byte step of a half-group (32 channels) in the residual / in y
+    constexpr int YH = INB ? 1024 : 64;                    // byte step of a half-group (32 channels) in the residual
     static_assert(XD >= 1 && XD <= NK && RD >= 1 && RD <= NH && NH % RD == 0 && WD >= 1 && WD <= NH, "prefetch depths (the residual ring must close over a tile)");
     static_assert(!HALO || INB, "the halo form reads the blocked layout");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        u32x4 oe[2];                                       // NHWC out: y of the even half-group, held until its odd partner completes the 128-byte line
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             // this half-group's pieces -> fragment layout, their ring slots refilled (this tile's later half-groups, then the next tile's first)
@@ -422,7 +431,15 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cw_store(OUTB ? o[j] : cw_f2m(j ? slot1 : slot0, lane, foff, o[j]), rs_y, cur.yo[j], h * YHO, p.stride == 77);
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (OUTB) cw_store(o[j], rs_y, cur.yo[j], h * 1024, p.stride == 77);
+                else if (h & 1) {                          // NHWC: the pair (h - 1, h) = 128 bytes per pixel leaves as full lines
+                    u32x4 lo, hi;
+                    cw_f2m_pair(slot0, lane, oe[j], o[j], lo, hi);
+                    cw_store(lo, rs_y, cur.yo[j], (h >> 1) * 128, p.stride == 77);
+                    cw_store(hi, rs_y, cur.yo[j], (h >> 1) * 128 + 8 * 512, p.stride == 77);
+                } else oe[j] = o[j];
+            }
             if constexpr (CMN > 0) {
 #pragma unroll
                 for (int i = 0; i < TN1; ++i) {
@@ -436,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
 
         // ---- t1' = relu(acc1 + b1'): tile pair q = 8 consecutive couts per lane ----------------------------------------------------
         if constexpr (CMN > 0) {
+            u32x4 te[2];
 #pragma unroll
             for (int q = 0; q < TN1 / 2; ++q) {
                 const float4 bA = *reinterpret_cast<const float4 *>(smem + B1L + (32 * q + 8 * fq) * 4);
@@ -446,9 +464,14 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
                     const float v[8] = {lo[0] + bA.x, lo[1] + bA.y, lo[2] + bA.z, lo[3] + bA.w, hi[0] + bB.x, hi[1] + bB.y, hi[2] + bB.z, hi[3] + bB.w};
                     u32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
-                    cw_store(OUTB ? o : cw_f2m(j ? slot1 : slot0, lane, foff, o), rs_t, cur.to[j], q * (OUTB ? 1024 : 64), p.stride == 77);
+                    for (int e = 0; e < 4; ++e) o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
+                    if constexpr (OUTB) cw_store(o, rs_t, cur.to[j], q * 1024, p.stride == 77);
+                    else if (q & 1) {
+                        u32x4 l0, l1;
+                        cw_f2m_pair(slot0, lane, te[j], o, l0, l1);
+                        cw_store(l0, rs_t, cur.to[j], (q >> 1) * 128, p.stride == 77);
+                        cw_store(l1, rs_t, cur.to[j], (q >> 1) * 128 + 8 * (CMN * 2), p.stride == 77);
+                    } else te[j] = o;
                 }
             }
         }

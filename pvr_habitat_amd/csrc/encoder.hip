@@ -430,11 +430,17 @@ static pvr_status build_schedules(pvr_encoder *e) {
         if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0) continue;
         const ConvOp &a2 = e->ops[A.conv2], &a3 = e->ops[A.conv3], &b2 = e->ops[B.conv2], &b3 = e->ops[B.conv3];
         const int a_cmn = e->ops[A.next1].cout;
-        if (!A.wave || !B.wave) continue;
-        if (B.t1_in != A.t1_out || b3.res_buf != a3.out_buf || !a3.tap.empty() || b2.h != a2.h || b2.w != a2.w) continue;
-        if (!chain_wave_blocked_ok(a_cmn, a2.h, a2.w)) continue;
         const char *env = getenv("PVR_CHAIN_BLOCKED");
         if (env && atoi(env) == 0) continue;
+        if (B.t1_in != A.t1_out || b3.res_buf != a3.out_buf || !a3.tap.empty() || b2.h != a2.h / a2.stride || b2.w != a2.w / a2.stride || b2.stride != 1) continue;
+        if (!A.wave && !B.wave) {
+            // two block-form tails (layer2): y = the next residual travels blocked (16-byte accesses of a lane land in 512-byte runs);
+            // t1' stays NHWC (the halo DMA wants contiguous pixel rows)
+            if ((b2.h * b2.w) % 16 == 0) { A.out_blk = 1; B.in_blk = 1; }
+            continue;
+        }
+        if (!A.wave || !B.wave) continue;
+        if (!chain_wave_blocked_ok(a_cmn, a2.h, a2.w)) continue;
         A.out_blk = 1; B.in_blk = 1;
         // ... and when A is layer1's first tail (downsample inside), its conv2 input t1 can arrive blocked too: from conv1's own launch,
         // which directly precedes it (conv_expand.hip writes either layout; whether THAT kernel runs is known per forward: batch size)
