@@ -10,6 +10,7 @@ batch of 256 frames that is already resident in HBM.  Frames shard across ranks 
   python bench.py                      (N = 1, 320 timed steps ~ 1 s over a 4096-frame pool, + parity / f16 / PCIe / ViT / BC legs)
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (no launcher: starts that torch.distributed.run command itself as a child process)
 """
 import argparse
 import ctypes as C
@@ -394,6 +395,34 @@ def parity_rel_l2(model, sd, frames_np):
     return float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
+    arguments>` as a CHILD process (this process has not touched a GPU and never does: no HIP call, no exec after one), let rank 0's single
+    JSON line and everything else pass through on the inherited stdout / stderr, and return the child's exit code (3 on a time-out)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                            # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    limit = float(os.environ.get('PVR_BENCH_LAUNCH_TIMEOUT', '3000'))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        print('bench.py: the %d-rank run did not finish within %.0f s; stopping it' % (n, limit), file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)            # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -422,8 +451,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))                   # `python bench.py --gpus N` as typed: one rank per GPU under torch.distributed.run
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d' % (world, args.gpus, args.gpus))
     # PVR_BENCH_ONE_GPU=1 (test aid for 1-GPU boxes): every rank on cuda:0 with the gloo backend, to exercise the N > 1 path
     one_gpu = os.environ.get('PVR_BENCH_ONE_GPU', '0') == '1'
     if one_gpu:

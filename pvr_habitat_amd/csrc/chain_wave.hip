@@ -23,7 +23,7 @@
 //     (profiles/experiments/r04_chain_wave.txt).  Two answers, both used:
 //       - NHWC tensors (the launch's boundary with other kernels): lane l moves pixel l >> 2 and one 16-byte chunk of a 64-byte piece;
 //         a write + a read of a wave-private 1 KB LDS slot turn a loaded register into a fragment and a result into a store register
-//         (cw_m2f / cw_f2m; ds_bpermute, tried first, costs ~5x the LDS time).
+//         (cw_m2f / cw_f2m_pair; outputs leave as full 128-byte lines).
 //       - BLOCKED tensors between two launches of this form ("P16C8": [pixel >> 4][channel >> 3][pixel & 15][8 channels], i.e. every
 //         (16 pixels x 8 channels) fragment column is 256 contiguous bytes): the fragment layout IS the coalesced layout - loads,
 //         stores and the residual need no permutation and a wave instruction moves 1 KB of contiguous memory.
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) << 4);   // fragment lane's 16 bytes inside a conversion slot (cw_m2f / cw_f2m)
+    const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) << 4);   // fragment lane's 16 bytes inside a conversion slot (cw_m2f)
     char *const slot0 = smem + SCR + wave * 2048, *const slot1 = slot0 + 1024;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);

@@ -53,3 +53,16 @@ def test_bench_line_two_ranks_on_one_gpu():
     dp = d['bc_finetune_dp']                                           # BASELINE config 4 leg: data-parallel finetune over the two ranks
     assert 'error' not in dp, dp
     assert dp['n_gpus'] == 2 and dp['value'] > 0 and dp['allreduce_ms'] > 0 and dp['allreduce_bytes'] == 4 * 18148868 - 4 * 1028 or dp['allreduce_bytes'] > 7e7
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` as a plain command (how a driver without a launcher would type it): the parent starts
+    torch.distributed.run as a child process, relays rank 0's single line and the exit code, and never initialises a GPU itself."""
+    env = dict(os.environ, PVR_BENCH_ONE_GPU='1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--no-dp'] + FAST, capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    _check(lines[0], 2)
