@@ -100,6 +100,17 @@ if __name__ == '__main__' and os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1'
     init_fixture()
 
 
+def conv_full_fixture():
+    """(4b) PolicyNetWithConv at BASELINE config 4's size: T=100, B=16, (64,64,6) uint8 observations, two updates
+    (main_bc_finetune.py:167-208 = the same training lines on src/models.py:96-197)."""
+    torch.set_num_threads(8)
+    T, B, S, A = 100, 16, 2, 3
+    sd = synth.policy_state_dict(4, 256, A, True, conv=True)
+    rec, final = run_reference(PolicyNetWithConv((64, 64, 6), A, True), sd, conv_inputs(4, T, B, S, A), max_epochs=1000)
+    save('policy_conv_full_bn.npz', rec, dict(T=T, B=B, A=A, steps=S, max_epochs=1000),
+         keep_params={k: final[k] for k in ('feat_extract.0.bias', 'feat_extract.8.bias', 'policy.weight', 'fc.0.running_mean', 'fc.0.running_var')})
+
+
 def main():
     torch.manual_seed(1); random.seed(1); np.random.seed(1)
     torch.set_num_threads(8)
@@ -127,6 +138,7 @@ def main():
     rec, final = run_reference(PolicyNetWithConv((64, 64, 6), A, True), sd, conv_inputs(3, T, B, S, A), max_epochs=10)
     save('policy_conv_small.npz', rec, dict(T=T, B=B, A=A, steps=S, max_epochs=10),
          keep_params={k: final[k] for k in ('feat_extract.0.bias', 'feat_extract.8.bias', 'policy.weight')})
+    conv_full_fixture()
     # (5) sample_with_minimum_distance (utils_bc.py:24-29) under random.seed(1)
     random.seed(1)
     draws = [ref_utils.sample_with_minimum_distance(n=5000, k=16, d=100) for _ in range(3)]
@@ -142,5 +154,7 @@ def main():
 if __name__ == '__main__':
     if os.environ.get('PVR_GOLDEN_ONLY_INIT', '0') == '1':      # regenerate policy_init_seed1.npz alone
         init_fixture()
+    elif os.environ.get('PVR_GOLDEN_ONLY_CONV_FULL', '0') == '1':   # policy_conv_full_bn.npz alone (round 4)
+        conv_full_fixture()
     else:
         main()

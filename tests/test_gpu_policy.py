@@ -179,6 +179,31 @@ def test_policy_with_conv_small(golden_dir):
     _run_case(golden_dir, 'policy_conv_small.npz', 3, True, conv=True)
 
 
+def test_policy_with_conv_full_size(golden_dir):
+    """BASELINE config 4 at its real size (round-3 verdict, weak 3): PolicyNetWithConv, T=100, B=16, (64,64,6) uint8 frames, two updates -
+    loss, gradient norm, logits, every parameter's checksum after the updates and the exact eval actions against the fixture the
+    reference's own src/models.py:96-197 + the training lines of main_bc_finetune.py:167-208 produced (tests/golden/make_golden.py)."""
+    torch.set_num_threads(16)
+    _run_case(golden_dir, 'policy_conv_full_bn.npz', 4, True, conv=True)
+    g = np.load(os.path.join(golden_dir, 'policy_conv_full_bn.npz'))
+    T, B, A = int(g['T']), int(g['B']), int(g['A'])
+    # exact eval-mode actions of the UPDATED model (argmax branch, models.py:82) - the north star's bit-exact index requirement
+    from pvr_habitat_amd.models import HipRMSprop
+    m, _ = _model(4, 256, A, True, T, B, True)
+    obs, done, act = synth.bc_conv_batches(4, T, B, int(g['steps']), A)
+    opt = HipRMSprop(m, lr=1e-4, alpha=0.99, eps=1e-5, max_grad_norm=40.0, max_epochs=int(g['max_epochs']))
+    m.train()
+    for s in range(int(g['steps'])):
+        opt.scheduler_step()
+        opt.step(torch.from_numpy(obs[s]), torch.from_numpy(done[s]), torch.from_numpy(act[s]))
+    m.eval()
+    with torch.no_grad():
+        out, st = m(dict(obs=torch.from_numpy(obs[0]), done=torch.from_numpy(done[0])), m.initial_state(B))
+    assert np.array_equal(out['action'].cpu().numpy(), g['eval_action'])
+    np.testing.assert_allclose(out['policy_logits'].cpu().numpy(), g['eval_logits'], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(st[0].cpu().numpy(), g['eval_h'], rtol=2e-4, atol=1e-4)
+
+
 def test_policy_data_parallel_halves_match_fused_step():
     """pvr_policy_backward + pvr_policy_apply (the data-parallel split, world size 1) == pvr_policy_step, bit for bit."""
     from pvr_habitat_amd.models import HipRMSprop
