@@ -53,6 +53,9 @@ typedef int pvr_status;
 #define PVR_ARCH_MAE_VIT_B16 5   /* MAE/timm ViT-B/16 encoder, CLS token  -> 768 (mae.py:202-222, embeddings.py:137-140,377-379) */
 
 const char *pvr_version(void);
+/* 1 if the library was built with its measured-slower experiment kernels (make EXPERIMENTS=1: conv_w4 = pvr_debug_set_conv_algo(4), the
+ * split-bf16 GEMM = pvr_debug_set_gemm_mode(1..3), PVR_POLICY_BWD_FUSED, PVR_POLICY_PERSIST_BWD); the shipped build returns 0 and refuses them */
+int32_t pvr_has_experiments(void);
 /* copies the calling thread's last error message; returns its length */
 size_t pvr_last_error(char *buf, size_t cap);
 

@@ -117,6 +117,9 @@ pvr_status pvr_op_conv2d(const void *in, const void *wgt, const float *bias, con
 
 pvr_status pvr_debug_set_conv_algo(int32_t algo) {
     PVR_REQUIRE(algo >= -1 && algo <= 4, "pvr_debug_set_conv_algo: algo must be -1 (auto), 0 (conv_igemm), 1 / 2 / 3 (conv_pp256 with 256- / 128- / 224-pixel tiles), 4 (conv_w4)");
+#ifndef PVR_EXPERIMENTS
+    PVR_REQUIRE(algo != 4, "pvr_debug_set_conv_algo: conv_w4 is an experiment kernel; this library was built without it (make EXPERIMENTS=1)");
+#endif
     set_conv_algo(algo);
     return PVR_OK;
 }
@@ -125,6 +128,15 @@ pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_
                           int32_t dtype, void *stream) {
     PVR_REQUIRE(in && out, "pvr_op_avgpool: null pointer");
     return launch_avgpool(in, out, out_stride, n, hw, c, in_f32, dtype, (hipStream_t)stream);
+}
+
+// 1 when the library carries the round-3 experiment kernels (conv_w4, split-bf16 GEMM, fused / persistent BPTT: make EXPERIMENTS=1), else 0
+int32_t pvr_has_experiments(void) {
+#ifdef PVR_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 // host-only helper used by the CPU tests: the weight conversion finalize() applies

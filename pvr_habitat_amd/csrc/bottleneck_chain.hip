@@ -567,11 +567,11 @@ static pvr_status launch_chain_one(ChainP &p, hipStream_t stream) {
     const size_t pipe = HALO ? (size_t)(CM / 64) * (CM == 64 ? 256 : 192) * 128 + (size_t)2 * CM * 128 : (size_t)2 * (128 + CM) * 128;
     const size_t phase_b = (CM / 64) * 16384 + 16384 + (CM / 64) * 8192 + CMN * 128;      // t2, y group, W3 group, W1' slice
     const size_t lds = phase_b <= pipe ? pipe : phase_b;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS, PFK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((bottleneck_chain_kernel<CM, CMN, F16, RD, OCC, HALO, DS, PFK>), dim3(grid), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <atomic>
 #include "../../include/pvr_hip.h"
 
 namespace pvr {
@@ -50,6 +51,16 @@ const std::string &last_error();
             return PVR_ERR_INVALID;                                                            \
         }                                                                                      \
     } while (0)
+
+// "done once per device" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, and a process that
+// later uses a second GPU must raise the limit there too (a process-wide bool would leave that device's launches failing).  Bit d of the
+// mask = device d; concurrent first calls at worst set the attribute twice.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & 63) : 0; }
+    bool needed() const { return !((mask.load(std::memory_order_relaxed) >> device()) & 1ull); }
+    void mark() { mask.fetch_or(1ull << device(), std::memory_order_relaxed); }
+};
 
 // ---- 16-bit storage types --------------------------------------------------------------------
 typedef __bf16 bf16_t;

@@ -199,10 +199,10 @@ bool conv3x3_halo_supported(int64_t M, int h, int w, int cin, int cout, int kh, 
 template <int CM, bool F16>
 static pvr_status launch_halo_inst(HaloP &p, hipStream_t stream) {
     const size_t lds = (size_t)(CM / 64) * (CM == 64 ? 256 : 192) * 128 + (size_t)2 * CM * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<CM, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<CM, F16>), dim3((p.M + 127) / 128), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();

@@ -220,10 +220,10 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
 template <int KS, int BN, bool F16, bool RES, int STRIDE>
 static pvr_status launch_expand_inst(ExpP &p, hipStream_t stream) {
     constexpr int lds = KS * BN * 128 + 2 * 64 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_expand_kernel<KS, BN, F16, RES, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((conv_expand_kernel<KS, BN, F16, RES, STRIDE>), dim3(p.n_mgroups * p.n_tiles), dim3(256), lds, stream, p);
     PVR_LAUNCH_CHECK();

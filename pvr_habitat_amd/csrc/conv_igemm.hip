@@ -411,11 +411,11 @@ template <int BM, int BN, bool F16, int STAGES, int RES, bool NK4 = false>
 static pvr_status launch_inst2(ConvP &p, hipStream_t stream) {
     const int grid = p.m_tiles * p.n_tiles;
     const size_t lds = STAGES * (BM + BN) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     const int ksplit = p.nk_split ? (p.KH * p.KW * (p.Cin / 64) + p.nk_split - 1) / p.nk_split : 1;
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, F16, STAGES, RES, NK4>), dim3(grid, ksplit), dim3(256), lds, stream, p);
@@ -489,8 +489,10 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         const int bm = algo == 1 ? 256 : algo == 2 ? 128 : algo == 3 ? 224
                      : (algo == -1 && deep) ? (tiles >= 160 ? (better224 ? 224 : 256) : (tiles128 >= 160 ? 128 : 0)) : 0;
         // algo 4 (round 3): the four-wave 128 x 128-per-wave kernel (conv_w4.hip) wherever it accepts the shape
+#ifdef PVR_EXPERIMENTS
         if (ok && algo == 4)
             return launch_conv_w4(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, stream);
+#endif
         if (ok && bm)
             return launch_conv_pp256(in, wgt, bias, res, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, of32, rf32, dtype, bm, stream);
     }

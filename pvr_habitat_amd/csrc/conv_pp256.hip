@@ -428,12 +428,12 @@ static int pp_persist_min() {
 template <int BM, bool F16, int RES>
 static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
     constexpr int lds = 2 * ((BM == 224 ? 256 : BM) * 128 + 32768);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if constexpr (BM != 128)
             PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_done.mark();
     }
     const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
     p.total_tiles = grid;

@@ -32,6 +32,7 @@
 //   then s_waitcnt lgkmcnt(0); s_barrier.
 //   Only plain loads, LDS writes and LDS reads; vmcnt retires in issue order and each wave counts only its own pieces.  Past the end of
 //   the K range the requests go to an out-of-range offset (zeros, no memory access): the step body has no branch.
+#ifdef PVR_EXPERIMENTS   // round-3 experiment (bit-identical, 11-60 % slower than conv_pp256: profiles/experiments/r03_conv_w4.txt); make EXPERIMENTS=1
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -338,10 +339,10 @@ long long conv_w4_launches() { return g_w4_launches; }
 template <bool F16, int RES>
 static pvr_status launch_w4_inst(PPP &p, hipStream_t stream) {
     constexpr int lds = 3 * (224 * 64) + 3 * (256 * 64) + 1024;      // three X stages + three W stages + a spare KB = 91 KB
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_w4_kernel<F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_done.mark();
     }
     const int grid = ((p.M + 223) / 224) * p.n_tiles;
     p.total_tiles = grid;
@@ -400,3 +401,5 @@ pvr_status launch_conv_w4(const void *in, const void *wgt, const float *bias, co
 }
 
 }  // namespace pvr
+
+#endif  // PVR_EXPERIMENTS

@@ -155,10 +155,10 @@ static pvr_status scratch_grow(float **buf, size_t *have, size_t need) {
 template <bool ATR, bool BTR, int BM, int BN>
 static pvr_status launch_gemm(const GemmP &g, dim3 gd, hipStream_t st) {
     constexpr size_t lds = gemm_f32_lds<BM, BN, ATR, BTR>();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)gemm_f32_kernel<ATR, BTR, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((gemm_f32_kernel<ATR, BTR, BM, BN>), gd, dim3(256), lds, st, g);
     return PVR_OK;
@@ -166,17 +166,19 @@ static pvr_status launch_gemm(const GemmP &g, dim3 gd, hipStream_t st) {
 
 static std::atomic<int> g_gemm_mode{-1};          // pvr_debug_set_gemm_mode
 
+#ifdef PVR_EXPERIMENTS
 template <bool ATR, bool BTR, int BM, int BN>
 static pvr_status launch_gemm_x3(const GemmP &g, dim3 gd, hipStream_t st) {
     constexpr size_t lds = gemm_bf16x3_lds<BM, BN>();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<ATR, BTR, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((gemm_bf16x3_kernel<ATR, BTR, BM, BN>), gd, dim3(256), lds, st, g);
     return PVR_OK;
 }
+#endif
 
 pvr_status gemm(const float *A, const float *B, const float *bias, const float *mask, float *C, int M, int N, int K,
                 bool a_km, bool b_kn, int relu, hipStream_t st) {
@@ -210,9 +212,10 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
         g.C = splitk_buf; g.bias = nullptr; g.mask = nullptr; g.relu = 0;
     }
     pvr_status ls = PVR_OK;
-    // round 3, opt-in (PVR_GEMM_BF16X3=1 or pvr_debug_set_gemm_mode): the same product on the bf16 matrix pipe (three-term exact split of
-    // both operands, gemm_bf16x3_kernel); 128 x 128 tiles when they fill the chip, else 64 x 64.  2.7 x more accurate than the fp32 chain
-    // and no faster (profiles/experiments/r03_gemm_split_bf16.txt), so the fp32 MFMA GEMM stays the default.
+    // round 3, experiment build only (make EXPERIMENTS=1; PVR_GEMM_BF16X3=1 or pvr_debug_set_gemm_mode): the same product on the bf16
+    // matrix pipe (three-term exact split of both operands, gemm_bf16x3_kernel).  2.7 x more accurate than the fp32 chain and no faster
+    // (profiles/experiments/r03_gemm_split_bf16.txt), so the fp32 MFMA GEMM is the product's.
+#ifdef PVR_EXPERIMENTS
     static const int x3_env = [] { const char *e = getenv("PVR_GEMM_BF16X3"); return e ? atoi(e) : 0; }();
     const int gm = g_gemm_mode.load();
     const int x3 = gm >= 0 ? gm : x3_env;
@@ -230,7 +233,9 @@ pvr_status gemm(const float *A, const float *B, const float *bias, const float *
         else ls = launch_gemm_x3<true, false, BM_, BM_>(g, gx, st);
         if (t128) { PVR_X3_CASE(128) } else { PVR_X3_CASE(64) }
 #undef PVR_X3_CASE
-    } else {
+    } else
+#endif
+    {
     const dim3 gd(grid, S);
 #define PVR_GEMM_CASE(T_, BM_, BN_)                                                                                     \
     case T_:                                                                                                            \
@@ -529,10 +534,13 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
     // ---- LSTM backward, layer 1 then layer 0 ------------------------------------------------------------------------
     float *scr_dc[2] = {pol->dc_carry, pol->dc_carry1}, *scr_rec[2] = {pol->rec_partial, pol->rec_partial1}, *scr_hp[2] = {pol->hprev, pol->hprev1};
     // opt-in, one launch per step (round 3): W_hh^T of both layers first, then lstm_bwd_step2_kernel per (wavefronted) step
-    const bool fused = pol->bwd_fused && H % 16 == 0 && (4 * H) % 512 == 0;
+#ifdef PVR_EXPERIMENTS
+    const bool fused = pol->bwd_fused && pol->whhT[0] && H % 16 == 0 && (4 * H) % 512 == 0;
     if (fused)
         for (int l = 0; l < 2; ++l)
             hipLaunchKernelGGL(transpose_kernel, dim3(H / 32, 4 * H / 32), dim3(256), 0, st, P + pol->o_whh[l], pol->whhT[l], 4 * H, H);
+#endif
+#ifdef PVR_EXPERIMENTS
     auto step_job = [&](int l, int t, const float *dh_ext_) {
         const bool has_next = t < T - 1;
         LstmStepP c;
@@ -548,14 +556,17 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         c.B = B; c.H = H;
         return c;
     };
+#endif
     auto bwd_steps = [&](int l, int t_hi, int t_lo, const float *dh_ext_, hipStream_t s_) {          // t = t_hi-1 ... t_lo
         for (int t = t_hi - 1; t >= t_lo; --t) {
+#ifdef PVR_EXPERIMENTS
             if (fused) {
                 LstmStep2P q = {};
                 q.active[0] = 1; q.j[0] = step_job(l, t, dh_ext_);
                 hipLaunchKernelGGL(lstm_bwd_step2_kernel, dim3(H / 16, 1), dim3(256), 0, s_, q);
                 continue;
             }
+#endif
             const bool has_next = t < T - 1;
             if (has_next) {
                 LstmRecP r;
@@ -607,11 +618,16 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
         return c;
     };
     // persistent BPTT: the chunk waves below, each as ONE launch (both layers' step ranges as the two jobs of lstm_bwd_seq_kernel)
+#ifdef PVR_EXPERIMENTS
     const bool bwd_persist = pol->persist_bwd && pol->persist_bwd_fits && pol->dGx[0] && !pol->persist_tripped && !pol->use_graph &&
                              pol->persist == 2 && pol->chunkwave && H == 1024 && B <= 64 && T > 1;
+#else
+    const bool bwd_persist = false;
+#endif
     if (pol->chunkwave && (NCH > 1 || bwd_persist)) {
         // chunk index c descending; launch pair s: layer 1 at the s-th step (from the top) of chunk c, layer 0 at the s-th of chunk c+1
         for (int c = NCH - 1; c >= -1; --c) {
+#ifdef PVR_EXPERIMENTS
             if (bwd_persist) {
                 LstmBwdSeqP q = {};
                 q.nd = pol->nd; q.T = T; q.B = B; q.H = H; q.drop_block = pol->debug_drop_block; q.status = pol->status_dev;
@@ -628,11 +644,13 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                 }
                 if (q.j[0].active || q.j[1].active) hipLaunchKernelGGL(lstm_bwd_seq_kernel, dim3(256, 2), dim3(256), 0, st, q);
             } else
+#endif
             for (int s_ = 0; s_ < CH; ++s_) {
                 const int hi1 = (c + 1) * CH < T ? (c + 1) * CH : T, hi0 = (c + 2) * CH < T ? (c + 2) * CH : T;
                 const int ta = hi1 - 1 - s_, tb = hi0 - 1 - s_;          // layer 1 step, layer 0 step
                 const bool a1 = c >= 0 && ta >= c * CH && ta >= 0, a0 = c + 1 < NCH && tb >= (c + 1) * CH && tb >= 0;
                 if (!a1 && !a0) continue;
+#ifdef PVR_EXPERIMENTS
                 if (fused) {
                     LstmStep2P q = {};
                     q.active[0] = a0; q.active[1] = a1;
@@ -641,6 +659,7 @@ static pvr_status backward_core(pvr_policy *pol, const float *P, const void *obs
                     hipLaunchKernelGGL(lstm_bwd_step2_kernel, dim3(H / 16, 2), dim3(256), 0, st, q);
                     continue;
                 }
+#endif
                 LstmRec2P r = {};
                 r.active[0] = a0 && tb < T - 1; r.active[1] = a1 && ta < T - 1;
                 if (r.active[0]) r.j[0] = rec_job(0, tb);
@@ -893,7 +912,6 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     for (int l = 0; l < 2; ++l) { A_(G[l], N * 4 * H); A_(Hs[l], N * H); A_(Cs[l], N * H); }
     A_(hprev, N * H); A_(nd, N); A_(zeros, 2 * B * H); A_(dc_carry, B * H); A_(rec_partial, 16 * B * H);
     A_(hprev1, N * H); A_(dc_carry1, B * H); A_(rec_partial1, 16 * B * H);
-    A_(whhT[0], (size_t)4 * H * H); A_(whhT[1], (size_t)4 * H * H);
     A_(logits, N * 16); A_(baseline, N); A_(dlogits, N * 16); A_(loss_row, N); A_(stats, 4); A_(partial, 1024);
     A_(action, N); A_(dA, N * H); A_(dB, N * H); A_(da0, N * O); A_(grads, (size_t)p->n_train);
     if (desc->conv_frames > 0) {
@@ -914,7 +932,10 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     if (const char *e = getenv("PVR_POLICY_PIPELINE")) p->pipeline = atoi(e) != 0;
     if (const char *e = getenv("PVR_POLICY_PERSIST")) p->persist = atoi(e);      // 1: counter hand-off, 2: data-as-flag hand-off
     if (const char *e = getenv("PVR_POLICY_CHUNKWAVE")) p->chunkwave = atoi(e) != 0;
+#ifdef PVR_EXPERIMENTS
     if (const char *e = getenv("PVR_POLICY_BWD_FUSED")) p->bwd_fused = atoi(e) != 0;
+    if (p->bwd_fused) { A_(whhT[0], (size_t)4 * H * H); A_(whhT[1], (size_t)4 * H * H); }   // (only that path reads W_hh^T: 32 MB at H = 1024)
+#endif
     A_(seq_counters, 64);
     if (!s) {
         // status word of the persistent recurrence: pinned host memory the GPU writes with a system-scope store
@@ -929,12 +950,16 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
         if (he == hipSuccess) he = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_fwd_seq_kernel, 256, 0);
         p->persist_fits = he == hipSuccess && (long long)per_cu * cus >= desc->hidden / 4;
+#ifdef PVR_EXPERIMENTS
         int per_cu_b = 0;
         if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, lstm_bwd_seq_kernel, 256, 0);
         p->persist_bwd_fits = he == hipSuccess && (long long)per_cu_b * cus >= 2 * 256 && desc->hidden == 1024;
+#endif
         (void)hipGetLastError();
     }
+#ifdef PVR_EXPERIMENTS
     if (const char *e = getenv("PVR_POLICY_PERSIST_BWD")) p->persist_bwd = atoi(e) != 0;
+#endif
     if (!s && p->persist_bwd && p->persist_bwd_fits && p->persist == 2) {
         for (int l = 0; l < 2 && !s; ++l) {
             const size_t px = (size_t)2 * 16 * B * desc->hidden;
@@ -1202,6 +1227,9 @@ pvr_status pvr_op_gemm_f32(const float *A, const float *B, const float *bias, fl
 
 pvr_status pvr_debug_set_gemm_mode(int32_t mode) {
     PVR_REQUIRE(mode >= -1 && mode <= 3, "pvr_debug_set_gemm_mode: mode must be -1 (default), 0 (fp32 MFMA), 1 / 2 / 3 (split-bf16 MFMA: automatic / 128 / 64 tiles)");
+#ifndef PVR_EXPERIMENTS
+    PVR_REQUIRE(mode <= 0, "pvr_debug_set_gemm_mode: the split-bf16 GEMM is an experiment kernel; this library was built without it (make EXPERIMENTS=1)");
+#endif
     g_gemm_mode = mode;
     return PVR_OK;
 }

@@ -152,6 +152,7 @@ template <int BM, int BN, bool ATR, bool BTR> constexpr size_t gemm_f32_lds() {
     return (size_t)2 * ((ATR ? 32 * (BM + 16) : BM * 36) + (BTR ? 32 * (BN + 16) : BN * 36)) * sizeof(float);
 }
 
+#ifdef PVR_EXPERIMENTS   // round-3 experiment, as accurate and no faster than gemm_f32_kernel (profiles/experiments/r03_gemm_split_bf16.txt)
 // ---------------------------------------------------------------------------------------------------------
 // The same GEMM on the bf16 matrix pipe (round 3): every fp32 operand value is split EXACTLY into three bf16 terms
 //     a = a1 + a2 + a3,   a1 = top 16 bits of a,  a2 = top 16 bits of (a - a1),  a3 = a - a1 - a2   (8 + 8 + 8 significand bits)
@@ -325,6 +326,7 @@ static __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmP p) {
             }
     }
 }
+#endif  // PVR_EXPERIMENTS
 
 // out = sum over the split-K slices (ascending), then the epilogue the GEMM kernel would have applied
 static __global__ __launch_bounds__(256) void splitk_sum_kernel(const float *__restrict__ part, float *__restrict__ out, const float *__restrict__ bias,
@@ -917,6 +919,7 @@ static __global__ __launch_bounds__(256) void lstm_bwd_cell2_kernel(LstmCellB2P 
     lstm_bwd_cell_body(pp.j[blockIdx.y]);
 }
 
+#ifdef PVR_EXPERIMENTS   // round-3 experiment, slower than the two launches it replaces (profiles/experiments/r03_bc_fused_bptt_step.txt)
 // ---------------------------------------------------------------------------------------------------------
 // BPTT step as ONE launch (round 3, opt-in PVR_POLICY_BWD_FUSED=1: correct and 2.5 x SLOWER per step than the two launches it replaces -
 // 128 blocks stream W_hh^T with 16 loads in flight per wave and every block re-reads all of dG[t+1]; the two-launch form's rec kernel
@@ -1000,7 +1003,9 @@ static __global__ __launch_bounds__(256) void lstm_bwd_step2_kernel(LstmStep2P p
     if (!pp.active[blockIdx.y]) return;
     lstm_bwd_step_body(pp.j[blockIdx.y]);
 }
+#endif  // PVR_EXPERIMENTS
 
+#ifdef PVR_EXPERIMENTS   // round-3 experiment, slower than the per-step launches (profiles/experiments/r03_bc_persistent_bptt.txt)
 // ---------------------------------------------------------------------------------------------------------
 // Persistent BPTT (round 3): ONE launch runs steps t_hi-1 ... t_lo of up to two independent jobs (blockIdx.y: layer 1 on one chunk of
 // the sequence, layer 0 on the chunk behind it - the chunked layer wavefront of the per-step launches, 2 x 256 blocks, co-resident).
@@ -1209,6 +1214,7 @@ static __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmBwdSeqP pp
     }
     if (cok) p.dc_carry[(size_t)cb * H + cu] = dc;
 }
+#endif  // PVR_EXPERIMENTS
 
 // Hprev_m[t][b][:] = nd[t][b] * h[t-1][b][:]  (h[-1] = h_init): the recurrent operand of dW_hh
 static __global__ __launch_bounds__(256) void hprev_kernel(const float *__restrict__ hs, const float *__restrict__ h_init,

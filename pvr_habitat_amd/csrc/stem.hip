@@ -514,8 +514,9 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
 bool stem_pool_u8_ok(const void *frames, int h, int w, int top, int left) {
     const char *e = getenv("PVR_STEM_U8"), *l = getenv("PVR_STEM_LDS");          // (read per call: the A/B test flips it inside one process)
     const bool enabled = (!e || atoi(e) != 0) && (!l || atoi(l) != 0);
-    return enabled && ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&      // (16-byte row DMA: every source chunk aligned) top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w &&
-           (long long)h * w * 3 < 0x7ffffff0ll;
+    // 16-byte row DMA: every source chunk aligned; the crop window inside the frame (an out-of-frame window would read wrong rows, not fail)
+    return enabled && ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&
+           top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w && (long long)h * w * 3 < 0x7ffffff0ll;
 }
 pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int top, int left, const void *wgt, const float *bias, void *out,
                                int dtype, hipStream_t stream) {
@@ -526,11 +527,11 @@ pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int t
     const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
     const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     U8Geo g;
     g.src = frames; g.pitch = w * 3; g.img_bytes = h * w * 3; g.off0 = (top * w + left) * 3;
@@ -570,11 +571,11 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
         return PVR_OK;
     }
     const size_t lds = 5 * 112 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.mark();
     }
     if (dtype == PVR_F16)
         hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), lds, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);

@@ -623,10 +623,10 @@ static pvr_status aa_prepare(pvr_encoder *e, int h, int w) {
 template <bool F16, int HD, int MAXNT, bool EXACT>
 static pvr_status launch_attention_inst(const u16 *qkv, u16 *out, int T, int TK, int W, int heads, int nb, hipStream_t st) {
     const size_t lds = (size_t)TK * (HD == 64 ? 128 : ((HD + 31) / 32 * 64 + 16)) + (size_t)HD * (TK + 4) * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
+    if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)attention_kernel<F16, HD, MAXNT, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL((attention_kernel<F16, HD, MAXNT, EXACT>), dim3(heads, nb), dim3(256), lds, st, qkv, out, T, TK, W);
     PVR_LAUNCH_CHECK();

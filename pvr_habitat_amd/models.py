@@ -155,7 +155,7 @@ class _PolicyFunction(torch.autograd.Function):
 
 class PolicyNet(nn.Module):
     _conv_frames = 0
-    _stats_groups = {}              # id(gradient process group) -> the SyncBN statistics group over the same ranks (one per process)
+    _stats_groups = {}              # ranks of the gradient process group (None = the world) -> the SyncBN statistics group over them (one per process)
 
     def __init__(self, observation_shape, num_actions, batch_norm=False, max_unroll=100, max_batch=32):
         super(PolicyNet, self).__init__()
@@ -344,27 +344,32 @@ class PolicyNet(nn.Module):
             action = torch.multinomial(F.softmax(logits.detach().view(T * B, A), dim=1), num_samples=1).view(T, B)
         return dict(policy_logits=logits, baseline=baseline, action=action), (h, c)
 
-    def set_data_parallel(self, group=None, sync_bn=True):
+    def set_data_parallel(self, group=None, sync_bn=True, stats_group=None):
         """Hand the library its collective (pvr_policy_set_data_parallel) for this policy's handle: every following training
         backward - fused step, step_data_parallel or loss.backward() through the autograd bridge - all-reduces its gradient
         buckets over `group` (and uses global-batch BatchNorm statistics with sync_bn).  World size 1 / no process group
-        uninstalls.  Re-installed when the handle, the group or the SyncBN choice changes."""
+        uninstalls.  Re-installed when the handle, the group or the SyncBN choice changes.
+
+        SyncBN statistics travel on their own process group (own RCCL communicator / stream, see make_allreduce_fn).  Pass it as
+        `stats_group` when `group` is a proper subgroup of the world: creating it here calls dist.new_group, a collective over the
+        DEFAULT group that every rank of the world - members of `group` or not - has to reach.  Without `stats_group` this method
+        creates one on first use (main_bc_finetune: group = the world, every rank reaches its first step), keyed by the group's
+        ranks (not by id(group), which a later group object can reuse)."""
         import torch.distributed as dist
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         sync = bool(self.batch_norm and sync_bn)
-        key = (self._handle.value if self._handle is not None else None, id(group), world, sync)
+        ranks = tuple(dist.get_process_group_ranks(group)) if (world > 1 and group is not None) else None
+        key = (self._handle.value if self._handle is not None else None, ranks, world, sync, id(stats_group) if stats_group is not None else None)
         if getattr(self, '_dp_key', None) == key:
             return world
         if world > 1:
-            stats_group = None
-            if sync:
-                # SyncBN statistics travel on their own process group (own RCCL communicator / stream): see make_allreduce_fn.  new_group
-                # is itself a collective over the default group - every rank reaches this line at its first data-parallel step.
+            if sync and stats_group is None:
                 cache = PolicyNet._stats_groups
-                if id(group) not in cache:
-                    ranks = dist.get_process_group_ranks(group) if group is not None else None
-                    cache[id(group)] = dist.new_group(ranks=ranks)
-                stats_group = cache[id(group)]
+                if ranks not in cache:
+                    cache[ranks] = dist.new_group(ranks=list(ranks) if ranks is not None else None)
+                stats_group = cache[ranks]
+            if not sync:
+                stats_group = None
             self._dp_cb, self._dp_errors = make_allreduce_fn(group, 'cuda', stats_group)       # (the ctypes thunk must stay alive while installed)
             _lib.check(_plib().pvr_policy_set_data_parallel(self._handle, world, int(sync), self._dp_cb, None))
         else:

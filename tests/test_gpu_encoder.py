@@ -182,6 +182,8 @@ def test_conv_pp256_is_bit_identical_to_conv_igemm(case, dt, conv_algo):
     assert _lib.lib().pvr_debug_pp_persistent_launches() == before + (4 if persistent else 0) + (4 if persistent224 else 0)
     # round 3: the four-wave kernel (conv_w4.hip: 112 x 128 outputs per wave, accumulators in a fixed AccVGPR block, four 32-deep LDS
     # stages, hand-counted LDS-DMA waits): same K order, same epilogue -> the same bits, on every repeat
+    if not _lib.lib().pvr_has_experiments():                       # the shipped library leaves its measured-slower kernels out (make EXPERIMENTS=1)
+        return
     conv_algo(4)
     for rep in range(6):
         out = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res == 2, cdt, tdt)

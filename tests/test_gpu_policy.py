@@ -42,6 +42,8 @@ def test_gemm_split_bf16_is_as_accurate_as_the_fp32_mfma_gemm(M, N, K, a_km, b_k
     with a wide dynamic range; both tile shapes, every operand layout, ragged sizes."""
     from pvr_habitat_amd.models import _plib
     L = _plib()
+    if not _lib.lib().pvr_has_experiments():
+        pytest.skip('experiment kernel: the shipped library is built without it (make -C pvr_habitat_amd/csrc EXPERIMENTS=1)')
     g = np.random.default_rng(M * 7 + N * 3 + K)
     A = torch.from_numpy((g.standard_normal((M, K)) * np.exp(g.uniform(-6, 3, (M, K)))).astype(np.float32))
     B = torch.from_numpy((g.standard_normal((N, K)) * np.exp(g.uniform(-6, 3, (N, K)))).astype(np.float32))
@@ -267,6 +269,10 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch, T, B):
     # whose summation order the persistent BPTT (bwd = 1) shares.  Bit-identity holds WITHIN each group; the two groups differ by fp32 regrouping only.
     cases = [(p_, q_, '0', '1') for p_, q_ in (('0', '1'), ('1', '1'), ('1', '0'), ('2', '1'), ('2', '0'))] + \
             [('0', '1', '0', '0'), ('2', '1', '1', '0'), ('2', '0', '1', '0')]
+    if not _lib.lib().pvr_has_experiments():
+        # the shipped library carries neither the fused BPTT step nor the persistent BPTT (measured slower: profiles/experiments/r03_bc_*):
+        # the two switches are ignored there, and what remains to prove is that every forward-recurrence mode gives the same bits
+        cases = [(p_, q_, '0', '0') for p_, q_ in (('0', '1'), ('1', '1'), ('1', '0'), ('2', '1'), ('2', '0'))]
     for persist, pipe, bwd, fused in cases:
         monkeypatch.setenv('PVR_POLICY_PERSIST', persist)
         monkeypatch.setenv('PVR_POLICY_PIPELINE', pipe)
@@ -285,9 +291,10 @@ def test_persistent_forward_recurrence_is_bit_identical(monkeypatch, T, B):
         m.close()
     for fused in ('1', '0'):
         grp = [v for k, v in finals.items() if k[3] == fused]
-        assert all(torch.equal(grp[0], v) for v in grp), 'modes with fused = %s differ' % fused
-    a, b = finals[('0', '1', '0', '1')], finals[('0', '1', '0', '0')]
-    assert float((a - b).abs().max()) <= 2e-6 + 1e-4 * float(b.abs().max()), float((a - b).abs().max())
+        assert all(torch.equal(grp[0], v) for v in grp), 'modes with fused = %s differ' % fused      # (an empty group passes)
+    if ('0', '1', '0', '1') in finals:
+        a, b = finals[('0', '1', '0', '1')], finals[('0', '1', '0', '0')]
+        assert float((a - b).abs().max()) <= 2e-6 + 1e-4 * float(b.abs().max()), float((a - b).abs().max())
 
 
 def test_persistent_recurrence_timeout_reaches_the_host(monkeypatch):
