@@ -385,6 +385,54 @@ def png_source_bench(model_sd, batch, dtype, n_traj=48, length=250, hw=64):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def save_obs_e2e_bench(batch, dtype, n_samples=100000, traj_len=500, hw=64):
+    """The real driver end to end (round-3 verdict item 3c): pvr_habitat_amd.save_embedded_obs.run(flags) - the drop-in for the reference's
+    behavioral_cloning/save_embedded_obs.py:96-172 - on a synthetic scene pickle of n_samples (hw, hw, 6) uint8 observations in the
+    reference's per-trajectory layout (save_opt_trajectories.py:100-106).  Wall clock of run(): scene index pass, streamed unpickling into
+    pinned blocks, embedding of both 3-channel planes of every row, shard file, stitch and the output pickle (protocol 5).  frames/s counts
+    embedded FRAMES (2 per sample).  The scene is written to a temporary directory first (untimed)."""
+    import contextlib, pickle, shutil, tempfile
+    from pvr_habitat_amd import save_embedded_obs as S
+    d = tempfile.mkdtemp(prefix='pvr_e2e_bench_')
+    try:
+        rng = np.random.default_rng(5)
+        lens = [traj_len] * (n_samples // traj_len) + ([n_samples % traj_len] if n_samples % traj_len else [])
+        base = rng.integers(0, 256, (traj_len, hw, hw, 6), dtype=np.uint8)
+        raw = dict(obs=[], action=[], reward=[], done=[], true_state=[])
+        for t, L in enumerate(lens):
+            raw['obs'].append(np.roll(base[:L], t, axis=1))            # distinct trajectories, cheap to make
+            raw['action'].append(rng.integers(0, 3, L)); raw['reward'].append(np.zeros(L)); raw['done'].append(np.arange(L) == L - 1)
+            raw['true_state'].append(np.zeros((L, 12), np.float32))
+        with open(os.path.join(d, 'scene.pickle'), 'wb') as f:
+            pickle.dump(raw, f, protocol=pickle.HIGHEST_PROTOCOL)
+        scene_bytes = os.path.getsize(os.path.join(d, 'scene.pickle'))
+        del raw, base
+        os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
+        argv = ['--data_path', d, '--env', 'scene', '--embedding_name', 'resnet50', '--disable_pretrained_embedding', '--source', 'pickle',
+                '--embed_batch', str(batch), '--compute_dtype', dtype]
+        with contextlib.redirect_stdout(open(os.devnull, 'w')):
+            # warm-up on a tiny scene of the same frame size (library load, plan, first launches, both lanes): not part of the measurement
+            wd = os.path.join(d, 'warm'); os.makedirs(wd)
+            with open(os.path.join(wd, 'scene.pickle'), 'wb') as f:
+                pickle.dump(dict(obs=[rng.integers(0, 256, (4 * batch, hw, hw, 6), dtype=np.uint8)], action=[np.zeros(4 * batch, np.int64)],
+                                 reward=[np.zeros(4 * batch)], done=[np.zeros(4 * batch, bool)], true_state=[np.zeros((4 * batch, 12), np.float32)]), f)
+            S.run(S.make_parser().parse_args(['--data_path', wd] + argv[2:]))
+            t0 = time.perf_counter()
+            S.run(S.make_parser().parse_args(argv))
+            el = time.perf_counter() - t0
+        out = os.path.join(d, 'scene_resnet50.pickle')
+        with open(out, 'rb') as f:
+            res = pickle.load(f)
+        assert res['obs'].shape == (n_samples, 2 * 2048) and np.isfinite(res['obs'][:1024]).all() and np.isfinite(res['obs'][-1024:]).all()
+        return {'metric': 'frames/sec embedded by save_embedded_obs.run end to end (scene pickle -> embeddings pickle)', 'value': round(2 * n_samples / el, 1),
+                'unit': 'frames/s', 'samples': n_samples, 'frames_per_sample': 2, 'frame': hw, 'dtype': dtype, 'wall_s': round(el, 2),
+                'scene_MB': round(scene_bytes / 1e6, 1), 'out_MB': round(os.path.getsize(out) / 1e6, 1),
+                'note': 'wall clock of run(flags): index pass + streamed unpickle into pinned blocks (reader thread) + H2D + ResNet50 on both planes + D2H + '
+                        'shard file + stitch + output pickle; 64x64 frames are bilinearly resized to 256 on the GPU (Resize(256), embeddings.py:80-85)'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def parity_rel_l2(model, sd, frames_np):
     """the TIMED model (same handle, same dtype) against the CPU oracle on a few frames of the bench's own pool"""
     from oracle import encoder_oracle as eo
@@ -439,6 +487,8 @@ def main():
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive streaming leg')
     ap.add_argument('--no-png', action='store_true', help='skip the PNG-source leg (writes 12 000 small files to a temporary directory)')
     ap.add_argument('--png-traj', type=int, default=48, help='trajectories (x 250 frames) of the PNG-source leg')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the save_embedded_obs end-to-end leg (writes a 2.4 GB synthetic scene pickle to a temporary directory)')
+    ap.add_argument('--e2e-samples', type=int, default=100000, help='observations of the end-to-end leg\'s synthetic scene')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
     ap.add_argument('--no-f16', action='store_true', help='skip the f16 (parity-mode) leg')
     ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel finetune leg (N > 1)')
@@ -678,6 +728,8 @@ def main():
             line['pcie_inclusive'] = pcie_bench(sd, args.batch, pool_np, args.dtype)
             # host uint8 -> H2D -> encode -> D2H fp32, the end-to-end rate of the "embeddings streamed to host" path (never `value`)
             line['value_pcie_inclusive'] = line['pcie_inclusive']['pinned_source']['value']
+        if world == 1 and not args.no_e2e and not args.no_pcie:
+            line['save_embedded_obs_e2e'] = save_obs_e2e_bench(args.batch, args.dtype, n_samples=args.e2e_samples)
         if world == 1 and not args.no_vit:
             vdt = 'f16' if args.dtype == 'f32' else args.dtype   # the fp32 mode covers the ResNet50 family only
             line['vit'] = [vit_bench('clip_b16', args.batch, 20, 2, vdt, lane_streams[:2] if len(lane_streams) >= 2 else None),

@@ -173,6 +173,11 @@ pvr_status pvr_debug_set_conv_algo(int32_t algo);
  * the sizes), read by `threads` native threads - one file per frame is a system-call workload (save_embedded_obs.py:71) */
 pvr_status pvr_file_sizes(const char *const *paths, int32_t n, int64_t *sizes, int32_t threads);
 pvr_status pvr_read_files(const char *const *paths, int32_t n, uint8_t *dst, const int64_t *offsets, int32_t threads);
+/* host frames -> a (pinned) staging buffer by `threads` native threads (reference save_embedded_obs.py:148-154 hands torch a pageable slice per
+ * batch): dst = rows x row_bytes contiguous bytes; source row r starts at src + r * src_row_stride and consists of runs of run_bytes bytes
+ * every run_stride bytes (run_bytes == row_bytes: plain rows; run_bytes 3, run_stride 3F: one 3-channel plane of (H, W, 3F) frames). */
+pvr_status pvr_stage_copy(void *dst, const void *src, int64_t rows, int64_t row_bytes, int64_t src_row_stride, int64_t run_bytes,
+                          int64_t run_stride, int32_t threads);
 int64_t pvr_png_scratch_bytes(int32_t n, int32_t h, int32_t w);
 pvr_status pvr_png_decode(const uint8_t *files_dev, const int64_t *offsets_dev, int32_t n, int32_t h, int32_t w, uint8_t *out_dev,
                           uint8_t *scratch_dev, int64_t scratch_bytes, int32_t *status_dev, void *hip_stream);

@@ -586,23 +586,49 @@ def lane_streams(dev_index=None):
     return list(_streams(dev_index)[2])
 
 
-def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
+def _stage_rows(dst, x, lo, m, threads):
+    """x[lo:lo+m] (uint8, host, possibly a channel-plane view of interleaved frames) -> the pinned tensor dst[:m], by the library's native
+    threads (pvr_stage_copy; the call releases the GIL).  Layouts it does not know fall back to torch's copy."""
+    src = x[lo:lo + m]
+    row = int(np.prod(src.shape[1:]))
+    st = src.stride()
+    if src.is_contiguous():
+        _lib.check(_lib.lib().pvr_stage_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), m, row, row, row, row, threads))
+    elif (src.dim() == 4 and src.shape[3] == 3 and st[3] == 1 and st[2] >= 3 and st[1] == src.shape[2] * st[2] and
+          (m == 1 or st[0] >= src.shape[1] * st[1])):
+        # one 3-channel plane of (N, H, W, 3F) frames: runs of 3 bytes every 3F bytes
+        _lib.check(_lib.lib().pvr_stage_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), m, row, st[0] if m > 1 else row, 3, st[2], threads))
+    else:
+        dst[:m].copy_(src)
+
+
+def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=None, planes=1):
     """Embed a large uint8 (N,H,W,3) array - host-resident, or a CUDA tensor (then only the compute and D2H stages run) - with H2D copies, HIP compute and D2H copies overlapped: a ring of `depth`
     device input / output buffers, one copy stream each way and TWO compute streams (each on its own encoder workspace lane, so
     batch k+1 starts while batch k drains) chained by events.  The ring is deeper than the number of batches in flight on the
     compute side: with only one buffer per lane the upload of batch k+2 cannot start before batch k has been computed, and the lane
     then idles for the whole copy (measured: 60 k frames/s at 11.8 GB/s on a link that sustains 56 GB/s).  Pageable sources are
-    staged through pinned buffers by a small thread pool (one memcpy thread moves ~3 GB/s).  Same rows, same order, same values as
-    calling `net` batch by batch; this is the "embeddings streamed to host" path of BASELINE config 5 and what save_embedded_obs
-    uses for big scenes.  Returns np.float32 (N, out_size) (no squeeze)."""
+    staged through pinned buffers by the library's native threads (pvr_stage_copy, `stage_threads` of them, default PVR_STAGE_THREADS
+    or 8: one memcpy thread moves ~3 GB/s) on a PRODUCER thread that runs up to `depth` batches ahead of the thread that enqueues the
+    GPU work (round 3 staged synchronously between two enqueues: 36 k frames/s from pageable memory).  Same rows, same order, same
+    values as calling `net` batch by batch; this is the "embeddings streamed to host" path of BASELINE config 5 and what
+    save_embedded_obs uses for big scenes.  Returns np.float32 (N, planes * out_size) (no squeeze).
+
+    planes = F > 1: frames_u8 is (N,H,W,3F) (the scene pickles hold current + goal frame interleaved, save_embedded_obs.py:148-150);
+    a batch of whole rows is uploaded ONCE, each 3-channel plane is sliced on the device and embedded into its column block of the
+    output row - what the reference builds with np.split / np.concatenate around its model call (:151-156)."""
     _lib.require_gpu()
+    if stage_threads is None:
+        stage_threads = int(os.environ.get('PVR_STAGE_THREADS', '8'))
     # a strided view (e.g. the channel slice obs[..., 3:6] of a (N,H,W,6) scene) is taken as it is: the staging threads gather it
     # into pinned memory batch by batch, overlapped with the GPU, instead of one np.ascontiguousarray pass over the scene up front
     x = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.from_numpy(frames_u8 if all(st >= 0 for st in frames_u8.strides)
                                                                                else np.ascontiguousarray(frames_u8))
-    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3
+    F_ = int(planes)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3 * F_
     n, osz = x.shape[0], net.out_size
-    res = torch.empty((n, osz), dtype=torch.float32, pin_memory=True) if out is None else out
+    res = torch.empty((n, F_ * osz), dtype=torch.float32, pin_memory=True) if out is None else out
+    assert tuple(res.shape) == (n, F_ * osz)
     dev = torch.device('cuda')
     if os.environ.get('PVR_STREAM_FRESH', '0') == '1':       # experiment: new streams per call
         h2d, d2h, comps = torch.cuda.Stream(), torch.cuda.Stream(), [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -615,17 +641,15 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
     two_lanes = getattr(model, 'lanes', 1) >= 2 and os.environ.get('PVR_STREAM_LANES', '2') != '1'
     depth = max(2, min(int(depth), (n + batch - 1) // batch + 1))
     device_src = x.is_cuda                                  # frames already in HBM (PNG source decoded on the GPU): no upload at all
-    pinned_src = device_src or x.is_pinned()                 # caller already holds page-locked frames: no staging copy
+    pinned_src = device_src or (x.is_pinned() and (F_ > 1 or x.is_contiguous()))   # caller already holds page-locked frames: no staging copy
     registered = None
     if (not pinned_src and stage_threads != 0 and os.environ.get('PVR_STREAM_REGISTER', '0') == '1' and x.is_contiguous()
             and x.numel() >= _REGISTER_MIN_BYTES):
         # OPT-IN (PVR_STREAM_REGISTER=1): page-lock the caller's array IN PLACE for the duration of the call (hipHostRegister), so the
-        # frames go straight from the caller's memory to the GPU by DMA - no staging copy (measured: 72 k frames/s vs 16-26 k through
-        # the pinned staging ring and 44 k through the driver's own staged copy of pageable memory).  Round 2 did this by default for any
+        # frames go straight from the caller's memory to the GPU by DMA - no staging copy.  Round 2 did this by default for any
         # pageable source, i.e. it locked and unlocked pages of the glibc heap that the package does not own, next to unrelated objects
         # (ADVICE round 2); now it needs the opt-in AND a buffer of >= 64 MiB, which glibc serves by a private mmap (above
-        # M_MMAP_THRESHOLD_MAX), so the locked pages belong to this array alone.  Callers that want the full rate by default hold
-        # their frames in pinned memory (torch.empty(..., pin_memory=True)), as bench.py's headline PCIe leg does.
+        # M_MMAP_THRESHOLD_MAX), so the locked pages belong to this array alone.
         try:
             if int(torch.cuda.cudart().cudaHostRegister(x.data_ptr(), x.numel(), 0)) == 0:
                 registered = x.data_ptr()
@@ -634,49 +658,77 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
             registered = None
     shape = (batch,) + tuple(x.shape[1:])
     direct = pinned_src or stage_threads == 0              # stage_threads = 0: hand pageable memory to the driver's own staged copy
-    stage_in = None if direct else [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    stage_in = None if direct else [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(depth)]
     dev_in = None if device_src else [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(depth)]
-    dev_out = [torch.empty((batch, osz), dtype=torch.float32, device=dev) for _ in range(depth)]
+    dev_pl = [torch.empty(shape[:3] + (3,), dtype=torch.uint8, device=dev) for _ in range(2)] if F_ > 1 else None   # one plane, per lane
+    dev_out = [torch.empty((batch, F_ * osz), dtype=torch.float32, device=dev) for _ in range(depth)]
     in_free = [torch.cuda.Event() for _ in range(depth)]    # compute finished reading dev_in[b]
     out_free = [torch.cuda.Event() for _ in range(depth)]   # D2H finished reading dev_out[b]
-    host_free = [torch.cuda.Event() for _ in range(depth)]  # H2D finished reading stage_in[b]
-    for e in in_free + out_free + host_free:
+    for e in in_free + out_free:
         e.record()
-    pool = None
-    if not direct and stage_threads > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=stage_threads)
+    starts = list(range(0, n, batch))
 
-    def stage(dst, lo, m):
-        """pageable -> pinned, split over the pool's threads (torch's copy releases the GIL)"""
-        if pool is None or m < 2 * stage_threads:
-            dst[:m].copy_(x[lo:lo + m])
-            return
-        step = (m + stage_threads - 1) // stage_threads
-        list(pool.map(lambda a: dst[a:min(a + step, m)].copy_(x[lo + a:lo + min(a + step, m)]), range(0, m, step)))
+    # producer thread: pageable -> pinned staging slot, up to `depth` batches ahead; a slot returns to it with the event that marks the end
+    # of the H2D copy that read it
+    import queue
+    import threading
+    free_q, ready_q = queue.Queue(), queue.Queue()
+    stop = threading.Event()
+
+    def producer():
+        try:
+            for i, lo in enumerate(starts):
+                b, ev = free_q.get()
+                if stop.is_set():
+                    return
+                if ev is not None:
+                    ev.synchronize()                             # the upload that last read this slot has finished
+                m = min(batch, n - lo)
+                _stage_rows(stage_in[b], x, lo, m, max(1, stage_threads))
+                ready_q.put((i, b))
+        except BaseException as exc:                             # noqa: BLE001 - handed to the consuming thread
+            ready_q.put(exc)
+
+    worker = None
+    if not direct:
+        for b in range(depth):
+            free_q.put((b, None))
+        worker = threading.Thread(target=producer, name='pvr-stage', daemon=True)
+        worker.start()
 
     try:
-        for i, lo in enumerate(range(0, n, batch)):
-            b, m = i % depth, min(batch, n - lo)
+        for i, lo in enumerate(starts):
+            m = min(batch, n - lo)
             if direct:
+                b = i % depth
                 src = x[lo:lo + m]
             else:
-                host_free[b].synchronize()                      # pinned staging buffer reusable
-                stage(stage_in[b], lo, m)
+                got = ready_q.get()
+                if isinstance(got, BaseException):
+                    raise got
+                assert got[0] == i
+                b = got[1]
                 src = stage_in[b][:m]
             if not device_src:
                 with torch.cuda.stream(h2d):
                     h2d.wait_event(in_free[b])
                     dev_in[b][:m].copy_(src, non_blocking=True)
-                    host_free[b].record(h2d)
                     ready = torch.cuda.Event(); ready.record(h2d)
+                if not direct:
+                    free_q.put((b, ready))                        # the staging slot is reusable once this upload has read it
             lane = (i & 1) if two_lanes else 0
             comp = comps[lane]
             with torch.cuda.stream(comp):
                 if not device_src:
                     comp.wait_event(ready)
                 comp.wait_event(out_free[b])
-                model.forward_into(src if device_src else dev_in[b][:m], dev_out[b][:m], lane=lane)
+                rows = src if device_src else dev_in[b][:m]
+                if F_ == 1:
+                    model.forward_into(rows, dev_out[b][:m], lane=lane)
+                else:
+                    for f in range(F_):
+                        dev_pl[lane][:m].copy_(rows[..., 3 * f:3 * f + 3])       # plane f, contiguous (same stream: ordered before its forward)
+                        model.forward_into(dev_pl[lane][:m], dev_out[b][:m, f * osz:(f + 1) * osz], lane=lane)
                 in_free[b].record(comp)
                 done = torch.cuda.Event(); done.record(comp)
             with torch.cuda.stream(d2h):
@@ -685,8 +737,10 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=4):
                 out_free[b].record(d2h)
         torch.cuda.synchronize()
     finally:
-        if pool is not None:
-            pool.shutdown()
+        stop.set()
+        if worker is not None:
+            free_q.put((0, None))                                 # wake a producer that waits for a slot
+            worker.join()
         if registered is not None:
             torch.cuda.synchronize()
             rc = int(torch.cuda.cudart().cudaHostUnregister(registered))

@@ -319,6 +319,76 @@ def stitch_shards(save_name, world, keys, copy_bytes=256 << 20):
             os.remove(q)
 
 
+def _weights_fingerprint(model):
+    """cheap identity of the embedding's weights for the shard-resume check: a shard left by a run with other weights must not be reused"""
+    import hashlib
+    h = hashlib.sha1()
+    try:
+        sd = model.state_dict()
+    except Exception:
+        return None
+    for k in sorted(sd)[:64]:
+        v = sd[k]
+        h.update(k.encode())
+        if hasattr(v, 'detach'):
+            h.update(v.detach().float().flatten()[:256].cpu().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+class BlockRing(object):
+    """A ring of package-owned, page-locked row blocks between a producer that deposits observation rows (scene_rows' `take`) and a
+    consumer that embeds whole blocks: rows are copied ONCE, from the unpickled trajectory buffer straight into pinned memory the
+    H2D DMA reads (round 3 copied every trajectory to a pageable array, concatenated the block and staged strided channel planes:
+    three host passes and 2x the block in memory).  put() blocks while every block is full and still being embedded; blocks come
+    back through release().  The last block may be ragged.  (Pinned only when a GPU is present: the ring logic is CPU-testable.)"""
+
+    def __init__(self, rows, row_shape, count=2, pinned=None):
+        import queue
+        pinned = torch.cuda.is_available() if pinned is None else pinned
+        self.blocks = [torch.empty((rows,) + tuple(row_shape), dtype=torch.uint8, pin_memory=bool(pinned)) for _ in range(count)]
+        self.rows = rows
+        self._free, self._full = queue.Queue(), queue.Queue()
+        for i in range(count):
+            self._free.put(i)
+        self._cur, self._fill = None, 0
+
+    # ---- producer side -----------------------------------------------------------------------------------------
+    def put(self, rows):
+        """rows: uint8 array (k,) + row_shape (a view is fine: it is copied before put returns)"""
+        src = torch.from_numpy(np.ascontiguousarray(rows)) if not isinstance(rows, torch.Tensor) else rows
+        done = 0
+        while done < len(src):
+            if self._cur is None:
+                self._cur, self._fill = self._free.get(), 0
+            k = min(len(src) - done, self.rows - self._fill)
+            self.blocks[self._cur][self._fill:self._fill + k].copy_(src[done:done + k])
+            self._fill += k
+            done += k
+            if self._fill == self.rows:
+                self._full.put((self._cur, self._fill))
+                self._cur = None
+
+    def close(self, error=None):
+        """no more rows: hand over the ragged last block, then the end marker (or the producer's exception)"""
+        if error is None and self._cur is not None and self._fill > 0:
+            self._full.put((self._cur, self._fill))
+        self._cur = None
+        self._full.put(error if error is not None else None)
+
+    # ---- consumer side -----------------------------------------------------------------------------------------
+    def get(self):
+        """(block index, tensor view of its filled rows), or None at the end; re-raises a producer failure"""
+        got = self._full.get()
+        if got is None:
+            return None
+        if isinstance(got, BaseException):
+            raise got
+        return got[0], self.blocks[got[0]][:got[1]]
+
+    def release(self, index):
+        self._free.put(index)
+
+
 def _block_rows(flags, row_bytes, batch):
     """observation rows embedded per block (bounds the host memory of a rank): --embed_block, else about 1 GiB of frames"""
     blk = int(getattr(flags, 'embed_block', 0) or 0)
@@ -347,7 +417,7 @@ def run(flags):
     batch = getattr(flags, 'embed_batch', 256)
     keys = ('obs', 'action', 'reward', 'done', 'true_state')
     cover = dict(rank=rank, world=world, source=flags.source, embedding=flags.embedding_name, crops=int(getattr(flags, 'crops', 1)),
-                 run_id=int(flags.run_id) if flags.embedding_name == 'random' else None)
+                 run_id=int(flags.run_id) if flags.embedding_name == 'random' else None, weights=_weights_fingerprint(embedding_model))
     if flags.source == 'png':
         # the goal frame is per trajectory, so the png source shards on trajectory boundaries: rank r takes trajectories [t_lo, t_hi)
         png_dir = os.path.join(flags.data_path, flags.env)
@@ -372,36 +442,63 @@ def run(flags):
         print('  ', 'avg. return is', small['reward'].sum() / max(1, len(lengths)))
         lo, hi = shard_bounds(n_samples, rank, world)
         cover['range'] = (int(lo), int(hi))
+        st_ = os.stat(scene)
+        cover['scene'] = (int(st_.st_size), int(st_.st_mtime))      # a regenerated scene of equal length is not the scene this shard embedded
         if load_complete_shard(save_name, rank, cover) is None:
             print('  ', 'passing observations through embedding model')
             writer = ShardWriter(save_name, rank)
             n_frames = max(frame_shape[2] // 3, 1) if frame_shape else 1
             hip = hasattr(getattr(embedding_model, 'embedding', None), 'forward_into')
             block = _block_rows(flags, int(np.prod(frame_shape)) if frame_shape else 1, batch)
-            pending, n_pending = [], [0]
+            if hip and hi > lo:
+                # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU test), so the
+                # per-batch split/stack/concat of save_embedded_obs.py:151-156 is reproduced by streaming whole (H,W,3F) rows through the
+                # overlapped H2D / compute / D2H path, each 3-channel plane embedded into its column block (stream_embed, planes=F).
+                # A reader thread unpickles the scene and deposits rows into a ring of pinned blocks one block ahead of the embedder.
+                import threading
+                block = min(block, hi - lo)
+                ring = BlockRing(block, frame_shape, count=2)
+                osz = embedding_model.out_size
+                out_buf = torch.empty((block, n_frames * osz), dtype=torch.float32, pin_memory=torch.cuda.is_available())
 
-            def flush():
-                if not pending:
-                    return
-                obs = pending[0] if len(pending) == 1 else np.concatenate(pending)
-                del pending[:]
-                n_pending[0] = 0
-                if hip:
-                    # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU test), so
-                    # the per-batch split/stack/concat of save_embedded_obs.py:151-156 is reproduced by streaming each 3-channel
-                    # frame plane through the overlapped H2D/compute/D2H path and concatenating on features
-                    writer.append(np.concatenate([stream_embed(embedding_model, obs[..., 3 * f:3 * f + 3], batch) for f in range(n_frames)], axis=-1))
-                else:
+                def reader():
+                    try:
+                        scene_rows(scene, lo, hi, ring.put)         # pass 2: only this rank's rows, straight into pinned blocks
+                        ring.close()
+                    except BaseException as exc:                    # noqa: BLE001 - re-raised by ring.get() in the embedding thread
+                        ring.close(exc)
+                th = threading.Thread(target=reader, name='pvr-scene-reader', daemon=True)
+                th.start()
+                try:
+                    while True:
+                        got = ring.get()
+                        if got is None:
+                            break
+                        idx, rows = got
+                        emb = stream_embed(embedding_model, rows, batch, out=out_buf[:len(rows)], planes=n_frames)
+                        writer.append(emb.numpy())
+                        ring.release(idx)
+                finally:
+                    th.join(timeout=60)
+            else:
+                pending, n_pending = [], [0]
+
+                def flush():
+                    if not pending:
+                        return
+                    obs = pending[0] if len(pending) == 1 else np.concatenate(pending)
+                    del pending[:]
+                    n_pending[0] = 0
                     writer.append(embed_rows(embedding_model, obs, n_frames, max(1, batch // n_frames)))
 
-            def take(rows):                                    # rows: a view of one trajectory's buffer - keep a copy, embed per block
-                pending.append(np.array(rows))
-                n_pending[0] += len(rows)
-                if n_pending[0] >= block:
-                    flush()
-            if hi > lo:
-                scene_rows(scene, lo, hi, take)                 # pass 2: only this rank's rows are kept, one block at a time
-            flush()
+                def take(rows):                                # rows: a view of one trajectory's buffer - keep a copy, embed per block
+                    pending.append(np.array(rows))
+                    n_pending[0] += len(rows)
+                    if n_pending[0] >= block:
+                        flush()
+                if hi > lo:
+                    scene_rows(scene, lo, hi, take)             # pass 2: only this rank's rows are kept, one block at a time
+                flush()
             writer.finish({k: small[k][lo:hi] for k in keys[1:]}, cover)
         else:
             print('  ', 'rank %d: shard %s is complete, nothing to embed' % (rank, os.path.basename(shard_name(save_name, rank))))

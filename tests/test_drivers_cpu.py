@@ -411,3 +411,62 @@ def test_png_source_fails_loudly_on_an_undecodable_frame(tmp_path, monkeypatch):
     with pytest.raises(Exception, match='1_1.png'):
         S.run(S.make_parser().parse_args(['--data_path', str(tmp_path), '--env', 'scene', '--embedding_name', 'fake', '--source', 'png', '--embed_batch', '4']))
     assert not os.path.isfile(tmp_path / 'scene_fake.pickle')
+
+
+def test_block_ring_reuses_blocks_and_hands_over_a_ragged_last_block():
+    """save_embedded_obs.BlockRing (round 4): rows deposited by a producer thread arrive at the consumer block by block, in order, the
+    two blocks are reused, puts larger than a block are split, the last block is ragged, and a producer failure reaches the consumer."""
+    import threading
+    from pvr_habitat_amd.save_embedded_obs import BlockRing
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, 256, (53, 2, 3, 6), dtype=np.uint8)
+    ring = BlockRing(8, (2, 3, 6), count=2, pinned=False)
+    cuts = [0, 5, 6, 19, 20, 41, 53]                              # trajectory-sized puts, one of them (13 rows) larger than a block
+
+    def producer():
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ring.put(rows[a:b])
+        ring.close()
+    th = threading.Thread(target=producer)
+    th.start()
+    got, used = [], []
+    while True:
+        g = ring.get()
+        if g is None:
+            break
+        idx, blk = g
+        used.append(idx)
+        got.append(blk.numpy().copy())
+        ring.release(idx)
+    th.join()
+    assert [len(g) for g in got] == [8] * 6 + [5] and set(used) == {0, 1}
+    assert np.array_equal(np.concatenate(got), rows)
+    ring = BlockRing(4, (1,), count=2, pinned=False)
+    ring.put(np.zeros((2, 1), np.uint8))
+    ring.close(ValueError('scene is corrupt'))
+    with pytest.raises(ValueError, match='corrupt'):
+        ring.get()
+
+
+def test_native_stage_copy_gathers_rows_and_channel_planes():
+    """pvr_stage_copy (host threads of libpvr_hip.so): plain rows and the 3-byte-run gather of a channel plane of (N,H,W,3F) frames, every
+    thread count, ragged sizes; invalid geometry is refused with a message."""
+    from pvr_habitat_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (37, 5, 7, 3), dtype=np.uint8)
+    for th in (1, 3, 16):
+        b = np.zeros_like(a)
+        _lib.check(L.pvr_stage_copy(b.ctypes.data, a.ctypes.data, 37, 105, 105, 105, 105, th))
+        assert np.array_equal(a, b)
+    for F in (2, 3):
+        s6 = rng.integers(0, 256, (29, 4, 9, 3 * F), dtype=np.uint8)
+        for f in range(F):
+            v, o = s6[..., 3 * f:3 * f + 3], np.zeros((29, 4, 9, 3), np.uint8)
+            _lib.check(L.pvr_stage_copy(o.ctypes.data, v.ctypes.data, 29, 108, s6.strides[0], 3, 3 * F, 4))
+            assert np.array_equal(o, v), (F, f)
+    big = rng.integers(0, 256, (3, 1 << 20), dtype=np.uint8)      # contiguous rows are split into 1 MiB pieces
+    o = np.zeros_like(big)
+    _lib.check(L.pvr_stage_copy(o.ctypes.data, big.ctypes.data, 3, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 8))
+    assert np.array_equal(o, big)
+    assert L.pvr_stage_copy(o.ctypes.data, big.ctypes.data, 3, 100, 100, 7, 7, 2) != 0 and 'pvr_stage_copy' in _lib.last_error()
