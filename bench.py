@@ -343,7 +343,7 @@ def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
         assert np.isfinite(out).all()
         res[kind] = {'value': round(fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(fr.numel() / el / 1e9, 2)}
     res['frames'] = int(fr.shape[0])
-    res['note'] = ('host uint8 frames (a pageable source is copied into a pinned staging ring by the library's native threads (pvr_stage_copy, 8 of them) on a producer thread that runs ahead of the GPU work; page-locking it in place is opt-in: PVR_STREAM_REGISTER=1) -> H2D -> encode (two lanes) -> D2H fp32, '
+    res['note'] = ('host uint8 frames (a pageable source is copied into a pinned staging ring by 8 native threads of the library (pvr_stage_copy) on a producer thread that runs ahead of the GPU work; page-locking it in place is opt-in: PVR_STREAM_REGISTER=1) -> H2D -> encode (two lanes) -> D2H fp32, '
                    'copies overlapped with compute on separate HIP streams; includes registering the source and allocating the page-locked result buffer')
     return res
 

@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
         bB[bp] = co < p.Cout ? *reinterpret_cast<const float4 *>(p.bias + co + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // FULL: 128-couts-per-block instances with NHWC output - the wave's 64 couts of a pixel are one 128-byte line (see the epilogue)
+    constexpr bool FULL = NP == 2 && KS % 2 == 0;
+    const int fl_c = ((lane & 7) ^ ((lane >> 3) & 7)) << 4;            // line form: lane l holds rows (l >> 3), (l >> 3) + 8, this 16-byte chunk of the 128
+    const int fl_f0 = fr * 128 + ((fq ^ (fr & 7)) << 4), fl_f1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);   // fragment (fr, fq) of cout pair 0 / 1 in the slot image
     u32x4 qx[3][2];                                                    // register stages of X slices
     u32x4 rA[RES ? NP * TM : 1], rB[RES ? NP * TM : 1];                // residual of the current / next tile (alternating)
     int ac[2], an[2];                                                  // X byte offsets of the current / next pixel tile
@@ -137,12 +141,21 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
     }
 #define EX_LOADRES(r_, mt_)                                                                                        \
     if constexpr (RES) {                                                                                           \
+        if constexpr (FULL) {                              /* whole 128-byte lines: rows (lane >> 3) and + 8 of pixel tile j */ \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                         \
+                _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                 \
+                    const int m = (mt_) * BM + wm * 32 + j * 16 + (lane >> 3) + 8 * hf;                            \
+                    const int vo = m < p.M ? (m * p.Cout + co0 + wn * 64) * 2 + fl_c : OOB;                        \
+                    r_[j * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, 0)); \
+                }                                                                                                  \
+        } else {                                                                                                   \
         _Pragma("unroll") for (int bp = 0; bp < NP; ++bp)                                                          \
             _Pragma("unroll") for (int j = 0; j < TM; ++j) {                                                       \
                 const int m = (mt_) * BM + wm * 32 + j * 16 + fr;                                                  \
                 const int vo = (m < p.M && cbase[bp] >= 0) ? (m * p.Cout + cbase[bp]) * 2 : OOB;                   \
                 r_[bp * TM + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, 0)); \
             }                                                                                                      \
+        }                                                                                                          \
     }
 #define EX_MATH(s_, st_)                                                                                           \
     {                                                                                                              \
@@ -175,6 +188,44 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
             __syncthreads();                                                                                       \
         }                                                                                                          \
         EX_MATH(KS - 1, (KS - 1 + (PAR_)) & 1);                                                                    \
+        if constexpr (FULL) {                                                                                      \
+            /* The wave's 64 couts are one whole 128-byte line per pixel: residual and output cross the texture-address path as full   */ \
+            /* lines (8 rows x 128 B per instruction) and change to / from the fragment layout through 2 KB of the X stage that is idle */ \
+            /* here (its last readers passed the barrier of the last slice); the barrier below keeps the next tile's first X store,    */ \
+            /* which goes to that stage, behind every wave's last use of it.                                                           */ \
+            char *slot = smem + X_OFF + ((((KS - 1 + (PAR_)) & 1) ^ 1) * XST) + wave * 2048;                       \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j) {                                                       \
+                u32x4 r[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};                                       \
+                if constexpr (RES) {                                                                               \
+                    *reinterpret_cast<u32x4 *>(slot + lane * 16) = RC_[j * 2];                                     \
+                    *reinterpret_cast<u32x4 *>(slot + 1024 + lane * 16) = RC_[j * 2 + 1];                          \
+                    r[0] = *reinterpret_cast<const u32x4 *>(slot + fl_f0);                                         \
+                    r[1] = *reinterpret_cast<const u32x4 *>(slot + fl_f1);                                         \
+                }                                                                                                  \
+                u32x4 o[2];                                                                                        \
+                _Pragma("unroll") for (int bp = 0; bp < 2; ++bp) {                                                 \
+                    const f32x4 lo = acc[2 * bp][j], hi = acc[2 * bp + 1][j];                                      \
+                    const float v[8] = {lo[0] + bA[bp].x, lo[1] + bA[bp].y, lo[2] + bA[bp].z, lo[3] + bA[bp].w,    \
+                                        hi[0] + bB[bp].x, hi[1] + bB[bp].y, hi[2] + bB[bp].z, hi[3] + bB[bp].w};   \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+                        float v0 = v[2 * e], v1 = v[2 * e + 1];                                                    \
+                        if constexpr (RES) { v0 += from_h<F16>((u16)(r[bp][e] & 0xffffu)); v1 += from_h<F16>((u16)(r[bp][e] >> 16)); } \
+                        if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                              \
+                        o[bp][e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);                      \
+                    }                                                                                              \
+                }                                                                                                  \
+                *reinterpret_cast<u32x4 *>(slot + fl_f0) = o[0];                                                   \
+                *reinterpret_cast<u32x4 *>(slot + fl_f1) = o[1];                                                   \
+                _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                 \
+                    const u32x4 ln = *reinterpret_cast<const u32x4 *>(slot + hf * 1024 + lane * 16);               \
+                    const int m = mt * BM + wm * 32 + j * 16 + (lane >> 3) + 8 * hf;                               \
+                    int vo = (m * p.Cout + co0 + wn * 64) * 2 + fl_c;                                              \
+                    vo = m < p.M ? vo : OOB;                                                                       \
+                    __builtin_amdgcn_raw_buffer_store_b128(ln, rs_out, vo, 0, 0);                                  \
+                }                                                                                                  \
+            }                                                                                                      \
+            __syncthreads();                                                                                       \
+        } else {                                                                                                   \
         _Pragma("unroll") for (int bp = 0; bp < NP; ++bp)                                                          \
             _Pragma("unroll") for (int j = 0; j < TM; ++j) {                                                       \
                 const int m = mt * BM + wm * 32 + j * 16 + fr;                                                     \
@@ -195,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                 vo = (m < p.M && cbase[bp] >= 0) ? vo : OOB;                                                       \
                 __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, 0);                                       \
             }                                                                                                      \
+        }                                                                                                          \
         mt = mtn; ac[0] = an[0]; ac[1] = an[1];                                                                    \
     }
 
