@@ -607,6 +607,8 @@ def main():
         return model_, els_sorted[(len(els) - 1) // 2], lanes_, els
 
     model, el, lanes, el_all = repeated_leg(args.dtype, args.steps, args.warmup, args.lanes)
+    # the same leg with ONE batch in flight (the headline keeps `--lanes` batches in flight; the roofline object below is a one-lane measurement)
+    el_one = repeated_leg(args.dtype, args.steps, 1, 1, min_total_s=0.4)[1] if lanes > 1 else el
     # the parity mode at the headline configuration, back to back with the headline leg (all ranks run it: weak scaling)
     leg16 = None
     if 'f16' in models and args.dtype != 'f16':
@@ -692,10 +694,12 @@ def main():
                        'frame_pool': '%d distinct frames per GPU resident in HBM, cycled batch by batch (every step embeds a different batch)' % n_pool,
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
             'tflops_whole_net': round(fps * GFLOP_PER_FRAME / 1e3, 2),
+            'one_lane': {'value': round(world * args.steps * args.batch / el_one, 1), 'unit': 'frames/s', 'ms_per_step': round(el_one / args.steps * 1e3, 3),
+                         'note': 'the same %d-step leg with one batch in flight per GPU (strictly one forward at a time)' % args.steps},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)
