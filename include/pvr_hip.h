@@ -88,6 +88,12 @@ pvr_status pvr_encoder_load_weights(pvr_encoder *enc, const char *name, const fl
  * 16-bit tiles, upload, allocate the workspace.  Fails with PVR_ERR_MISSING_WEIGHT naming the
  * first absent key (the reference asserts len(missing_keys)==0, moco.py:24). */
 pvr_status pvr_encoder_finalize(pvr_encoder *enc);
+/* Host (CPU) backend, to be selected between create and finalize - the reference runs on the CPU when disable_cuda is set or no GPU is
+ * present (src/embeddings.py:367-370; BASELINE configs[0] is a CPU plumbing run).  on != 0: finalize keeps fp32 BN-folded weights on the
+ * host and makes no HIP call; pvr_encoder_forward / _forward_lane then take HOST pointers for frames and output and run plain C++ loops
+ * over the same op list on this process's threads (PVR_HOST_THREADS, default all cores); hip_stream is ignored.  torchvision ResNet family
+ * (arch RESNET50 / _L3 / _L4 / RESNET18 / RESNET34) with dtype PVR_F32 only; taps, profiling and lanes are GPU-plan features. */
+pvr_status pvr_encoder_set_host_backend(pvr_encoder *enc, int32_t on);
 int32_t pvr_encoder_out_size(const pvr_encoder *enc);
 /* frames_dev: uint8 (n,h,w,3) on the device; out_dev: fp32, row i written at
  * out_dev + i*out_stride (elements), out_size values — pass an offset pointer to build the

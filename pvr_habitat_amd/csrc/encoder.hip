@@ -622,10 +622,18 @@ pvr_status pvr_encoder_load_weights(pvr_encoder *enc, const char *name, const fl
     return PVR_OK;
 }
 
+pvr_status pvr_encoder_set_host_backend(pvr_encoder *enc, int32_t on) {
+    PVR_REQUIRE(enc, "null encoder");
+    PVR_REQUIRE(!enc->finalized, "pvr_encoder_set_host_backend: call between create and finalize");
+    enc->host = on != 0;
+    return PVR_OK;
+}
+
 pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     PVR_REQUIRE(enc, "null encoder");
     PVR_REQUIRE(!enc->finalized, "encoder already finalized");
     pvr_status s;
+    if (enc->host) return host_finalize(enc);                   // CPU plan: no HIP call
     if (enc->vit || enc->rnd) {
         if ((s = enc->vit ? vit_finalize(enc) : random5_finalize(enc))) return s;
         PVR_HIP_TRY(hipDeviceSynchronize());
@@ -884,8 +892,15 @@ static pvr_status lane_forward(pvr_encoder *enc, int lane, const uint8_t *frames
 
 extern "C" {
 
+#define PVR_NO_HOST(enc_, what_) PVR_REQUIRE(!((enc_) && (enc_)->host), what_ ": not available on a host-backend encoder")
+
 pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
                                int64_t out_stride, void *hip_stream) {
+    if (enc && enc->host) {
+        PVR_REQUIRE(enc->finalized, "encoder not finalized");
+        PVR_REQUIRE(n <= enc->desc.max_batch, "n=%d exceeds max_batch=%d", n, enc->desc.max_batch);
+        return host_forward(enc, frames, n, h, w, out, out_stride);
+    }
     PVR_REQUIRE(enc, "pvr_encoder_forward: null encoder");
     TraceScope trace("pvr_encoder_forward");
     if (enc->finalized && !enc->vit && !enc->rnd) { pvr_status s = use_lane(enc, 0); if (s) return s; }
@@ -896,6 +911,7 @@ pvr_status pvr_encoder_forward(pvr_encoder *enc, const uint8_t *frames, int32_t 
 
 pvr_status pvr_encoder_forward_lane(pvr_encoder *enc, int32_t lane, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out,
                                     int64_t out_stride, void *hip_stream) {
+    if (enc && enc->host) return pvr_encoder_forward(enc, frames, n, h, w, out, out_stride, hip_stream);
     PVR_REQUIRE(enc, "pvr_encoder_forward_lane: null encoder");
     TraceScope trace(lane == 0 ? "pvr_encoder_forward_lane 0" : "pvr_encoder_forward_lane 1+");
     PVR_REQUIRE(lane >= 0 && lane < PVR_MAX_LANES, "pvr_encoder_forward_lane: lane must be 0..%d", PVR_MAX_LANES - 1);
@@ -913,6 +929,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                int64_t out_stride, void *hip_stream, float *op_ms, double *op_flops, int32_t cap,
                                int32_t *n_ops) {
     PVR_REQUIRE(enc && op_ms && op_flops && n_ops, "pvr_encoder_profile: null argument");
+    PVR_NO_HOST(enc, "pvr_encoder_profile");
     PVR_REQUIRE(n <= enc->desc.chunk, "profile: n=%d must fit one chunk (%d)", n, enc->desc.chunk);
     std::vector<hipEvent_t> ev;
     pvr_status s = (enc->finalized && !enc->vit && !enc->rnd) ? use_lane(enc, 0) : PVR_OK;
@@ -998,6 +1015,7 @@ pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap) {
 
 pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64_t cap, int64_t *count, void *hip_stream) {
     PVR_REQUIRE(enc && name && out && count, "pvr_encoder_tap: null argument");
+    PVR_NO_HOST(enc, "pvr_encoder_tap");
     if (!enc->finalized || enc->last_n == 0) { set_error("no forward has run"); return PVR_ERR_STATE; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (enc->vit) return vit_tap(enc, name, out, cap, count, st);
@@ -1034,6 +1052,7 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
 
 void pvr_encoder_destroy(pvr_encoder *enc) {
     if (!enc) return;
+    if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
     for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }

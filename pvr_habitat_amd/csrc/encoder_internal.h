@@ -78,6 +78,8 @@ struct Launch {
 
 using namespace pvr;
 
+namespace pvr { struct HostPlan; }
+
 struct pvr_encoder {
     pvr_encoder_desc desc;
     std::map<std::string, HostTensor> weights;
@@ -111,6 +113,8 @@ struct pvr_encoder {
     u16 *ap_wqkv = nullptr, *ap_wc = nullptr;
     float *ap_bqkv = nullptr, *ap_bc = nullptr, *ap_pos = nullptr, *ap_out = nullptr;
     struct pvr_vit *vit = nullptr;
+    bool host = false;                                               // pvr_encoder_set_host_backend: CPU plan (host_encoder.hip), host pointers in / out
+    struct pvr::HostPlan *hplan = nullptr;
     struct pvr_random5 *rnd = nullptr;                               // 'random' 5-conv PVR (random_pvr.hip)                                   // CLIP ViT plan (vit.hip) when arch >= PVR_ARCH_CLIP_VIT_B32
 };
 
@@ -134,6 +138,10 @@ pvr_status random5_create(pvr_encoder *e);
 pvr_status random5_finalize(pvr_encoder *e);
 pvr_status random5_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride, hipStream_t st);
 void random5_destroy(pvr_encoder *e);
+// host_encoder.hip (CPU plan behind the same ABI)
+pvr_status host_finalize(pvr_encoder *e);
+pvr_status host_forward(pvr_encoder *e, const uint8_t *frames, int n, int h, int w, float *out, int64_t out_stride);
+void host_destroy(pvr_encoder *e);
 // vit.hip
 pvr_status vit_create(pvr_encoder *e);
 pvr_status vit_finalize(pvr_encoder *e);

@@ -178,9 +178,10 @@ class HipResNet50(_Node):
     variant: 'conv5' | 'conv4' | 'conv3' (ResNet50 family, torchvision names) or 'clip_b32' | 'clip_b16'
     (openai/CLIP visual tower, `visual.*` names)."""
 
-    def __init__(self, state_dict, variant='conv5', compute_dtype=None, max_batch=None, chunk=None):
+    def __init__(self, state_dict, variant='conv5', compute_dtype=None, max_batch=None, chunk=None, host=False):
         super().__init__()
         self.variant = variant
+        self._host = bool(host)                   # CPU plan of the library (pvr_encoder_set_host_backend): host tensors in and out, fp32
         self.out_size = OUT_SIZE[variant]
         self._clip = variant.startswith('clip')
         self._mae = variant.startswith('mae')
@@ -217,14 +218,18 @@ class HipResNet50(_Node):
 
     def _build(self):
         L = _lib.lib()
+        if self._host and (self._clip or self._mae or self.variant == 'random5'):
+            raise NotImplementedError("host backend (disable_cuda / no GPU): only the torchvision ResNet family has a CPU plan, not '%s'" % self.variant)
         tr = transforms_for('clip' if self._clip else 'mae' if self._mae else '')     # (the interpolation mode follows from the arch)
-        desc = _lib.EncoderDesc(arch=_ARCH[self.variant], dtype=self._dtype, max_batch=self._max_batch,
+        desc = _lib.EncoderDesc(arch=_ARCH[self.variant], dtype=_lib.PVR_F32 if self._host else self._dtype, max_batch=self._max_batch,
                                 chunk=self._chunk, resize=tr.resize, crop=tr.crop)
         desc.mean[:] = tr.mean                                             # embeddings.py:313 / :84
         desc.std_[:] = tr.std
         h = C.c_void_p()
         _lib.check(L.pvr_encoder_create(C.byref(desc), C.byref(h)))
         try:
+            if self._host:
+                _lib.check(L.pvr_encoder_set_host_backend(h, 1))
             for k, v in self.state_dict().items():
                 if k.endswith('num_batches_tracked'):
                     continue
@@ -236,6 +241,8 @@ class HipResNet50(_Node):
             L.pvr_encoder_destroy(h)
             raise
         self._handle = h
+        if self._host:
+            return
         if getattr(self, '_low_latency', False):
             self.set_low_latency(True)
 
@@ -253,17 +260,20 @@ class HipResNet50(_Node):
         lane selects one of the activation workspaces: forwards on different lanes may be in flight at once on different
         streams (pvr_encoder_forward_lane); same-lane forwards issued on different streams are chained by the library
         (a per-lane event), so a workspace is never shared by two forwards in flight."""
-        _lib.require_gpu()
+        if not self._host:
+            _lib.require_gpu()
         if self._handle is None:
             self._build()
         n, h, w, c = frames_u8.shape
         assert c == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
         assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[1] == self.out_size
+        if self._host:
+            assert not frames_u8.is_cuda and not out.is_cuda, 'host-backend encoder: frames and output live in host memory'
         L = _lib.lib()
         for i in range(0, n, self._max_batch):
             m = min(self._max_batch, n - i)
             _lib.check(L.pvr_encoder_forward_lane(self._handle, lane, C.c_void_p(frames_u8[i:i + m].data_ptr()), m, h, w,
-                                                  C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), _lib.stream_ptr()))
+                                                  C.c_void_p(out[i:i + m].data_ptr()), out.stride(0), None if self._host else _lib.stream_ptr()))
 
     def op_names(self):
         """conv launches of the current HIP plan, in launch order (fused bottleneck tails read 'a.conv2+conv3+b.conv1')."""
@@ -508,17 +518,20 @@ class EmbeddingNet(nn.Module):
         if self.embedding_name == 'true_state':
             return
         self.in_channels = in_channels
+        # disable_cuda, or no GPU in the box: the reference falls back to the CPU (embeddings.py:367-370); here that is the library's host
+        # backend (csrc/host_encoder.hip: plain C++ loops behind the same pvr_encoder_* ABI, fp32) - the ResNet family only
+        self._host = bool(disable_cuda) or not torch.cuda.is_available()
+        if self._host and os.environ.get('PVR_HOST_BACKEND', '1') == '0':
+            raise NotImplementedError('disable_cuda=True / no GPU: the host backend is disabled (PVR_HOST_BACKEND=0)')
         self.embedding, self.transforms = _get_embedding(embedding_name, in_channels, pretrained, train,
-                                                         compute_dtype=compute_dtype, max_batch=max_batch, chunk=chunk)
+                                                         compute_dtype=compute_dtype, max_batch=max_batch, chunk=chunk, host=self._host)
         assert crops in (1, 5), 'crops: 1 (the reference CenterCrop) or 5 (corner + centre windows, FiveCrop order)'
         if crops == 5:
             self.embedding = FiveCrop(self.embedding)
         # the reference discovers these with a dummy CPU forward (embeddings.py:359-363)
         self.in_shape = torch.Size((in_channels, 224, 224))
         self.out_size = int(self.embedding.out_size)
-        if disable_cuda:
-            raise NotImplementedError('disable_cuda=True: pvr_habitat_amd has no CPU path (HIP kernels only)')
-        self.device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        self.device = torch.device('cpu') if self._host else torch.device('cuda')
         self.training = self.embedding.training
 
     def _forward(self, observation_u8):
@@ -531,8 +544,9 @@ class EmbeddingNet(nn.Module):
                 m.close()
 
     def embed_device(self, observation):
-        """uint8 (N,H,W,3) -> cuda fp32 (N, out_size); no host sync (for streaming callers)."""
-        _lib.require_gpu()
+        """uint8 (N,H,W,3) -> fp32 (N, out_size) on self.device (cuda; host memory for a host-backend encoder); no host sync (for streaming callers)."""
+        if not self._host:
+            _lib.require_gpu()
         observation = observation.to(device=self.device, non_blocking=True).contiguous()
         return self._forward(observation)
 

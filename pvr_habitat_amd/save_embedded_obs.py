@@ -448,7 +448,8 @@ def run(flags):
             print('  ', 'passing observations through embedding model')
             writer = ShardWriter(save_name, rank)
             n_frames = max(frame_shape[2] // 3, 1) if frame_shape else 1
-            hip = hasattr(getattr(embedding_model, 'embedding', None), 'forward_into')
+            # (a host-backend encoder - disable_cuda / no GPU - takes the reference's own batch loop below: nothing to overlap on the CPU)
+            hip = hasattr(getattr(embedding_model, 'embedding', None), 'forward_into') and not getattr(embedding_model, '_host', False)
             block = _block_rows(flags, int(np.prod(frame_shape)) if frame_shape else 1, batch)
             if hip and hi > lo:
                 # HIP encoder: every frame is embedded independently (bit-exact batch-composition invariance is a GPU test), so the
