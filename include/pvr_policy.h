@@ -36,6 +36,12 @@ typedef struct pvr_policy_desc {
 } pvr_policy_desc;
 
 pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out);
+/* The same handle on the HOST (CPU) backend - BASELINE configs[0] runs main_bc_2.py's policy without a GPU, and the reference's model
+ * lives wherever flags.device says (main_bc_2.py:64-66).  No HIP call is made; params / square_avg / BatchNorm buffers / obs / done /
+ * actions / outputs of pvr_policy_forward and pvr_policy_step are HOST pointers, hip_stream is ignored, and the arithmetic is plain fp32
+ * C++ on this process's threads (PVR_HOST_THREADS).  Vector observations only (conv_frames must be 0); the split entry points
+ * (backward / apply / backward_dlogits / data parallel) belong to the HIP plan and are refused. */
+pvr_status pvr_policy_create_host(const pvr_policy_desc *desc, pvr_policy **out);
 void pvr_policy_destroy(pvr_policy *pol);
 
 /* number of fp32 elements of the flat parameter buffer, and of its trainable prefix */

@@ -25,7 +25,9 @@ def _bind():
 
 class DeviceDataset(object):
     def __init__(self, obs, action, done, device='cuda'):
-        _lib.require_gpu()
+        self._host = torch.device(device).type != 'cuda'        # no GPU / --disable_cuda: the reference's own host-side gather (BASELINE configs[0])
+        if not self._host:
+            _lib.require_gpu()
         obs = obs if isinstance(obs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(obs))
         if obs.dtype not in (torch.uint8, torch.float32):
             obs = obs.float()                                   # (true_state is float64 on disk; the policy computes in fp32)
@@ -42,6 +44,9 @@ class DeviceDataset(object):
         sample_with_minimum_distance: row (t, b) = dataset row (starting_i[b] + t) mod n  (main_bc_2.py:194-201)."""
         B, T = len(starting_i), int(unroll_length)
         dev = self.obs.device
+        if self._host:                                          # main_bc_2.py:194-201 as written: mod(arange(i, i + T), n) rows stacked on axis 1
+            idx = (torch.tensor(list(starting_i), dtype=torch.int64)[None, :] + torch.arange(T, dtype=torch.int64)[:, None]) % self.n
+            return self.obs[idx], self.action[idx], self.done[idx].bool()
         starts = torch.tensor(list(starting_i), dtype=torch.int64).to(dev)
         o = torch.empty((T, B) + tuple(self.obs.shape[1:]), dtype=self.obs.dtype, device=dev)
         a = torch.empty((T, B), dtype=torch.int64, device=dev)

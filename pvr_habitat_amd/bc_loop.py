@@ -123,7 +123,8 @@ def train(flags, obs, action, reward, done, save_path, to_env, stats=None, env=N
                             'actor_model_optimizer_state_dict': optimizer.state_dict(),
                             'scheduler_state_dict': sched_sd,
                             'flags': {k: v for k, v in vars(flags).items() if k != 'device'}}, save_path + '.tar')
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     actor_model.check_status()
     actor_model.close()                                         # library handles are freed here, not at garbage-collection time
     test_model.close()

@@ -13,9 +13,8 @@
 //                fp32 vectors; BN folded (eps 1e-5), bias, residual, ReLU in the epilogue
 //   head         global average pool (2048 / 512) or the C-major flatten of the compression heads (moco.py:57-60)
 // ResNet50 / _l3 / _l4 / ResNet18 / ResNet34 (the torchvision family); PVR_F32 plans only.
-#include <atomic>
-#include <thread>
 #include "encoder_internal.h"
+#include "host_math.h"
 
 namespace pvr {
 
@@ -32,59 +31,6 @@ struct HostPlan {
     std::vector<float> buf[B_COUNT], img, stem;          // activations (fp32 NHWC, real channel counts), normalised crop, un-pooled stem
     int threads = 1;
 };
-
-typedef float v8f __attribute__((vector_size(32)));
-
-template <class F>
-static void host_parallel_for(int n, int threads, F f) {
-    if (threads > n) threads = n;
-    if (threads <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-    std::atomic<int> next(0);
-    auto work = [&] { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i); };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-}
-
-// out[p][co] = sum_k A[p][k] * W[co][k] for p < np (<= 4), co < nc (<= 4): a 4 x 4 block of 8-wide partial sums, K in steps of 8, tail scalar
-#define PVR_HOST_DOT_BODY                                                                                          \
-    v8f acc[4][4];                                                                                                 \
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = v8f{0, 0, 0, 0, 0, 0, 0, 0};               \
-    int k = 0;                                                                                                     \
-    if (np == 4 && nc == 4) {                                                                                      \
-        for (; k + 8 <= K; k += 8) {                                                                               \
-            v8f a[4], w[4];                                                                                        \
-            for (int i = 0; i < 4; ++i) memcpy(&a[i], A[i] + k, 32);                                               \
-            for (int j = 0; j < 4; ++j) memcpy(&w[j], W[j] + k, 32);                                               \
-            for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * w[j];                      \
-        }                                                                                                          \
-    } else {                                                                                                       \
-        for (; k + 8 <= K; k += 8)                                                                                 \
-            for (int i = 0; i < np; ++i) {                                                                         \
-                v8f a; memcpy(&a, A[i] + k, 32);                                                                   \
-                for (int j = 0; j < nc; ++j) { v8f w; memcpy(&w, W[j] + k, 32); acc[i][j] += a * w; }              \
-            }                                                                                                      \
-    }                                                                                                              \
-    for (int i = 0; i < np; ++i)                                                                                   \
-        for (int j = 0; j < nc; ++j) {                                                                             \
-            float s = 0.f;                                                                                         \
-            for (int e = 0; e < 8; ++e) s += acc[i][j][e];                                                         \
-            for (int kk = k; kk < K; ++kk) s += A[i][kk] * W[j][kk];                                               \
-            out[i][j] = s;                                                                                         \
-        }
-static void host_dot_block_generic(const float *const *A, const float *const *W, int K, int np, int nc, float out[4][4]) { PVR_HOST_DOT_BODY }
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
-__attribute__((target("avx2,fma"))) static void host_dot_block_avx2(const float *const *A, const float *const *W, int K, int np, int nc, float out[4][4]) { PVR_HOST_DOT_BODY }
-static void host_dot_block(const float *const *A, const float *const *W, int K, int np, int nc, float out[4][4]) {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
-    if (avx2) host_dot_block_avx2(A, W, K, np, nc, out);
-    else host_dot_block_generic(A, W, K, np, nc, out);
-}
-#else
-static void host_dot_block(const float *const *A, const float *const *W, int K, int np, int nc, float out[4][4]) { host_dot_block_generic(A, W, K, np, nc, out); }
-#endif
-#undef PVR_HOST_DOT_BODY
 
 // one convolution over n frames: direct for 1x1 / stride 1 (the input row IS the K vector), im2col rows per pixel tile otherwise
 static void host_conv(const HostConv &c, const float *in, const float *res, float *out, int n, int threads) {

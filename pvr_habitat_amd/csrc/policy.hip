@@ -5,6 +5,7 @@
 // The reference steps nn.LSTM one timestep at a time from Python (models.py:66-73: 100 x cuDNN calls with M = 16);
 // here the input projections of all T steps are hoisted into one GEMM per layer and only the recurrent product
 // stays sequential (one launch per layer-step, weights served from L2 / Infinity Cache: 16.8 MB per layer).
+#include "host_policy.h"
 #include <map>
 #include <string>
 #include <vector>
@@ -25,6 +26,7 @@ constexpr int CONV_WG_WAVES_MAX = 4096;
 constexpr int CONV_BG_BLOCKS_MAX = 2048;      // row blocks of a conv bias-gradient column sum
 
 struct pvr_policy {
+    pvr::HostPolicy *hostp = nullptr;       // pvr_policy_create_host: the CPU plan (host_policy.hip); every device member below stays null
     pvr_policy_desc d;
     std::map<std::string, Slot> slots;
     int64_t n_total = 0, n_train = 0;
@@ -870,8 +872,13 @@ static void drop_graph(pvr_policy *pol) {
 
 extern "C" {
 
-pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
+static pvr_status policy_create_impl(const pvr_policy_desc *desc, pvr_policy **out, bool host);
+pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) { return policy_create_impl(desc, out, false); }
+pvr_status pvr_policy_create_host(const pvr_policy_desc *desc, pvr_policy **out) { return policy_create_impl(desc, out, true); }
+
+static pvr_status policy_create_impl(const pvr_policy_desc *desc, pvr_policy **out, bool host) {
     PVR_REQUIRE(desc && out, "pvr_policy_create: null argument");
+    PVR_REQUIRE(!host || desc->conv_frames == 0, "pvr_policy_create_host: PolicyNetWithConv has no CPU plan (vector observations only)");
     PVR_REQUIRE(desc->hidden > 0 && desc->hidden % 1024 == 0, "hidden must be a positive multiple of 1024 (got %d)", desc->hidden);
     PVR_REQUIRE(desc->obs_size > 0 && desc->obs_size % 4 == 0, "obs_size must be a positive multiple of 4 (got %d)", desc->obs_size);
     PVR_REQUIRE(desc->num_actions > 0 && desc->num_actions <= 16, "num_actions must be in 1..16");
@@ -905,6 +912,16 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
     p->o_bw = add_slot(p, "baseline.weight", H);
     p->o_bb = add_slot(p, "baseline.bias", 1);
 
+    if (host) {                                    // CPU plan: the layout above is all it shares with the HIP plan; no HIP call is made
+        pvr::HostPolicyLayout lay;
+        lay.O = (int)O; lay.H = (int)H; lay.A = (int)A; lay.bn = desc->batch_norm ? 1 : 0; lay.n_total = p->n_total; lay.n_train = p->n_train;
+        lay.o_bnw = p->o_bnw; lay.o_bnb = p->o_bnb; lay.o_fc1w = p->o_fc1w; lay.o_fc1b = p->o_fc1b; lay.o_fc2w = p->o_fc2w; lay.o_fc2b = p->o_fc2b;
+        for (int l = 0; l < 2; ++l) { lay.o_wih[l] = p->o_wih[l]; lay.o_whh[l] = p->o_whh[l]; lay.o_bih[l] = p->o_bih[l]; lay.o_bhh[l] = p->o_bhh[l]; }
+        lay.o_pw = p->o_pw; lay.o_pb = p->o_pb; lay.o_bw = p->o_bw; lay.o_bb = p->o_bb;
+        p->hostp = pvr::host_policy_new(lay);
+        *out = p;
+        return PVR_OK;
+    }
     const size_t N = (size_t)desc->max_t * desc->max_b, B = desc->max_b;
     pvr_status s = PVR_OK;
 #define A_(ptr, n) if (!s) s = dalloc(&p->ptr, (n))
@@ -987,6 +1004,7 @@ pvr_status pvr_policy_create(const pvr_policy_desc *desc, pvr_policy **out) {
 
 void pvr_policy_destroy(pvr_policy *p) {
     if (!p) return;
+    if (p->hostp) { pvr::host_policy_free(p->hostp); delete p; return; }
     void *ptrs[] = {p->a0, p->bn_mean, p->bn_invstd, p->a1, p->a2, p->G[0], p->G[1], p->Hs[0], p->Hs[1], p->Cs[0], p->Cs[1],
                     p->hprev, p->nd, p->zeros, p->dc_carry, p->rec_partial, p->logits, p->baseline, p->dlogits,
                     p->loss_row, p->stats, p->partial, p->action, p->dA, p->dB, p->da0, p->grads, p->feat, p->dfeat,
@@ -1011,6 +1029,7 @@ void pvr_policy_destroy(pvr_policy *p) {
 
 pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int32_t sync_bn, pvr_allreduce_fn fn, void *user) {
     PVR_REQUIRE(pol, "pvr_policy_set_data_parallel: null policy");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_set_data_parallel: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     const bool on = fn && world_size > 1;
     if (on && !pol->comm_stream) {
         PVR_HIP_TRY(hipStreamCreateWithFlags(&pol->comm_stream, hipStreamNonBlocking));
@@ -1026,6 +1045,7 @@ pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int
 // The persistent recurrence's spin ran out in an earlier launch of this handle: report it once, stay on per-step launches afterwards.
 pvr_status pvr_policy_status(pvr_policy *pol) {
     PVR_REQUIRE(pol, "pvr_policy_status: null policy");
+    if (pol->hostp) return PVR_OK;
     const unsigned w = pol->status_host ? __atomic_load_n(pol->status_host, __ATOMIC_ACQUIRE) : 0u;
     if (!w) return PVR_OK;
     __atomic_store_n(pol->status_host, 0u, __ATOMIC_RELEASE);
@@ -1044,6 +1064,7 @@ pvr_status pvr_policy_debug_drop_block(pvr_policy *pol, int32_t block) {
 
 int32_t pvr_policy_recurrence_mode(const pvr_policy *pol) {
     if (!pol) return -1;
+    if (pol->hostp) return 0;
     return (!pol->persist_fits || pol->persist_tripped) ? 0 : (pol->persist == 2 && pol->use_graph) ? 0 : pol->persist;
 }
 
@@ -1062,6 +1083,8 @@ pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_po
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B, int32_t training,
                               float *logits, float *baseline, int64_t *action, float *h_out, float *c_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done, "pvr_policy_forward: null argument");
+    if (pol->hostp)                                              // CPU plan: every pointer is a host pointer, hip_stream is ignored
+        return pvr::host_policy_forward(pol->hostp, params, bn, (const float *)obs, done, h0, c0, T, B, training, logits, baseline, action, h_out, c_out);
     TraceScope trace("pvr_policy_forward");
     ScratchScope scratch_scope(pol);
     TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
@@ -1085,6 +1108,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
                                const int64_t *actions, int32_t T, int32_t B, float *grads, float *stats_out, float *logits_out,
                                void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && done && actions && grads, "pvr_policy_backward: null argument");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_backward: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     TraceScope trace("pvr_policy_backward");
     ScratchScope scratch_scope(pol);
     TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
@@ -1100,6 +1124,7 @@ pvr_status pvr_policy_backward(pvr_policy *pol, const float *params, const pvr_p
 pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, const float *grads, float lr, float alpha, float eps,
                             float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && grads, "pvr_policy_apply: null argument");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_apply: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     ScratchScope scratch_scope(pol);
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
@@ -1111,6 +1136,7 @@ pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, c
 pvr_status pvr_policy_backward_dlogits(pvr_policy *pol, const float *params, const void *obs, const float *dlogits, int32_t T, int32_t B,
                                        float *grads, void *hip_stream) {
     PVR_REQUIRE(pol && params && obs && dlogits && grads, "pvr_policy_backward_dlogits: null argument");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_backward_dlogits: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     ScratchScope scratch_scope(pol);
     TRY(pvr_policy_status(pol));
     if (pol->fwd_T != T || pol->fwd_B != B) {
@@ -1129,6 +1155,7 @@ pvr_status pvr_policy_backward_dlogits(pvr_policy *pol, const float *params, con
 pvr_status pvr_policy_apply_momentum(pvr_policy *pol, float *params, float *square_avg, float *momentum_buf, const float *grads, float lr,
                                      float alpha, float eps, float momentum, float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && momentum_buf && grads, "pvr_policy_apply_momentum: null argument");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_apply_momentum: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     const size_t nt = (size_t)pol->n_train;
@@ -1144,6 +1171,7 @@ pvr_status pvr_policy_apply_momentum(pvr_policy *pol, float *params, float *squa
 pvr_status pvr_policy_apply_adam(pvr_policy *pol, float *params, float *exp_avg, float *exp_avg_sq, const float *grads, float lr, float beta1,
                                  float beta2, float eps, int64_t step, float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && exp_avg && exp_avg_sq && grads && step >= 1, "pvr_policy_apply_adam: null argument or step < 1");
+    PVR_REQUIRE(!pol->hostp, "pvr_policy_apply_adam: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     const size_t nt = (size_t)pol->n_train;
@@ -1161,6 +1189,8 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
                            const uint8_t *done, const int64_t *actions, int32_t T, int32_t B, float lr, float alpha, float eps,
                            float max_grad_norm, float *stats_out, float *logits_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && obs && done && actions, "pvr_policy_step: null argument");
+    if (pol->hostp)
+        return pvr::host_policy_step(pol->hostp, params, square_avg, bn, (const float *)obs, done, actions, T, B, lr, alpha, eps, max_grad_norm, stats_out, logits_out);
     TraceScope trace("pvr_policy_step");
     ScratchScope scratch_scope(pol);
     TRY(pvr_policy_status(pol));                                 // (sticky: a time-out of an earlier launch surfaces here)
@@ -1213,6 +1243,7 @@ pvr_status pvr_policy_step(pvr_policy *pol, float *params, float *square_avg, co
 
 pvr_status pvr_policy_last_grads(pvr_policy *pol, float *grads_out, void *hip_stream) {
     PVR_REQUIRE(pol && grads_out, "pvr_policy_last_grads: null argument");
+    if (pol->hostp) return pvr::host_policy_last_grads(pol->hostp, grads_out);
     if (!pol->have_grads) { set_error("no training step has run"); return PVR_ERR_STATE; }
     PVR_HIP_TRY(hipMemcpyAsync(grads_out, pol->grads, (size_t)pol->n_train * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
     return PVR_OK;

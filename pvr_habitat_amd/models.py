@@ -15,6 +15,7 @@ the reference's keys and shapes (`fc.0.*` BatchNorm, `fc.1/fc.3` linears, `core.
     (main_bc_2.py:209-227) run as written and update the flat buffer through the parameter views.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -45,6 +46,8 @@ def _plib():
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.pvr_policy_create.restype = C.c_int
         L.pvr_policy_create.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp)]
+        L.pvr_policy_create_host.restype = C.c_int
+        L.pvr_policy_create_host.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp)]
         L.pvr_policy_destroy.restype = None
         L.pvr_policy_destroy.argtypes = [vp]
         L.pvr_policy_param_count.restype = i64
@@ -267,11 +270,23 @@ class PolicyNet(nn.Module):
         """0 per-step launches, 1 / 2 persistent forward recurrence (counter / data-as-flag hand-off) - what the next forward uses"""
         return int(_plib().pvr_policy_recurrence_mode(self._handle)) if self._handle is not None else -1
 
+    @property
+    def _host(self):
+        """parameters in host memory -> the library's HOST backend (pvr_policy_create_host: plain C++ loops, forward + fused step);
+        the reference's model lives wherever flags.device says (main_bc_2.py:64-66), the CPU when there is no GPU"""
+        return not self._flat.is_cuda
+
+    def _stream(self):
+        return None if self._host else _lib.stream_ptr()
+
     def _ensure(self, T, B):
-        _lib.require_gpu()
-        if not self._flat.is_cuda:
-            raise RuntimeError('PolicyNet parameters are on %s: call .to(device="cuda") first (no CPU path)' % self._flat.device)
-        if self._handle is not None and T <= self._max_t and B <= self._max_b:
+        if self._host:
+            if self._conv_frames or os.environ.get('PVR_HOST_BACKEND', '1') == '0':
+                raise RuntimeError('PolicyNet parameters are on %s: call .to(device="cuda") first (the host backend carries the vector policy only)'
+                                   % self._flat.device)
+        else:
+            _lib.require_gpu()
+        if self._handle is not None and T <= self._max_t and B <= self._max_b and getattr(self, '_handle_host', None) == self._host:
             return
         self._release()
         self._max_t, self._max_b = max(self._max_t, T), max(self._max_b, B)
@@ -279,8 +294,8 @@ class PolicyNet(nn.Module):
         d = PolicyDesc(self.obs_size, self.hidden, self.num_actions, int(self.batch_norm), self._max_t, self._max_b,
                        self._conv_frames)
         h = C.c_void_p()
-        _lib.check(L.pvr_policy_create(C.byref(d), C.byref(h)))
-        self._handle = h
+        _lib.check((L.pvr_policy_create_host if self._host else L.pvr_policy_create)(C.byref(d), C.byref(h)))
+        self._handle, self._handle_host = h, self._host
         assert L.pvr_policy_param_count(h) == self._flat.numel(), 'flat layout mismatch with libpvr_hip'
         assert L.pvr_policy_trainable_count(h) == self._n_train
         for k in self._order:
@@ -313,7 +328,7 @@ class PolicyNet(nn.Module):
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(_plib().pvr_policy_forward(self._handle, vp(self._flat), C.byref(bn) if bn else None, vp(x), vp(done),
                                               vp(h0), vp(c0), T, B, int(training), vp(logits), vp(baseline), vp(action),
-                                              vp(h), vp(c), _lib.stream_ptr()))
+                                              vp(h), vp(c), self._stream()))
         return logits, baseline, action, h, c
 
     def forward(self, inputs, core_state=()):
@@ -335,6 +350,9 @@ class PolicyNet(nn.Module):
                 h0 = core_state[0].to(device=dev, dtype=torch.float32).contiguous()
                 c0 = core_state[1].to(device=dev, dtype=torch.float32).contiguous()
         A = self.num_actions
+        if want_grad and self._host:
+            raise NotImplementedError('host backend: the autograd bridge (loss.backward() through the library) is a HIP-plan feature; use the '
+                                      'fused iteration (HipRMSprop.step, what main_bc_2 runs by default) or torch.no_grad() for inference')
         if want_grad:
             params = [self._param(k)[0]._parameters[self._param(k)[1]] for k in self._order]
             logits, baseline, action, h, c = _PolicyFunction.apply(self, x, done, h0, c0, T, B, *params)
@@ -395,7 +413,7 @@ class PolicyNet(nn.Module):
     def last_grads(self):
         """Flat pre-clip gradient of the last fused step as {state_dict key: tensor} (parity tests)."""
         g = torch.empty(self._n_train, dtype=torch.float32, device=self.device)
-        _lib.check(_plib().pvr_policy_last_grads(self._handle, C.c_void_p(g.data_ptr()), _lib.stream_ptr()))
+        _lib.check(_plib().pvr_policy_last_grads(self._handle, C.c_void_p(g.data_ptr()), self._stream()))
         out = {}
         for k in self._order:
             o, shp = self._slots[k]
@@ -600,7 +618,7 @@ class HipRMSprop(_HipOptimizer):
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         m._checked(_plib().pvr_policy_step(m._handle, vp(m._flat), vp(self.square_avg), C.byref(bn) if bn else None, vp(x), vp(d),
                                            vp(a), T, B, self.current_lr(), self.alpha, self.eps, self.max_grad_norm, vp(stats),
-                                           vp(logits), _lib.stream_ptr()))
+                                           vp(logits), m._stream()))
         self.steps += 1
         return (stats[0], stats[1], logits) if return_logits else (stats[0], stats[1])
 
