@@ -31,6 +31,9 @@ def train(flags, obs, action, reward, done, save_path, to_env, stats=None, env=N
         'actions in the data (%d..%d) do not fit num_actions=%d' % (int(np.min(action)), int(np.max(action)), n_actions)
     actor_model = policy_cls(obs_shape, n_actions, flags.batch_norm, max_unroll=flags.unroll_length,
                              max_batch=flags.batch_size).to(device=flags.device)
+    host = bool(getattr(flags, 'disable_cuda', False))            # --disable_cuda: the library's host backend (BASELINE configs[0]); else a CPU device fails loudly
+    if hasattr(actor_model, 'use_host_backend'):
+        actor_model.use_host_backend(host)
     max_epochs = flags.max_frames // (flags.unroll_length * flags.batch_size) + 1
     autograd_step = bool(getattr(flags, 'autograd_step', False))
     if autograd_step:
@@ -55,6 +58,8 @@ def train(flags, obs, action, reward, done, save_path, to_env, stats=None, env=N
         else:
             optimizer.last_epoch = checkpoint['scheduler_state_dict']['last_epoch']
     test_model = policy_cls(obs_shape, n_actions, flags.batch_norm, max_unroll=1, max_batch=1).to(device=flags.device)
+    if hasattr(test_model, 'use_host_backend'):
+        test_model.use_host_backend(host)
     test_model.eval()
     stat_keys = ['episode_return', 'episode_success']
 

@@ -8,7 +8,8 @@ Mirrors reference src/embeddings.py:
   * `EmbeddingWrapper.observation`                           (:441-444)
 and the checkpoint loaders of src/vision_models/moco.py:6-113 / resnet.py:6-104 (key remapping and
 their asserts).  All arithmetic (transforms + network) runs in libpvr_hip.so on the MI355X; this
-module only owns names, state_dicts and tensors.  There is no CPU path: `disable_cuda=True` or a
+module only owns names, state_dicts and tensors.  `disable_cuda=True` selects the library's host backend (ResNet family, fp32 C++ loops);
+without that flag there is no CPU path: a
 box without a GPU raises instead of silently computing something else.
 """
 import ctypes as C
@@ -518,11 +519,10 @@ class EmbeddingNet(nn.Module):
         if self.embedding_name == 'true_state':
             return
         self.in_channels = in_channels
-        # disable_cuda, or no GPU in the box: the reference falls back to the CPU (embeddings.py:367-370); here that is the library's host
-        # backend (csrc/host_encoder.hip: plain C++ loops behind the same pvr_encoder_* ABI, fp32) - the ResNet family only
-        self._host = bool(disable_cuda) or not torch.cuda.is_available()
-        if self._host and os.environ.get('PVR_HOST_BACKEND', '1') == '0':
-            raise NotImplementedError('disable_cuda=True / no GPU: the host backend is disabled (PVR_HOST_BACKEND=0)')
+        # disable_cuda: the reference then runs on the CPU (embeddings.py:367-370); here that is the library's host backend
+        # (csrc/host_encoder.hip: plain C++ loops behind the same pvr_encoder_* ABI, fp32) - the ResNet family only.
+        # It is selected EXPLICITLY (the reference's own flag); a box whose GPU is missing or invisible still fails loudly (no silent fallback).
+        self._host = bool(disable_cuda)
         self.embedding, self.transforms = _get_embedding(embedding_name, in_channels, pretrained, train,
                                                          compute_dtype=compute_dtype, max_batch=max_batch, chunk=chunk, host=self._host)
         assert crops in (1, 5), 'crops: 1 (the reference CenterCrop) or 5 (corner + centre windows, FiveCrop order)'

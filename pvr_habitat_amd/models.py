@@ -276,14 +276,20 @@ class PolicyNet(nn.Module):
         the reference's model lives wherever flags.device says (main_bc_2.py:64-66), the CPU when there is no GPU"""
         return not self._flat.is_cuda
 
+    def use_host_backend(self, on=True):
+        """allow this policy to run on the library's host (CPU) backend while its parameters are in host memory (reference: --disable_cuda)"""
+        self._host_ok = bool(on)
+        return self
+
     def _stream(self):
         return None if self._host else _lib.stream_ptr()
 
     def _ensure(self, T, B):
         if self._host:
-            if self._conv_frames or os.environ.get('PVR_HOST_BACKEND', '1') == '0':
-                raise RuntimeError('PolicyNet parameters are on %s: call .to(device="cuda") first (the host backend carries the vector policy only)'
-                                   % self._flat.device)
+            # explicit opt-in only (use_host_backend(): bc_loop does it for --disable_cuda): parameters forgotten on the CPU fail loudly
+            if self._conv_frames or not getattr(self, '_host_ok', False):
+                raise RuntimeError('PolicyNet parameters are on %s: call .to(device="cuda") first (or use_host_backend(True) for the CPU plan of '
+                                   'the vector policy: forward + fused step, what --disable_cuda selects)' % self._flat.device)
         else:
             _lib.require_gpu()
         if self._handle is not None and T <= self._max_t and B <= self._max_b and getattr(self, '_handle_host', None) == self._host:

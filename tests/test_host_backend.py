@@ -94,6 +94,9 @@ def test_host_policy_matches_the_reference_fixtures(name, seed, bn):
     m = PolicyNet((O,), A, bn, max_unroll=T, max_batch=B)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     assert m._host and m.device == torch.device('cpu')
+    with pytest.raises(RuntimeError, match='use_host_backend'):              # parameters left on the CPU are an error unless the host plan is asked for
+        m(dict(obs=torch.zeros(T, B, O), done=torch.zeros(T, B, dtype=torch.bool)), m.initial_state(B))
+    m.use_host_backend(True)
     m.train()
     opt = HipRMSprop(m, lr=1e-4, alpha=0.99, eps=1e-5, max_grad_norm=40.0, max_epochs=int(g['max_epochs']))
     obs, done, act = synth.bc_batches(seed, T, B, O, A, S)
