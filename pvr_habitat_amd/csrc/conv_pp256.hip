@@ -69,7 +69,7 @@ __device__ unsigned long long pp_stamps[2][8];
 // per-lane staging offsets of one output tile (pixel rows m0 .., couts co0 ..): see "staging" in the kernel
 template <int BM, int XI>
 __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int wave, int lane, int (&a_off)[2][XI], int (&a_mask)[2][XI],
-                                              int (&b_off)[2][2]) {
+                                              int (&b_off)[2][2], bool natural) {
     constexpr int XH = BM / 2, OOB = 0x7ffffff0;       // (BM = 224: 112 pixel rows per half tile in a 128-row LDS half; rows 112..127 stay zero)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -96,7 +96,10 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
                 a_mask[h][i < XI ? i : 0] = mask;
             }
             const int R = h * 128 + r;                                  // A-operand row inside the 256-cout tile
-            const int co = co0 + (R & ~31) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
+            // 16-bit outputs: rows permuted so that a lane's tile PAIR is 8 consecutive couts (one 16-byte store).  fp32 outputs with an fp32
+            // (or no) residual - the transformer GEMMs: natural order, a lane's tile is 4 consecutive couts = 16 bytes of fp32 and the four
+            // lanes of a pixel cover 64 contiguous bytes (the permuted order left 16-byte pieces 32 bytes apart: chain_wave.hip, memory layouts)
+            const int co = natural ? co0 + R : co0 + (R & ~31) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3);
             b_off[h][i] = co < p.CoutPad ? (co * p.K + lch * 8) * 2 : OOB;
         }
 }
@@ -136,11 +139,12 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 
     // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
     int a_off[2][XI], a_mask[2][XI], b_off[2][2];
+    const bool natural = p.out_f32 && RES != 1;   // weight rows (= the accumulators' couts) in natural order: see pp_tile_setup
 #define PP_TILE_SETUP(v_)                                                                                        \
     {                                                                                                            \
         const int swz_ = xcd_remap((v_), PERSIST ? p.total_tiles : (int)gridDim.x);                               \
         m0 = (swz_ / p.n_tiles) * BM; co0 = (swz_ % p.n_tiles) * 256;                                             \
-        pp_tile_setup<BM, XI>(p, m0, co0, wave, lane, a_off, a_mask, b_off);                                      \
+        pp_tile_setup<BM, XI>(p, m0, co0, wave, lane, a_off, a_mask, b_off, natural);                             \
     }
     PP_TILE_SETUP(vb);
     const int cpt = p.Cin >> 6;                   // K tiles per filter tap
@@ -333,13 +337,14 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, RES ? p.res_bytes : 0, 0x00020000);
     float bs[2][8];
-    bool cok[2];
+    bool cok[2], cok2[2];                          // validity of the lane's first / second group of 4 couts (they differ only in natural order)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int c = eco0 + wc * 64 + q * 32 + fq * 8;
-        cok[q] = c < p.Cout;
+        // the lane's 8 values of tile pair q: couts c .. c + 7 (permuted rows), or c .. c + 3 and c + 16 .. c + 19 (natural rows)
+        const int c = eco0 + wc * 64 + q * 32 + fq * (natural ? 4 : 8), c2 = c + (natural ? 16 : 4);
+        cok[q] = c < p.Cout; cok2[q] = c2 < p.Cout;
         const float4 lo = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 hi = cok[q] ? *reinterpret_cast<const float4 *>(p.bias + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 hi = cok2[q] ? *reinterpret_cast<const float4 *>(p.bias + c2) : make_float4(0.f, 0.f, 0.f, 0.f);
         bs[q][0] = lo.x; bs[q][1] = lo.y; bs[q][2] = lo.z; bs[q][3] = lo.w;
         bs[q][4] = hi.x; bs[q][5] = hi.y; bs[q][6] = hi.z; bs[q][7] = hi.w;
     }
@@ -352,15 +357,18 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         if constexpr (RES != 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int c = eco0 + wc * 64 + q * 32 + fq * 8;
+                const int c = eco0 + wc * 64 + q * 32 + fq * (natural ? 4 : 8);
                 const int ro = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_r : OOB;
                 rr[q][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0));
-                if constexpr (RES == 2) rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 16, 0));
+                if constexpr (RES == 2) {
+                    const int ro2 = (m < p.M && cok2[q]) ? (m * p.Cout + c) * esz_r + (natural ? 64 : 16) : OOB;
+                    rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro2, 0, 0));
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int c = eco0 + wc * 64 + q * 32 + fq * 8;
+            const int c = eco0 + wc * 64 + q * 32 + fq * (natural ? 4 : 8);
             const f32x4 lo = acc[2 * q][j], hi = acc[2 * q + 1][j];
             float v[8] = {lo[0] + bs[q][0], lo[1] + bs[q][1], lo[2] + bs[q][2], lo[3] + bs[q][3],
                           hi[0] + bs[q][4], hi[1] + bs[q][5], hi[2] + bs[q][6], hi[3] + bs[q][7]};
@@ -390,7 +398,8 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             const int oo = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_o : OOB;
             if (p.out_f32) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_out, oo, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo + 16, 0, 0);
+                const int oo2 = (m < p.M && cok2[q]) ? (m * p.Cout + c) * esz_o + (natural ? 64 : 16) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo2, 0, 0);
             } else {
                 u32x4 o;
 #pragma unroll
