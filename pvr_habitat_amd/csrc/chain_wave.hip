@@ -499,7 +499,11 @@ static int cw_num_cus() {
 template <int CMN, bool F16, bool DS, bool W3G, bool INB, bool OUTB, bool HALO, int XD, int RD, int WD>
 static pvr_status launch_cw_one(ChainP &p, hipStream_t stream) {
     const size_t lds = (size_t)(W3G ? 73728 : 73728 + 32768) + (size_t)CMN * 512 + 256 + 1024 + 512 + 8 * 2048;
-    PVR_HIP_TRY(hipFuncSetAttribute((const void *)chain_wave_kernel<CMN, F16, DS, W3G, INB, OUTB, HALO, XD, RD, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static DeviceOnce attr_done;                           // per device; NOT per launch: the call costs host time that shows up as a gap in front of the kernel
+    if (attr_done.needed()) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)chain_wave_kernel<CMN, F16, DS, W3G, INB, OUTB, HALO, XD, RD, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done.mark();
+    }
     const int nch = (p.M + 255) / 256;
     int grid = cw_num_cus() & ~7;                          // one persistent block per CU; a multiple of 8 (blocks b and b + 8 share an XCD)
     if (grid < 8) grid = 8;
