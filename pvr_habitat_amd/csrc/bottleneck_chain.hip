@@ -51,8 +51,9 @@ __device__ unsigned long long chain_stamps[8192][12];
 #define CH_KNOCK 0      // timing experiments (scripts/chain_stamps.hip -DCH_KNOCK=bits): 1 no y / t1' stores, 2 residual loads out of range (zeros, no traffic);
                         // phase A of the halo form: 4 no W2 ring stores, 8 no W2 loads, 16 no per-step barrier, 32 no fragment reads
 #endif
+template <int AUX = 0>
 __device__ __forceinline__ void store_b128_imm(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm) {
-    if constexpr (!(CH_KNOCK & 1)) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
+    if constexpr (!(CH_KNOCK & 1)) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, AUX);
 }
 
 // RD: residual prefetch depth in 64-cout groups (RD x 16 VGPRs); OCC: blocks per CU the register budget is capped for
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         if constexpr (!DS) {                                                                                            \
             _Pragma("unroll") for (int d = 0; d < RD; ++d)                                                              \
                 _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                          \
-                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), d * r_gs, 0)); \
+                    rres[d][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), d * r_gs, DS ? 0 : PVR_NT_AUX(16))); \
         }                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < W3_CH; ++i)                                                               \
             w3r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, W3_G(i), 0, 0));            \
@@ -478,13 +479,13 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                     o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
                 }
             }
-            store_b128_imm(o, rs_y, Y_OFF(j) + g * y_gs, 0);
+            store_b128_imm<PVR_NT_AUX(4)>(o, rs_y, Y_OFF(j) + g * y_gs, 0);
             if constexpr (CMN > 0) *reinterpret_cast<u32x4 *>(smem + yg_wr[j]) = o;
         }
         if (!DS && g + RD < G) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), (g + RD) * r_gs, 0));
+                rres[g % RD][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CH_KNOCK & 2) ? OOB : R_OFF(j), (g + RD) * r_gs, DS ? 0 : PVR_NT_AUX(16)));
         }
         if (g == 1) CH_T(8);
         __syncthreads();                          // y group visible; every wave is done with this W3 group
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
-                store_b128_imm(o, rs_t, T_OFF(j), q * 64);
+                store_b128_imm<PVR_NT_AUX(8)>(o, rs_t, T_OFF(j), q * 64);
             }
         }
     }

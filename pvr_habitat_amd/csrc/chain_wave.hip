@@ -44,10 +44,16 @@ __device__ __forceinline__ int cw_row_source(int row) { return (row & ~31) + 8 *
 #define CW_KNOCK 0      // timing experiments (scripts/chain_wave_bench.hip -DCW_KNOCK=bits): 1 no y / t1' stores, 2 residual loads out of range (zeros, no
                         // traffic), 4 conv2 pixel loads out of range
 #endif
+#ifndef CW_AUX_ST
+#define CW_AUX_ST PVR_NT_AUX(1)     // cache policy of the y / t1' stores and of the residual loads (raw-buffer aux bits: 2 = nt, streaming)
+#endif
+#ifndef CW_AUX_RES
+#define CW_AUX_RES PVR_NT_AUX(2)
+#endif
 // 16-byte buffer store, byte offset in voffset + immediate (never soffset: bottleneck_chain.hip, store_b128_imm)
 __device__ __forceinline__ void cw_store(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm, int never = 0) {
-    if constexpr (CW_KNOCK & 1) { if (never) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0); }
-    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, 0);
+    if constexpr (CW_KNOCK & 1) { if (never) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, CW_AUX_ST); }
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, CW_AUX_ST);
 }
 
 typedef float cw_f32x2 __attribute__((ext_vector_type(2)));
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
 #define CW_ISSUE_RES(slot_, h_, A_)                                                                                     \
     {                                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
-            rres[slot_][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CW_KNOCK & 2) ? OOB : A_.yi[j], (h_) * YH, 0)); \
+            rres[slot_][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (CW_KNOCK & 2) ? OOB : A_.yi[j], (h_) * YH, CW_AUX_RES)); \
     }
     // W3 (W3G) / Wd (DS) from L2, row-permuted [256][64] in the blocked layout [row >> 4][chunk][row & 15][8]: the fragment of rows
     // 32 h + 16 t + fr, channels 32 ks + 8 fq .. is 1 KB of contiguous memory

@@ -55,6 +55,16 @@ const std::string &last_error();
 // "done once per device" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, and a process that
 // later uses a second GPU must raise the limit there too (a process-wide bool would leave that device's launches failing).  Bit d of the
 // mask = device d; concurrent first calls at worst set the attribute twice.
+// Cache policy of the pure streams (outputs written once, residuals read once): raw-buffer aux 2 = nt (streaming: the line is the
+// first to leave L2), so that the rows a kernel re-reads (3x3 halos, the resident weights) stay.  PVR_NT is a build-time mask for
+// A/B runs (profiles/experiments/r04_nt_streams.txt): 1 chain_wave stores, 2 chain_wave residual loads, 4 / 8 bottleneck_chain y /
+// t1' stores, 16 its residual loads, 32 / 64 conv_expand stores / residual loads, 128 stem stores, 256 / 512 conv_pp256 stores /
+// residual loads.
+#ifndef PVR_NT
+#define PVR_NT 119  // 1+2 wave stores / residual, 4+16 block-form y stores / residual, 32+64 conv_expand with a residual (layer3 / layer4 conv3)
+#endif
+#define PVR_NT_AUX(bit_) ((PVR_NT & (bit_)) ? 2 : 0)
+
 struct DeviceOnce {
     std::atomic<unsigned long long> mask{0};
     static int device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & 63) : 0; }

@@ -146,14 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                 _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                 \
                     const int m = (mt_) * BM + wm * 32 + j * 16 + (lane >> 3) + 8 * hf;                            \
                     const int vo = m < p.M ? (m * p.Cout + co0 + wn * 64) * 2 + fl_c : OOB;                        \
-                    r_[j * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, 0)); \
+                    r_[j * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, (RES ? PVR_NT_AUX(64) : 0))); \
                 }                                                                                                  \
         } else {                                                                                                   \
         _Pragma("unroll") for (int bp = 0; bp < NP; ++bp)                                                          \
             _Pragma("unroll") for (int j = 0; j < TM; ++j) {                                                       \
                 const int m = (mt_) * BM + wm * 32 + j * 16 + fr;                                                  \
                 const int vo = (m < p.M && cbase[bp] >= 0) ? (m * p.Cout + cbase[bp]) * 2 : OOB;                   \
-                r_[bp * TM + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, 0)); \
+                r_[bp * TM + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo, 0, (RES ? PVR_NT_AUX(64) : 0))); \
             }                                                                                                      \
         }                                                                                                          \
     }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                     const int m = mt * BM + wm * 32 + j * 16 + (lane >> 3) + 8 * hf;                               \
                     int vo = (m * p.Cout + co0 + wn * 64) * 2 + fl_c;                                              \
                     vo = m < p.M ? vo : OOB;                                                                       \
-                    __builtin_amdgcn_raw_buffer_store_b128(ln, rs_out, vo, 0, 0);                                  \
+                    __builtin_amdgcn_raw_buffer_store_b128(ln, rs_out, vo, 0, (RES ? PVR_NT_AUX(32) : 0));                                  \
                 }                                                                                                  \
             }                                                                                                      \
             __syncthreads();                                                                                       \
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                 int vo = (m * p.Cout + cbase[bp]) * 2;                                                             \
                 if (p.out_blk) vo = ((m >> 4) * (p.Cout >> 3) + (cbase[bp] >> 3)) * 256 + (m & 15) * 16;           \
                 vo = (m < p.M && cbase[bp] >= 0) ? vo : OOB;                                                       \
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, 0);                                       \
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, (RES ? PVR_NT_AUX(32) : 0));                                       \
             }                                                                                                      \
         }                                                                                                          \
         mt = mtn; ac[0] = an[0]; ac[1] = an[1];                                                                    \

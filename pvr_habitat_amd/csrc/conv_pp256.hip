@@ -359,10 +359,10 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             for (int q = 0; q < 2; ++q) {
                 const int c = eco0 + wc * 64 + q * 32 + fq * (natural ? 4 : 8);
                 const int ro = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_r : OOB;
-                rr[q][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0));
+                rr[q][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, PVR_NT_AUX(512)));
                 if constexpr (RES == 2) {
                     const int ro2 = (m < p.M && cok2[q]) ? (m * p.Cout + c) * esz_r + (natural ? 64 : 16) : OOB;
-                    rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro2, 0, 0));
+                    rr[q][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro2, 0, PVR_NT_AUX(512)));
                 }
             }
         }
@@ -397,14 +397,14 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             // byte offsets go into voffset (soffset stays 0): see store_b128_imm in bottleneck_chain.hip
             const int oo = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_o : OOB;
             if (p.out_f32) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_out, oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_out, oo, 0, PVR_NT_AUX(256));
                 const int oo2 = (m < p.M && cok2[q]) ? (m * p.Cout + c) * esz_o + (natural ? 64 : 16) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo2, 0, PVR_NT_AUX(256));
             } else {
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, oo, 0, PVR_NT_AUX(256));
             }
         }
     }

@@ -382,7 +382,9 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
                     }
                 }
             }
-            *reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pc) * STEM_CO + k * 8) = u32x4{mx[0], mx[1], mx[2], mx[3]};
+            u32x4 *const dst = reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pc) * STEM_CO + k * 8);
+            if constexpr (PVR_NT & 128) __builtin_nontemporal_store(u32x4{mx[0], mx[1], mx[2], mx[3]}, dst);
+            else *dst = u32x4{mx[0], mx[1], mx[2], mx[3]};
         }
         // (the conv tile is rewritten only after the barriers at the top of the next image)
     }

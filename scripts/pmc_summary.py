@@ -25,11 +25,11 @@ for k in sorted(f, key=lambda k: -f[k][2]):
                      avg_us=round(dur * 1e6, 1), hbm_TBps=round((fetch + write) / dur / 1e12, 2)))
 for r in rows[:14]:
     print(json.dumps(r))
-conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain', 'conv_expand'))]
+conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain', 'chain_wave', 'conv_expand'))]
 tot_b = sum((r['fetch_MB'] + r['write_MB']) * r['launches'] for r in conv); tot_n = sum(r['launches'] for r in conv)
 print('conv family: avg HBM traffic per launch = %.1f MB over %d launches' % (tot_b / tot_n, tot_n))
 if len(sys.argv) > 3:
-    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + conv_expand_kernel (all instantiations)', 'launches': tot_n,
+    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel (all instantiations)', 'launches': tot_n,
            'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
            'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]}
     if len(sys.argv) > 4:                                  # the launch plan these counters belong to (bench.py refuses them for any other plan)
