@@ -672,6 +672,19 @@ def main():
         for i in range(n_ops.value):
             tfl = op_fl[i] / (op_ms[i] * 1e-3) / 1e12 if op_ms[i] > 0 else 0.0
             print('%-28s %8.3f ms %8.1f TFLOP/s' % (names[i] if i < len(names) else '?', op_ms[i], tfl), file=sys.stderr)
+    # The conv family's time in an UNPERTURBED one-lane forward: two events only (start of the first conv launch, end of the last).  The
+    # per-launch pass above puts an event between every two launches; each costs a few microseconds of dispatch serialisation, so its
+    # sum overstates the family by ~4 % against rocprofv3's kernel durations (profiles/r04_kernel_stats_lanes1.csv).  The span still
+    # contains the real launch-to-launch gaps, so it is an upper bound of the sum of kernel durations.
+    span_ms, sp = 0.0, C.c_float()
+    first_conv, last_conv = 3, n_ops.value - 2
+    for r_ in range(reps + 1):
+        _lib.check(_lib.lib().pvr_encoder_profile_span(model._handle, C.c_void_p(batches[r_ % len(batches)].data_ptr()), chunk, args.frame, args.frame,
+                                                       C.c_void_p(out.data_ptr()), out.stride(0), _lib.stream_ptr(), first_conv, last_conv, C.byref(sp)))
+        if r_ > 0:
+            span_ms += sp.value
+    events_ms = conv_ms                                     # per-launch event sums (reps forwards), kept for the stage / per-op tables
+    conv_ms = span_ms
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     peak = PEAK_F32_TFLOPS if args.dtype == 'f32' else PEAK_BF16_TFLOPS
     barrier()
@@ -699,7 +712,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events on the launch stream, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)
@@ -708,6 +721,10 @@ def main():
                              'frac': round(traffic * n_conv / (el / args.steps) / 8e12, 4),
                              'note': 'conv-launch HBM bytes per batch (committed PMC passes) / step time of THIS run'},
                          'conv_ms_per_chunk': round(conv_ms / reps, 3), 'other_ms_per_chunk': round(other_ms / reps, 3),
+                         'method': 'conv_ms_per_chunk = HIP-event time from the start of the first to the end of the last conv launch of a one-lane forward that '
+                                   'carries only those two events (launch-to-launch gaps included); per_launch_events = the older method, the sum of per-launch '
+                                   'durations from a forward with an event between every two launches (stages / --per-op use it)',
+                         'per_launch_events': {'conv_ms_per_chunk': round(events_ms / reps, 3), 'frac': round(conv_fl / (events_ms * 1e-3) / 1e12 / peak, 4)},
                          # both roofs at once (extra to the contract's single-roof frac): sum over the conv launches of max(FLOPs / MFMA peak,
                          # algorithmic bytes / 8 TB/s) against the sum of their measured durations - layer1 / layer2 launches are bounded by HBM
                          'two_roof': None if bound_ms == 0.0 else {'bound_ms_per_chunk': round(bound_ms / reps, 3), 'frac': round(bound_ms / conv_ms, 4),

@@ -138,6 +138,11 @@ pvr_status pvr_encoder_debug_stop_after(pvr_encoder *enc, const char *tap);
 pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w,
                                float *out_dev, int64_t out_stride, void *hip_stream, float *op_ms,
                                double *op_flops, int32_t cap, int32_t *n_ops);
+/* Wall time (ms) from the start of launch first_op to the end of launch last_op - indices as pvr_encoder_profile reports them - of one
+ * forward that carries only those two events.  bench.py's conv-family time (launches 3 .. n_ops-2): the per-launch events of
+ * pvr_encoder_profile serialise the dispatcher for a few microseconds each, which this figure does not contain. */
+pvr_status pvr_encoder_profile_span(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, float *out_dev,
+                                    int64_t out_stride, void *hip_stream, int32_t first_op, int32_t last_op, float *span_ms);
 void pvr_encoder_destroy(pvr_encoder *enc);
 
 /* ---------------------------------------------------------------------------------------------

@@ -105,6 +105,7 @@ struct pvr_encoder {
     hipEvent_t lane_done[PVR_MAX_LANES] = {nullptr};   // recorded after each forward on the lane; the next forward on it waits
     hipStream_t lane_stream[PVR_MAX_LANES] = {nullptr};   // stream of that forward (no wait when the stream is the same)
     int crop_pos = 0;                                // 0 centre (reference), 1..4 corner crops (pvr_encoder_set_crop_position)
+    int span_first = -1, span_last = -1;             // pvr_encoder_profile_span: the two marks of the forward that are recorded
     int last_n = 0;
     std::string stop_after;                                          // debug: end the forward after this tap
     std::map<std::string, std::pair<int, std::vector<int>>> taps;   // name -> (buf, {h,w,c,is_f32})
