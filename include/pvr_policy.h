@@ -93,8 +93,14 @@ int32_t pvr_policy_recurrence_mode(const pvr_policy *pol);
 pvr_status pvr_policy_debug_drop_block(pvr_policy *pol, int32_t block);
 
 /* PolicyNet.forward (models.py:57-89).  obs (T,B,obs_size) fp32 (uint8 (T,B,64,64,3n) when conv_frames = n > 0), done (T,B) uint8, h0/c0 (2,B,hidden) fp32 are
- * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82), h_out/c_out
+ * device inputs; logits (T,B,A), baseline (T,B), action (T,B) int64 = argmax (eval branch, :82; a sample in training mode after pvr_policy_set_action_sampling), h_out/c_out
  * (2,B,hidden) are device outputs.  training != 0 uses batch statistics and updates the BN buffers (:31-34). */
+/* Training-mode action of PolicyNet.forward (models.py:78-80: torch.multinomial(F.softmax(policy_logits, dim=1), num_samples=1)).  With
+ * on != 0 every following training-mode pvr_policy_forward writes ONE SAMPLE of softmax(logits) per row into `action` instead of the
+ * argmax, drawn inside the heads kernel (Gumbel-max over a counter-based Philox-4x32-10 stream keyed by `seed` and counted by call and
+ * row: reproducible for a seed, independent of the launch geometry; torch's own generator stream is not reproduced - the contract is the
+ * distribution).  Calling it again restarts the stream.  Eval-mode forwards and pvr_policy_step are unaffected.  Default off. */
+pvr_status pvr_policy_set_action_sampling(pvr_policy *pol, int32_t on, uint64_t seed);
 pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B,
                               int32_t training, float *logits, float *baseline, int64_t *action, float *h_out,

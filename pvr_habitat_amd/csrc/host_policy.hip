@@ -11,6 +11,7 @@
 #include <cmath>
 #include "host_policy.h"
 #include "host_math.h"
+#include "sample_rng.h"
 
 namespace pvr {
 
@@ -18,6 +19,8 @@ struct HostPolicy {
     HostPolicyLayout L;
     std::vector<float> xhat, invstd, a0, a1, a2, Gx[2], Hs[2], Cs[2], HM[2], dG[2], dX, dA, dB, grads, logits, dlogits, nd;
     bool have_grads = false;
+    bool sample_on = false;                    // pvr_policy_set_action_sampling
+    unsigned long long sample_seed = 0, sample_call = 0;
 };
 
 HostPolicy *host_policy_new(const HostPolicyLayout &lay) {
@@ -116,7 +119,10 @@ static pvr_status forward_impl(HostPolicy *hp, const float *P, const pvr_policy_
     host_gemm_nt(hp->Hs[1].data(), P + L.o_pw, P + L.o_pb, hp->logits.data(), N, A, H, false);
     if (logits) memcpy(logits, hp->logits.data(), (size_t)N * A * 4);
     if (baseline) host_gemm_nt(hp->Hs[1].data(), P + L.o_bw, P + L.o_bb, baseline, N, 1, H, false);
-    if (action)
+    if (action && training && hp->sample_on) {             // models.py:78-80: one sample of softmax(logits) per row
+        const unsigned long long call = hp->sample_call++;
+        for (int n = 0; n < N; ++n) action[n] = sample_softmax_row(hp->logits.data() + (size_t)n * A, A, hp->sample_seed, call, (unsigned long long)n);
+    } else if (action)
         for (int n = 0; n < N; ++n) {
             int best = 0;
             for (int a = 1; a < A; ++a) if (hp->logits[(size_t)n * A + a] > hp->logits[(size_t)n * A + best]) best = a;   // first max on ties (torch.argmax)
@@ -124,6 +130,8 @@ static pvr_status forward_impl(HostPolicy *hp, const float *P, const pvr_policy_
         }
     return PVR_OK;
 }
+
+void host_policy_set_sampling(HostPolicy *hp, int on, unsigned long long seed) { hp->sample_on = on != 0; hp->sample_seed = seed; hp->sample_call = 0; }
 
 pvr_status host_policy_forward(HostPolicy *hp, const float *params, const pvr_policy_bn *bn, const float *obs, const uint8_t *done, const float *h0,
                                const float *c0, int T, int B, int training, float *logits, float *baseline, int64_t *action, float *h_out, float *c_out) {

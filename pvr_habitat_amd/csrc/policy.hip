@@ -75,6 +75,8 @@ struct pvr_policy {
     float *dA = nullptr, *dB = nullptr, *da0 = nullptr;   // [N][H] scratch x2, [N][O]
     float *grads = nullptr;
     bool have_grads = false;
+    int sample_on = 0;                      // pvr_policy_set_action_sampling: training-mode forwards write a SAMPLE of softmax(logits) as the action
+    unsigned long long sample_seed = 0, sample_call = 0;
     int fwd_T = 0, fwd_B = 0;               // shape of the last training-mode forward (pvr_policy_backward_dlogits needs its activations)
     // PolicyNetWithConv front end (conv_frames > 0)
     float *act[5] = {nullptr}, *dact[5] = {nullptr}, *wp[5] = {nullptr}, *wt[5] = {nullptr}, *feat = nullptr, *dfeat = nullptr;
@@ -503,6 +505,7 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
     hp.out = pol->Hs[1]; hp.Wp = P + pol->o_pw; hp.bp = P + pol->o_pb; hp.Wb = P + pol->o_bw; hp.bb = P + pol->o_bb;
     hp.logits = pol->logits; hp.baseline = pol->baseline; hp.dlogits = pol->dlogits; hp.loss_row = pol->loss_row;
     hp.action = pol->action; hp.target = target; hp.N = N; hp.H = H; hp.A = d.num_actions;
+    hp.sample = pol->sample_on && training && !target; hp.seed = pol->sample_seed; hp.call = hp.sample ? pol->sample_call++ : 0;
     hipLaunchKernelGGL(heads_kernel, dim3((N + 3) / 4), dim3(256), 0, st, hp);
     PVR_LAUNCH_CHECK();
     if (fill_err != hipSuccess) {
@@ -1043,6 +1046,13 @@ pvr_status pvr_policy_set_data_parallel(pvr_policy *pol, int32_t world_size, int
 }
 
 // The persistent recurrence's spin ran out in an earlier launch of this handle: report it once, stay on per-step launches afterwards.
+pvr_status pvr_policy_set_action_sampling(pvr_policy *pol, int32_t on, uint64_t seed) {
+    PVR_REQUIRE(pol, "pvr_policy_set_action_sampling: null policy");
+    if (pol->hostp) { pvr::host_policy_set_sampling(pol->hostp, on, seed); return PVR_OK; }
+    pol->sample_on = on != 0; pol->sample_seed = seed; pol->sample_call = 0;
+    return PVR_OK;
+}
+
 pvr_status pvr_policy_status(pvr_policy *pol) {
     PVR_REQUIRE(pol, "pvr_policy_status: null policy");
     if (pol->hostp) return PVR_OK;

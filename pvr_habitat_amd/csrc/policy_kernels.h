@@ -8,6 +8,7 @@
 // "Matrix cores"): lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D col = l&15, row = 4*(l>>4)+reg.
 #pragma once
 #include "common.h"
+#include "sample_rng.h"
 
 namespace pvr {
 
@@ -1243,6 +1244,8 @@ struct HeadP {
     long long *action;
     const long long *target;
     int N, H, A;
+    int sample;                                     // training-mode forward: action = one sample of softmax(logits) (sample_rng.h)
+    unsigned long long seed, call;
 };
 
 static __global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
@@ -1268,7 +1271,7 @@ static __global__ __launch_bounds__(256) void heads_kernel(HeadP p) {
     for (int a = 1; a < p.A; ++a) if (l[a] > mx) { mx = l[a]; best = a; }
     for (int a = 0; a < p.A; ++a) p.logits[(size_t)n * p.A + a] = l[a];
     p.baseline[n] = l[p.A];
-    p.action[n] = best;
+    p.action[n] = p.sample ? sample_softmax_row(l, p.A, p.seed, p.call, (unsigned long long)n) : best;
     if (p.target) {
         float se = 0.f;
         for (int a = 0; a < p.A; ++a) se += expf(l[a] - mx);

@@ -74,6 +74,8 @@ def _plib():
         L.pvr_policy_apply_adam.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, f32, vp, vp]
         L.pvr_policy_last_grads.restype = C.c_int
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
+        L.pvr_policy_set_action_sampling.restype = C.c_int
+        L.pvr_policy_set_action_sampling.argtypes = [vp, C.c_int32, C.c_uint64]
         L.pvr_policy_status.restype = C.c_int
         L.pvr_policy_status.argtypes = [vp]
         L.pvr_policy_recurrence_mode.restype = i32
@@ -302,6 +304,9 @@ class PolicyNet(nn.Module):
         h = C.c_void_p()
         _lib.check((L.pvr_policy_create_host if self._host else L.pvr_policy_create)(C.byref(d), C.byref(h)))
         self._handle, self._handle_host = h, self._host
+        # training-mode forwards sample their action inside the library (models.py:78-80); the stream is keyed by torch's seed so that
+        # torch.manual_seed(k) before the first forward fixes it (torch's own generator stream cannot be reproduced, the distribution is)
+        _lib.check(L.pvr_policy_set_action_sampling(h, 1, C.c_uint64(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)))
         assert L.pvr_policy_param_count(h) == self._flat.numel(), 'flat layout mismatch with libpvr_hip'
         assert L.pvr_policy_trainable_count(h) == self._n_train
         for k in self._order:
@@ -364,8 +369,7 @@ class PolicyNet(nn.Module):
             logits, baseline, action, h, c = _PolicyFunction.apply(self, x, done, h0, c0, T, B, *params)
         else:
             logits, baseline, action, h, c = self._forward_raw(x, done, h0, c0, T, B, self.training)
-        if self.training:                                     # models.py:78-80 (sample is unused by the BC loss)
-            action = torch.multinomial(F.softmax(logits.detach().view(T * B, A), dim=1), num_samples=1).view(T, B)
+        # training mode: `action` is already the library's sample of softmax(logits) (models.py:78-80; pvr_policy_set_action_sampling)
         return dict(policy_logits=logits, baseline=baseline, action=action), (h, c)
 
     def set_data_parallel(self, group=None, sync_bn=True, stats_group=None):

@@ -662,3 +662,15 @@ def test_out_of_range_action_fails_loudly():
     before = m._flat.clone()
     loss, gn = opt.step(torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(act[0]))
     assert not np.isfinite(float(loss))
+
+
+@pytest.mark.gpu
+def test_training_forward_samples_actions_inside_the_library():
+    """reference models.py:78-80: in training mode the action is torch.multinomial(softmax(logits), 1).  Here the heads kernel draws it
+    (pvr_policy_set_action_sampling: Gumbel-max over a Philox stream keyed by torch's seed): frequencies over 7680 draws match the
+    softmax probabilities within 5 sigma per action, near-one-hot rows return their action, calls differ, a seed reproduces its
+    stream, eval stays argmax - and no torch sampling kernel runs on the path."""
+    from test_host_backend import _sampling_check, _sampling_net
+    m = _sampling_net().to('cuda')
+    _sampling_check(m, 'cuda')
+    m.close()

@@ -148,3 +148,64 @@ def test_config0_pipeline_without_a_gpu(tmp_path, monkeypatch):
     assert len(st['frames']) >= 2 and all(np.isfinite(st['training_loss'][1:])) and all(np.isfinite(st['gradient_norm'][1:]))
     ck = torch.load(tmp_path / 'bc' / 'scene_emresnet50_s1_scene.tar', weights_only=False)
     assert ck['actor_model_state_dict']['fc.1.weight'].shape == (1024, 4096)
+
+
+def _sampling_check(m, dev, T=40, B=16, O=64, calls=12):
+    """shared by the host (CPU) and the GPU test: training-mode actions are samples of softmax(logits) (reference models.py:78-80)"""
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randn(T, B, O, generator=g).to(dev)
+    done = torch.zeros(T, B, dtype=torch.bool, device=dev)
+    A = m.num_actions
+    m.train()
+    counts = np.zeros(A)
+    acts = []
+    with torch.no_grad():
+        for _ in range(calls):
+            out, _ = m(dict(obs=obs, done=done), m.initial_state(B))
+            a = out['action'].cpu().numpy()
+            assert a.shape == (T, B) and a.min() >= 0 and a.max() < A
+            acts.append(a)
+            counts += np.bincount(a.ravel(), minlength=A)
+        p = torch.softmax(out['policy_logits'].float().cpu().view(T * B, A), dim=1).numpy()
+    assert p.max() > 0.5 and p.min() < 0.05, 'the test needs skewed rows to mean anything'
+    expect = p.sum(0) * calls
+    sigma = np.sqrt((p * (1 - p)).sum(0) * calls)
+    assert np.all(np.abs(counts - expect) < 5 * sigma + 1), (counts, expect, sigma)
+    # rows with one dominant action: the sample is that action (almost) always, a uniform draw would not be
+    dom = p.max(1) > 0.999
+    if dom.any():
+        hit = np.mean([(a.ravel()[dom] == p.argmax(1)[dom]).mean() for a in acts])
+        assert hit > 0.99
+    assert any(not np.array_equal(acts[0], a) for a in acts[1:]), 'every call must draw new samples'
+    # the stream restarts with the seed: same seed -> same actions, another seed -> others
+    from pvr_habitat_amd.models import _plib
+    import ctypes as C
+    def draw(seed):
+        assert _plib().pvr_policy_set_action_sampling(m._handle, 1, C.c_uint64(seed)) == 0
+        with torch.no_grad():
+            return m(dict(obs=obs, done=done), m.initial_state(B))[0]['action'].cpu().numpy()
+    a1, a2, a3 = draw(77), draw(77), draw(78)
+    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
+    m.eval()
+    with torch.no_grad():
+        out, _ = m(dict(obs=obs, done=done), m.initial_state(B))
+    assert np.array_equal(out['action'].cpu().numpy().ravel(), out['policy_logits'].float().cpu().view(T * B, A).argmax(1).numpy())
+
+
+def _sampling_net(O=64, A=6):
+    from pvr_habitat_amd.models import PolicyNet
+    m = PolicyNet((O,), A, False, max_unroll=40, max_batch=16)
+    sd = synth.policy_state_dict(9, O, A, False)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    sd['policy.weight'] = sd['policy.weight'] * 60.0                 # skewed rows: some near one-hot, some spread
+    m.load_state_dict(sd)
+    return m
+
+
+def test_host_policy_samples_training_actions_from_softmax():
+    """pvr_policy_set_action_sampling on the host plan: the training-mode action is a sample of softmax(logits) drawn in the library
+    (no torch.multinomial on the path), frequencies match the probabilities, eval stays argmax."""
+    m = _sampling_net()
+    m.use_host_backend(True)
+    _sampling_check(m, 'cpu')
+    m.close()
