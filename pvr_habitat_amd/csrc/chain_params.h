@@ -34,6 +34,7 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
 // chain_wave.hip: the barrier-free form (stride-1 blocks with Cm = 64)
 bool chain_wave_supported(int cm, int cmn, int stride, bool ds);
 bool chain_wave_blocked_ok(int cmn_first, int h, int w);
+bool chain_wave_halo_enabled();                    // PVR_CHAIN_WAVE_HALO != 0
 pvr_status launch_chain_wave(ChainP &p, int cmn, int dtype, hipStream_t stream);
 
 }  // namespace pvr

@@ -521,10 +521,9 @@ static pvr_status launch_cw_one(ChainP &p, hipStream_t stream) {
 }
 
 // PVR_CHAIN_WAVE_HALO=0: blocked inputs through the per-K-step load ring instead of the halo registers (A/B runs)
-static int cw_halo() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PVR_CHAIN_WAVE_HALO"); v = e ? atoi(e) : 1; }
-    return v;
+static int cw_halo() {                                     // (read per call: plans built under different settings coexist in the tests)
+    const char *e = getenv("PVR_CHAIN_WAVE_HALO");
+    return e ? atoi(e) : 1;
 }
 
 template <bool F16>
@@ -542,6 +541,7 @@ static pvr_status launch_cw_dt(ChainP &p, int cmn, hipStream_t stream) {
         return halo ? launch_cw_one<64, F16, false, false, true, false, true, 1, 4, 1>(p, stream)
                     : launch_cw_one<64, F16, false, false, true, false, false, 4, 4, 1>(p, stream);
     } else if (cmn == 128 && !ob) {                        // layer1's last block: t1' feeds layer2's block form (NHWC)
+        if (halo) return launch_cw_one<128, F16, false, true, true, false, true, 1, 1, 1>(p, stream);   // 254 VGPRs: residual / W3 rings of depth 1 make room for the halo
         return ib ? launch_cw_one<128, F16, false, true, true, false, false, 3, 4, 2>(p, stream)
                   : launch_cw_one<128, F16, false, true, false, false, false, 3, 4, 2>(p, stream);
     } else if (cmn == 0 && !ob) {
@@ -565,6 +565,7 @@ bool chain_wave_supported(int cm, int cmn, int stride, bool ds) {
 
 // can the tensors between two consecutive wave-form launches (y = the next residual, t1' = the next conv2 input) use the blocked layout?
 bool chain_wave_blocked_ok(int cmn_first, int h, int w) { return cmn_first == 64 && (h * w) % 32 == 0; }
+bool chain_wave_halo_enabled() { return cw_halo() != 0; }
 
 pvr_status launch_chain_wave(ChainP &p, int cmn, int dtype, hipStream_t stream) {
     PVR_REQUIRE((int64_t)(p.M + 64) * 512 < 0x7ffffff0ll, "bottleneck chain (wave form): operand larger than 2 GiB (use a smaller chunk)");

@@ -444,7 +444,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
         A.out_blk = 1; B.in_blk = 1;
         // ... and when A is layer1's first tail (downsample inside), its conv2 input t1 can arrive blocked too: from conv1's own launch,
         // which directly precedes it (conv_expand.hip writes either layout; whether THAT kernel runs is known per forward: batch size)
-        if (A.ds >= 0 && a > 0 && a2.w == 56) {
+        if (A.ds >= 0 && a > 0 && a2.w == 56 && chain_wave_halo_enabled()) {   // (the downsample tail reads a blocked t1 through the halo form only)
             Launch &C = e->sched_fused[a - 1];
             if (C.conv3 < 0 && C.conv2 >= 0) {
                 const ConvOp &c1 = e->ops[C.conv2];

@@ -761,7 +761,7 @@ def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
     """chain_wave.hip (layer1's stride-1 tails: wave-owned pixels, weights resident in LDS, no barrier) computes what
     bottleneck_chain.hip's block form computes, bit for bit - same rounding points, same K order per accumulator - whether its
     launches hand y and t1' over in the blocked layout (default) or in NHWC (PVR_CHAIN_BLOCKED=0), with the downsample inside the
-    first tail (ds=1) or as its own launch, with layer1's last tail (Cmn = 128) on the wave form too (w128=1; off by default: slower).
+    first tail (ds=1) or as its own launch, with layer1's last tail (Cmn = 128) on the wave form (w128=1, the default) or on the block form, with the halo-in-registers conv2 or the load ring.
     n = 40: enough pixel tiles for conv_expand to run layer1.0.conv1, which then hands t1 over in the blocked layout as well.
     The form is chosen when the plan is built, so every setting gets its own encoder."""
     from pvr_habitat_amd.embeddings import HipResNet50
@@ -770,9 +770,10 @@ def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
     monkeypatch.setenv('PVR_CHAIN_DS', ds)
     monkeypatch.setenv('PVR_CHAIN_WAVE_128', w128)
     outs = {}
-    for key, wave, blocked in (('block', '0', '1'), ('wave', '1', '1'), ('wave_nhwc', '1', '0')):
+    for key, wave, blocked, halo in (('block', '0', '1', '1'), ('wave', '1', '1', '1'), ('wave_nhwc', '1', '0', '1'), ('wave_ring', '1', '1', '0')):
         monkeypatch.setenv('PVR_CHAIN_WAVE', wave)
         monkeypatch.setenv('PVR_CHAIN_BLOCKED', blocked)
+        monkeypatch.setenv('PVR_CHAIN_WAVE_HALO', halo)        # 0: blocked inputs through the per-K-step load ring instead of the halo registers
         m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=max(8, n))
         outs[key] = m(fr).clone()
         assert torch.equal(outs[key], m(fr))
@@ -780,6 +781,7 @@ def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
     assert torch.isfinite(outs['block']).all() and float(outs['block'].abs().max()) > 0
     assert torch.equal(outs['wave'], outs['block']), float((outs['wave'] - outs['block']).abs().max())
     assert torch.equal(outs['wave_nhwc'], outs['block']), float((outs['wave_nhwc'] - outs['block']).abs().max())
+    assert torch.equal(outs['wave_ring'], outs['block']), float((outs['wave_ring'] - outs['block']).abs().max())
 
 
 @pytest.mark.parametrize('dtype,n', [('bf16', 3), ('f16', 5), ('f16', 1)])
