@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                 int vo = (m * p.Cout + cbase[bp]) * 2;                                                             \
                 if (p.out_blk) vo = ((m >> 4) * (p.Cout >> 3) + (cbase[bp] >> 3)) * 256 + (m & 15) * 16;           \
                 vo = (m < p.M && cbase[bp] >= 0) ? vo : OOB;                                                       \
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, (RES ? PVR_NT_AUX(32) : 0));                                       \
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo, 0, 0);   /* 32-byte pieces: nt would give up write combining (PMC: +30 % written) */ \
             }                                                                                                      \
         }                                                                                                          \
         mt = mtn; ac[0] = an[0]; ac[1] = an[1];                                                                    \
