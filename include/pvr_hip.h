@@ -56,6 +56,10 @@ const char *pvr_version(void);
 /* 1 if the library was built with its measured-slower experiment kernels (make EXPERIMENTS=1: conv_w4 = pvr_debug_set_conv_algo(4), the
  * split-bf16 GEMM = pvr_debug_set_gemm_mode(1..3), PVR_POLICY_BWD_FUSED, PVR_POLICY_PERSIST_BWD); the shipped build returns 0 and refuses them */
 int32_t pvr_has_experiments(void);
+/* test hook for the uint8-reading stem (stem.hip): 1 if frames of h x w uint8 pixels at `frames` with the 224 x 224 crop window at (top, left)
+ * can take the path without a preprocess launch - the window must lie inside the frame and the rows must be 16-byte aligned; the
+ * encoder falls back to preprocess + stem otherwise.  Host-side predicate, no GPU work. */
+int32_t pvr_debug_stem_u8_geometry_ok(const void *frames, int32_t h, int32_t w, int32_t top, int32_t left);
 /* copies the calling thread's last error message; returns its length */
 size_t pvr_last_error(char *buf, size_t cap);
 

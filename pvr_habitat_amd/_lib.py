@@ -20,6 +20,7 @@ _lib = None
 _SIGS = {
     'pvr_version': (C.c_char_p, []),
     'pvr_has_experiments': (C.c_int32, []),
+    'pvr_debug_stem_u8_geometry_ok': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'pvr_encoder_set_host_backend': (C.c_int, [C.c_void_p, C.c_int32]),
     'pvr_stage_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     'pvr_last_error': (C.c_size_t, [C.c_char_p, C.c_size_t]),

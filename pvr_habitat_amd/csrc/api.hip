@@ -45,6 +45,7 @@ pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, i
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
+bool stem_pool_u8_ok(const void *, int, int, int, int);
 pvr_status launch_conv(const void *, const void *, const float *, const void *, void *, const void *, int, int, int, int,
                        int, int, int, int, int, int, int, int, hipStream_t);
 
@@ -129,6 +130,8 @@ pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_
     PVR_REQUIRE(in && out, "pvr_op_avgpool: null pointer");
     return launch_avgpool(in, out, out_stride, n, hw, c, in_f32, dtype, (hipStream_t)stream);
 }
+
+int32_t pvr_debug_stem_u8_geometry_ok(const void *frames, int32_t h, int32_t w, int32_t top, int32_t left) { return stem_pool_u8_ok(frames, h, w, top, left) ? 1 : 0; }
 
 // 1 when the library carries the round-3 experiment kernels (conv_w4, split-bf16 GEMM, fused / persistent BPTT: make EXPERIMENTS=1), else 0
 int32_t pvr_has_experiments(void) {

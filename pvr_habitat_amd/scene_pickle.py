@@ -10,8 +10,14 @@ order = row order) the moment it has been read, hands the rows a caller asked fo
 trajectory at a time:
     index pass   `scene_index(path)`            -> trajectory lengths + the small per-row arrays (action, reward, done, true_state)
     row pass     `scene_rows(path, lo, hi, fn)`  -> fn(block) for the observation rows [lo, hi) in order, block by block
-Both passes read the file sequentially (8 ranks share the page cache)."""
+Both passes read the file sequentially (8 ranks share the page cache).
+
+The one-trajectory bound holds for pickle protocol >= 3 (bytes payloads; save_opt_trajectories.py writes protocol 4 under Python >= 3.8,
+and the bound is tested for 3, 4 and 5).  A protocol <= 2 scene still reads correctly, but its payload arrives as a latin-1 str through
+_codecs.encode and stays in the unpickler's memo until the end of the pass (measured: 58 MB peak for 49 MB of frames at protocol 2):
+both passes warn about it."""
 import pickle
+import warnings
 
 import numpy as np
 
@@ -89,6 +95,12 @@ class _SceneUnpickler(pickle._Unpickler):
 def _pass(path, lo, hi, sink):
     rows = _Rows(lo, hi, sink)
     with open(path, 'rb') as f:
+        head = f.read(2)
+        f.seek(0)
+        proto = head[1] if len(head) == 2 and head[0] == 0x80 else 0
+        if proto < 3:
+            warnings.warn('%s is a protocol-%d pickle: it reads correctly, but the one-trajectory memory bound of this reader needs protocol >= 3 '
+                          '(re-save the scene with pickle.dump(..., protocol=4) for scenes that do not fit the host)' % (path, proto), RuntimeWarning)
         data = _SceneUnpickler(f, rows).load()
     return data, rows
 

@@ -271,6 +271,36 @@ def test_scene_pickle_reads_row_ranges_without_holding_the_scene(tmp_path, proto
     assert peak < 0.25 * os.path.getsize(p), (peak, os.path.getsize(p))
 
 
+def test_scene_pickle_protocol_2_reads_correctly_and_warns_about_its_memory_bound(tmp_path):
+    """a protocol-2 scene (Python-2 era pickles): rows are still right, and the reader says that its one-trajectory memory bound does not
+    hold there (the payload travels as a latin-1 str that the unpickler memoizes)."""
+    from pvr_habitat_amd import scene_pickle as SP
+    raw = _scene(np.random.default_rng(4), (4, 6, 2))
+    p = str(tmp_path / 's2.pickle')
+    pickle.dump(raw, open(p, 'wb'), protocol=2)
+    with pytest.warns(RuntimeWarning, match='protocol-2'):
+        lengths, frame_shape, _ = SP.scene_index(p)
+    assert lengths == [4, 6, 2] and frame_shape == (8, 8, 6)
+    got = []
+    with pytest.warns(RuntimeWarning, match='protocol-2'):
+        assert SP.scene_rows(p, 3, 11, lambda b: got.append(np.array(b))) == 8
+    np.testing.assert_array_equal(np.concatenate(got), np.concatenate(raw['obs'])[3:11])
+
+
+def test_uint8_stem_refuses_a_crop_window_outside_the_frame():
+    """stem.hip's uint8-reading form takes the crop window's rows by a range-checked DMA: a window outside the frame would read zeros, not
+    fail, so the geometry predicate (also behind the launcher's PVR_REQUIRE) must say no.  Host-side, no GPU needed."""
+    import ctypes as C
+    from pvr_habitat_amd import _lib
+    ok = _lib.lib().pvr_debug_stem_u8_geometry_ok
+    buf = C.create_string_buffer(64)
+    base = (C.addressof(buf) + 15) & ~15                         # a 16-byte aligned address stands in for the frames pointer
+    assert ok(C.c_void_p(base), 256, 256, 16, 16) == 1           # the bench geometry: centre crop of a 256 x 256 frame
+    assert ok(C.c_void_p(base), 224, 224, 0, 0) == 1
+    for h, w, top, left in ((256, 256, -16, 16), (256, 256, 16, -16), (256, 256, 48, 16), (256, 256, 16, 48), (200, 256, 0, 16), (256, 200, 16, 0)):
+        assert ok(C.c_void_p(base), h, w, top, left) == 0, (h, w, top, left)
+
+
 def test_stitch_shards_streams_rows_from_disk(tmp_path):
     """Rank 0's stitch (save_embedded_obs.stitch_shards): shard row files -> the reference's single pickle through a file-backed
     memmap; peak Python-side memory stays far below the size of the embedding matrix (round 2 concatenated every shard in RAM)."""
