@@ -360,6 +360,9 @@ class BlockRing(object):
         while done < len(src):
             if self._cur is None:
                 self._cur, self._fill = self._free.get(), 0
+                if self._cur < 0:                                   # abort(): the consumer failed, nobody will release a block again
+                    self._cur = None
+                    raise RuntimeError('BlockRing: the consumer stopped')
             k = min(len(src) - done, self.rows - self._fill)
             self.blocks[self._cur][self._fill:self._fill + k].copy_(src[done:done + k])
             self._fill += k
@@ -387,6 +390,10 @@ class BlockRing(object):
 
     def release(self, index):
         self._free.put(index)
+
+    def abort(self):
+        """consumer side, on failure: a producer blocked in put() (every block full) wakes up and raises instead of waiting forever"""
+        self._free.put(-1)
 
 
 def _block_rows(flags, row_bytes, batch):
@@ -480,6 +487,7 @@ def run(flags):
                         writer.append(emb.numpy())
                         ring.release(idx)
                 finally:
+                    ring.abort()                                    # (a no-op after a clean end: the reader has returned)
                     th.join(timeout=60)
             else:
                 pending, n_pending = [], [0]

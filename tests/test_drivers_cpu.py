@@ -476,6 +476,21 @@ def test_block_ring_reuses_blocks_and_hands_over_a_ragged_last_block():
     ring.close(ValueError('scene is corrupt'))
     with pytest.raises(ValueError, match='corrupt'):
         ring.get()
+    # a consumer that fails must not leave the producer blocked in put() (both blocks full, none released): abort() wakes it with an error
+    ring = BlockRing(2, (1,), count=2, pinned=False)
+    failed = []
+
+    def stuck_producer():
+        try:
+            ring.put(np.zeros((6, 1), np.uint8))                  # fills both blocks, then waits for a free one
+        except RuntimeError as e:
+            failed.append(str(e))
+    th = threading.Thread(target=stuck_producer)
+    th.start()
+    assert ring.get() is not None                                 # the consumer takes one block and dies without releasing it
+    ring.abort()
+    th.join(timeout=20)
+    assert not th.is_alive() and failed and 'consumer stopped' in failed[0]
 
 
 def test_native_stage_copy_gathers_rows_and_channel_planes():
