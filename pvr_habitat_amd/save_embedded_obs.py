@@ -346,6 +346,7 @@ class BlockRing(object):
         import queue
         pinned = torch.cuda.is_available() if pinned is None else pinned
         self.blocks = [torch.empty((rows,) + tuple(row_shape), dtype=torch.uint8, pin_memory=bool(pinned)) for _ in range(count)]
+        self._np = [b.numpy() for b in self.blocks]             # put() copies through these views: one memcpy per deposit (see put)
         self.rows = rows
         self._free, self._full = queue.Queue(), queue.Queue()
         for i in range(count):
@@ -355,7 +356,9 @@ class BlockRing(object):
     # ---- producer side -----------------------------------------------------------------------------------------
     def put(self, rows):
         """rows: uint8 array (k,) + row_shape (a view is fine: it is copied before put returns)"""
-        src = torch.from_numpy(np.ascontiguousarray(rows)) if not isinstance(rows, torch.Tensor) else rows
+        # numpy's copy, not torch's copy_: the latter runs on torch's intra-op pool, and from a reader thread on a 256-core host every
+        # 12 MB deposit paid ~29 ms of thread wake-ups (0.36 GB/s measured; 2.3 GB/s = the unpickling rate with the plain memcpy)
+        src = rows.numpy() if isinstance(rows, torch.Tensor) else np.asarray(rows)
         done = 0
         while done < len(src):
             if self._cur is None:
@@ -364,7 +367,7 @@ class BlockRing(object):
                     self._cur = None
                     raise RuntimeError('BlockRing: the consumer stopped')
             k = min(len(src) - done, self.rows - self._fill)
-            self.blocks[self._cur][self._fill:self._fill + k].copy_(src[done:done + k])
+            np.copyto(self._np[self._cur][self._fill:self._fill + k], src[done:done + k])
             self._fill += k
             done += k
             if self._fill == self.rows:
