@@ -414,6 +414,14 @@ def run(flags):
     np.random.seed(flags.run_id)
     random.seed(flags.run_id)
     flags.device = torch.device('cuda') if torch.cuda.is_available() and not flags.disable_cuda else torch.device('cpu')
+    index_job = None
+    if flags.source != 'png' and os.path.isfile(os.path.join(flags.data_path, flags.env) + '.pickle'):
+        # pass 1 over the scene (lengths + the small arrays: file I/O and unpickling, no GPU) runs while the encoder is being built
+        from concurrent.futures import ThreadPoolExecutor
+        from .scene_pickle import scene_index as _scene_index
+        _pool = ThreadPoolExecutor(max_workers=1)
+        index_job = _pool.submit(_scene_index, os.path.join(flags.data_path, flags.env) + '.pickle')
+        _pool.shutdown(wait=False)
     embedding_model = EmbeddingNet(flags.embedding_name, in_channels=3, pretrained=flags.pretrained_embedding,
                                    train=flags.train_embedding, disable_cuda=flags.disable_cuda,
                                    compute_dtype=getattr(flags, 'compute_dtype', None),
@@ -445,7 +453,8 @@ def run(flags):
         from .scene_pickle import scene_index, scene_rows
         scene = os.path.join(flags.data_path, flags.env) + '.pickle'
         print('loading %s ...' % scene[:-len('.pickle')])
-        lengths, frame_shape, small = scene_index(scene)        # pass 1: trajectory lengths + the small arrays; no frame is kept
+        # pass 1: trajectory lengths + the small arrays; no frame is kept (started above, beside the encoder's construction)
+        lengths, frame_shape, small = index_job.result() if index_job is not None else scene_index(scene)
         small = {k: np.concatenate(v) for k, v in small.items()}
         n_samples = int(sum(lengths))
         print('  ', '%d trajectories for a total of %d samples' % (len(lengths), n_samples))
