@@ -258,6 +258,60 @@ class ShardWriter(object):
         os.replace(self.meta_path + '.tmp', self.meta_path)
 
 
+class _ObsStandIn(object):
+    """Pickles the way numpy pickles a C-contiguous (n, width) float32 array under protocol 5 with in-band buffers -
+    `_frombuffer(<payload>, dtype, shape, 'C')` - but with a 64 KiB sentinel bytearray where the n * width * 4 payload bytes belong."""
+
+    def __init__(self, shape, sentinel):
+        self.shape, self.sentinel = tuple(int(v) for v in shape), sentinel
+
+    def __reduce_ex__(self, protocol):
+        frombuffer = np.zeros(1, np.float32).__reduce_ex__(5)[0]        # numpy's own reconstructor, whatever module this numpy keeps it in
+        return frombuffer, (self.sentinel, np.dtype(np.float32), self.shape, 'C')
+
+
+class DirectPickleWriter(object):
+    """Single-rank runs: embedding rows go STRAIGHT into the reference's output pickle (save_embedded_obs.py:165-172) - no shard row file,
+    no stitch copy of the (N, D) matrix (1.6 GB for 100 k samples of two ResNet50 embeddings).  Possible because a pickle keeps a large
+    buffer outside its frames as [opcode, 8-byte length, payload]: the stream around the payload is produced once, up front, by pickling
+    the final dict with a stand-in for `obs` (same reconstructor, dtype, shape and order as numpy's own reduce) around a sentinel, and
+    split at the sentinel; rows are then appended between the two halves.  The file is written under a temporary name and renamed at
+    the end, so an interrupted run leaves no output (and restarts from scratch, as a single rank did before).  Same append / finish
+    interface as ShardWriter."""
+
+    def __init__(self, save_name, n_rows, width, small, keys):
+        import struct
+        self.save_name, self.tmp = save_name, save_name + '.tmp'
+        self.n_rows, self.width, self.rows = int(n_rows), int(width), 0
+        sentinel = bytearray(os.urandom(32)) * 2049                        # 65 568 B: above the pickler's 64 KiB frame target -> written outside the frames
+        data = {'obs': _ObsStandIn((self.n_rows, self.width), sentinel)}
+        for k in keys[1:]:
+            data[k] = small[k]
+        blob = pickle.dumps(data, protocol=pickle.HIGHEST_PROTOCOL)
+        pos = blob.find(bytes(sentinel))
+        assert pos >= 9 and blob.find(bytes(sentinel), pos + 1) < 0, 'sentinel not found exactly once'
+        assert blob[pos - 9] == 0x96 and struct.unpack('<Q', blob[pos - 8:pos])[0] == len(sentinel), 'expected BYTEARRAY8 in front of the payload'
+        self.suffix = blob[pos + len(sentinel):]
+        self.f = open(self.tmp, 'wb')
+        self.f.write(blob[:pos - 8] + struct.pack('<Q', 4 * self.n_rows * self.width))
+
+    def append(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.shape[0] == 0:
+            return
+        assert rows.ndim == 2 and rows.shape[1] == self.width and self.rows + rows.shape[0] <= self.n_rows, (rows.shape, self.rows, self.n_rows, self.width)
+        self.f.write(memoryview(rows).cast('B'))
+        self.rows += rows.shape[0]
+
+    def finish(self, small=None, cover=None):
+        assert self.rows == self.n_rows, 'embedded %d rows of %d' % (self.rows, self.n_rows)
+        self.f.write(self.suffix)
+        self.f.flush()
+        os.fsync(self.f.fileno())
+        self.f.close()
+        os.replace(self.tmp, self.save_name)
+
+
 def load_complete_shard(save_name, rank, cover):
     """the shard's small arrays if <base>.rank<r>.pickle exists, covers exactly `cover` and its row file has the size it states"""
     path = shard_name(save_name, rank)
@@ -465,8 +519,15 @@ def run(flags):
         cover['scene'] = (int(st_.st_size), int(st_.st_mtime))      # a regenerated scene of equal length is not the scene this shard embedded
         if load_complete_shard(save_name, rank, cover) is None:
             print('  ', 'passing observations through embedding model')
-            writer = ShardWriter(save_name, rank)
             n_frames = max(frame_shape[2] // 3, 1) if frame_shape else 1
+            direct = (world == 1 and hi > lo and frame_shape and hasattr(getattr(embedding_model, 'embedding', None), 'forward_into')
+                      and os.environ.get('PVR_DIRECT_PICKLE', '1') != '0')
+            if direct:
+                # one rank: rows go straight into the output pickle (no shard row file, no stitch copy)
+                writer = DirectPickleWriter(save_name, hi - lo, n_frames * embedding_model.out_size, small, keys)
+                print('  ', 'total number of samples', hi - lo)
+            else:
+                writer = ShardWriter(save_name, rank)
             # (a host-backend encoder - disable_cuda / no GPU - takes the reference's own batch loop below: nothing to overlap on the CPU)
             hip = hasattr(getattr(embedding_model, 'embedding', None), 'forward_into') and not getattr(embedding_model, '_host', False)
             block = _block_rows(flags, int(np.prod(frame_shape)) if frame_shape else 1, batch)
@@ -521,6 +582,8 @@ def run(flags):
                     scene_rows(scene, lo, hi, take)             # pass 2: only this rank's rows are kept, one block at a time
                 flush()
             writer.finish({k: small[k][lo:hi] for k in keys[1:]}, cover)
+            if direct:
+                return                                              # the output pickle is complete
         else:
             print('  ', 'rank %d: shard %s is complete, nothing to embed' % (rank, os.path.basename(shard_name(save_name, rank))))
     # every rank has written its own shard files; rank 0 stitches them in rank order (= the reference's row order): nothing but a

@@ -301,6 +301,37 @@ def test_uint8_stem_refuses_a_crop_window_outside_the_frame():
         assert ok(C.c_void_p(base), h, w, top, left) == 0, (h, w, top, left)
 
 
+def test_direct_pickle_writer_equals_pickle_dump(tmp_path):
+    """save_embedded_obs.DirectPickleWriter (single-rank runs): rows appended block by block between the two halves of a pre-computed
+    pickle stream give the file pickle.dump would have written for the finished dict - byte for byte once the matrix is larger than the
+    pickler's 64 KiB frame target (what every real run is), and an equal, writable array for tiny ones; a short run is refused."""
+    from pvr_habitat_amd.save_embedded_obs import DirectPickleWriter
+    rng = np.random.default_rng(0)
+    keys = ('obs', 'action', 'reward', 'done', 'true_state')
+    for n, w in ((5000, 64), (7, 3), (1, 1)):
+        obs = rng.standard_normal((n, w)).astype(np.float32)
+        small = dict(action=rng.integers(0, 3, n), reward=np.zeros(n), done=np.zeros(n, bool), true_state=np.zeros((n, 12), np.float32))
+        p = str(tmp_path / ('o_%d.pickle' % n))
+        wr = DirectPickleWriter(p, n, w, small, keys)
+        assert not os.path.exists(p)                                  # nothing under the final name until finish()
+        for a in range(0, n, 999):
+            wr.append(obs[a:a + 999])
+        wr.finish()
+        with open(p, 'rb') as f:
+            got = pickle.load(f)
+        assert list(got.keys()) == list(keys) and got['obs'].dtype == np.float32 and got['obs'].flags.writeable
+        np.testing.assert_array_equal(got['obs'], obs)
+        for k in keys[1:]:
+            np.testing.assert_array_equal(got[k], small[k])
+        if obs.nbytes > (64 << 10):
+            assert open(p, 'rb').read() == pickle.dumps(dict(obs=obs, **small), protocol=pickle.HIGHEST_PROTOCOL)
+    wr = DirectPickleWriter(str(tmp_path / 'short.pickle'), 10, 4, dict(action=np.zeros(10), reward=np.zeros(10), done=np.zeros(10, bool), true_state=np.zeros((10, 12))), keys)
+    wr.append(np.zeros((6, 4), np.float32))
+    with pytest.raises(AssertionError, match='embedded 6 rows of 10'):
+        wr.finish()
+    assert not os.path.exists(str(tmp_path / 'short.pickle'))
+
+
 def test_stitch_shards_streams_rows_from_disk(tmp_path):
     """Rank 0's stitch (save_embedded_obs.stitch_shards): shard row files -> the reference's single pickle through a file-backed
     memmap; peak Python-side memory stays far below the size of the embedding matrix (round 2 concatenated every shard in RAM)."""
