@@ -1135,6 +1135,7 @@ pvr_status pvr_policy_apply(pvr_policy *pol, float *params, float *square_avg, c
                             float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && grads, "pvr_policy_apply: null argument");
     PVR_REQUIRE(!pol->hostp, "pvr_policy_apply: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
+    PVR_REQUIRE(((uintptr_t)grads & 15) == 0, "pvr_policy_apply: grads must be 16-byte aligned (the norm kernel reads float4s)");
     ScratchScope scratch_scope(pol);
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
@@ -1166,6 +1167,7 @@ pvr_status pvr_policy_apply_momentum(pvr_policy *pol, float *params, float *squa
                                      float alpha, float eps, float momentum, float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && square_avg && momentum_buf && grads, "pvr_policy_apply_momentum: null argument");
     PVR_REQUIRE(!pol->hostp, "pvr_policy_apply_momentum: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
+    PVR_REQUIRE(((uintptr_t)grads & 15) == 0, "pvr_policy_apply_momentum: grads must be 16-byte aligned (the norm kernel reads float4s)");
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     const size_t nt = (size_t)pol->n_train;
@@ -1182,6 +1184,7 @@ pvr_status pvr_policy_apply_adam(pvr_policy *pol, float *params, float *exp_avg,
                                  float beta2, float eps, int64_t step, float max_grad_norm, float *stats_out, void *hip_stream) {
     PVR_REQUIRE(pol && params && exp_avg && exp_avg_sq && grads && step >= 1, "pvr_policy_apply_adam: null argument or step < 1");
     PVR_REQUIRE(!pol->hostp, "pvr_policy_apply_adam: not part of the host (CPU) plan - it carries pvr_policy_forward and pvr_policy_step");
+    PVR_REQUIRE(((uintptr_t)grads & 15) == 0, "pvr_policy_apply_adam: grads must be 16-byte aligned (the norm kernel reads float4s)");
     hipStream_t st = (hipStream_t)hip_stream;
     TRY(set_lr(pol, lr, st));
     const size_t nt = (size_t)pol->n_train;
