@@ -33,6 +33,7 @@
 //       RAW  one counted wait per K tile, in phase 3 after that phase's DMA issue: vmcnt(4) leaves X-lo/X-hi(t+2) in flight
 //            and retires everything of tile t+1; every wave then passes at least one barrier before any wave reads tile t+1.
 #include "common.h"
+#include <type_traits>
 
 namespace pvr {
 
@@ -46,9 +47,16 @@ struct PPP {
     int act, out_f32;
     int n_tiles;
     int total_tiles;               // pixel tiles x cout tiles (the persistent form walks them with a stride of gridDim.x)
+    int pointwise;                 // KH = KW = 1, stride 1, pad 0: pp_tile_setup needs no (n, ho, wo) decomposition
+    int bias_lds;                  // the bias vector (<= 4096 floats, zero past Cout) is copied to LDS once per block: see the epilogue
 };
 
 #define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
+
+// LDS reads of the epilogue as inline assembly: while LDS-DMA is in flight (the persistent form requests the next tile's first K tile in
+// front of the epilogue) hipcc puts an s_waitcnt vmcnt(0) in front of every C++ LDS access.  The consumers are tied to the wait.
+__device__ __forceinline__ f32x4 pp_lds_read16(unsigned addr) { f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v; }
+__device__ __forceinline__ void pp_lds_wait(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); }
 
 // Diagnostic build only (scripts/pp256_stamps.hip defines PP_STAMP): s_memtime stamps of one steady-state K tile, one wave of
 // each group of block 0, written to a buffer nothing else reads.  Compiles to nothing in the library.
@@ -66,6 +74,15 @@ __device__ unsigned long long pp_stamps[2][8];
 #define PP_STAMP_LATCH()
 #endif
 
+// Second diagnostic (scripts/pp256_tile_stamps.hip defines PP_TSTAMP = the tile iteration to sample): s_memtime at the boundaries of one
+// whole tile iteration of the persistent form (drain wait, barriers, K loop, next tile's setup + prologue issue, epilogue), block 8, one wave per group.
+#ifdef PP_TSTAMP
+__device__ unsigned long long pp_tstamps[2][8];
+#define PP_TS(k_) { if (tile_it_ == PP_TSTAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tts_[k_]) :: "memory"); }
+#else
+#define PP_TS(k_)
+#endif
+
 // per-lane staging offsets of one output tile (pixel rows m0 .., couts co0 ..): see "staging" in the kernel
 template <int BM, int XI>
 __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int wave, int lane, int (&a_off)[2][XI], int (&a_mask)[2][XI],
@@ -81,6 +98,14 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
                 const int m = m0 + h * XH + r;
                 const bool ok = m < p.M && r < XH;
                 const int mm = ok ? m : 0;
+                if (p.pointwise) {
+                    // 1 x 1, stride 1, no padding (every transformer GEMM, the conv1 launches): input pixel = output pixel, one tap, no border.
+                    // The general path below costs four integer divisions per entry - ~3 k cycles of a 46 k-cycle tile iteration of the
+                    // persistent form, once per tile (s_memtime stamps, scripts/pp256_tile_stamps.hip)
+                    a_off[h][i < XI ? i : 0] = (mm * p.Cin + lch * 8) * 2;
+                    a_mask[h][i < XI ? i : 0] = ok ? 1 : 0;
+                }
+                if (!p.pointwise) {
                 const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
                 const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
                 a_off[h][i < XI ? i : 0] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lch * 8) * 2;
@@ -94,6 +119,7 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
 #pragma unroll
                 for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
                 a_mask[h][i < XI ? i : 0] = mask;
+                }
             }
             const int R = h * 128 + r;                                  // A-operand row inside the 256-cout tile
             // 16-bit outputs: rows permuted so that a lane's tile PAIR is 8 consecutive couts (one 16-byte store).  fp32 outputs with an fp32
@@ -136,6 +162,16 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
+    // the bias vector -> LDS, behind the two staging buffers (read by the epilogues; the K loops' barriers order it before the first one)
+    const unsigned bias_l = (unsigned)(size_t)PP_LDS_PTR(2 * BUF);
+    if (p.bias_lds) {
+        for (int c4 = tid; c4 * 4 < p.CoutPad; c4 += 512) {
+            f32x4 b4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = c4 * 4 + e < p.Cout ? p.bias[c4 * 4 + e] : 0.f;
+            *reinterpret_cast<f32x4 *>(smem + 2 * BUF + c4 * 16) = b4;
+        }
+    }
 
     // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
     int a_off[2][XI], a_mask[2][XI], b_off[2][2];
@@ -202,7 +238,12 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     }
     PP_PROLOGUE_ISSUE();
     bool first_tile = true;
+#ifdef PP_TSTAMP
+    int tile_it_ = 0;
+    unsigned long long tts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {                                      // tiles of this block (one pass unless PERSIST)
+    PP_TS(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -213,11 +254,13 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    PP_TS(1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave group runs one half-phase behind
     __builtin_amdgcn_sched_barrier(0);
+    PP_TS(2);
 
 #define PP_FEED_DONE()                                                                                           \
     PP_T(sti++);                                                                                                 \
@@ -310,6 +353,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
     __builtin_amdgcn_sched_barrier(0);
+    PP_TS(3);
     const int em0 = m0, eco0 = co0;               // the epilogue's tile
     bool more = false;
     if constexpr (PERSIST) {
@@ -322,6 +366,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         first_tile = false;
         __builtin_amdgcn_sched_barrier(0);
     }
+    PP_TS(4);
 #ifdef PP_STAMP
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_) :: "memory");
     if (blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
@@ -338,6 +383,22 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, RES ? p.res_bytes : 0, 0x00020000);
     float bs[2][8];
     bool cok[2], cok2[2];                          // validity of the lane's first / second group of 4 couts (they differ only in natural order)
+    if (p.bias_lds) {
+        // bias from the block's LDS copy: a global load here returns in order BEHIND the next tile's prologue DMA (96 KB), i.e. it held the
+        // epilogue until that DMA had landed - 2.2 k of a 46 k-cycle tile iteration (s_memtime stamps, scripts/pp256_tile_stamps.hip)
+        f32x4 t[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = eco0 + wc * 64 + q * 32 + fq * (natural ? 4 : 8), c2 = c + (natural ? 16 : 4);
+            cok[q] = c < p.Cout; cok2[q] = c2 < p.Cout;
+            t[2 * q] = pp_lds_read16(bias_l + c * 4); t[2 * q + 1] = pp_lds_read16(bias_l + c2 * 4);
+        }
+        pp_lds_wait(t[0], t[1], t[2], t[3]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bs[q][e] = t[2 * q][e]; bs[q][4 + e] = t[2 * q + 1][e]; }
+    } else {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         // the lane's 8 values of tile pair q: couts c .. c + 7 (permuted rows), or c .. c + 3 and c + 16 .. c + 19 (natural rows)
@@ -348,10 +409,19 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
         bs[q][0] = lo.x; bs[q][1] = lo.y; bs[q][2] = lo.z; bs[q][3] = lo.w;
         bs[q][4] = hi.x; bs[q][5] = hi.y; bs[q][6] = hi.z; bs[q][7] = hi.w;
     }
-    const int esz_o = p.out_f32 ? 4 : 2;
+    }
+    // The activation and the output type are run-time parameters; the loop below is compiled once per (activation, output type) and the
+    // choice made ONCE per tile: with the tests inside the loop every tile pair paid scalar branches and register shuffles between the
+    // variants' register layouts (567 v_mov in the epilogue's ISA; ~800 cycles per pixel tile, s_memtime stamps).
     constexpr int esz_r = RES == 2 ? 4 : 2;
+    auto epilogue = [&](auto act_c, auto of32_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool OF32 = decltype(of32_c)::value;
+    constexpr int esz_o = OF32 ? 4 : 2;
 #pragma unroll
     for (int j = 0; j < TMW; ++j) {
+        if (j == 1) PP_TS(6);
+        if (j == 4) PP_TS(7);
         const int m = em0 + wr * XH + j * 16 + fr;
         u32x4 rr[2][2];
         if constexpr (RES != 0) {
@@ -384,19 +454,19 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
-            if (p.act == 1) {
+            if constexpr (ACT == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == 2) {
+            } else if constexpr (ACT == 2) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));   // v_rcp_f32 (1 ulp): an IEEE division here cost 15 % of the FC1 launch
-            } else if (p.act == 3) {
+            } else if constexpr (ACT == 3) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
             }
             // byte offsets go into voffset (soffset stays 0): see store_b128_imm in bottleneck_chain.hip
             const int oo = (m < p.M && cok[q]) ? (m * p.Cout + c) * esz_o : OOB;
-            if (p.out_f32) {
+            if constexpr (OF32) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_out, oo, 0, PVR_NT_AUX(256));
                 const int oo2 = (m < p.M && cok2[q]) ? (m * p.Cout + c) * esz_o + (natural ? 64 : 16) : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_out, oo2, 0, PVR_NT_AUX(256));
@@ -408,6 +478,24 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             }
         }
     }
+    };
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
+        if (p.out_f32) {
+            if (p.act == 0) epilogue(I0{}, BT{}); else if (p.act == 1) epilogue(I1{}, BT{}); else if (p.act == 2) epilogue(I2{}, BT{}); else epilogue(I3{}, BT{});
+        } else {
+            if (p.act == 0) epilogue(I0{}, BF{}); else if (p.act == 1) epilogue(I1{}, BF{}); else if (p.act == 2) epilogue(I2{}, BF{}); else epilogue(I3{}, BF{});
+        }
+    }
+    PP_TS(5);
+#ifdef PP_TSTAMP
+    if (tile_it_ == PP_TSTAMP && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pp_tstamps[wr][k] = tts_[k];
+    }
+    ++tile_it_;
+#endif
     if (!more) break;
   }
 #undef PP_TILE128
@@ -436,7 +524,7 @@ static int pp_persist_min() {
 
 template <int BM, bool F16, int RES>
 static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
-    constexpr int lds = 2 * ((BM == 224 ? 256 : BM) * 128 + 32768);
+    constexpr int lds = 2 * ((BM == 224 ? 256 : BM) * 128 + 32768) + 16384;      // two staging buffers + the bias vector (<= 4096 floats)
     static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
     if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -446,6 +534,8 @@ static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
     }
     const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
     p.total_tiles = grid;
+    p.pointwise = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+    p.bias_lds = p.CoutPad <= 4096 ? 1 : 0;
     if constexpr (BM != 128) {
         if (pp_persist_min() > 0 && grid >= pp_persist_min()) {       // one block per CU (128 KB of LDS each), several tiles per block
             ++g_pp_persistent_launches;
