@@ -12,6 +12,7 @@ const std::string &last_error() { static std::string s; return s; }
 int main(int argc, char **argv) {
     using namespace pvr;
     const int n = 256, h = 197, w = 1, cin = argc > 1 ? atoi(argv[1]) : 768, cout = argc > 2 ? atoi(argv[2]) : 2304, k = 1;
+    const int res32 = argc > 3 ? atoi(argv[3]) : 0;      // 1: fp32 output accumulated in place (out += ..., the transformer's residual stream)
     const size_t xin = (size_t)n * h * w * cin, wn = (size_t)cout * cin, on = (size_t)n * h * w * cout;
     std::vector<u16> hx(xin), hw(wn);
     std::mt19937 rng(1);
@@ -19,13 +20,13 @@ int main(int argc, char **argv) {
     for (auto &v : hx) v = f32_to_bf16_bits(nd(rng));
     for (auto &v : hw) v = f32_to_bf16_bits(nd(rng) * 0.02f);
     u16 *dx, *dw, *dout; float *db;
-    hipMalloc(&dx, xin * 2); hipMalloc(&dw, wn * 2); hipMalloc(&dout, on * 2); hipMalloc(&db, cout * 4);
+    hipMalloc(&dx, xin * 2); hipMalloc(&dw, wn * 2); hipMalloc(&dout, on * 4); hipMemset(dout, 0, on * 4); hipMalloc(&db, cout * 4);
     hipMemcpy(dx, hx.data(), xin * 2, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), wn * 2, hipMemcpyHostToDevice);
     hipMemset(db, 0, cout * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 5; ++rep) if (launch_conv_pp256(dx, dw, db, nullptr, dout, n, h, w, cin, cout, k, k, 1, 0, 0, 0, 0, PVR_BF16, 256, 0)) return 1;
+    for (int rep = 0; rep < 5; ++rep) if (launch_conv_pp256(dx, dw, db, res32 ? (void *)dout : nullptr, dout, n, h, w, cin, cout, k, k, 1, 0, 0, res32, res32, PVR_BF16, cout == 768 ? 224 : 256, 0)) return 1;
     hipEventRecord(e0, 0);
-    for (int rep = 0; rep < 50; ++rep) if (launch_conv_pp256(dx, dw, db, nullptr, dout, n, h, w, cin, cout, k, k, 1, 0, 0, 0, 0, PVR_BF16, 256, 0)) return 1;
+    for (int rep = 0; rep < 50; ++rep) if (launch_conv_pp256(dx, dw, db, res32 ? (void *)dout : nullptr, dout, n, h, w, cin, cout, k, k, 1, 0, 0, res32, res32, PVR_BF16, cout == 768 ? 224 : 256, 0)) return 1;
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long st[2][8];
