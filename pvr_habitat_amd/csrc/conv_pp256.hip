@@ -55,6 +55,7 @@ struct PPP {
 
 // LDS reads of the epilogue as inline assembly: while LDS-DMA is in flight (the persistent form requests the next tile's first K tile in
 // front of the epilogue) hipcc puts an s_waitcnt vmcnt(0) in front of every C++ LDS access.  The consumers are tied to the wait.
+__device__ __forceinline__ void pp_lds_write16(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ f32x4 pp_lds_read16(unsigned addr) { f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v; }
 __device__ __forceinline__ void pp_lds_wait(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); }
 
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     // choice made ONCE per tile: with the tests inside the loop every tile pair paid scalar branches and register shuffles between the
     // variants' register layouts (567 v_mov in the epilogue's ISA; ~800 cycles per pixel tile, s_memtime stamps).
     constexpr int esz_r = RES == 2 ? 4 : 2;
+    const unsigned ep_slot = (unsigned)(size_t)PP_LDS_PTR(BUF + WOFF + wave * 4096);   // two 2 KB transposition slots per wave (fp32 outputs)
     auto epilogue = [&](auto act_c, auto of32_c) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_c)::value;
     constexpr bool OF32 = decltype(of32_c)::value;
@@ -422,6 +424,58 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     for (int j = 0; j < TMW; ++j) {
         if (j == 1) PP_TS(6);
         if (j == 4) PP_TS(7);
+        if constexpr (OF32 && RES != 1) {
+            // fp32 outputs in natural cout order (the transformer GEMMs; += into the fp32 residual stream when RES = 2): whole 128-byte lines.
+            // A lane's 8 values of tile pair q are two 16-byte chunks (fq, 4 + fq) of the line (pixel fr, couts 32 q .. 32 q + 31); in that
+            // layout a load / store instruction covers 16 rows x 64 B, which the texture-address path takes about twice as long over as
+            // 8 rows x 128 B - and this epilogue is a bandwidth pass (458 KB per tile, 27 k of the out-projection's 62 k-cycle tile
+            // iteration).  A wave-private 2 KB LDS slot per pair ([16 rows][128 B], chunk c of row r at c ^ (r & 7); inline-asm DS
+            // accesses, see pp_lds_read16) turns lines into fragments and back: lane l moves rows l >> 3 and (l >> 3) + 8, chunk
+            // (l & 7) ^ (l >> 3).  The slots are the W half tiles of buffer 1, which the next tile's prologue DMA does not touch.
+            const int sw = fr & 7, lr = lane >> 3, ch = (lane & 7) ^ lr;
+            const int mrow = em0 + wr * XH + j * 16 + lr;
+            int lo_off[2], hi_off[2];
+            f32x4 rl[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cq = eco0 + wc * 64 + q * 32 + ch * 4;
+                lo_off[q] = (mrow < p.M && cq < p.Cout) ? (mrow * p.Cout + cq) * 4 : OOB;
+                hi_off[q] = (mrow + 8 < p.M && cq < p.Cout) ? ((mrow + 8) * p.Cout + cq) * 4 : OOB;
+                if constexpr (RES == 2) {
+                    rl[q][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, lo_off[q], 0, PVR_NT_AUX(512)));
+                    rl[q][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, hi_off[q], 0, PVR_NT_AUX(512)));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned sq = ep_slot + q * 2048;
+                const unsigned f0 = sq + fr * 128 + ((fq ^ sw) << 4), f1 = sq + fr * 128 + (((4 + fq) ^ sw) << 4);
+                const f32x4 a_lo = acc[2 * q][j], a_hi = acc[2 * q + 1][j];
+                f32x4 v0 = {a_lo[0] + bs[q][0], a_lo[1] + bs[q][1], a_lo[2] + bs[q][2], a_lo[3] + bs[q][3]};
+                f32x4 v1 = {a_hi[0] + bs[q][4], a_hi[1] + bs[q][5], a_hi[2] + bs[q][6], a_hi[3] + bs[q][7]};
+                if constexpr (RES == 2) {
+                    pp_lds_write16(sq + lane * 16, rl[q][0]);
+                    pp_lds_write16(sq + 1024 + lane * 16, rl[q][1]);
+                    f32x4 r0 = pp_lds_read16(f0), r1 = pp_lds_read16(f1);
+                    pp_lds_wait(r0, r1, v0, v1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] += r0[e]; v1[e] += r1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (ACT == 1) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    else if constexpr (ACT == 2) { v0[e] = v0[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0[e])); v1[e] = v1[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1[e])); }
+                    else if constexpr (ACT == 3) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
+                }
+                pp_lds_write16(f0, v0);
+                pp_lds_write16(f1, v1);
+                f32x4 o_lo = pp_lds_read16(sq + lane * 16), o_hi = pp_lds_read16(sq + 1024 + lane * 16);
+                pp_lds_wait(o_lo, o_hi, v0, v1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_lo), rs_out, lo_off[q], 0, PVR_NT_AUX(256));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_hi), rs_out, hi_off[q], 0, PVR_NT_AUX(256));
+            }
+            continue;
+        }
         const int m = em0 + wr * XH + j * 16 + fr;
         u32x4 rr[2][2];
         if constexpr (RES != 0) {
