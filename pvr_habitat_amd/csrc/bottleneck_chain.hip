@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
         for (int j = 0; j < TM; ++j) {
             const int row = wm * 64 + j * 16 + fr;
             const f32x4 a = acc2[i][j];
-            const unsigned lo = (unsigned)to_h<F16>(fmaxf(a[0] + bv.x, 0.f)) | ((unsigned)to_h<F16>(fmaxf(a[1] + bv.y, 0.f)) << 16);
-            const unsigned hi = (unsigned)to_h<F16>(fmaxf(a[2] + bv.z, 0.f)) | ((unsigned)to_h<F16>(fmaxf(a[3] + bv.w, 0.f)) << 16);
+            const unsigned lo = pack2_h<F16>(fmaxf(a[0] + bv.x, 0.f), fmaxf(a[1] + bv.y, 0.f));
+            const unsigned hi = pack2_h<F16>(fmaxf(a[2] + bv.z, 0.f), fmaxf(a[3] + bv.w, 0.f));
             const int cc = c & 63;
             char *dst = smem + T2_OFF + (c >> 6) * 16384 + row * 128 + ((((cc >> 3) ^ ((row >> 1) & 7))) << 4) + (cc & 4) * 2;
             *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
@@ -469,14 +469,14 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
             if constexpr (DS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                    o[e] = pack2_h<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
             } else {
                 const u32x4 r = rres[g % RD][j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v0 = fmaxf(v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), 0.f);
                     const float v1 = fmaxf(v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16)), 0.f);
-                    o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                    o[e] = pack2_h<F16>(v0, v1);
                 }
             }
             // nt only for the blocked layout's 1 KB runs: on NHWC 16-byte pieces it gives up write combining (PMC: 266 MB written for 205)
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                    o[e] = pack2_h<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
                 store_b128_imm<PVR_NT_AUX(8)>(o, rs_t, T_OFF(j), q * 64);
             }
         }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const u16 *__restrict__ i
             }
         u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(acc[2 * e] * 0.25f) | ((unsigned)to_h<F16>(acc[2 * e + 1] * 0.25f) << 16);
+        for (int e = 0; e < 4; ++e) o[e] = pack2_h<F16>(acc[2 * e] * 0.25f, acc[2 * e + 1] * 0.25f);
         *reinterpret_cast<u32x4 *>(out + pix * c + ch) = o;
     }
 }

@@ -139,6 +139,16 @@ template <bool F16> __device__ __forceinline__ u16 to_h(float v) {
     typename HT<F16>::T t = (typename HT<F16>::T)v;
     return __builtin_bit_cast(u16, t);
 }
+// two floats -> one dword of two 16-bit values (round to nearest even, as to_h): ONE v_cvt_pk instruction.  `to_h(a) | to_h(b) << 16` makes
+// hipcc convert with its own pairing and then re-pack with three more instructions per dword.
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16> __device__ __forceinline__ unsigned pack2_h(float a, float b) {
+    const pk_f32x2 v = {a, b};
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_f16x2));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_bf16x2));
+}
 template <bool F16> __device__ __forceinline__ float from_h(u16 b) {
     return (float)__builtin_bit_cast(typename HT<F16>::T, b);
 }

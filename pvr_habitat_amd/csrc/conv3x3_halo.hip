@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloP p) {
                 float v0 = v[2 * e], v1 = v[2 * e + 1];
                 if (p.res) { v0 += from_h<F16>((u16)(rres[bp][j][e] & 0xffffu)); v1 += from_h<F16>((u16)(rres[bp][j][e] >> 16)); }
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                o[e] = pack2_h<F16>(v0, v1);
             }
             if (o_off[j] >= 0) *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(p.out) + o_off[j] + bp * 64) = o;
         }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                         float v0 = v[2 * e], v1 = v[2 * e + 1];                                                    \
                         if constexpr (RES) { v0 += from_h<F16>((u16)(r[bp][e] & 0xffffu)); v1 += from_h<F16>((u16)(r[bp][e] >> 16)); } \
                         if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                              \
-                        o[bp][e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);                      \
+                        o[bp][e] = pack2_h<F16>(v0, v1);                      \
                     }                                                                                              \
                 }                                                                                                  \
                 *reinterpret_cast<u32x4 *>(slot + fl_f0) = o[0];                                                   \
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_expand_kernel(ExpP p) {
                     float v0 = v[2 * e], v1 = v[2 * e + 1];                                                        \
                     if constexpr (RES) { v0 += from_h<F16>((u16)(r[e] & 0xffffu)); v1 += from_h<F16>((u16)(r[e] >> 16)); } \
                     if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                                  \
-                    o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);                              \
+                    o[e] = pack2_h<F16>(v0, v1);                              \
                 }                                                                                                  \
                 int vo = (m * p.Cout + cbase[bp]) * 2;                                                             \
                 if (p.out_blk) vo = ((m >> 4) * (p.Cout >> 3) + (cbase[bp] >> 3)) * 256 + (m & 15) * 16;           \

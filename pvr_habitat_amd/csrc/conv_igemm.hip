@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || BM == 64) ? 3 : 2) void conv_i
                 for (int e = 0; e < 4; ++e) {
                     float v0 = v[2 * e] + from_h<F16>((u16)(r[e] & 0xffffu)), v1 = v[2 * e + 1] + from_h<F16>((u16)(r[e] >> 16));
                     if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                    o[e] = (unsigned)to_h<F16>(v0) | ((unsigned)to_h<F16>(v1) << 16);
+                    o[e] = pack2_h<F16>(v0, v1);
                 }
                 if (m < p.M && co < p.Cout) *reinterpret_cast<u32x4 *>((u16 *)p.out + (size_t)m * p.Cout + co) = o;
             }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || BM == 64) ? 3 : 2) void conv_i
                 u32x4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+                    r[e] = pack2_h<F16>(v[2 * e], v[2 * e + 1]);
                 *reinterpret_cast<u32x4 *>((u16 *)p.out + o) = r;
             }
         }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         } else {
             u32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) r[e] = pack2_h<F16>(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<u32x4 *>((u16 *)out + o) = r;
         }
     }

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
             } else {
                 u32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
+                for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);   // (pack2_h measured 2.6 % slower on ViT-B/16 here)
                 __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, oo, 0, PVR_NT_AUX(256));
             }
         }
