@@ -266,12 +266,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
 #pragma unroll
         for (int ks = 0; ks < MAXNT / 2; ++ks) {
             if (ks * 32 < TK) {
-                u16 pe[8];
+                u32x4 pw;                                  // (one v_cvt_pk per dword: common.h::pack2_h)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pe[j] = to_h<F16>(s[2 * ks + (j >> 2)][j & 3]);
-                u32x4 pw;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pw[e] = (unsigned)pe[2 * e] | ((unsigned)pe[2 * e + 1] << 16);
+                for (int e = 0; e < 4; ++e) pw[e] = pack2_h<F16>(s[2 * ks + (e >> 1)][(2 * e) & 3], s[2 * ks + (e >> 1)][(2 * e + 1) & 3]);
                 const V8 pf = __builtin_bit_cast(V8, pw);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -286,10 +283,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
             u16 *orow = out + ((size_t)b * T + query) * W + hd * HD + fq * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                ushort4 r;
-                r.x = to_h<F16>(o[mt][0] * inv); r.y = to_h<F16>(o[mt][1] * inv);
-                r.z = to_h<F16>(o[mt][2] * inv); r.w = to_h<F16>(o[mt][3] * inv);
-                *reinterpret_cast<ushort4 *>(orow + mt * 16) = r;
+                const uint2 r = {pack2_h<F16>(o[mt][0] * inv, o[mt][1] * inv), pack2_h<F16>(o[mt][2] * inv, o[mt][3] * inv)};
+                *reinterpret_cast<uint2 *>(orow + mt * 16) = r;
             }
         }
     }
