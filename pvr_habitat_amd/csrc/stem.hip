@@ -65,12 +65,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const u16 *__restrict__ img, 
         u16 *o = out + (((size_t)n * OW + ho) * OW + wo0 + px) * STEM_CO + g * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ushort4 r;
-            r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
-            r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
-            r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
-            r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
-            *reinterpret_cast<ushort4 *>(o + i * 16) = r;
+            const uint2 r = {pack2_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f), fmaxf(acc[i][1] + bv[i].y, 0.f)), pack2_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f), fmaxf(acc[i][3] + bv[i].w, 0.f))};   // (one v_cvt_pk per dword)
+            *reinterpret_cast<uint2 *>(o + i * 16) = r;
         }
     }
 }
@@ -136,13 +132,9 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ 
         char *prow = smem + ((size_t)lr * OW + col) * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ushort4 r;
-            r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
-            r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
-            r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
-            r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
+            const uint2 r = {pack2_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f), fmaxf(acc[i][1] + bv[i].y, 0.f)), pack2_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f), fmaxf(acc[i][3] + bv[i].w, 0.f))};   // (one v_cvt_pk per dword)
             const int c16 = i * 2 + (g >> 1);                        // 16-byte chunk of channels 16i+4g .. +3
-            *reinterpret_cast<ushort4 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
+            *reinterpret_cast<uint2 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
         }
     }
     __syncthreads();
@@ -268,9 +260,8 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
             char *dst = zb + r * ROWB + (4 * k + 3) * 8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ushort4 o;
-                o.x = to_h<F16>(f[3 * q] - off); o.y = to_h<F16>(f[3 * q + 1] - off); o.z = to_h<F16>(f[3 * q + 2] - off); o.w = to_h<F16>(one);
-                *reinterpret_cast<ushort4 *>(dst + q * 8) = o;
+                const uint2 o = {pack2_h<F16>(f[3 * q] - off, f[3 * q + 1] - off), pack2_h<F16>(f[3 * q + 2] - off, one)};
+                *reinterpret_cast<uint2 *>(dst + q * 8) = o;
             }
         }
         if (tid < 15 * 8) {                                           // the zero border: padded columns 0..2 and 227..231 of every row
@@ -336,13 +327,9 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
                 char *prow = smem + ((size_t)lr * OW + col) * 128;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ushort4 r;
-                    r.x = to_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f));
-                    r.y = to_h<F16>(fmaxf(acc[i][1] + bv[i].y, 0.f));
-                    r.z = to_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f));
-                    r.w = to_h<F16>(fmaxf(acc[i][3] + bv[i].w, 0.f));
+                    const uint2 r = {pack2_h<F16>(fmaxf(acc[i][0] + bv[i].x, 0.f), fmaxf(acc[i][1] + bv[i].y, 0.f)), pack2_h<F16>(fmaxf(acc[i][2] + bv[i].z, 0.f), fmaxf(acc[i][3] + bv[i].w, 0.f))};   // (one v_cvt_pk per dword)
                     const int c16 = i * 2 + (g >> 1);                    // 16-byte chunk of channels 16i+4g .. +3
-                    *reinterpret_cast<ushort4 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
+                    *reinterpret_cast<uint2 *>(prow + ((c16 ^ (col & 7)) << 4) + (g & 1) * 8) = r;
                 }
             }
         }
