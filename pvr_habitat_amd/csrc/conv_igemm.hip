@@ -485,7 +485,12 @@ pvr_status launch_conv(const void *in, const void *wgt, const float *bias, const
         // 224 instead of 256 when it needs fewer CU-rounds x rows (batch 256 at 14 x 14: 196 tiles of 256 on 256 CUs vs 224 tiles of 224)
         const int64_t tiles224 = ((M + 223) / 224) * nt;
         static const bool use224 = [] { const char *e = getenv("PVR_PP_BM224"); return !e || atoi(e) != 0; }();
-        const bool better224 = use224 && ((tiles224 + 255) / 256) * 224 < ((tiles + 255) / 256) * 256;
+        // Rounds first: a tile iteration of the persistent form costs about the same for 224 and 256 rows (its cadence is set by the feed
+        // half-phases and ~12 k cycles of epilogue / setup, scripts/pp256_tile_stamps.hip), so more, smaller tiles only pay when they do not
+        // add a round (fc1 of ViT-B/16: 10 rounds of 256 rows instead of 11 of 224).  PVR_PP_BM224=2 restores round 2's rows-only rule.
+        static const int rule224 = [] { const char *e = getenv("PVR_PP_BM224"); return e ? atoi(e) : 1; }();
+        const int64_t r224 = (tiles224 + 255) / 256, r256 = (tiles + 255) / 256;
+        const bool better224 = use224 && (rule224 == 2 ? r224 * 224 < r256 * 256 : (r224 <= r256 && r224 * 224 < r256 * 256));
         const int bm = algo == 1 ? 256 : algo == 2 ? 128 : algo == 3 ? 224
                      : (algo == -1 && deep) ? (tiles >= 160 ? (better224 ? 224 : 256) : (tiles128 >= 160 ? 128 : 0)) : 0;
         // algo 4 (round 3): the four-wave 128 x 128-per-wave kernel (conv_w4.hip) wherever it accepts the shape
