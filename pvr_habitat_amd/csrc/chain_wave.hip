@@ -51,10 +51,14 @@ __device__ __forceinline__ int cw_row_source(int row) { return (row & ~31) + 8 *
 #define CW_AUX_RES PVR_NT_AUX(2)
 #endif
 // 16-byte buffer store, byte offset in voffset + immediate (never soffset: bottleneck_chain.hip, store_b128_imm)
+template <int AUX = CW_AUX_ST>
 __device__ __forceinline__ void cw_store(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int imm, int never = 0) {
-    if constexpr (CW_KNOCK & 1) { if (never) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, CW_AUX_ST); }
-    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, CW_AUX_ST);
+    if constexpr (CW_KNOCK & 1) { if (never) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, AUX); }
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + imm, 0, AUX);
 }
+#ifndef CW_AUX_T1
+#define CW_AUX_T1 CW_AUX_ST          // t1' stores (A/B: -DCW_AUX_T1=0 keeps the next launch's conv2 input in L2 / MALL)
+#endif
 
 typedef float cw_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 cw_bf16x2 __attribute__((ext_vector_type(2)));
@@ -471,12 +475,12 @@ __global__ __launch_bounds__(512, 2) void chain_wave_kernel(ChainP p) {
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = cw_pack2<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
-                    if constexpr (OUTB) cw_store(o, rs_t, cur.to[j], q * 1024, p.stride == 77);
+                    if constexpr (OUTB) cw_store<CW_AUX_T1>(o, rs_t, cur.to[j], q * 1024, p.stride == 77);
                     else if (q & 1) {
                         u32x4 l0, l1;
                         cw_f2m_pair(slot0, lane, te[j], o, l0, l1);
-                        cw_store(l0, rs_t, cur.to[j], (q >> 1) * 128, p.stride == 77);
-                        cw_store(l1, rs_t, cur.to[j], (q >> 1) * 128 + 8 * (CMN * 2), p.stride == 77);
+                        cw_store<CW_AUX_T1>(l0, rs_t, cur.to[j], (q >> 1) * 128, p.stride == 77);
+                        cw_store<CW_AUX_T1>(l1, rs_t, cur.to[j], (q >> 1) * 128 + 8 * (CMN * 2), p.stride == 77);
                     } else te[j] = o;
                 }
             }
