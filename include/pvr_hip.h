@@ -60,6 +60,9 @@ int32_t pvr_has_experiments(void);
  * can take the path without a preprocess launch - the window must lie inside the frame and the rows must be 16-byte aligned; the
  * encoder falls back to preprocess + stem otherwise.  Host-side predicate, no GPU work. */
 int32_t pvr_debug_stem_u8_geometry_ok(const void *frames, int32_t h, int32_t w, int32_t top, int32_t left);
+/* test hook: the uniform in the OPEN interval (0, 1) that the training-mode action sampler (pvr_policy_set_action_sampling) makes of 32 random
+ * bits; never 0 or 1 for any input.  Host arithmetic, no GPU work. */
+float pvr_debug_sample_uniform(uint32_t bits);
 /* copies the calling thread's last error message; returns its length */
 size_t pvr_last_error(char *buf, size_t cap);
 

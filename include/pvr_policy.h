@@ -101,6 +101,11 @@ pvr_status pvr_policy_debug_drop_block(pvr_policy *pol, int32_t block);
  * row: reproducible for a seed, independent of the launch geometry; torch's own generator stream is not reproduced - the contract is the
  * distribution).  Calling it again restarts the stream.  Eval-mode forwards and pvr_policy_step are unaffected.  Default off. */
 pvr_status pvr_policy_set_action_sampling(pvr_policy *pol, int32_t on, uint64_t seed);
+/* Position of that stream = the number of sampling forwards since pvr_policy_set_action_sampling; a caller that replaces a handle (larger
+ * T / B, another device) reads it from the old handle and sets it on the new one, so the noise stream continues instead of replaying
+ * (the reference's torch.multinomial consumes the global generator, which no module re-arms: src/models.py:78-80). */
+uint64_t pvr_policy_action_sampling_call(const pvr_policy *pol);
+pvr_status pvr_policy_set_action_sampling_call(pvr_policy *pol, uint64_t call);
 pvr_status pvr_policy_forward(pvr_policy *pol, const float *params, const pvr_policy_bn *bn, const void *obs,
                               const uint8_t *done, const float *h0, const float *c0, int32_t T, int32_t B,
                               int32_t training, float *logits, float *baseline, int64_t *action, float *h_out,

@@ -1,6 +1,7 @@
 // C-ABI glue: error state, version, single-operator entry points (include/pvr_hip.h).
 #include <stdarg.h>
 #include "common.h"
+#include "sample_rng.h"
 #include <dlfcn.h>
 
 namespace pvr {
@@ -132,6 +133,9 @@ pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_
 }
 
 int32_t pvr_debug_stem_u8_geometry_ok(const void *frames, int32_t h, int32_t w, int32_t top, int32_t left) { return stem_pool_u8_ok(frames, h, w, top, left) ? 1 : 0; }
+
+// test hook: the uniform in (0, 1) the action sampler makes of 32 random bits (sample_rng.h) - host arithmetic, no GPU work
+float pvr_debug_sample_uniform(uint32_t bits) { return pvr::uniform_open01(bits); }
 
 // 1 when the library carries the round-3 experiment kernels (conv_w4, split-bf16 GEMM, fused / persistent BPTT: make EXPERIMENTS=1), else 0
 int32_t pvr_has_experiments(void) {

@@ -322,6 +322,8 @@ long long conv_expand_launches() { return g_expand_launches; }
 // M = output pixels (n * ho * wo); h, w = input height / width (used for stride 2)
 pvr_status launch_conv_expand(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
                               int cout, int stride, int relu, int dtype, hipStream_t stream, int out_blk) {
+    // the blocked (P16C8) output layout exists in the per-pair epilogue only; the full-line epilogue (cin 256 / 512 instances) writes NHWC
+    PVR_REQUIRE(!out_blk || cin == 64, "conv_expand: blocked output is built for the cin = 64 instances only (cin = %d)", cin);
     ExpP p;
     p.out_blk = out_blk;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.res = (const u16 *)res; p.bias = bias; p.out = (u16 *)out;

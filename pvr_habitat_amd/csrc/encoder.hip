@@ -842,7 +842,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             } else if (op.ksplit > 1) {
                 s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, (float *)enc->d_buf[op.ks_buf],
                                        op.ksplit, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
-            } else if (l.out_blk && conv_algo() == -1 &&
+            } else if (l.out_blk && conv_algo() == -1 && op.cin == 64 &&    // (blocked output: the cin = 64 instances of conv_expand only)
                        conv_expand_supported((int64_t)nb * op.h * op.w, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, op.relu, 0, false)) {
                 // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
                 s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);

@@ -16,6 +16,8 @@ struct HostPolicy;
 HostPolicy *host_policy_new(const HostPolicyLayout &lay);
 void host_policy_free(HostPolicy *hp);
 void host_policy_set_sampling(HostPolicy *hp, int on, unsigned long long seed);
+unsigned long long host_policy_sampling_call(const HostPolicy *hp);
+void host_policy_set_sampling_call(HostPolicy *hp, unsigned long long call);
 pvr_status host_policy_forward(HostPolicy *hp, const float *params, const pvr_policy_bn *bn, const float *obs, const uint8_t *done, const float *h0,
                                const float *c0, int T, int B, int training, float *logits, float *baseline, int64_t *action, float *h_out, float *c_out);
 pvr_status host_policy_step(HostPolicy *hp, float *params, float *square_avg, const pvr_policy_bn *bn, const float *obs, const uint8_t *done,

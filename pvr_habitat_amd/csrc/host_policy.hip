@@ -76,6 +76,8 @@ static pvr_status forward_impl(HostPolicy *hp, const float *P, const pvr_policy_
     const int N = T * B, O = L.O, H = L.H, A = L.A;
     PVR_REQUIRE(P && obs && done && T > 0 && B > 0, "policy (host): null argument");
     PVR_REQUIRE(!L.bn || (bn && bn->running_mean && bn->running_var), "policy (host): batch_norm needs its buffers");
+    // torch: "Expected more than 1 value per channel when training" (F.batch_norm on an (N = 1, C) input): the unbiased variance does not exist
+    PVR_REQUIRE(!(L.bn && training && N == 1), "policy (host): BatchNorm in training mode needs more than one row (T * B = 1), as torch.nn.BatchNorm1d does");
     hp->nd.resize(N);
     for (int n = 0; n < N; ++n) hp->nd[n] = done[n] ? 0.f : 1.f;
     hp->a0.resize((size_t)N * O);
@@ -132,6 +134,8 @@ static pvr_status forward_impl(HostPolicy *hp, const float *P, const pvr_policy_
 }
 
 void host_policy_set_sampling(HostPolicy *hp, int on, unsigned long long seed) { hp->sample_on = on != 0; hp->sample_seed = seed; hp->sample_call = 0; }
+unsigned long long host_policy_sampling_call(const HostPolicy *hp) { return hp->sample_call; }
+void host_policy_set_sampling_call(HostPolicy *hp, unsigned long long call) { hp->sample_call = call; }
 
 pvr_status host_policy_forward(HostPolicy *hp, const float *params, const pvr_policy_bn *bn, const float *obs, const uint8_t *done, const float *h0,
                                const float *c0, int T, int B, int training, float *logits, float *baseline, int64_t *action, float *h_out, float *c_out) {
@@ -180,6 +184,9 @@ pvr_status host_policy_step(HostPolicy *hp, float *P, float *sq, const pvr_polic
     const HostPolicyLayout &L = hp->L;
     const int N = T * B, O = L.O, H = L.H, A = L.A;
     PVR_REQUIRE(P && sq && actions && stats_out, "policy step (host): null argument");
+    // reject the batch BEFORE the forward touches any state (the BatchNorm running statistics are updated in there), as the HIP plan and torch do
+    for (int n = 0; n < N; ++n)
+        PVR_REQUIRE(actions[n] >= 0 && actions[n] < A, "policy step (host): action %lld outside 0..%d", (long long)actions[n], A - 1);
     pvr_status s = forward_impl(hp, P, bn, obs, done, nullptr, nullptr, T, B, 1, logits_out, nullptr, nullptr, nullptr, nullptr);
     if (s) return s;
     // loss = mean over rows of -log_softmax(logits)[target]; dlogits = (softmax - onehot) / N
@@ -188,7 +195,6 @@ pvr_status host_policy_step(HostPolicy *hp, float *P, float *sq, const pvr_polic
     for (int n = 0; n < N; ++n) {
         const float *lg = hp->logits.data() + (size_t)n * A;
         const int64_t tg = actions[n];
-        PVR_REQUIRE(tg >= 0 && tg < A, "policy step (host): action %lld outside 0..%d", (long long)tg, A - 1);
         float mx = lg[0];
         for (int a = 1; a < A; ++a) mx = lg[a] > mx ? lg[a] : mx;
         double se = 0.0;

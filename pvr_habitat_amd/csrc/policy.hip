@@ -339,6 +339,8 @@ pvr_status forward_core(pvr_policy *pol, const float *P, const pvr_policy_bn *bn
                         hipStream_t st) {
     const auto &d = pol->d;
     const int N = T * B, H = d.hidden, O = d.obs_size;
+    // torch: "Expected more than 1 value per channel when training" (nn.BatchNorm1d on one row): no unbiased variance to put in running_var
+    PVR_REQUIRE(!(d.batch_norm && training && N == 1), "policy: BatchNorm in training mode needs more than one row (T * B = 1), as torch.nn.BatchNorm1d does");
     hipLaunchKernelGGL(notdone_kernel, dim3((N + 255) / 256), dim3(256), 0, st, done, pol->nd, N);
     const float *obs = (const float *)obs_in;
     if (d.conv_frames > 0) {
@@ -1050,6 +1052,19 @@ pvr_status pvr_policy_set_action_sampling(pvr_policy *pol, int32_t on, uint64_t 
     PVR_REQUIRE(pol, "pvr_policy_set_action_sampling: null policy");
     if (pol->hostp) { pvr::host_policy_set_sampling(pol->hostp, on, seed); return PVR_OK; }
     pol->sample_on = on != 0; pol->sample_seed = seed; pol->sample_call = 0;
+    return PVR_OK;
+}
+
+// the stream's position (number of sampling forwards so far) - read before a handle is destroyed, restored on its replacement, so that a handle
+// rebuilt because T or B grew (or after .to()) continues the noise stream instead of replaying it
+uint64_t pvr_policy_action_sampling_call(const pvr_policy *pol) {
+    if (!pol) return 0;
+    return pol->hostp ? pvr::host_policy_sampling_call(pol->hostp) : pol->sample_call;
+}
+pvr_status pvr_policy_set_action_sampling_call(pvr_policy *pol, uint64_t call) {
+    PVR_REQUIRE(pol, "pvr_policy_set_action_sampling_call: null policy");
+    if (pol->hostp) { pvr::host_policy_set_sampling_call(pol->hostp, call); return PVR_OK; }
+    pol->sample_call = call;
     return PVR_OK;
 }
 

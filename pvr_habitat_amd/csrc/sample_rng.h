@@ -19,6 +19,10 @@ __host__ __device__ inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
+// 32 random bits -> a uniform in the OPEN interval (0, 1): 23 bits, so that x + 0.5 is exact in fp32 (x < 2^23) and the result is never 0 or 1
+// (with 24 bits, 2^24 - 1 + 0.5 rounds to 2^24: u = 1, -log(-log u) = +inf and that action would win whatever the logits say)
+__host__ __device__ inline float uniform_open01(uint32_t bits) { return ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
 // one sample of softmax(l[0..A)), A <= 16
 __host__ __device__ inline int sample_softmax_row(const float *l, int A, uint64_t seed, uint64_t call, uint64_t row) {
     int best = 0;
@@ -27,7 +31,7 @@ __host__ __device__ inline int sample_softmax_row(const float *l, int A, uint64_
         uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)(a0 >> 2) << 24), (uint32_t)call, (uint32_t)(call >> 32)};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         for (int j = 0; j < 4 && a0 + j < A; ++j) {
-            const float u = ((float)(c[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1): 24 random bits, never 0 or 1
+            const float u = uniform_open01(c[j]);
             const float v = l[a0 + j] - logf(-logf(u));
             if ((a0 + j) == 0 || v > bv) { bv = v; best = a0 + j; }
         }

@@ -76,6 +76,10 @@ def _plib():
         L.pvr_policy_last_grads.argtypes = [vp, vp, vp]
         L.pvr_policy_set_action_sampling.restype = C.c_int
         L.pvr_policy_set_action_sampling.argtypes = [vp, C.c_int32, C.c_uint64]
+        L.pvr_policy_action_sampling_call.restype = C.c_uint64
+        L.pvr_policy_action_sampling_call.argtypes = [vp]
+        L.pvr_policy_set_action_sampling_call.restype = C.c_int
+        L.pvr_policy_set_action_sampling_call.argtypes = [vp, C.c_uint64]
         L.pvr_policy_status.restype = C.c_int
         L.pvr_policy_status.argtypes = [vp]
         L.pvr_policy_recurrence_mode.restype = i32
@@ -304,9 +308,10 @@ class PolicyNet(nn.Module):
         h = C.c_void_p()
         _lib.check((L.pvr_policy_create_host if self._host else L.pvr_policy_create)(C.byref(d), C.byref(h)))
         self._handle, self._handle_host = h, self._host
-        # training-mode forwards sample their action inside the library (models.py:78-80); the stream is keyed by torch's seed so that
-        # torch.manual_seed(k) before the first forward fixes it (torch's own generator stream cannot be reproduced, the distribution is)
-        _lib.check(L.pvr_policy_set_action_sampling(h, 1, C.c_uint64(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)))
+        # training-mode forwards sample their action inside the library (models.py:78-80).  A handle rebuilt for a larger T / B or after
+        # .to() continues this module's noise stream (key and position kept here) instead of replaying it from call 0
+        # (keyed per forward from torch's generator: _arm_sampling; a handle built here starts with sampling on and the last key)
+        _lib.check(L.pvr_policy_set_action_sampling(h, 1, C.c_uint64(getattr(self, '_sample_key', None) or (torch.initial_seed() & 0x3FFFFFFFFFFFFFFF))))
         assert L.pvr_policy_param_count(h) == self._flat.numel(), 'flat layout mismatch with libpvr_hip'
         assert L.pvr_policy_trainable_count(h) == self._n_train
         for k in self._order:
@@ -327,8 +332,21 @@ class PolicyNet(nn.Module):
     def initial_state(self, batch_size):
         return tuple(torch.zeros(2, batch_size, self.hidden) for _ in range(2))
 
+    def _arm_sampling(self):
+        """Key of the action noise of ONE training-mode forward.  The reference's torch.multinomial (models.py:78-80) consumes torch's
+        GLOBAL generator at every such forward: two modules never see the same noise, torch.manual_seed() restarts it at any time, and
+        nothing replays when a module is rebuilt.  torch's sample stream itself cannot be reproduced (its Philox offsets depend on its
+        launch geometry), so the library's counter-based stream is keyed, per forward, by one 62-bit draw FROM that generator: the noise
+        is a function of the generator state at the call, exactly the reference's dependency structure (same seed + same call order ->
+        same actions)."""
+        nonce = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self._sample_key = nonce
+        _lib.check(_plib().pvr_policy_set_action_sampling(self._handle, 1, C.c_uint64(nonce)))
+
     def _forward_raw(self, x, done, h0, c0, T, B, training):
         """one pvr_policy_forward enqueue on prepared device tensors -> (logits, baseline, action, h, c)"""
+        if training:
+            self._arm_sampling()
         dev, A = self.device, self.num_actions
         logits = torch.empty((T, B, A), dtype=torch.float32, device=dev)
         baseline = torch.empty((T, B), dtype=torch.float32, device=dev)

@@ -39,6 +39,21 @@ def test_host_weight_conversion_is_rne(dtype, tdt):
     assert np.array_equal(out, ref)
 
 
+def test_action_sampler_uniform_is_never_zero_or_one():
+    """the Gumbel-max sampler's uniform (csrc/sample_rng.h) stays inside (0, 1) for every 32-bit input: u = 1 would make -log(-log u) = +inf
+    and that action win whatever the logits say (with 24 random bits 0xFFFFFFFF rounded up to exactly 1.0)"""
+    L = C.CDLL(_lib.LIB_PATH)
+    L.pvr_debug_sample_uniform.restype = C.c_float
+    L.pvr_debug_sample_uniform.argtypes = [C.c_uint32]
+    rng = np.random.default_rng(3)
+    edge = [0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFDFF, 0xFFFFFE00, 0xFFFFFFFE, 0xFFFFFFFF]
+    us = np.array([L.pvr_debug_sample_uniform(int(b)) for b in edge + list(rng.integers(0, 2 ** 32, 2000))], np.float32)
+    assert us.min() > 0.0 and us.max() < 1.0
+    g = -np.log(-np.log(us.astype(np.float64)))
+    assert np.isfinite(g).all()
+    assert L.pvr_debug_sample_uniform(0xFFFFFFFF) == np.float32(1.0 - 2.0 ** -24) and L.pvr_debug_sample_uniform(0) == np.float32(2.0 ** -24)
+
+
 def test_errors_cross_the_abi_as_status_and_message():
     L = _lib.lib()
     h = C.c_void_p()

@@ -546,3 +546,25 @@ def test_native_stage_copy_gathers_rows_and_channel_planes():
     _lib.check(L.pvr_stage_copy(o.ctypes.data, big.ctypes.data, 3, 1 << 20, 1 << 20, 1 << 20, 1 << 20, 8))
     assert np.array_equal(o, big)
     assert L.pvr_stage_copy(o.ctypes.data, big.ctypes.data, 3, 100, 100, 7, 7, 2) != 0 and 'pvr_stage_copy' in _lib.last_error()
+
+
+def test_weights_fingerprint_covers_every_tensor():
+    """the shard-resume cover's `weights` field: a checkpoint that differs only in its LAST layers (a fine-tuned layer4, another compression
+    head) must not be mistaken for the one a half-finished shard was made with"""
+    from pvr_habitat_amd.save_embedded_obs import _weights_fingerprint
+
+    class _M:
+        def __init__(self, sd): self.sd = sd
+        def state_dict(self): return self.sd
+    g = torch.Generator().manual_seed(0)
+    sd = {'layer%02d.%d.weight' % (i // 4, i % 4): torch.randn(64, 300, generator=g) for i in range(90)}
+    sd['bn.num_batches_tracked'] = torch.tensor(7)
+    base = _weights_fingerprint(_M(sd))
+    assert base == _weights_fingerprint(_M({k: v.clone() for k, v in sd.items()}))
+    lk = sorted(k for k in sd if k.startswith('layer'))
+    for key, idx in ((lk[-1], -1), (lk[70], 5000), (lk[0], 0)):
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2[key].view(-1)[idx] += 1e-3
+        assert _weights_fingerprint(_M(sd2)) != base, key
+    sd3 = dict(sd); sd3['bn.num_batches_tracked'] = torch.tensor(8)
+    assert _weights_fingerprint(_M(sd3)) != base

@@ -178,14 +178,30 @@ def _sampling_check(m, dev, T=40, B=16, O=64, calls=12):
         assert hit > 0.99
     assert any(not np.array_equal(acts[0], a) for a in acts[1:]), 'every call must draw new samples'
     # the stream restarts with the seed: same seed -> same actions, another seed -> others
+    # the noise is a function of torch's global generator at the call, as the reference's torch.multinomial is: re-seeding restarts it,
+    # another seed gives other actions, a second module (or a rebuilt handle) continues the generator's stream instead of replaying
+    def draw(seed, net=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        with torch.no_grad():
+            return (net or m)(dict(obs=obs, done=done), m.initial_state(B))[0]['action'].cpu().numpy()
+    a1, a1b, a2, a3 = draw(77), draw(None), draw(77), draw(78)
+    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3) and not np.array_equal(a1, a1b)
+    m2 = _sampling_net()
+    m2 = m2.to(dev) if dev != 'cpu' else m2.use_host_backend(True)
+    m2.train()
+    torch.manual_seed(77)
+    b1, b2 = draw(None), draw(None, m2)                       # two modules, one generator: the second does not repeat the first
+    assert np.array_equal(b1, a1) and not np.array_equal(b2, b1)
+    m._release()                                              # a rebuilt handle does not replay either
+    assert not np.array_equal(draw(None), b1)
+    m2.close()
+    # the library's stream position travels with a handle replacement for hosts that key it once (pvr_policy_action_sampling_call)
     from pvr_habitat_amd.models import _plib
     import ctypes as C
-    def draw(seed):
-        assert _plib().pvr_policy_set_action_sampling(m._handle, 1, C.c_uint64(seed)) == 0
-        with torch.no_grad():
-            return m(dict(obs=obs, done=done), m.initial_state(B))[0]['action'].cpu().numpy()
-    a1, a2, a3 = draw(77), draw(77), draw(78)
-    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
+    L = _plib()
+    assert L.pvr_policy_set_action_sampling(m._handle, 1, C.c_uint64(5)) == 0 and int(L.pvr_policy_action_sampling_call(m._handle)) == 0
+    assert L.pvr_policy_set_action_sampling_call(m._handle, C.c_uint64(41)) == 0 and int(L.pvr_policy_action_sampling_call(m._handle)) == 41
     m.eval()
     with torch.no_grad():
         out, _ = m(dict(obs=obs, done=done), m.initial_state(B))
@@ -208,4 +224,31 @@ def test_host_policy_samples_training_actions_from_softmax():
     m = _sampling_net()
     m.use_host_backend(True)
     _sampling_check(m, 'cpu')
+    m.close()
+
+
+def test_host_policy_step_rejects_a_bad_batch_before_touching_state():
+    """an out-of-range target action fails the step BEFORE the forward has updated the BatchNorm running statistics (the HIP plan and torch reject the
+    batch up front too); and BatchNorm in training mode refuses a single row, as nn.BatchNorm1d does"""
+    from pvr_habitat_amd.models import PolicyNet, HipRMSprop
+    O, A, T, B = 64, 3, 4, 2
+    m = PolicyNet((O,), A, True, max_unroll=T, max_batch=B)
+    sd = synth.policy_state_dict(3, O, A, True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.use_host_backend(True).train()
+    obs, done, act = synth.bc_batches(3, T, B, O, A, 1)
+    opt = HipRMSprop(m, max_epochs=10)
+    bad = act[0].copy(); bad[1, 1] = A
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    with pytest.raises(RuntimeError, match='outside 0'):
+        opt.step(torch.from_numpy(obs[0]), torch.from_numpy(done[0]), torch.from_numpy(bad))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                   # running_mean / running_var / num_batches_tracked / parameters untouched
+    with pytest.raises(RuntimeError, match='more than one row'):
+        with torch.no_grad():
+            m(dict(obs=torch.from_numpy(obs[0][:1, :1]), done=torch.zeros(1, 1, dtype=torch.bool)), m.initial_state(1))
+    m.eval()
+    with torch.no_grad():
+        out, _ = m(dict(obs=torch.from_numpy(obs[0][:1, :1]), done=torch.zeros(1, 1, dtype=torch.bool)), m.initial_state(1))
+    assert out['action'].shape == (1, 1)
     m.close()
