@@ -75,18 +75,48 @@ def conv_algorithmic_bytes(n, names=None):
     return tot * 2 * n
 
 
+def cpu_limits():
+    """what this process may actually use: the scheduler affinity mask and the cgroup CPU quota (cpu.max: "<quota> <period>" or "max")"""
+    lim = {'os_cpu_count': os.cpu_count()}
+    try:
+        lim['affinity_cores'] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        lim['affinity_cores'] = None
+    quota = None
+    for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(f).read().split()
+            if f.endswith('cpu.max'):
+                quota = None if txt[0] == 'max' else round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0])
+                quota = None if q <= 0 else round(q / int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    lim['cgroup_cpu_quota'] = quota                       # CPUs' worth of time per period; None = unlimited
+    return lim
+
+
 def cpu_baseline(sd, frames_u8, budget_s=12.0):
     """The oracle (torch fp32 eager restatement of the reference path) timed on this box's host cores,
-    batch 64 like the reference's 32 obs x 2 frames (save_embedded_obs.py:151-153)."""
+    batch 64 like the reference's 32 obs x 2 frames (save_embedded_obs.py:151-153).  `cores` = the thread count of the timed sample = the
+    fastest of a sweep (torch's CPU convolutions stop scaling - and regress - at high thread counts: the sweep is in the line, next to the
+    affinity mask and the cgroup quota, so that `cores` can be read against what the process was allowed to use)."""
     from oracle import encoder_oracle as eo
-    # torch CPU convs stop scaling (and regress) at very high thread counts: probe a few, keep the fastest
-    best, best_t = 1, float('inf')
-    for th in sorted({min(os.cpu_count() or 1, t) for t in (16, 32, 64, 128)}):
+    lim = cpu_limits()
+    avail = lim['affinity_cores'] or os.cpu_count() or 1
+    if lim['cgroup_cpu_quota']:
+        avail = max(1, min(avail, int(lim['cgroup_cpu_quota'])))
+    sweep, best, best_t = {}, 1, float('inf')
+    for th in sorted({min(avail, t) for t in (1, 4, 8, 16, 32, 64, 128, 256)}):
         torch.set_num_threads(th)
-        eo.embed(sd, frames_u8[:8], 'conv5')                  # warm-up at this thread count
-        t0 = time.perf_counter(); eo.embed(sd, frames_u8[:16], 'conv5'); dt = time.perf_counter() - t0
-        if dt < best_t:
-            best, best_t = th, dt
+        nfr = 4 if th == 1 else 16
+        eo.embed(sd, frames_u8[:min(8, nfr)], 'conv5')         # warm-up at this thread count
+        t0 = time.perf_counter(); eo.embed(sd, frames_u8[:nfr], 'conv5'); dt = time.perf_counter() - t0
+        sweep[str(th)] = round(nfr / dt, 2)
+        if dt / nfr < best_t:
+            best, best_t = th, dt / nfr
     torch.set_num_threads(best)
     done, t0 = 0, time.perf_counter()
     while True:
@@ -97,7 +127,9 @@ def cpu_baseline(sd, frames_u8, budget_s=12.0):
             break
     res = dict(value=round(done / el, 2), unit='frames/s', cores=torch.get_num_threads(), kind='port',
                sample='%d synthetic 256x256 frames in batches of 64, torch fp32 eager oracle, %.1f s' % (done, el),
-               cpu_model=cpu_model(), box_cores=os.cpu_count())
+               cpu_model=cpu_model(), box_cores=os.cpu_count(), affinity_cores=lim['affinity_cores'], cgroup_cpu_quota=lim['cgroup_cpu_quota'],
+               thread_sweep_frames_per_s=sweep,
+               thread_sweep_note='one 16-frame batch per thread count (4 frames at 1 thread) after a warm-up; `cores` = the fastest, used for the timed sample')
     # the reference launchers pin OMP_NUM_THREADS=1 (slurm_eo.py:13): the same oracle on ONE thread, on a smaller sample
     torch.set_num_threads(1)
     eo.embed(sd, frames_u8[:2], 'conv5')
@@ -320,12 +352,17 @@ def vit_bench(variant, batch, steps, warmup, dtype, streams=None):
             'frac_of_mfma_peak': round(fps * VIT_GFLOP[variant] / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 
-def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
+def pcie_bench(model_sd, batch, frames_np, dtype, passes=2, dist=None):
     """PCIe-inclusive rate (never the headline `value`): host-resident uint8 frames -> (pinned staging ->) H2D ->
     encoder -> D2H fp32 embeddings, overlapped on separate HIP streams (embeddings.stream_embed, the path save_embedded_obs uses).
     The whole frame pool (4096 frames = 16 batches) is streamed `passes` times per measurement, so pipeline fill / drain and the
-    one-off buffer set-up are a small part of the timed region."""
+    one-off buffer set-up are a small part of the timed region.
+
+    dist (N > 1, round 5): every rank streams its own pool at the same time (barrier on both sides, MAX over ranks) - the ranks share the
+    host's memory bandwidth, staging threads and PCIe root complexes, which is what SURVEY 8e names as the scaling limit of the
+    precompute path; the aggregate is all ranks' frames over the slowest rank's time."""
     from pvr_habitat_amd.embeddings import HipResNet50, stream_embed
+    world = dist.get_world_size() if dist is not None else 1
 
     class _Net:                                           # minimal EmbeddingNet-like holder
         pass
@@ -337,14 +374,25 @@ def pcie_bench(model_sd, batch, frames_np, dtype, passes=2):
     res = {}
     for kind, src in (('pageable_source', fr), ('pinned_source', fr.pin_memory())):
         stream_embed(net, src, batch)                     # untimed full pass: the GPU has idled through the CPU legs before this one (clock ramp)
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         out = stream_embed(net, src, batch)
+        if dist is not None:
+            dist.barrier()
         el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
         assert np.isfinite(out).all()
-        res[kind] = {'value': round(fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(fr.numel() / el / 1e9, 2)}
-    res['frames'] = int(fr.shape[0])
+        res[kind] = {'value': round(world * fr.shape[0] / el, 1), 'unit': 'frames/s', 'h2d_GBps': round(world * fr.numel() / el / 1e9, 2)}
+    res['frames'] = int(fr.shape[0]) * world
+    res['n_gpus'] = world
     res['note'] = ('host uint8 frames (a pageable source is copied into a pinned staging ring by 8 native threads of the library (pvr_stage_copy) on a producer thread that runs ahead of the GPU work; page-locking it in place is opt-in: PVR_STREAM_REGISTER=1) -> H2D -> encode (two lanes) -> D2H fp32, '
-                   'copies overlapped with compute on separate HIP streams; includes registering the source and allocating the page-locked result buffer')
+                   'copies overlapped with compute on separate HIP streams; includes registering the source and allocating the page-locked result buffer'
+                   + ('' if world == 1 else '; all %d ranks stream their own pool concurrently (barrier on both sides, max over ranks): aggregate rate' % world))
+    net.embedding.close()
     return res
 
 
@@ -385,62 +433,146 @@ def png_source_bench(model_sd, batch, dtype, n_traj=48, length=250, hw=64):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def save_obs_e2e_bench(batch, dtype, n_samples=100000, traj_len=500, hw=64):
+def save_obs_e2e_bench(batch, dtype, n_samples=100000, traj_len=500, hw=64, dist=None, reps=3):
     """The real driver end to end (round-3 verdict item 3c): pvr_habitat_amd.save_embedded_obs.run(flags) - the drop-in for the reference's
     behavioral_cloning/save_embedded_obs.py:96-172 - on a synthetic scene pickle of n_samples (hw, hw, 6) uint8 observations in the
     reference's per-trajectory layout (save_opt_trajectories.py:100-106).  Wall clock of run(): scene index pass, streamed unpickling into
     pinned blocks, embedding of both 3-channel planes of every row, shard file, stitch and the output pickle (protocol 5).  frames/s counts
-    embedded FRAMES (2 per sample).  The scene is written to a temporary directory first (untimed)."""
+    embedded FRAMES (2 per sample).  The scene is written to a temporary directory first (untimed).  The timed run is repeated `reps` times
+    (the output removed in between) and the MEDIAN reported with all samples: one run swung 50-59 k with the leg order in round 4.
+
+    dist (N > 1, round 5): ONE scene, every rank embeds its contiguous row range into its own shard file, rank 0 stitches (the
+    host - readers, pinned memory - is what limits this path's scaling); the wall clock is barrier to barrier, MAX over ranks."""
     import contextlib, pickle, shutil, tempfile
     from pvr_habitat_amd import save_embedded_obs as S
-    d = tempfile.mkdtemp(prefix='pvr_e2e_bench_')
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    d = tempfile.mkdtemp(prefix='pvr_e2e_bench_') if rank == 0 else None
+    if dist is not None:
+        box = [d]
+        dist.broadcast_object_list(box, 0)
+        d = box[0]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
     try:
         rng = np.random.default_rng(5)
-        lens = [traj_len] * (n_samples // traj_len) + ([n_samples % traj_len] if n_samples % traj_len else [])
-        base = rng.integers(0, 256, (traj_len, hw, hw, 6), dtype=np.uint8)
-        raw = dict(obs=[], action=[], reward=[], done=[], true_state=[])
-        for t, L in enumerate(lens):
-            raw['obs'].append(np.roll(base[:L], t, axis=1))            # distinct trajectories, cheap to make
-            raw['action'].append(rng.integers(0, 3, L)); raw['reward'].append(np.zeros(L)); raw['done'].append(np.arange(L) == L - 1)
-            raw['true_state'].append(np.zeros((L, 12), np.float32))
-        with open(os.path.join(d, 'scene.pickle'), 'wb') as f:
-            pickle.dump(raw, f, protocol=pickle.HIGHEST_PROTOCOL)
-        scene_bytes = os.path.getsize(os.path.join(d, 'scene.pickle'))
-        del raw, base
+        scene_bytes = 0
+        if rank == 0:
+            lens = [traj_len] * (n_samples // traj_len) + ([n_samples % traj_len] if n_samples % traj_len else [])
+            base = rng.integers(0, 256, (traj_len, hw, hw, 6), dtype=np.uint8)
+            raw = dict(obs=[], action=[], reward=[], done=[], true_state=[])
+            for t, L in enumerate(lens):
+                raw['obs'].append(np.roll(base[:L], t, axis=1))            # distinct trajectories, cheap to make
+                raw['action'].append(rng.integers(0, 3, L)); raw['reward'].append(np.zeros(L)); raw['done'].append(np.arange(L) == L - 1)
+                raw['true_state'].append(np.zeros((L, 12), np.float32))
+            with open(os.path.join(d, 'scene.pickle'), 'wb') as f:
+                pickle.dump(raw, f, protocol=pickle.HIGHEST_PROTOCOL)
+            scene_bytes = os.path.getsize(os.path.join(d, 'scene.pickle'))
+            del raw, base
+            wd = os.path.join(d, 'warm'); os.makedirs(wd)
+            with open(os.path.join(wd, 'scene.pickle'), 'wb') as f:
+                nw = 4 * batch * world
+                pickle.dump(dict(obs=[rng.integers(0, 256, (nw, hw, hw, 6), dtype=np.uint8)], action=[np.zeros(nw, np.int64)],
+                                 reward=[np.zeros(nw)], done=[np.zeros(nw, bool)], true_state=[np.zeros((nw, 12), np.float32)]), f)
+        barrier()
         os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
         argv = ['--data_path', d, '--env', 'scene', '--embedding_name', 'resnet50', '--disable_pretrained_embedding', '--source', 'pickle',
                 '--embed_batch', str(batch), '--compute_dtype', dtype]
+        out = os.path.join(d, 'scene_resnet50.pickle')
+        els = []
         with contextlib.redirect_stdout(open(os.devnull, 'w')):
             # warm-up on a tiny scene of the same frame size (library load, plan, first launches, both lanes): not part of the measurement
-            wd = os.path.join(d, 'warm'); os.makedirs(wd)
-            with open(os.path.join(wd, 'scene.pickle'), 'wb') as f:
-                pickle.dump(dict(obs=[rng.integers(0, 256, (4 * batch, hw, hw, 6), dtype=np.uint8)], action=[np.zeros(4 * batch, np.int64)],
-                                 reward=[np.zeros(4 * batch)], done=[np.zeros(4 * batch, bool)], true_state=[np.zeros((4 * batch, 12), np.float32)]), f)
-            S.run(S.make_parser().parse_args(['--data_path', wd] + argv[2:]))
-            t0 = time.perf_counter()
-            S.run(S.make_parser().parse_args(argv))
-            el = time.perf_counter() - t0
-        out = os.path.join(d, 'scene_resnet50.pickle')
+            S.run(S.make_parser().parse_args(['--data_path', os.path.join(d, 'warm')] + argv[2:]))
+            for r_ in range(reps):
+                barrier()
+                if rank == 0 and os.path.isfile(out):
+                    os.remove(out)                          # (run() returns at once when its output exists: save_embedded_obs.py:97-101)
+                barrier()
+                t0 = time.perf_counter()
+                S.run(S.make_parser().parse_args(argv))
+                barrier()
+                el = time.perf_counter() - t0
+                if dist is not None:
+                    t = torch.tensor([el], dtype=torch.float64, device='cuda')
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    el = float(t.item())
+                els.append(el)
+        if rank != 0:
+            return None
         with open(out, 'rb') as f:
             res = pickle.load(f)
         assert res['obs'].shape == (n_samples, 2 * 2048) and np.isfinite(res['obs'][:1024]).all() and np.isfinite(res['obs'][-1024:]).all()
+        el = sorted(els)[(len(els) - 1) // 2]
         return {'metric': 'frames/sec embedded by save_embedded_obs.run end to end (scene pickle -> embeddings pickle)', 'value': round(2 * n_samples / el, 1),
-                'unit': 'frames/s', 'samples': n_samples, 'frames_per_sample': 2, 'frame': hw, 'dtype': dtype, 'wall_s': round(el, 2),
-                'scene_MB': round(scene_bytes / 1e6, 1), 'out_MB': round(os.path.getsize(out) / 1e6, 1),
-                'note': 'wall clock of run(flags): index pass + streamed unpickle into pinned blocks (reader thread) + H2D + ResNet50 on both planes + D2H + '
-                        'shard file + stitch + output pickle; 64x64 frames are bilinearly resized to 256 on the GPU (Resize(256), embeddings.py:80-85)'}
+                'unit': 'frames/s', 'samples': n_samples, 'frames_per_sample': 2, 'frame': hw, 'dtype': dtype, 'wall_s': round(el, 2), 'n_gpus': world,
+                'runs_frames_per_s': [round(2 * n_samples / e, 1) for e in els], 'scene_MB': round(scene_bytes / 1e6, 1), 'out_MB': round(os.path.getsize(out) / 1e6, 1),
+                'note': 'MEDIAN of %d runs of run(flags), wall clock%s: index pass + streamed unpickle into pinned blocks (reader thread) + H2D + ResNet50 on both planes + D2H + '
+                        '%s + output pickle; 64x64 frames are bilinearly resized to 256 on the GPU (Resize(256), embeddings.py:80-85)'
+                        % (len(els), '' if world == 1 else ' barrier to barrier, max over ranks', 'rows straight into the output pickle' if world == 1 else
+                           'per-rank shard files (contiguous row ranges of the one scene) + rank-0 stitch')}
     finally:
-        shutil.rmtree(d, ignore_errors=True)
+        barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
 
 
-def parity_rel_l2(model, sd, frames_np):
-    """the TIMED model (same handle, same dtype) against the CPU oracle on a few frames of the bench's own pool"""
+def uber5crop_bench(batch, dtype, n_frames=1024, frame=256):
+    """BASELINE configs[4]: the paper's best PVR - moco_aug_uber_345 (three separately loaded ResNet50 trunks: l3-compressed, l4-compressed,
+    conv5; src/embeddings.py:44-57,195-280) on 5 crop windows per frame (corner + centre, torchvision FiveCrop order: the build-defined
+    extension of configs[4]), 256x256 uint8 frames in pinned host memory -> H2D -> 15 trunk forwards per frame -> D2H of 31 310 floats
+    per frame, overlapped (stream_embed: "embeddings streamed to host").  frames/s and the trunks' rate against the MFMA peak
+    (115.69 GFLOP per frame)."""
+    os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
+    from pvr_habitat_amd import synth
+    from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed
+    net = EmbeddingNet('moco_aug_uber_345', pretrained=False, crops=5, max_batch=batch, compute_dtype=dtype)
+    assert net.out_size == 5 * 6262
+    fr = torch.from_numpy(synth.frames(5, n_frames, frame, frame)).pin_memory()
+    out = torch.empty((n_frames, net.out_size), dtype=torch.float32).pin_memory()
+    stream_embed(net, fr[:2 * batch], batch=batch, out=out[:2 * batch])         # warm-up (allocations, first-use attributes, both lanes)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    stream_embed(net, fr, batch=batch, out=out)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    assert np.isfinite(out.numpy()[::97]).all()
+    net.close()
+    fps = n_frames / el
+    gflop = 5 * 23.138
+    return {'metric': 'frames/sec embedded (5-crop moco_aug_uber_345, 256x256, streamed to host)', 'value': round(fps, 1), 'unit': 'frames/s', 'dtype': dtype,
+            'frames': n_frames, 'floats_per_frame': int(net.out_size), 'trunk_forwards_per_frame': 15, 'trunk_frames_per_s': round(15 * fps, 1),
+            'd2h_GBps': round(fps * net.out_size * 4 / 1e9, 3), 'tflops': round(fps * gflop / 1e3, 1),
+            'frac_of_mfma_peak': round(fps * gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
+            'note': 'algorithmic %.2f GFLOP per frame (5 windows x 23.138); in f16 the l3 / l4 members run their last stage and head in fp32 on the f32-input '
+                    'MFMA (1/16 the rate: the parity plan of the compressed PVRs, DESIGN 2), so the f16 figure is not comparable with the 16-bit peak' % gflop}
+
+
+_ORACLE_REF = {}
+
+
+def parity_stats(model, sd, frames_np, n_frames=8):
+    """the TIMED model (same handle, same dtype) against the CPU oracle on a few frames of the bench's own pool: rel-L2, max|d| / max|ref|,
+    and the ELEMENT-WISE relative error |out - ref| / |ref| over the elements with |ref| > 1e-2 max|ref| (below that a post-ReLU average is
+    indistinguishable from zero and a relative error means nothing): p50 / p99 / max.  The oracle forward is computed once per run."""
     from oracle import encoder_oracle as eo
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    fr = frames_np[:4]
-    ref = eo.embed(sd, fr, 'conv5', squeeze=False)
-    out = model(torch.from_numpy(fr).cuda()).cpu().numpy()
-    return float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+    key = (id(sd), n_frames)
+    fr = frames_np[:n_frames]
+    if key not in _ORACLE_REF:
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16))
+        _ORACLE_REF[key] = eo.embed(sd, fr, 'conv5', squeeze=False).astype(np.float64)
+    ref = _ORACLE_REF[key]
+    out = model(torch.from_numpy(fr).cuda()).cpu().numpy().astype(np.float64)
+    d = np.abs(out - ref)
+    big = np.abs(ref) > 1e-2 * np.abs(ref).max()
+    rel = d[big] / np.abs(ref[big])
+    return {'rel_l2': float(np.linalg.norm(out - ref) / np.linalg.norm(ref)), 'max_norm': float(d.max() / np.abs(ref).max()),
+            'elementwise': {'p50': float(np.percentile(rel, 50)), 'p99': float(np.percentile(rel, 99)), 'max': float(rel.max()),
+                            'n_elements': int(big.sum()), 'of': int(ref.size), 'frames': int(len(fr)),
+                            'note': '|out - ref| / |ref| over the elements with |ref| > 1e-2 * max|ref|, fp32 CPU oracle'}}
+
+
+def _r(x, nd=6):
+    return float('%.*g' % (nd, x))
 
 
 def self_launch(n):
@@ -478,7 +610,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--frame', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--dtype', default='f16', choices=['bf16', 'f16', 'f32'],
+                    help='storage / MFMA input type of the headline leg.  f16 (default since round 5) is the product default and the type that meets the '
+                         'north-star 1e-3 parity bound; the other 16-bit type (bf16: BASELINE configs[1] names it, 3e-3) runs as a second leg of the SAME length')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--lanes', type=int, default=2, help='batches in flight per GPU (1 = strictly one forward at a time)')
     ap.add_argument('--pool', type=int, default=4096, help='distinct frames resident in HBM, cycled batch by batch (SURVEY 8d frame pool)')
@@ -490,7 +624,8 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the save_embedded_obs end-to-end leg (writes a 2.4 GB synthetic scene pickle to a temporary directory)')
     ap.add_argument('--e2e-samples', type=int, default=100000, help='observations of the end-to-end leg\'s synthetic scene')
     ap.add_argument('--no-vit', action='store_true', help='skip the CLIP ViT legs (BASELINE config 3)')
-    ap.add_argument('--no-f16', action='store_true', help='skip the f16 (parity-mode) leg')
+    ap.add_argument('--no-f16', '--no-alt-dtype', dest='no_f16', action='store_true', help='skip the second 16-bit leg (bf16 beside an f16 headline, f16 beside a bf16 one)')
+    ap.add_argument('--no-uber', action='store_true', help='skip the configs[4] leg (5-crop moco_aug_uber_345 streamed to the host)')
     ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel finetune leg (N > 1)')
     ap.add_argument('--no-fuse', action='store_true', help='one launch per convolution (A/B against the fused bottleneck tails)')
     ap.add_argument('--per-op', action='store_true', help='print per-launch ms / TFLOP/s of one chunk to stderr')
@@ -541,8 +676,11 @@ def main():
     # is allocated right after another model's 5 GB workspace was freed ran 14 % slower; scripts/sustained_rate.py: with both
     # resident, ten back-to-back 1 s legs give bf16 80.3 k and f16 79.3 k frames/s, flat).
     models = {args.dtype: make_model(args.dtype, args.lanes)}
-    if not args.no_f16 and args.dtype != 'f16':
-        models['f16'] = make_model('f16', args.lanes)
+    alt = {'f16': 'bf16', 'bf16': 'f16'}.get(args.dtype)        # the other 16-bit storage type, timed at the same length beside the headline
+    if args.no_f16:
+        alt = None
+    if alt:
+        models[alt] = make_model(alt, args.lanes)
 
     # the compute streams of every leg, created once: HIP maps streams onto a few hardware queues in creation order, and two lanes whose
     # streams land on the same hardware queue serialise (a leg on freshly created streams measured the one-lane rate)
@@ -611,9 +749,9 @@ def main():
     el_one = repeated_leg(args.dtype, args.steps, 1, 1, min_total_s=0.4)[1] if lanes > 1 else el
     # the parity mode at the headline configuration, back to back with the headline leg (all ranks run it: weak scaling)
     leg16 = None
-    if 'f16' in models and args.dtype != 'f16':
-        k16 = max(args.steps // 2, 2 * args.lanes)
-        m16, el16, l16, el16_all = repeated_leg('f16', k16, args.warmup, args.lanes)
+    if alt:
+        k16 = args.steps                                      # full length: the two 16-bit types are reported side by side
+        m16, el16, l16, el16_all = repeated_leg(alt, k16, args.warmup, args.lanes)
         leg16 = (m16, el16, l16, k16, el16_all)
     out = torch.empty((args.batch, model.out_size), dtype=torch.float32, device='cuda')
     frames = batches[0]
@@ -702,7 +840,9 @@ def main():
                               'note': 'the %d-step leg (barrier + synchronize on both sides) repeated until the timed regions total >= 1 s; '
                                       'value / ms_per_step / timed_region_s are the MEDIAN leg' % args.steps},
             'config': {'workload': 'configs[1]: ResNet50 (MoCo-v2 layout) frozen, %dx%d uint8 frames resident in HBM, batch %d/GPU, '
-                                   'random-init synthetic weights' % (args.frame, args.frame, args.batch),
+                                   'random-init synthetic weights, %s storage / MFMA inputs with fp32 accumulation%s'
+                                   % (args.frame, args.frame, args.batch, args.dtype,
+                                      ' (the product default, inside the 1e-3 parity bound; configs[1] names bf16: the `bf16` leg of the same length is in this line)' if args.dtype == 'f16' else ''),
                        'global_batch': world * args.batch, 'frame': args.frame, 'chunk': chunk, 'batches_in_flight': lanes,
                        'frame_pool': '%d distinct frames per GPU resident in HBM, cycled batch by batch (every step embeds a different batch)' % n_pool,
                        'parallelism': 'frame shards, no collective (dp%d)' % world},
@@ -732,25 +872,51 @@ def main():
                          'stages': stages},
         }
         # parity of what was timed: the same model handle / dtype vs the fp32 CPU oracle (north-star tolerance 1e-3 relative fp32)
-        line['parity_rel_l2'] = round(parity_rel_l2(model, sd, pool_np), 6)
-        line['parity_note'] = ('rel-L2 of the timed %s embeddings vs the fp32 CPU oracle on 4 frames of the pool; north-star bound 1e-3: '
-                               'met by the f16 leg below (same kernels, same speed class), bf16 storage (8-bit mantissa) sits at ~3e-3' % args.dtype)
+        ps = parity_stats(model, sd, pool_np)
+        line['parity_rel_l2'] = round(ps['rel_l2'], 6)
+        line['parity'] = {args.dtype: {'rel_l2': _r(ps['rel_l2']), 'max_norm': _r(ps['max_norm']), 'elementwise': {k: (_r(v) if isinstance(v, float) else v) for k, v in ps['elementwise'].items()}}}
+        line['parity_note'] = ('timed embeddings vs the fp32 CPU oracle on 8 frames of the pool, per storage type: rel-L2, max|d| / max|ref| and the element-wise '
+                               'relative error distribution.  North-star bound 1e-3: met by f16 (the product default and, since round 5, the headline); bf16 '
+                               'storage (8-bit significand) sits at ~3e-3')
     if leg16 is not None and rank == 0:
         m16, el16, l16, k16, el16_all = leg16
-        line['f16'] = {'metric': 'frames/sec embedded (ResNet50, 256x256), f16 storage (parity mode)', 'value': round(world * k16 * args.batch / el16, 1),
-                       'unit': 'frames/s', 'dtype': 'f16', 'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 3), 'batches_in_flight': l16,
-                       'timed_region_s': round(el16, 3), 'timed_repeats': len(el16_all), 'parity_rel_l2': round(parity_rel_l2(m16, sd, pool_np), 6)}
+        ps16 = parity_stats(m16, sd, pool_np)
+        line['parity'][alt] = {'rel_l2': _r(ps16['rel_l2']), 'max_norm': _r(ps16['max_norm']), 'elementwise': {k: (_r(v) if isinstance(v, float) else v) for k, v in ps16['elementwise'].items()}}
+        line[alt] = {'metric': 'frames/sec embedded (ResNet50, 256x256), %s storage' % alt, 'value': round(world * k16 * args.batch / el16, 1),
+                     'unit': 'frames/s', 'dtype': alt, 'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 3), 'batches_in_flight': l16,
+                     'timed_region_s': round(el16, 3), 'timed_repeats': len(el16_all), 'parity_rel_l2': round(ps16['rel_l2'], 6),
+                     'note': 'the same leg as the headline (same steps, same frame pool, same kernels) with the other 16-bit storage type'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, pool_np[:args.batch])
         if world == 1 and not args.no_png:
             line['png_source'] = png_source_bench(sd, args.batch, args.dtype, n_traj=args.png_traj)
-        if world == 1 and not args.no_pcie:
-            line['pcie_inclusive'] = pcie_bench(sd, args.batch, pool_np, args.dtype)
+    # The host-fed legs run at every N (round 5): at N > 1 all ranks run them concurrently, so that the line says what the HOST side
+    # (pinned-memory bandwidth, staging / reader threads, the file system) does to the scaling of the precompute path - the HBM-resident
+    # `value` cannot fail to scale.  A failure here must not cost the headline: it is reported inside the line.
+    def host_leg(key, fn):
+        try:
+            r = fn()
+            if rank == 0 and r is not None:
+                line[key] = r
+        except Exception as e:                                  # noqa: BLE001
+            if world == 1:
+                raise
+            if rank == 0:
+                line[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if not args.no_pcie:
+        host_leg('pcie_inclusive', lambda: pcie_bench(sd, args.batch, pool_np, args.dtype, dist=dist))
+        if rank == 0 and 'pinned_source' in line.get('pcie_inclusive', {}):
             # host uint8 -> H2D -> encode -> D2H fp32, the end-to-end rate of the "embeddings streamed to host" path (never `value`)
             line['value_pcie_inclusive'] = line['pcie_inclusive']['pinned_source']['value']
-        if world == 1 and not args.no_e2e and not args.no_pcie:
-            line['save_embedded_obs_e2e'] = save_obs_e2e_bench(args.batch, args.dtype, n_samples=args.e2e_samples)
+    if not args.no_e2e and not args.no_pcie:
+        host_leg('save_embedded_obs_e2e', lambda: save_obs_e2e_bench(args.batch, args.dtype, n_samples=args.e2e_samples, dist=dist))
+    if rank == 0:
+        if world == 1 and not args.no_uber:
+            # configs[4]: bf16 = the throughput plan (every trunk 16-bit), f16 = the parity plan of the compressed members (fp32 last stage)
+            line['uber5crop'] = uber5crop_bench(args.batch, 'bf16')
+            line['uber5crop']['f16_parity_plan'] = {k: v for k, v in uber5crop_bench(args.batch, 'f16', n_frames=512).items()
+                                                    if k in ('value', 'unit', 'dtype', 'frames', 'trunk_frames_per_s', 'tflops', 'frac_of_mfma_peak')}
         if world == 1 and not args.no_vit:
             vdt = 'f16' if args.dtype == 'f32' else args.dtype   # the fp32 mode covers the ResNet50 family only
             line['vit'] = [vit_bench('clip_b16', args.batch, 20, 2, vdt, lane_streams[:2] if len(lane_streams) >= 2 else None),

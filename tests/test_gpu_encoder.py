@@ -784,6 +784,36 @@ def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
     assert torch.equal(outs['wave_ring'], outs['block']), float((outs['wave_ring'] - outs['block']).abs().max())
 
 
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_chain_wave_equals_block_form_at_the_bench_batch(dtype, monkeypatch):
+    """The same bit-identity at the headline configuration (batch 256 of random 256 x 256 frames, where every CU runs many tiles, the
+    XCD-aware chunk walk wraps and the persistent launches are full): EVERY element of layer1's output (205 M values), of layer2's output
+    and of the embedding, wave form against block form.  (Until round 5 this every-element check at batch 256 lived only in
+    scripts/chain_wave_bench.hip.)"""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    n = 256
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    fr = torch.from_numpy(synth.frames(5, n, 256, 256)).cuda()
+    got = {}
+    for key, wave in (('block', '0'), ('wave', '1')):
+        monkeypatch.setenv('PVR_CHAIN_WAVE', wave)
+        m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=n)
+        taps = {}
+        for name, hw, c in (('layer1', 56, 256), ('layer2', 28, 512)):
+            m.debug_stop_after(name)
+            m(fr)
+            taps[name] = m.tap(name, n * hw * hw * c).clone()
+        m.debug_stop_after('')
+        taps['embedding'] = m(fr).clone()
+        names = m.op_names()
+        m.close()
+        got[key] = taps
+    for name in ('layer1', 'layer2', 'embedding'):
+        a, b = got['wave'][name], got['block'][name]
+        assert torch.isfinite(b).all() and float(b.abs().max()) > 0
+        assert torch.equal(a, b), (name, int((a != b).sum()), float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize('dtype,n', [('bf16', 3), ('f16', 5), ('f16', 1)])
 def test_downsample_inside_the_chain(dtype, n):
     """layer1.0: the downsample convolution is accumulated in fp32 inside the fused tail's conv3 (K extension by the block input's 64

@@ -136,6 +136,8 @@ def _run_case(golden_dir, name, seed, bn, conv=False):
             got, ref = sdm[k[6:]].cpu().numpy(), g[k]
             if loose and k[6:].startswith(('fc.0', 'fc.1', 'feat_extract')):
                 bad = np.abs(got - ref) > 2e-5 + 2e-4 * np.abs(ref)        # (these tensors start near zero and have moved by ~2e-3)
+                print('\n[%s] %s: %.4f %% of the elements outside the tight bound, max |d| %.2e (reference threads 3 vs 8: see golden/policy_conv_full_bn_spread.json)'
+                      % (name, k[6:], 100.0 * float(bad.mean()), float(np.abs(got - ref).max())))
                 assert bad.mean() <= 0.02 and np.abs(got - ref).max() < 2.5e-3 * S, (k, float(bad.mean()), float(np.abs(got - ref).max()))
             else:
                 np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6, err_msg=k)
@@ -144,6 +146,10 @@ def _run_case(golden_dir, name, seed, bn, conv=False):
     with torch.no_grad():
         out, st = m(dict(obs=torch.from_numpy(obs[0]), done=torch.from_numpy(done[0])), m.initial_state(B))
     ev = dict(rtol=2e-3, atol=5e-4) if loose else dict(rtol=1e-4, atol=5e-5)            # (loose: a few parameters took the other sign-like step)
+    if loose:
+        dl = np.abs(out['policy_logits'].cpu().numpy() - g['eval_logits'])
+        print('[%s] eval logits after %d updates: max |d| %.2e, max rel %.2e; h %.2e, c %.2e' % (name, S, float(dl.max()), float((dl / (np.abs(g['eval_logits']) + 1e-12)).max()),
+              float(np.abs(st[0].cpu().numpy() - g['eval_h']).max()), float(np.abs(st[1].cpu().numpy() - g['eval_c']).max())))
     np.testing.assert_allclose(out['policy_logits'].cpu().numpy(), g['eval_logits'], **ev)
     np.testing.assert_allclose(out['baseline'].cpu().numpy(), g['eval_baseline'], **ev)
     assert out['action'].dtype == torch.int64 and out['action'].shape == (T, B)
@@ -560,6 +566,8 @@ def test_reference_training_lines_run_unchanged_through_the_autograd_bridge(name
             got, ref = sdm[k[6:]].cpu().numpy(), g[k]
             if loose and k[6:].startswith(('fc.0', 'fc.1', 'feat_extract')):
                 bad = np.abs(got - ref) > 2e-5 + 2e-4 * np.abs(ref)        # (these tensors start near zero and have moved by ~2e-3)
+                print('\n[%s] %s: %.4f %% of the elements outside the tight bound, max |d| %.2e (reference threads 3 vs 8: see golden/policy_conv_full_bn_spread.json)'
+                      % (name, k[6:], 100.0 * float(bad.mean()), float(np.abs(got - ref).max())))
                 assert bad.mean() <= 0.02 and np.abs(got - ref).max() < 2.5e-3 * S, (k, float(bad.mean()), float(np.abs(got - ref).max()))
             else:
                 np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6, err_msg=k)
