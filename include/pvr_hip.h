@@ -175,6 +175,20 @@ pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *b
                          const void *residual_dev, void *out_dev, int32_t n, int32_t h, int32_t w,
                          int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                          int32_t relu, int32_t out_f32, int32_t dtype, void *hip_stream);
+/* Per-frame fused tail of a layer3 bottleneck (torchvision Bottleneck, reference src/embeddings.py:118-120; bneck_frame.hip): t1 (n,14,14,256) 16-bit
+ * -> conv2 3x3 pad 1 (+ b2, ReLU, rounded to the storage type) -> conv3 1x1 to 1024 channels (+ b3 + residual (n,14,14,1024), ReLU) -> y (n,14,14,1024).
+ * w2: (256, 3*3*256), w3: (1024, 256) in the fragment-blocked layout pvr_op_pack_frag_weights makes of pvr_op_conv2d's weight layout.  phases 1: conv2 only, its output to t2_out (n,14,14,256); phases 3: both
+ * (t2_out optional).  One workgroup per frame; bit-identical to the two pvr_op_conv2d calls it replaces. */
+pvr_status pvr_op_bneck_frame(const void *t1_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev, const float *b3_dev,
+                              const void *residual_dev, void *y_dev, void *t2_out_dev, int32_t n, int32_t phases, int32_t dtype, void *hip_stream);
+/* (rows, k) 16-bit weights in pvr_op_conv2d's layout -> the MFMA-fragment-blocked layout [row tile][k / 8][16 rows][8] with the rows permuted inside
+ * every 32-row block (row 16 t + 4 a + c holds output channel 8 a + 4 t + c), same size; rows % 32 == 0, k % 32 == 0.  Device to device, enqueued. */
+pvr_status pvr_op_pack_frag_weights(const void *w_dev, void *out_dev, int32_t rows, int32_t k, void *hip_stream);
+/* diagnostics: the same launch (phases 3) writing s_memtime stamps of workgroup 8 to stamps_dev (20 x uint64: waves 0 and 4, ten phase boundaries each) */
+pvr_status pvr_debug_bneck_frame_stamps(const void *t1_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev, const float *b3_dev,
+                                        const void *residual_dev, void *y_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
+/* launches of that kernel so far (tests: the layer3 plan really took it) */
+int64_t pvr_debug_bneck_frame_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */
@@ -206,6 +220,10 @@ int64_t pvr_debug_pp_persistent_launches(void);
 /* global average pool of NHWC (16-bit or fp32) -> fp32 rows at out + i*out_stride */
 pvr_status pvr_op_avgpool(const void *in_dev, float *out_dev, int64_t out_stride, int32_t n, int32_t hw,
                           int32_t c, int32_t in_f32, int32_t dtype, void *hip_stream);
+/* Finite check of fp32 results on the device: rows x cols values with row stride `stride` (elements); sets *flag_dev (a device int32 the caller
+ * zeroed) to 1 if any value is inf or NaN.  Enqueued on `stream`, no synchronisation.  The streaming embedder checks every batch this way and
+ * reads the flag once per call (the reference has no such check: its fp32 path cannot overflow a 16-bit storage type). */
+pvr_status pvr_op_nonfinite_flag(const float *x_dev, int64_t rows, int64_t cols, int64_t stride, int32_t *flag_dev, void *hip_stream);
 
 /* host-only: the fp32 -> bf16/f16 round-to-nearest-even conversion finalize() applies to weights */
 pvr_status pvr_debug_convert(const float *src, uint16_t *dst, int64_t n, int32_t dtype);

@@ -52,6 +52,10 @@ pvr_status launch_conv(const void *, const void *, const float *, const void *, 
 
 void set_conv_algo(int a);
 long long conv_expand_launches();
+long long bneck_frame_launches();
+pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, hipStream_t stream);
+pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *res, void *y,
+                              void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr);
 long long pp_persistent_launches();
 
 static void *g_zero = nullptr;
@@ -74,6 +78,24 @@ extern "C" {
 const char *pvr_version(void) { return "pvr_hip 0.1.0 (gfx950)"; }
 
 int64_t pvr_debug_conv_expand_launches(void) { return (int64_t)conv_expand_launches(); }
+int64_t pvr_debug_bneck_frame_launches(void) { return (int64_t)bneck_frame_launches(); }
+// (rows, K) 16-bit weights in pvr_op_conv2d's layout -> the fragment-blocked layout pvr_op_bneck_frame reads (same size; rows % 32 == 0, K % 32 == 0)
+pvr_status pvr_op_pack_frag_weights(const void *w, void *out, int32_t rows, int32_t k, void *stream) {
+    return launch_pack_frag_weights(w, out, rows, k, (hipStream_t)stream);
+}
+
+// single-operator entry point of the per-frame fused layer3 bottleneck tail (bneck_frame.hip), for the op-level parity tests
+pvr_status pvr_op_bneck_frame(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *residual, void *y,
+                              void *t2_out, int32_t n, int32_t phases, int32_t dtype, void *stream) {
+    PVR_REQUIRE(n > 0 && n <= 1300 && (phases == 1 || phases == 3), "pvr_op_bneck_frame: n must be 1..1300, phases 1 (conv2 only) or 3 (conv2 + conv3)");
+    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, t2_out, n, phases, dtype, (hipStream_t)stream);
+}
+// the same launch with s_memtime stamps of block 8 (20 x uint64 on the device: waves 0 and 4, ten phase boundaries each) - diagnostics only
+pvr_status pvr_debug_bneck_frame_stamps(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *residual, void *y,
+                                        int32_t n, int32_t dtype, uint64_t *stamps_dev, void *stream) {
+    PVR_REQUIRE(stamps_dev && n > 8, "pvr_debug_bneck_frame_stamps: needs a stamp buffer and more than 8 frames");
+    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, 3, dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev);
+}
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {
@@ -130,6 +152,29 @@ pvr_status pvr_op_avgpool(const void *in, float *out, int64_t out_stride, int32_
                           int32_t dtype, void *stream) {
     PVR_REQUIRE(in && out, "pvr_op_avgpool: null pointer");
     return launch_avgpool(in, out, out_stride, n, hw, c, in_f32, dtype, (hipStream_t)stream);
+}
+
+// Finite check of an embedding block ON THE DEVICE: rows x cols fp32 with row stride `stride`; *flag (a device int32 the caller zeroed) is
+// set to 1 if any value is inf / NaN.  stream_embed checks every batch this way and reads the flag once at the end, instead of a host pass over
+// the whole result (np.isfinite over 31 310 floats x N frames of the 5-crop uber PVR was 19 % of that leg's wall clock).
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *x, long long rows, long long cols, long long stride, int *flag) {
+    const long long n = rows * cols;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[(i / cols) * stride + (i % cols)];
+        bad |= (__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+pvr_status pvr_op_nonfinite_flag(const float *x, int64_t rows, int64_t cols, int64_t stride, int32_t *flag, void *stream) {
+    PVR_REQUIRE(x && flag && rows >= 0 && cols > 0 && stride >= cols, "pvr_op_nonfinite_flag: bad argument");
+    if (rows == 0) return PVR_OK;
+    const long long n = rows * cols;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, (long long)cols, (long long)stride, flag);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
 }
 
 int32_t pvr_debug_stem_u8_geometry_ok(const void *frames, int32_t h, int32_t w, int32_t top, int32_t left) { return stem_pool_u8_ok(frames, h, w, top, left) ? 1 : 0; }

@@ -1,0 +1,310 @@
+// Per-frame fused bottleneck tail for layer3 (round 5): conv2 3x3 (256 -> 256) -> conv3 1x1 (256 -> 1024) + residual + ReLU of one 14 x 14
+// image per workgroup, with the block's conv2 INPUT (t1: 196 pixels x 256 channels = 98 KB of 16-bit values) resident in LDS for the whole
+// launch and conv2's output handed to conv3 through the same LDS image.  torchvision Bottleneck (conv2 / bn2 / relu / conv3 / bn3 / += identity /
+// relu) reached from reference src/embeddings.py:118-120 and src/vision_models/moco.py:6-26; BatchNorm is folded into the weights (encoder.hip).
+//
+// Why per frame: a 14 x 14 image is 196 pixels, so a whole image is ONE pixel tile of a GEMM - the 3x3 neighbourhood never leaves the workgroup
+// (no halo, no im2col gather from HBM: the nine taps are nine row offsets into the LDS image), 256 frames are 256 workgroups = one per CU (the
+// deep-K launches of conv_pp256 fill 224 of 256 CUs at this shape), t2 never goes to HBM (-51 MB per block at batch 256), and two launches' fixed
+// costs (ramp, first DMA round trip, output burst: ~11 us each, scripts/pp256_fixed_cost.py) become one.
+//
+// Structure (second form; the first one - conv_pp256's ping-pong phases with the weights in an LDS-DMA ring - measured 3140 cycles per 64-deep K tile
+// against an MFMA issue floor of 1664: every half-phase paid ~390 cycles of LDS latency + barrier whatever its MFMA count,
+// profiles/experiments/r05_bneck_frame.txt):
+//   * NO barrier inside a convolution.  The pixel operand never changes while a convolution runs (the image is resident), so only the weights move -
+//     and they go straight from L2 into registers as whole MFMA fragments: wave w owns 32 output channels (two 16-row A-operand tiles) x ALL 13
+//     pixel tiles = 104 accumulator VGPRs, and per 64-deep K tile it needs four 1 KB weight fragments that no other wave of the workgroup needs.
+//     The weights are pre-packed in the fragment-blocked layout [row tile][K / 8][16 rows][8] (rows permuted inside every 32-row block as in
+//     conv_pp256: a lane's tile pair is 8 consecutive output channels), so a fragment is one contiguous 1 KB load, requested one K tile ahead.
+//   * per K tile and pixel tile: two ds_read_b128 of the image (the two 32-deep k-steps; second address = first XOR 64) feed four MFMAs.  The two
+//     waves of a SIMD interleave on their own: one wave's LDS latency is the other's MFMA time.
+//   * conv2's B operand: pixel p = 16 j + (lane & 15) of tile j reads row p + 14 dy + dx of the image for tap (dy, dx); lanes whose neighbour is
+//     outside the image (and the 12 padding pixels of tile 12) read the zero row instead.  The row address and its swizzle are per-lane values
+//     computed once per tap and tile.
+//   * LDS (109.5 KB): T = 4 channel slices x [209 rows][64 channels] (rows of 128 B, the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 as in
+//     conv_pp256; row 208 of every slice stays zero) | b2, b3 as fp32.  Three workgroup barriers per launch: image landed, image free, t2 written.
+//   * conv3 runs in four chunks of 256 couts over the t2 image; per chunk: 4 K tiles, then bias + residual + ReLU + 16-bit stores straight from the
+//     accumulators (8 consecutive couts of one pixel per lane = one 16-byte load / store).
+// Same GEMM view, operand roles (weights = MFMA A operand, pixels = B operand), K order (filter taps ascending, 64-channel slices ascending, two
+// 32-deep MFMA steps per slice) and rounding points (t2 and y rounded to the 16-bit storage type after bias + ReLU) as the separate conv_pp256 /
+// conv_expand launches: bit-identical to them (tests/test_gpu_encoder.py::test_frame_bottleneck_op_is_bit_identical).
+#include "common.h"
+
+namespace pvr {
+
+struct BFP {
+    const u16 *t1, *w2, *w3, *res;  // w2 / w3: fragment-blocked (pack_frag_weights)
+    const float *b2, *b3;
+    u16 *y, *t2_out;               // t2_out != nullptr (tests): conv2's output also goes to HBM, NHWC
+    int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3
+    unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes;
+    unsigned long long *stamps;    // diagnostics (scripts/bneck_frame_time.py): s_memtime at the phase boundaries of block 8, waves 0 and 4; nullptr in the product
+};
+
+#define BF_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int NPIX = 196, IW = 14, CM = 256, CO = 1024, NT = 13;
+    constexpr int SROWS = 209, SLICE = SROWS * 128, ZROW = 208;
+    constexpr int BIAS_OFF = 4 * SLICE;                   // 107 008; + 5 KB of bias
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n = blockIdx.x;
+    unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define BF_TS(k_) { if (p.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_[k_]) :: "memory"); }
+#define BF_TS_OUT() { if (p.stamps && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) { _Pragma("unroll") for (int k = 0; k < 10; ++k) p.stamps[(wave >> 2) * 10 + k] = ts_[k]; } }
+    BF_TS(0);
+
+    const auto rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.t1), 0, p.t1_bytes, 0x00020000);
+    const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
+    const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
+
+    // ---- LDS set-up that uses ordinary stores: BEFORE any LDS-DMA is in flight (hipcc waits vmcnt(0) in front of C++ LDS accesses otherwise)
+    if (tid < 32) *reinterpret_cast<u32x4 *>(smem + (tid >> 3) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int c = tid; c < (p.phases > 1 ? CM + CO : CM); c += 512) reinterpret_cast<float *>(smem + BIAS_OFF)[c] = c < CM ? p.b2[c] : p.b3[c - CM];
+    __syncthreads();
+
+    // ---- the frame's t1 image -> T: 4 slices x 26 groups of 8 rows, one 1 KB DMA each (rows >= 196: offset past num_records -> zeros)
+    for (int u = wave; u < 104; u += 8) {
+        const int s = u / 26, g = u % 26;
+        const int row = g * 8 + (lane >> 3), lch = (lane & 7) ^ ((row >> 1) & 7);
+        const int vo = row < NPIX ? ((n * NPIX + row) * CM + s * 64 + lch * 8) * 2 : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t1, BF_LDS_PTR(s * SLICE + g * 1024), 16, vo, 0, 0, 0);
+    }
+
+    // ---- weights: fragment (row tile rt, 32-deep k-step kk) of a matrix with KC = K / 8 chunks per row = 1 KB at ((rt * KC + 4 kk) * 256) bytes;
+    //      this wave's row tiles are 2 w and 2 w + 1 (conv3: + 16 per chunk of 256 couts)
+    const int wlane = lane * 16;
+    V8 wa[2][2], wb[2][2];                                // two K tiles of fragments [row tile][k-step]: the one in use and the one in flight
+#define BF_LOAD_W(dst_, rs_, rt0_, KC_, kt_)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
+            dst_[i][ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_, wlane, (((rt0_) + i) * (KC_) + 4 * (2 * (kt_) + ks)) * 256, 0));
+    BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, 0);
+
+    const int sw = (fr >> 1) & 7;
+    // border masks of conv2: bit (3 (dy+1) + (dx+1)) of vmask[j] set <=> pixel 16 j + fr exists and its (dy, dx) neighbour is inside the image
+    int vmask[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int pp = 16 * j + fr, py = pp / IW, px = pp % IW;
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            m |= (int)(pp < NPIX && (unsigned)yy < (unsigned)IW && (unsigned)xx < (unsigned)IW) << t;
+        }
+        vmask[j] = m;
+    }
+    const int zaddr = ZROW * 128 + (fq << 4);             // the zero row (its XOR-64 partner is in the row too)
+
+    f32x4 acc[2][NT];
+#define BF_ZERO_ACC()                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Four 64-deep K tiles (channel slices 0..3 of the image at the addresses xa[]) as ONE software pipeline of 52 (slice, pixel tile) steps: the
+    // two fragment reads of step q + 2 are issued before the four MFMAs of step q, into a rotating set of three fragment pairs; inline-asm reads and
+    // counted lgkmcnt waits (hipcc's own schedule kept every read next to its use: read, wait, 4 MFMAs - the LDS latency of every tile exposed).
+    // W0_ / W1_ hold the weight fragments of slices 0, 2 / 1, 3; NEXT0_ .. NEXT3_ request the fragments of the following K tiles at the slice starts.
+    V8 xs[3][2];
+#define BF_XREAD(q_)                                                                                            \
+    {                                                                                                          \
+        const int a0_ = xa[(q_) % NT] + ((q_) / NT) * SLICE;                                                    \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][0]) : "v"(a0_));                                 \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][1]) : "v"(a0_ ^ 64));                            \
+    }
+#define BF_STEP(q_, W_)                                                                                         \
+    {                                                                                                          \
+        if ((q_) + 2 < 4 * NT) BF_XREAD((q_) + 2);                                                              \
+        if ((q_) + 2 < 4 * NT) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));      \
+        else if ((q_) + 1 < 4 * NT) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1])); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));               \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        constexpr int j_ = (q_) % NT;                                                                           \
+        acc[0][j_] = mfma16<F16>(W_[0][0], xs[(q_) % 3][0], acc[0][j_]);                                        \
+        acc[1][j_] = mfma16<F16>(W_[1][0], xs[(q_) % 3][0], acc[1][j_]);                                        \
+        acc[0][j_] = mfma16<F16>(W_[0][1], xs[(q_) % 3][1], acc[0][j_]);                                        \
+        acc[1][j_] = mfma16<F16>(W_[1][1], xs[(q_) % 3][1], acc[1][j_]);                                        \
+    }
+#define BF_SLICE(s_, W_)                                                                                        \
+    BF_STEP((s_) * NT + 0, W_) BF_STEP((s_) * NT + 1, W_) BF_STEP((s_) * NT + 2, W_) BF_STEP((s_) * NT + 3, W_)  \
+    BF_STEP((s_) * NT + 4, W_) BF_STEP((s_) * NT + 5, W_) BF_STEP((s_) * NT + 6, W_) BF_STEP((s_) * NT + 7, W_)  \
+    BF_STEP((s_) * NT + 8, W_) BF_STEP((s_) * NT + 9, W_) BF_STEP((s_) * NT + 10, W_) BF_STEP((s_) * NT + 11, W_) \
+    BF_STEP((s_) * NT + 12, W_)
+#define BF_FOUR_KTILES(NEXT0_, NEXT1_, NEXT2_, NEXT3_)                                                          \
+    {                                                                                                          \
+        BF_XREAD(0); BF_XREAD(1);                                                                               \
+        NEXT0_; BF_SLICE(0, wa)                                                                                 \
+        NEXT1_; BF_SLICE(1, wb)                                                                                 \
+        NEXT2_; BF_SLICE(2, wa)                                                                                 \
+        NEXT3_; BF_SLICE(3, wb)                                                                                 \
+    }
+
+    BF_ZERO_ACC();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the image has landed (this wave's part; the first weight fragments too)
+    __syncthreads();
+    BF_TS(1);
+
+    // =================================================== conv2: 9 taps x 4 slices =====================================================
+    int xa[NT];
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        // row offset and swizzle of this tap's neighbour pixel; per tile: the image row or the zero row
+        const int off = (tap / 3 - 1) * IW + (tap % 3 - 1);
+        const int rsw = ((fr + off + 32) >> 1) & 7;
+        const int b0 = (fr + off) * 128 + ((fq ^ rsw) << 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) xa[j] = ((vmask[j] >> tap) & 1) ? b0 + j * 2048 : zaddr;
+        const int kt = tap * 4;
+        // (the last request of the last tap is conv3's first K tile - or, in the conv2-only mode, a harmless repeat: never a branch around loads,
+        //  behind which hipcc can no longer count the loads in flight and waits for all of them)
+        const bool last = tap == 8;
+        const auto rs_n = (last && p.phases > 1) ? rs_w3 : rs_w2;
+        const int rt_n = 2 * wave, kc_n = (last && p.phases > 1) ? CM / 8 : 9 * CM / 8, kt_n = last ? 0 : kt + 4;
+        BF_FOUR_KTILES(BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 1), BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, kt + 2),
+                       BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 3), BF_LOAD_W(wa, rs_n, rt_n, kc_n, kt_n));
+    }
+    BF_TS(2);
+    __syncthreads();                                            // every wave's reads of the t1 image are done
+    // ---- t2 = relu(conv2 + b2), rounded to the storage type, into the image: this wave's 32 channels = half of slice w >> 1
+    {
+        const auto rs_t2 = __builtin_amdgcn_make_buffer_rsrc(p.t2_out, 0, p.t2_out ? p.t2_bytes : 0, 0x00020000);
+        const int c = 32 * wave + 8 * fq;
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + c * 4), bh = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + c * 4 + 16);
+        char *tbase = smem + (wave >> 1) * SLICE + (((4 * (wave & 1) + fq) ^ sw) << 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int pp = 16 * j + fr;
+            if (pp < NPIX) {
+                const f32x4 lo = acc[0][j], hi = acc[1][j];
+                const float v[8] = {lo[0] + bl[0], lo[1] + bl[1], lo[2] + bl[2], lo[3] + bl[3], hi[0] + bh[0], hi[1] + bh[1], hi[2] + bh[2], hi[3] + bh[3]};
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                *reinterpret_cast<u32x4 *>(tbase + pp * 128) = o;
+                if (p.t2_out) __builtin_amdgcn_raw_buffer_store_b128(o, rs_t2, ((n * NPIX + pp) * CM + c) * 2, 0, 0);
+            }
+        }
+    }
+    BF_TS(3);
+    if (p.phases <= 1) { BF_TS_OUT(); return; }
+    __syncthreads();                                            // every wave's part of t2 is in the image
+
+    // =================================================== conv3: 4 chunks of 256 couts x 4 slices ========================================
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);     // centre tap (padding pixels read zero-filled rows; their columns are never stored)
+    BF_TS(4);
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
+        BF_ZERO_ACC();
+        const int rt0 = 16 * ch + 2 * wave;
+        const int rt_n = ch < 3 ? rt0 + 16 : rt0;              // (after the last chunk: a harmless repeat, see conv2)
+        BF_FOUR_KTILES(BF_LOAD_W(wb, rs_w3, rt0, CM / 8, 1), BF_LOAD_W(wa, rs_w3, rt0, CM / 8, 2), BF_LOAD_W(wb, rs_w3, rt0, CM / 8, 3),
+                       BF_LOAD_W(wa, rs_w3, rt_n, CM / 8, 0));
+        if (ch == 0) BF_TS(5);
+        // ---- y = relu(conv3 + b3 + identity), rounded, NHWC; a lane's tile pair = 8 consecutive couts of one pixel
+        const int c = 256 * ch + 32 * wave + 8 * fq;
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + (CM + c) * 4), bh = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + (CM + c) * 4 + 16);
+        // (all thirteen identity loads first, then the stores: a load issued behind a store can only be waited for together with that store)
+        u32x4 rr[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int pp = 16 * j + fr;
+            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, pp < NPIX ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(512)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int pp = 16 * j + fr;
+            const f32x4 lo = acc[0][j], hi = acc[1][j];
+            float v[8] = {lo[0] + bl[0], lo[1] + bl[1], lo[2] + bl[2], lo[3] + bl[3], hi[0] + bh[0], hi[1] + bh[1], hi[2] + bh[2], hi[3] + bh[3]};
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] += from_h<F16>((u16)(rr[j][e] & 0xffffu));
+                v[2 * e + 1] += from_h<F16>((u16)(rr[j][e] >> 16));
+                o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, pp < NPIX ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(256));
+        }
+        if (ch == 0) BF_TS(6);
+        if (ch == 2) BF_TS(7);
+    }
+    BF_TS(8);
+    if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BF_TS(9);
+    BF_TS_OUT();
+#undef BF_TS_OUT
+#undef BF_TS
+#undef BF_FOUR_KTILES
+#undef BF_SLICE
+#undef BF_STEP
+#undef BF_XREAD
+#undef BF_ZERO_ACC
+#undef BF_LOAD_W
+}
+
+// natural [rows][K] 16-bit weights -> the fragment-blocked layout the kernel reads: rows permuted inside every 32-row block (row 16 t + 4 a + c holds
+// cout 8 a + 4 t + c: chain_row_source), then [row >> 4][k >> 3][row & 15][8]
+__global__ __launch_bounds__(256) void pack_frag_weights_kernel(const u16 *w, u16 *out, int rows, int K) {
+    const long long chunks = (long long)rows * (K / 8);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i % 16), kc = (int)((i / 16) % (K / 8)), rt = (int)(i / 16 / (K / 8));
+        const int row = rt * 16 + r;
+        const int src = (row & ~31) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3);
+        reinterpret_cast<u32x4 *>(out)[i] = *reinterpret_cast<const u32x4 *>(w + (size_t)src * K + kc * 8);
+    }
+}
+
+pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, hipStream_t stream) {
+    PVR_REQUIRE(w && out && rows % 32 == 0 && K % 32 == 0, "pack_frag_weights: rows and K must be multiples of 32");
+    const long long chunks = (long long)rows * (K / 8);
+    hipLaunchKernelGGL(pack_frag_weights_kernel, dim3((unsigned)((chunks + 255) / 256 < 1024 ? (chunks + 255) / 256 : 1024)), dim3(256), 0, stream, (const u16 *)w, (u16 *)out, rows, K);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+static long long g_bneck_frame_launches = 0;
+long long bneck_frame_launches() { return g_bneck_frame_launches; }
+
+// shapes the kernel is built for: layer3's stride-1 bottlenecks (14 x 14 x 256 -> 14 x 14 x 1024) in the 16-bit storage types
+bool bneck_frame_supported(int n, int h, int w, int cm, int cout, int stride) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("PVR_FRAME_BNECK"); on = e ? atoi(e) : 1; }
+    return on && h == 14 && w == 14 && cm == 256 && cout == 1024 && stride == 1 && n >= 1 && (int64_t)n * 196 * 1024 * 2 < 0x7ffffff0ll;
+}
+
+// w2p / w3p: fragment-blocked weights (launch_pack_frag_weights of the (256, 2304) / (1024, 256) matrices)
+pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
+                              void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps) {
+    PVR_REQUIRE(t1 && w2p && b2 && (phases <= 1 || (w3p && b3 && res && y)) && (phases > 1 || t2_out), "bneck_frame: null argument");
+    PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "bneck_frame: 16-bit storage types only");
+    BFP p;
+    p.t1 = (const u16 *)t1; p.w2 = (const u16 *)w2p; p.w3 = (const u16 *)w3p; p.res = (const u16 *)res; p.b2 = b2; p.b3 = b3;
+    p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases; p.stamps = stamps;
+    p.t1_bytes = p.t2_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
+    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0;
+    p.res_bytes = p.y_bytes = (unsigned)((size_t)n * 196 * 1024 * 2);
+    constexpr int lds = 4 * 209 * 128 + (256 + 1024) * 4;
+    static DeviceOnce attr_done;
+    if (attr_done.needed()) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done.mark();
+    }
+    ++g_bneck_frame_launches;
+    if (dtype == PVR_F16) hipLaunchKernelGGL(bneck_frame_kernel<true>, dim3(n), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(bneck_frame_kernel<false>, dim3(n), dim3(512), lds, stream, p);
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+}  // namespace pvr

@@ -129,6 +129,44 @@ def _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res_f32,
     return out
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('n', [1, 3, 64, 256])
+def test_frame_bottleneck_op_is_bit_identical(dt, n):
+    """bneck_frame.hip (round 5): conv2 3x3 -> conv3 1x1 + residual of a layer3 bottleneck, one workgroup per 14 x 14 frame with the conv2 input
+    resident in LDS, against the two separate launches it replaces (pvr_op_conv2d: conv_pp256 / conv_expand): EVERY element of t2 (conv2 only
+    mode) and of y, bit for bit - same MFMA operand roles, K order and rounding points."""
+    tdt, cdt = DT[dt]
+    L = _lib.lib()
+    x = torch.from_numpy(synth.normal(5, 'bf_t1_%d' % n, (n, 14, 14, 256))).clamp_(min=0).to(tdt).cuda()
+    w2 = torch.from_numpy(synth.normal(5, 'bf_w2', (256, 9 * 256), std=float(np.sqrt(2.0 / 2304)))).to(tdt).cuda()
+    w3 = torch.from_numpy(synth.normal(5, 'bf_w3', (1024, 256), std=float(np.sqrt(2.0 / 256)))).to(tdt).cuda()
+    b2 = torch.from_numpy(synth.uniform(5, 'bf_b2', (256,), -0.5, 0.5)).cuda()
+    b3 = torch.from_numpy(synth.uniform(5, 'bf_b3', (1024,), -0.5, 0.5)).cuda()
+    r = torch.from_numpy(synth.normal(5, 'bf_res_%d' % n, (n, 14, 14, 1024))).clamp_(min=0).to(tdt).cuda()
+    t2_ref = _run_conv(x, w2, b2, None, n, 14, 14, 256, 256, 3, 1, 1, 0, 0, cdt, tdt)
+    y_ref = _run_conv(t2_ref, w3, b3, r, n, 14, 14, 256, 1024, 1, 1, 1, 0, 0, cdt, tdt)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    w2n, w3n = w2, w3                                                   # (the separate launches above read the natural layout)
+    w2, w3 = torch.empty_like(w2n), torch.empty_like(w3n)               # the fused kernel reads whole MFMA fragments: blocked copies
+    _lib.check(L.pvr_op_pack_frag_weights(vp(w2n), vp(w2), 256, 2304, _lib.stream_ptr()))
+    _lib.check(L.pvr_op_pack_frag_weights(vp(w3n), vp(w3), 1024, 256, _lib.stream_ptr()))
+    t2 = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda')
+    _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), None, None, None, None, vp(t2), n, 1, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(t2.view(torch.int16), t2_ref.view(torch.int16)), (int((t2.view(torch.int16) != t2_ref.view(torch.int16)).sum()), float((t2.float() - t2_ref.float()).abs().max()))
+    for with_t2 in (False, True):
+        y = torch.full((n, 14, 14, 1024), float('nan'), dtype=tdt, device='cuda')
+        t2b = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda') if with_t2 else None
+        before = L.pvr_debug_bneck_frame_launches()
+        _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y), vp(t2b), n, 3, cdt, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert L.pvr_debug_bneck_frame_launches() == before + 1
+        assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) > 0
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), (int((y.view(torch.int16) != y_ref.view(torch.int16)).sum()), float((y.float() - y_ref.float()).abs().max()))
+        if with_t2:
+            assert torch.equal(t2b.view(torch.int16), t2_ref.view(torch.int16))
+
+
 PP_CASES = [
     # n, h, w, cin, cout, k, stride, act, res(0 none, 1 16-bit, 2 fp32), out_f32     -- shapes of the deep-K launches
     (64, 14, 14, 256, 256, 3, 1, 1, 0, 0),       # layer3 conv2: K = 2304
@@ -418,6 +456,9 @@ def test_f16_activation_range(monkeypatch):
     net.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
     with pytest.raises(FloatingPointError):
         net(torch.from_numpy(fr))
+    from pvr_habitat_amd.embeddings import stream_embed
+    with pytest.raises(FloatingPointError):                    # the streaming path checks every batch on the device (pvr_op_nonfinite_flag)
+        stream_embed(net, torch.from_numpy(np.concatenate([fr, fr, fr])), batch=4)
     netb = EmbeddingNet('resnet50', pretrained=False, compute_dtype='bf16', max_batch=4)
     netb.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
     ob = netb(torch.from_numpy(fr))
