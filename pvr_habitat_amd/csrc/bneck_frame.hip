@@ -25,6 +25,11 @@
 //     conv_pp256; row 208 of every slice stays zero) | b2, b3 as fp32.  Three workgroup barriers per launch: image landed, image free, t2 written.
 //   * conv3 runs in four chunks of 256 couts over the t2 image; per chunk: 4 K tiles, then bias + residual + ReLU + 16-bit stores straight from the
 //     accumulators (8 consecutive couts of one pixel per lane = one 16-byte load / store).
+//   * NEXT1 (form 3: every block but the stage's last): the conv3 phase waits for HBM (identity in, y out: 206 MB per launch at batch 256) with the
+//     matrix pipe 40 % busy, so the NEXT block's conv1 (1x1, 1024 -> 256) runs inside it instead of as its own launch that reads y again: conv3 goes
+//     in eight rounds of 128 couts (waves 2 pixel halves x 4 cout quads), every round's y values go to HBM and, as a [208 rows][128 channels] image, to
+//     a second LDS region; after a barrier each wave adds that round's 128-deep slice of W1' . y to ITS 32 channels x 13 pixel tiles of t1' (104 more
+//     accumulator VGPRs, alive across the rounds).  Two raw barriers per round (LDS writes visible / image free again); identity loads one round ahead.
 // Same GEMM view, operand roles (weights = MFMA A operand, pixels = B operand), K order (filter taps ascending, 64-channel slices ascending, two
 // 32-deep MFMA steps per slice) and rounding points (t2 and y rounded to the 16-bit storage type after bias + ReLU) as the separate conv_pp256 /
 // conv_expand launches: bit-identical to them (tests/test_gpu_encoder.py::test_frame_bottleneck_op_is_bit_identical).
@@ -36,19 +41,22 @@ struct BFP {
     const u16 *t1, *w2, *w3, *res;  // w2 / w3: fragment-blocked (pack_frag_weights)
     const float *b2, *b3;
     u16 *y, *t2_out;               // t2_out != nullptr (tests): conv2's output also goes to HBM, NHWC
-    int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3
-    unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes;
+    const u16 *w1n;                // NEXT1: the next block's conv1 weights (256, 1024), fragment-blocked; its bias; its output (n,14,14,256)
+    const float *b1n;
+    u16 *t1n;
+    int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3, 7: + the next block's conv1
+    unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes, w1n_bytes, t1n_bytes;
     unsigned long long *stamps;    // diagnostics (scripts/bneck_frame_time.py): s_memtime at the phase boundaries of block 8, waves 0 and 4; nullptr in the product
 };
 
 #define BF_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
-template <bool F16>
+template <bool F16, bool NEXT1>
 __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int NPIX = 196, IW = 14, CM = 256, CO = 1024, NT = 13;
     constexpr int SROWS = 209, SLICE = SROWS * 128, ZROW = 208;
-    constexpr int BIAS_OFF = 4 * SLICE;                   // 107 008; + 5 KB of bias
+    constexpr int Y_OFF = 4 * SLICE, YS = 208 * 128;      // NEXT1: the round's y image, 2 slices x [208 rows][64 channels] behind T (107 008 + 53 248 = 160 256 B)
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -65,11 +73,6 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
     const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
 
-    // ---- LDS set-up that uses ordinary stores: BEFORE any LDS-DMA is in flight (hipcc waits vmcnt(0) in front of C++ LDS accesses otherwise)
-    if (tid < 32) *reinterpret_cast<u32x4 *>(smem + (tid >> 3) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
-    for (int c = tid; c < (p.phases > 1 ? CM + CO : CM); c += 512) reinterpret_cast<float *>(smem + BIAS_OFF)[c] = c < CM ? p.b2[c] : p.b3[c - CM];
-    __syncthreads();
-
     // ---- the frame's t1 image -> T: 4 slices x 26 groups of 8 rows, one 1 KB DMA each (rows >= 196: offset past num_records -> zeros)
     for (int u = wave; u < 104; u += 8) {
         const int s = u / 26, g = u % 26;
@@ -77,6 +80,8 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         const int vo = row < NPIX ? ((n * NPIX + row) * CM + s * 64 + lch * 8) * 2 : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t1, BF_LDS_PTR(s * SLICE + g * 1024), 16, vo, 0, 0, 0);
     }
+    // the zero rows (ordinary stores: hipcc waits for the DMA above in front of them - the wait this prologue needs anyway)
+    if (tid < 32) *reinterpret_cast<u32x4 *>(smem + (tid >> 3) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- weights: fragment (row tile rt, 32-deep k-step kk) of a matrix with KC = K / 8 chunks per row = 1 KB at ((rt * KC + 4 kk) * 256) bytes;
     //      this wave's row tiles are 2 w and 2 w + 1 (conv3: + 16 per chunk of 256 couts)
@@ -165,18 +170,19 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         // (the last request of the last tap is conv3's first K tile - or, in the conv2-only mode, a harmless repeat: never a branch around loads,
         //  behind which hipcc can no longer count the loads in flight and waits for all of them)
         const bool last = tap == 8;
-        const auto rs_n = (last && p.phases > 1) ? rs_w3 : rs_w2;
-        const int rt_n = 2 * wave, kc_n = (last && p.phases > 1) ? CM / 8 : 9 * CM / 8, kt_n = last ? 0 : kt + 4;
+        const auto rs_n = (last && (p.phases & 15) > 1) ? rs_w3 : rs_w2;
+        const int rt_n = (NEXT1 && last) ? 2 * (wave & 3) : 2 * wave, kc_n = (last && (p.phases & 15) > 1) ? CM / 8 : 9 * CM / 8, kt_n = last ? 0 : kt + 4;
         BF_FOUR_KTILES(BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 1), BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, kt + 2),
                        BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 3), BF_LOAD_W(wa, rs_n, rt_n, kc_n, kt_n));
     }
     BF_TS(2);
-    __syncthreads();                                            // every wave's reads of the t1 image are done
+#define BF_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    BF_BARRIER();                                               // every wave's reads of the t1 image are done
     // ---- t2 = relu(conv2 + b2), rounded to the storage type, into the image: this wave's 32 channels = half of slice w >> 1
     {
         const auto rs_t2 = __builtin_amdgcn_make_buffer_rsrc(p.t2_out, 0, p.t2_out ? p.t2_bytes : 0, 0x00020000);
         const int c = 32 * wave + 8 * fq;
-        const f32x4 bl = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + c * 4), bh = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + c * 4 + 16);
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b2 + c), bh = *reinterpret_cast<const f32x4 *>(p.b2 + c + 4);
         char *tbase = smem + (wave >> 1) * SLICE + (((4 * (wave & 1) + fq) ^ sw) << 4);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -193,12 +199,119 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         }
     }
     BF_TS(3);
-    if (p.phases <= 1) { BF_TS_OUT(); return; }
-    __syncthreads();                                            // every wave's part of t2 is in the image
+    if ((p.phases & 15) <= 1) { BF_TS_OUT(); return; }
+    BF_BARRIER();                                               // every wave's part of t2 is in the image
 
     // =================================================== conv3: 4 chunks of 256 couts x 4 slices ========================================
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    if constexpr (NEXT1) {
+    // ---- form 3: conv3 in eight rounds of 128 couts + the next block's conv1 over each round's y image
+    const int wr = wave >> 2, wc = wave & 3;
+    const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1n), 0, p.w1n_bytes, 0x00020000);
+    const auto rs_t1n = __builtin_amdgcn_make_buffer_rsrc(p.t1n, 0, p.t1n_bytes, 0x00020000);
+    const int xc = fr * 128 + ((fq ^ sw) << 4);                 // centre tap of pixel tile 0; tile j: + 2048 j (no border masks in a 1x1 convolution)
+    const int xc3 = xc + wr * (7 * 2048);                       // conv3: this wave's pixel tiles are 7 wr .. 7 wr + 6 (the second half has six)
+    f32x4 acc1[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The round's 7 pixel tiles go in two halves (4 + 3) that share the round's weights: 56 + 28 live registers for the conv3 accumulators and the
+    // identity values of all seven tiles, next to the 104 of t1', did not fit (41 spilled); a half needs 32 + 16.
+    u32x4 rr[4];
+#define BF_LOAD_RES(r_, h_)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+        const int jj = 4 * (h_) + j, pp = 16 * (7 * wr + jj) + fr;                                              \
+        rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp < NPIX && jj < (wr == 0 ? 7 : 6)) ? ((n * NPIX + pp) * CO + 128 * (r_) + 32 * wc + 8 * fq) * 2 : OOB, 0, PVR_NT_AUX(512))); \
+    }
+    // one 64-deep K tile of conv3 (image slice s_, pixel tiles 4 h_ .. 4 h_ + 3 of this wave's seven) / of the next conv1 (y image slice s_, all 13 pixel tiles)
+#define BF_KT3(s_, h_, W_)                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+        if (4 * (h_) + j < 6 || (4 * (h_) + j == 6 && wr == 0)) {                                               \
+            const V8 x0 = *reinterpret_cast<const V8 *>(smem + xc3 + (4 * (h_) + j) * 2048 + (s_) * SLICE);     \
+            const V8 x1 = *reinterpret_cast<const V8 *>(smem + ((xc3 + (4 * (h_) + j) * 2048 + (s_) * SLICE) ^ 64)); \
+            acc3[0][j] = mfma16<F16>(W_[0][0], x0, acc3[0][j]); acc3[1][j] = mfma16<F16>(W_[1][0], x0, acc3[1][j]);   \
+            acc3[0][j] = mfma16<F16>(W_[0][1], x1, acc3[0][j]); acc3[1][j] = mfma16<F16>(W_[1][1], x1, acc3[1][j]);   \
+        }
+#define BF_KT1(s_, W_)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                            \
+        const V8 x0 = *reinterpret_cast<const V8 *>(smem + Y_OFF + xc + j * 2048 + (s_) * YS);                  \
+        const V8 x1 = *reinterpret_cast<const V8 *>(smem + ((Y_OFF + xc + j * 2048 + (s_) * YS) ^ 64));         \
+        acc1[0][j] = mfma16<F16>(W_[0][0], x0, acc1[0][j]); acc1[1][j] = mfma16<F16>(W_[1][0], x0, acc1[1][j]);       \
+        acc1[0][j] = mfma16<F16>(W_[0][1], x1, acc1[0][j]); acc1[1][j] = mfma16<F16>(W_[1][1], x1, acc1[1][j]);       \
+    }
+    // y = relu(conv3 + b3 + identity), rounded, of the half's tiles: to HBM (NHWC) and into the y image (slice wc >> 1, row = pixel)
+#define BF_EPI3(h_)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+        const int jj = 4 * (h_) + j, pp = 16 * (7 * wr + jj) + fr;                                              \
+        const bool ok = pp < NPIX && jj < (wr == 0 ? 7 : 6);                                                    \
+        const f32x4 lo = acc3[0][j], hi = acc3[1][j];                                                           \
+        float v[8] = {lo[0] + bl[0], lo[1] + bl[1], lo[2] + bl[2], lo[3] + bl[3], hi[0] + bh[0], hi[1] + bh[1], hi[2] + bh[2], hi[3] + bh[3]};   \
+        u32x4 o;                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
+            v[2 * e] += from_h<F16>((u16)(rr[j][e] & 0xffffu));                                                 \
+            v[2 * e + 1] += from_h<F16>((u16)(rr[j][e] >> 16));                                                 \
+            o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);   \
+        }                                                                                                       \
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, ok ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(256));   \
+        if (ok) *reinterpret_cast<u32x4 *>(ybase + pp * 128) = o;                                               \
+    }
+#define BF_ZERO3()                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BF_LOAD_RES(0, 0);
+    BF_TS(4);
+    char *const ybase = smem + Y_OFF + (wc >> 1) * YS + (((4 * (wc & 1) + fq) ^ sw) << 4);
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        f32x4 acc3[2][4];
+        const int rt3 = 8 * r + 2 * wc;                         // W3 row tiles of this wave and round (shared with wave w ^ 4)
+        const int c = 128 * r + 32 * wc + 8 * fq;
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b3 + c), bh = *reinterpret_cast<const f32x4 *>(p.b3 + c + 4);
+        BF_ZERO3();
+        BF_LOAD_W(wb, rs_w3, rt3, CM / 8, 1); BF_KT3(0, 0, wa);
+        BF_LOAD_W(wa, rs_w3, rt3, CM / 8, 2); BF_KT3(1, 0, wb);
+        BF_LOAD_W(wb, rs_w3, rt3, CM / 8, 3); BF_KT3(2, 0, wa);
+        BF_LOAD_W(wa, rs_w3, rt3, CM / 8, 0); BF_KT3(3, 0, wb);
+        if (r == 0) BF_TS(5);
+        if (r > 0) BF_BARRIER();                                // every wave has finished reading the previous round's y image
+        BF_EPI3(0);
+        BF_LOAD_RES(r, 1);
+        BF_ZERO3();
+        BF_LOAD_W(wb, rs_w3, rt3, CM / 8, 1); BF_KT3(0, 1, wa);
+        BF_LOAD_W(wa, rs_w3, rt3, CM / 8, 2); BF_KT3(1, 1, wb);
+        BF_LOAD_W(wb, rs_w3, rt3, CM / 8, 3); BF_KT3(2, 1, wa);
+        BF_LOAD_W(wa, rs_w1, 2 * wave, CO / 8, 2 * r); BF_KT3(3, 1, wb);       // next conv1: K tile 2 r of 16 (its K = the 1024 channels of y)
+        BF_EPI3(1);
+        BF_LOAD_RES(r < 7 ? r + 1 : 7, 0);                      // the next round's identity values arrive under this round's conv1 work
+        if (r == 0) BF_TS(6);
+        BF_BARRIER();                                           // every wave's part of the y image is written
+        BF_LOAD_W(wb, rs_w1, 2 * wave, CO / 8, 2 * r + 1); BF_KT1(0, wa);
+        BF_LOAD_W(wa, rs_w3, r < 7 ? rt3 + 8 : rt3, CM / 8, 0); BF_KT1(1, wb);
+        if (r == 5) BF_TS(7);
+    }
+#undef BF_ZERO3
+#undef BF_EPI3
+    // ---- t1' = relu(conv1' + b1'), rounded, NHWC: this wave's 32 channels
+    {
+        const int c1 = 32 * wave + 8 * fq;
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b1n + c1), bh = *reinterpret_cast<const f32x4 *>(p.b1n + c1 + 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int pp = 16 * j + fr;
+            const f32x4 lo = acc1[0][j], hi = acc1[1][j];
+            const float v[8] = {lo[0] + bl[0], lo[1] + bl[1], lo[2] + bl[2], lo[3] + bl[3], hi[0] + bh[0], hi[1] + bh[1], hi[2] + bh[2], hi[3] + bh[3]};
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_t1n, pp < NPIX ? ((n * NPIX + pp) * CM + c1) * 2 : OOB, 0, 0);
+        }
+    }
+#undef BF_KT1
+#undef BF_KT3
+#undef BF_LOAD_RES
+    } else {
 #pragma unroll
     for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);     // centre tap (padding pixels read zero-filled rows; their columns are never stored)
     BF_TS(4);
@@ -212,13 +325,13 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         if (ch == 0) BF_TS(5);
         // ---- y = relu(conv3 + b3 + identity), rounded, NHWC; a lane's tile pair = 8 consecutive couts of one pixel
         const int c = 256 * ch + 32 * wave + 8 * fq;
-        const f32x4 bl = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + (CM + c) * 4), bh = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + (CM + c) * 4 + 16);
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b3 + c), bh = *reinterpret_cast<const f32x4 *>(p.b3 + c + 4);
         // (all thirteen identity loads first, then the stores: a load issued behind a store can only be waited for together with that store)
         u32x4 rr[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int pp = 16 * j + fr;
-            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, pp < NPIX ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(512)));
+            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp < NPIX && !(p.phases & 32)) ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(512)));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -233,10 +346,11 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
                 v[2 * e + 1] += from_h<F16>((u16)(rr[j][e] >> 16));
                 o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, pp < NPIX ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(256));
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, (pp < NPIX && !(p.phases & 16)) ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(256));
         }
         if (ch == 0) BF_TS(6);
         if (ch == 2) BF_TS(7);
+    }
     }
     BF_TS(8);
     if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -244,6 +358,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     BF_TS_OUT();
 #undef BF_TS_OUT
 #undef BF_TS
+#undef BF_BARRIER
 #undef BF_FOUR_KTILES
 #undef BF_SLICE
 #undef BF_STEP
@@ -277,32 +392,42 @@ long long bneck_frame_launches() { return g_bneck_frame_launches; }
 
 // shapes the kernel is built for: layer3's stride-1 bottlenecks (14 x 14 x 256 -> 14 x 14 x 1024) in the 16-bit storage types
 bool bneck_frame_supported(int n, int h, int w, int cm, int cout, int stride) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("PVR_FRAME_BNECK"); on = e ? atoi(e) : 1; }
+    const char *e = getenv("PVR_FRAME_BNECK");                  // (read when a plan is built: A/B switch, default on)
+    const int on = e ? atoi(e) : 1;
     return on && h == 14 && w == 14 && cm == 256 && cout == 1024 && stride == 1 && n >= 1 && (int64_t)n * 196 * 1024 * 2 < 0x7ffffff0ll;
 }
 
-// w2p / w3p: fragment-blocked weights (launch_pack_frag_weights of the (256, 2304) / (1024, 256) matrices)
+// w2p / w3p / w1np: fragment-blocked weights (launch_pack_frag_weights of the (256, 2304) / (1024, 256) / (256, 1024) matrices)
 pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
-                              void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps) {
-    PVR_REQUIRE(t1 && w2p && b2 && (phases <= 1 || (w3p && b3 && res && y)) && (phases > 1 || t2_out), "bneck_frame: null argument");
+                              void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps, const void *w1np,
+                              const float *b1n, void *t1n) {
+    PVR_REQUIRE(t1 && w2p && b2 && ((phases & 15) <= 1 || (w3p && b3 && res && y)) && ((phases & 15) > 1 || t2_out) && ((phases & 15) < 7 || (w1np && b1n && t1n)), "bneck_frame: null argument");
+    PVR_REQUIRE((phases & 15) == 1 || (phases & 15) == 3 || (phases & 15) == 7, "bneck_frame: phases must be 1, 3 or 7 (+ 16 / 32: timing knock-outs of the y stores / identity loads)");
     PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "bneck_frame: 16-bit storage types only");
     BFP p;
     p.t1 = (const u16 *)t1; p.w2 = (const u16 *)w2p; p.w3 = (const u16 *)w3p; p.res = (const u16 *)res; p.b2 = b2; p.b3 = b3;
     p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases; p.stamps = stamps;
-    p.t1_bytes = p.t2_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
-    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0;
+    p.w1n = (const u16 *)w1np; p.b1n = b1n; p.t1n = (u16 *)t1n;
+    p.t1_bytes = p.t2_bytes = p.t1n_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
+    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0; p.w1n_bytes = w1np ? 256u * 1024 * 2 : 0;
     p.res_bytes = p.y_bytes = (unsigned)((size_t)n * 196 * 1024 * 2);
-    constexpr int lds = 4 * 209 * 128 + (256 + 1024) * 4;
+    constexpr int lds = 4 * 209 * 128, lds1 = lds + 2 * 208 * 128;
     static DeviceOnce attr_done;
     if (attr_done.needed()) {
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
         attr_done.mark();
     }
     ++g_bneck_frame_launches;
-    if (dtype == PVR_F16) hipLaunchKernelGGL(bneck_frame_kernel<true>, dim3(n), dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL(bneck_frame_kernel<false>, dim3(n), dim3(512), lds, stream, p);
+    if ((phases & 15) == 7) {
+        if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, true>), dim3(n), dim3(512), lds1, stream, p);
+        else hipLaunchKernelGGL((bneck_frame_kernel<false, true>), dim3(n), dim3(512), lds1, stream, p);
+    } else {
+        if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false>), dim3(n), dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((bneck_frame_kernel<false, false>), dim3(n), dim3(512), lds, stream, p);
+    }
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }

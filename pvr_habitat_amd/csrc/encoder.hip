@@ -337,6 +337,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
     if (e->desc.dtype == PVR_F32 || e->desc.arch == PVR_ARCH_CLIP_RN50) { e->sched_fused = e->sched_plain; return PVR_OK; }   // (CLIP: pools between the convolutions)
     int cur_t1 = B_T1;
     bool conv1_done = false;
+    int conv1_frame_out = -1;                                   // t1 buffer the previous per-frame launch wrote the next conv1's output to
     for (int i = 0; i < n;) {
         ConvOp &op = e->ops[i];
         if (ends_with(op.conv, ".conv1") && conv1_done) { conv1_done = false; ++i; continue; }
@@ -352,6 +353,38 @@ static pvr_status build_schedules(pvr_encoder *e) {
                 return -1;
             return c;
         };
+        // layer3's stride-1 bottlenecks: conv2 -> conv3 + residual of one 14 x 14 image per workgroup (bneck_frame.hip); with PVR_FRAME_NEXT1=1 the
+        // next block's conv1 rides in the same launch (it then reads / writes the two t1 buffers in turns, as the layer1 / layer2 chains do)
+        if (ends_with(op.conv, ".conv2") && op.k == 3 && !op.f32op && i + 1 < n && ends_with(e->ops[i + 1].conv, ".conv3") && !e->ops[i + 1].f32op &&
+            !e->ops[i + 1].out_f32 && e->ops[i + 1].relu == 1 && e->ops[i + 1].res_buf != B_NONE && op.relu == 1 && op.cin == op.cout && op.cin_real == op.cin &&
+            e->ops[i + 1].cout_real == e->ops[i + 1].cout && bneck_frame_supported(e->desc.chunk, op.h, op.w, op.cout, e->ops[i + 1].cout, op.stride)) {
+            Launch l;
+            l.conv2 = i; l.conv3 = i + 1; l.frame = 1; l.t1_in = conv1_frame_out >= 0 ? conv1_frame_out : op.in_buf;
+            conv1_frame_out = -1;
+            const char *f1 = getenv("PVR_FRAME_NEXT1");         // (read when the plan is built)
+            const bool next1_on = f1 && atoi(f1) != 0;
+            const int nx = i + 2;
+            if (next1_on && nx + 2 < n && ends_with(e->ops[nx].conv, ".conv1") && e->ops[nx].k == 1 && e->ops[nx].stride == 1 && e->ops[nx].relu == 1 && !e->ops[nx].f32op &&
+                e->ops[nx].cin == e->ops[i + 1].cout && e->ops[nx].cout == op.cout && e->ops[nx].in_buf == e->ops[i + 1].out_buf && e->ops[nx].cout_real == e->ops[nx].cout &&
+                e->ops[i + 1].tap.empty() && ends_with(e->ops[nx + 1].conv, ".conv2") && ends_with(e->ops[nx + 2].conv, ".conv3") &&
+                bneck_frame_supported(e->desc.chunk, e->ops[nx + 1].h, e->ops[nx + 1].w, e->ops[nx + 1].cout, e->ops[nx + 2].cout, e->ops[nx + 1].stride)) {
+                l.next1 = nx;
+                l.t1_out = l.t1_in == B_T1 ? B_T2 : B_T1;
+                conv1_frame_out = l.t1_out;
+                conv1_done = true;                              // (the loop skips that conv1: it ran inside this launch)
+            }
+            e->sched_fused.push_back(l);
+            for (int oi : {l.conv2, l.conv3, l.next1}) {
+                if (oi < 0 || e->ops[oi].d_wfb) continue;
+                ConvOp &o = e->ops[oi];
+                const size_t K = (size_t)o.k * o.k * o.cin;
+                PVR_HIP_TRY(hipMalloc((void **)&o.d_wfb, (size_t)o.cout * K * 2));
+                pvr_status s = launch_pack_frag_weights(o.d_w, o.d_wfb, o.cout, (int)K, nullptr);
+                if (s) return s;
+            }
+            i += 2;
+            continue;
+        }
         const int c3 = chain_end(i);
         if (c3 < 0) {
             Launch l; l.conv2 = i;
@@ -421,13 +454,13 @@ static pvr_status build_schedules(pvr_encoder *e) {
     // Two consecutive wave-form tails hand y (the second one's residual) and t1' (its conv2 input) over in the blocked layout
     // (chain_wave.hip): only when nothing else reads those two buffers in between - no tap, no other launch - and the geometry allows it.
     for (Launch &l : e->sched_fused)
-        if (l.conv3 >= 0) {
+        if (l.conv3 >= 0 && !l.frame) {
             const ConvOp &c2 = e->ops[l.conv2];
             l.wave = chain_uses_wave_form(c2.cout, l.next1 >= 0 ? e->ops[l.next1].cout : 0, c2.stride, l.ds >= 0);
         }
     for (size_t a = 0; a + 1 < e->sched_fused.size(); ++a) {
         Launch &A = e->sched_fused[a], &B = e->sched_fused[a + 1];
-        if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0) continue;
+        if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0 || A.frame || B.frame) continue;
         const ConvOp &a2 = e->ops[A.conv2], &a3 = e->ops[A.conv3], &b2 = e->ops[B.conv2], &b3 = e->ops[B.conv3];
         const int a_cmn = e->ops[A.next1].cout;
         const char *env = getenv("PVR_CHAIN_BLOCKED");
@@ -649,6 +682,7 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     if ((s = build_schedules(enc))) return s;
     for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); op.h_b.clear(); op.h_b.shrink_to_fit(); }
     if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
+    if (const char *f = getenv("PVR_FRAME_MIN_N")) enc->frame_min_n = atoi(f);
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
     plan_splitk(enc);
@@ -819,7 +853,29 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         for (const Launch &l : (enc->fuse ? enc->sched_fused : enc->sched_plain)) {
             const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
-            if (l.conv3 >= 0) {
+            if (l.frame) {
+                const ConvOp &c2 = enc->ops[l.conv2];
+                const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
+                if (nb >= enc->frame_min_n && !enc->low_latency) {
+                    s = launch_bneck_frame(enc->d_buf[l.t1_in], c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, c1 ? 7 : 3, dt, st,
+                                           nullptr, c1 ? c1->d_wfb : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr);
+                } else {
+                    // small batches (a frame per workgroup leaves most CUs idle): the member convolutions as their own launches - bit-identical.
+                    // t2 goes to the t1 buffer this launch does not read.
+                    const int t2b = l.t1_in == B_T1 ? B_T2 : B_T1;
+                    auto one = [&](const ConvOp &o, const void *in, const void *r_, void *out) {
+                        const int ks = small_batch_ksplit(enc, o, nb);
+                        if (ks) {
+                            if (!enc->d_smallk[enc->cur_lane] && hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES) != hipSuccess) { set_error("hipMalloc failed (split-K scratch)"); return (pvr_status)PVR_ERR_HIP; }
+                            return launch_conv_splitk(in, o.d_w, o.d_b, r_, out, enc->d_zero, enc->d_smallk[enc->cur_lane], ks, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+                        }
+                        return launch_conv(in, o.d_w, o.d_b, r_, out, enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+                    };
+                    s = one(c2, enc->d_buf[l.t1_in], nullptr, enc->d_buf[t2b]);
+                    if (!s) s = one(op, enc->d_buf[t2b], res, enc->d_buf[op.out_buf]);
+                    if (!s && c1) s = one(*c1, enc->d_buf[op.out_buf], nullptr, enc->d_buf[l.t1_out]);
+                }
+            } else if (l.conv3 >= 0) {
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
                 const ConvOp *cd = l.ds >= 0 ? &enc->ops[l.ds] : nullptr;
@@ -1080,7 +1136,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

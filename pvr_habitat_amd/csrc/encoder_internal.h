@@ -37,6 +37,13 @@ pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias,
 int conv_algo();
 void set_conv_algo(int a);
 
+// bneck_frame.hip: per-frame fused tail of the layer3 bottlenecks (conv2 -> conv3 + residual [-> the next block's conv1]); weights in the fragment-blocked layout
+bool bneck_frame_supported(int n, int h, int w, int cm, int cout, int stride);
+pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, hipStream_t stream);
+pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
+                              void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
+                              const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr);
+
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;
@@ -54,6 +61,7 @@ struct ConvOp {
     bool f32op = false;            // convolution on fp32 buffers with fp32 weights on the f32-input MFMA (conv_f32.hip) inside a 16-bit plan
     u16 *d_w = nullptr;
     u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
+    u16 *d_wfb = nullptr;          // fragment-blocked copy of d_w for the per-frame layer3 tail (bneck_frame.hip: launch_pack_frag_weights)
     u16 *d_wpb = nullptr;          // ... and that copy in the blocked layout [row >> 4][cin >> 3][row & 15][8] (chain_wave.hip reads W3 / Wd pieces from L2)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
@@ -71,6 +79,7 @@ struct Launch {
     int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
     int wave = 0;                             // chain: the wave form runs it (chain_wave.hip)
+    int frame = 0;                            // per-frame form (bneck_frame.hip, layer3): conv2 -> conv3 + residual [-> next1] of one 14 x 14 image per workgroup
     int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip)
 };
 
@@ -87,6 +96,7 @@ struct pvr_encoder {
     std::vector<Launch> sched_plain, sched_fused;   // one launch per op / with the layer1-layer2 bottleneck tails fused
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
     bool low_latency = false;                       // pvr_encoder_set_low_latency: split-K plan for forwards of <= 4 frames
+    int frame_min_n = 128;                          // frames per forward from which layer3's per-frame tails run as such (PVR_FRAME_MIN_N; smaller forwards: the member convolutions)
     float *d_smallk[PVR_MAX_LANES] = {nullptr};     // its fp32 partial planes, per lane (allocated on first use)
     bool tail32 = false;                            // round 3: + the last trunk stage entirely in fp32 (conv_f32.hip), fp32 stream one stage earlier
     bool resid32 = false;                           // compressed PVRs, f16: fp32 residual stream from layer3 on + fp32 compression head

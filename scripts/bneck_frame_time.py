@@ -39,27 +39,39 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-w2p, w3p = torch.empty_like(w2), torch.empty_like(w3)
+w2p, w3p, w1p = torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w1)
+_lib.check(L.pvr_op_pack_frag_weights(vp(w1), vp(w1p), 256, 1024, st()))
+t1n = torch.empty_like(t1)
 _lib.check(L.pvr_op_pack_frag_weights(vp(w2), vp(w2p), 256, 2304, st()))
 _lib.check(L.pvr_op_pack_frag_weights(vp(w3), vp(w3p), 1024, 256, st()))
 sep2 = timed(lambda: conv(x, w2, b2, None, t2, 256, 256, 3))
 sep3 = timed(lambda: conv(t2, w3, b3, r, y, 256, 1024, 1))
 sep1 = timed(lambda: conv(xin, w1, b1, None, t1, 1024, 256, 1))
 both = timed(lambda: (conv(x, w2, b2, None, t2, 256, 256, 3), conv(t2, w3, b3, r, y, 256, 1024, 1)))
-f1 = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), None, None, None, None, vp(t2), n, 1, cdt, st())))
-f3 = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), None, n, 3, cdt, st())))
+f1 = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), None, None, None, None, vp(t2), None, None, None, n, 1, cdt, st())))
+f3 = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), None, None, None, None, n, 3, cdt, st())))
+f7 = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), None, vp(w1p), vp(b1), vp(t1n), n, 7, cdt, st())))
+conv(y, w1, b1, None, t1, 1024, 256, 1)
+all3 = timed(lambda: (conv(x, w2, b2, None, t2, 256, 256, 3), conv(t2, w3, b3, r, y, 256, 1024, 1), conv(y, w1, b1, None, t1, 1024, 256, 1)))
 torch.cuda.synchronize()
-same = bool(torch.equal(y.view(torch.int16), y2.view(torch.int16)))
+same = bool(torch.equal(y.view(torch.int16), y2.view(torch.int16))) and bool(torch.equal(t1.view(torch.int16), t1n.view(torch.int16)))
+gf1 = 2 * n * 196 * 256 * 1024 / 1e9
 gf2, gf3 = 2 * n * 196 * 256 * 2304 / 1e9, 2 * n * 196 * 1024 * 256 / 1e9
-print('%s n=%d: separate conv1 %.1f us | conv2 %.1f us (%.0f TF) + conv3 %.1f us (%.0f TF) = %.1f us back to back %.1f us | fused conv2 only %.1f us (%.0f TF), conv2+conv3 %.1f us (%.0f TF)  bit-identical: %s'
-      % (dt, n, sep1, sep2, gf2 / sep2 * 1e3, sep3, gf3 / sep3 * 1e3, sep2 + sep3, both, f1, gf2 / f1 * 1e3, f3, (gf2 + gf3) / f3 * 1e3, same), flush=True)
+print('%s n=%d: separate conv1 %.1f us | conv2 %.1f us (%.0f TF) + conv3 %.1f us (%.0f TF) = %.1f us back to back %.1f us | fused conv2 only %.1f us (%.0f TF), conv2+conv3 %.1f us (%.0f TF), conv2+conv3+next conv1 %.1f us (%.0f TF) vs the three launches back to back %.1f us  bit-identical (y, t1n): %s'
+      % (dt, n, sep1, sep2, gf2 / sep2 * 1e3, sep3, gf3 / sep3 * 1e3, sep2 + sep3, both, f1, gf2 / f1 * 1e3, f3, (gf2 + gf3) / f3 * 1e3, f7, (gf1 + gf2 + gf3) / f7 * 1e3, all3, same), flush=True)
 
-if hasattr(L, 'pvr_debug_bneck_frame_stamps') and n > 8:
+for mode7 in ((False, True) if n > 8 else ()):
     stamps = torch.zeros(20, dtype=torch.int64, device='cuda')
     for _ in range(20):
-        _lib.check(L.pvr_debug_bneck_frame_stamps(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), n, cdt, vp(stamps), st()))
+        _lib.check(L.pvr_debug_bneck_frame_stamps(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), vp(w1p) if mode7 else None, vp(b1) if mode7 else None, vp(t1n) if mode7 else None, n, cdt, vp(stamps), st()))
     torch.cuda.synchronize()
     t = stamps.cpu().numpy().reshape(2, 10)
-    names = ['start', 'prologue done', 'conv2 loop done', 't2 written', 'conv3 start', 'chunk0 K loop', 'chunk0 epilogue', 'chunk2 done', 'all issued', 'stores drained']
+    names = ['start', 'prologue done', 'conv2 loop done', 't2 written', 'conv3 start', 'chunk/round0 K loop', 'chunk/round0 epilogue', 'chunk2/round5 done', 'all issued', 'stores drained']
+    print('stamps, %s:' % ('conv2 + conv3 + next conv1' if mode7 else 'conv2 + conv3'))
     for g_ in range(2):
         print('group %d cycles: ' % g_ + ', '.join('%s +%d' % (names[k], t[g_, k] - t[g_, k - 1]) for k in range(1, 10)) + ' | total %d' % (t[g_, 9] - t[g_, 0]))
+
+# timing knock-outs of the conv3 phase (results are wrong by construction): 16 = no y stores, 32 = no identity loads
+for ko in (16, 32, 48):
+    t_ = timed(lambda: _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), None, None, None, None, n, 3 | ko, cdt, st())))
+    print('knock-out %s: conv2+conv3 %.1f us' % ({16: 'no y stores', 32: 'no identity loads', 48: 'neither'}[ko], t_))

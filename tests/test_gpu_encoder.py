@@ -132,39 +132,47 @@ def _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, act, out_f32, res_f32,
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
 @pytest.mark.parametrize('n', [1, 3, 64, 256])
 def test_frame_bottleneck_op_is_bit_identical(dt, n):
-    """bneck_frame.hip (round 5): conv2 3x3 -> conv3 1x1 + residual of a layer3 bottleneck, one workgroup per 14 x 14 frame with the conv2 input
-    resident in LDS, against the two separate launches it replaces (pvr_op_conv2d: conv_pp256 / conv_expand): EVERY element of t2 (conv2 only
-    mode) and of y, bit for bit - same MFMA operand roles, K order and rounding points."""
+    """bneck_frame.hip (round 5): conv2 3x3 -> conv3 1x1 + residual [-> the next block's conv1 1x1] of a layer3 bottleneck, one workgroup per 14 x 14
+    frame with the conv2 input resident in LDS, against the separate launches it replaces (pvr_op_conv2d: conv_pp256 / conv_expand): EVERY element
+    of t2 (conv2 only mode), of y and of the next block's t1, bit for bit - same MFMA operand roles, K order and rounding points."""
     tdt, cdt = DT[dt]
     L = _lib.lib()
     x = torch.from_numpy(synth.normal(5, 'bf_t1_%d' % n, (n, 14, 14, 256))).clamp_(min=0).to(tdt).cuda()
-    w2 = torch.from_numpy(synth.normal(5, 'bf_w2', (256, 9 * 256), std=float(np.sqrt(2.0 / 2304)))).to(tdt).cuda()
-    w3 = torch.from_numpy(synth.normal(5, 'bf_w3', (1024, 256), std=float(np.sqrt(2.0 / 256)))).to(tdt).cuda()
+    w2n = torch.from_numpy(synth.normal(5, 'bf_w2', (256, 9 * 256), std=float(np.sqrt(2.0 / 2304)))).to(tdt).cuda()
+    w3n = torch.from_numpy(synth.normal(5, 'bf_w3', (1024, 256), std=float(np.sqrt(2.0 / 256)))).to(tdt).cuda()
+    w1n = torch.from_numpy(synth.normal(5, 'bf_w1n', (256, 1024), std=float(np.sqrt(2.0 / 1024)))).to(tdt).cuda()
     b2 = torch.from_numpy(synth.uniform(5, 'bf_b2', (256,), -0.5, 0.5)).cuda()
     b3 = torch.from_numpy(synth.uniform(5, 'bf_b3', (1024,), -0.5, 0.5)).cuda()
+    b1 = torch.from_numpy(synth.uniform(5, 'bf_b1n', (256,), -0.5, 0.5)).cuda()
     r = torch.from_numpy(synth.normal(5, 'bf_res_%d' % n, (n, 14, 14, 1024))).clamp_(min=0).to(tdt).cuda()
-    t2_ref = _run_conv(x, w2, b2, None, n, 14, 14, 256, 256, 3, 1, 1, 0, 0, cdt, tdt)
-    y_ref = _run_conv(t2_ref, w3, b3, r, n, 14, 14, 256, 1024, 1, 1, 1, 0, 0, cdt, tdt)
+    t2_ref = _run_conv(x, w2n, b2, None, n, 14, 14, 256, 256, 3, 1, 1, 0, 0, cdt, tdt)
+    y_ref = _run_conv(t2_ref, w3n, b3, r, n, 14, 14, 256, 1024, 1, 1, 1, 0, 0, cdt, tdt)
+    t1n_ref = _run_conv(y_ref, w1n, b1, None, n, 14, 14, 1024, 256, 1, 1, 1, 0, 0, cdt, tdt)
     vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    w2n, w3n = w2, w3                                                   # (the separate launches above read the natural layout)
-    w2, w3 = torch.empty_like(w2n), torch.empty_like(w3n)               # the fused kernel reads whole MFMA fragments: blocked copies
-    _lib.check(L.pvr_op_pack_frag_weights(vp(w2n), vp(w2), 256, 2304, _lib.stream_ptr()))
-    _lib.check(L.pvr_op_pack_frag_weights(vp(w3n), vp(w3), 1024, 256, _lib.stream_ptr()))
+    same = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    diff = lambda a, b: (int((a.view(torch.int16) != b.view(torch.int16)).sum()), float((a.float() - b.float()).abs().max()))
+    w2, w3, w1 = torch.empty_like(w2n), torch.empty_like(w3n), torch.empty_like(w1n)     # the fused kernel reads whole MFMA fragments: blocked copies
+    for src, dst, rows, k in ((w2n, w2, 256, 2304), (w3n, w3, 1024, 256), (w1n, w1, 256, 1024)):
+        _lib.check(L.pvr_op_pack_frag_weights(vp(src), vp(dst), rows, k, _lib.stream_ptr()))
     t2 = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda')
-    _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), None, None, None, None, vp(t2), n, 1, cdt, _lib.stream_ptr()))
+    _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), None, None, None, None, vp(t2), None, None, None, n, 1, cdt, _lib.stream_ptr()))
     torch.cuda.synchronize()
-    assert torch.equal(t2.view(torch.int16), t2_ref.view(torch.int16)), (int((t2.view(torch.int16) != t2_ref.view(torch.int16)).sum()), float((t2.float() - t2_ref.float()).abs().max()))
-    for with_t2 in (False, True):
+    assert same(t2, t2_ref), diff(t2, t2_ref)
+    for phases, with_t2 in ((3, False), (3, True), (7, False)):
         y = torch.full((n, 14, 14, 1024), float('nan'), dtype=tdt, device='cuda')
         t2b = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda') if with_t2 else None
+        t1n = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda') if phases == 7 else None
         before = L.pvr_debug_bneck_frame_launches()
-        _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y), vp(t2b), n, 3, cdt, _lib.stream_ptr()))
+        _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y), vp(t2b), vp(w1) if phases == 7 else None,
+                                        vp(b1) if phases == 7 else None, vp(t1n), n, phases, cdt, _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert L.pvr_debug_bneck_frame_launches() == before + 1
         assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) > 0
-        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), (int((y.view(torch.int16) != y_ref.view(torch.int16)).sum()), float((y.float() - y_ref.float()).abs().max()))
+        assert same(y, y_ref), (phases, diff(y, y_ref))
         if with_t2:
-            assert torch.equal(t2b.view(torch.int16), t2_ref.view(torch.int16))
+            assert same(t2b, t2_ref)
+        if phases == 7:
+            assert torch.isfinite(t1n.float()).all() and same(t1n, t1n_ref), diff(t1n, t1n_ref)
 
 
 PP_CASES = [
@@ -794,6 +802,48 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch)
     again = m(fr)
     assert torch.equal(fused, plain), float((fused - plain).abs().max())
     assert torch.equal(fused, again)
+
+
+@pytest.mark.parametrize('variant,dtype,n', [('conv5', 'bf16', 3), ('conv5', 'f16', 5), ('conv4', 'bf16', 2), ('conv5', 'bf16', 130)])
+def test_frame_bottleneck_plan_is_bit_identical(variant, dtype, n, monkeypatch):
+    """The layer3 plan with the per-frame fused tails (bneck_frame.hip: conv2 -> conv3 + residual of one 14 x 14 image per workgroup; with
+    PVR_FRAME_NEXT1=1 also the next block's conv1) against the plan of separate launches (PVR_FRAME_BNECK=0): layer3's output and the embedding, every
+    element, bit for bit; the launch names say which plan ran and the kernel's launch counter that it did.  n = 130: above the default batch
+    threshold; the small batches force the kernel with PVR_FRAME_MIN_N=1 and also check the below-threshold path (member convolutions)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    L = _lib.lib()
+    sd = synth.resnet50_state_dict(8, variant)
+    fr = torch.from_numpy(synth.smooth_frames(40 + n, n, 96, 128)).cuda()
+    outs = {}
+    for key, on, next1, min_n in (('sep', '0', '0', None), ('frame', '1', '0', '1'), ('frame_next1', '1', '1', '1'), ('below', '1', '1', '100000')):
+        monkeypatch.setenv('PVR_FRAME_BNECK', on)
+        monkeypatch.setenv('PVR_FRAME_NEXT1', next1)
+        if min_n is None:
+            monkeypatch.delenv('PVR_FRAME_MIN_N', raising=False)
+        else:
+            monkeypatch.setenv('PVR_FRAME_MIN_N', min_n)
+        m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=max(8, n))
+        names = m.op_names()
+        before = L.pvr_debug_bneck_frame_launches()
+        m.debug_stop_after('layer3')
+        m(fr)
+        t3 = m.tap('layer3', n * 14 * 14 * 1024).clone()
+        m.debug_stop_after('')
+        emb = m(fr).clone()
+        ran = L.pvr_debug_bneck_frame_launches() - before
+        m.close()
+        outs[key] = (t3, emb)
+        if key == 'sep':
+            assert not any(x.startswith('layer3') and '+' in x for x in names), names
+            assert ran == 0
+        else:
+            assert 'layer3.1.conv2+conv3' + ('+layer3.2.conv1' if next1 == '1' else '') in names, names
+            assert 'layer3.5.conv2+conv3' in names and 'layer3.0.conv2' in names           # the stride-2 block keeps its launches; the last block has no next conv1
+            assert ran == (10 if key != 'below' else 0), ran                                # five tails per forward, two forwards
+    for key in ('frame', 'frame_next1', 'below'):
+        for a, b, what in ((outs[key][0], outs['sep'][0], 'layer3'), (outs[key][1], outs['sep'][1], 'embedding')):
+            assert torch.isfinite(b).all() and float(b.abs().max()) > 0
+            assert torch.equal(a, b), (key, what, int((a != b).sum()), float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize('variant,dtype,n,ds,w128', [('conv5', 'bf16', 3, '1', '0'), ('conv5', 'f16', 5, '0', '1'), ('conv3', 'f16', 2, '1', '0'), ('conv5', 'bf16', 1, '1', '1'),
