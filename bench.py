@@ -56,7 +56,9 @@ def conv_algorithmic_bytes(n, names=None):
         head = parts[0].split('.')
         layer, block, kind = int(head[0][5:]), int(head[1]), head[2]
         planes, hi, ho, inpl = geom(layer, block)
-        if len(parts) > 1:                                   # conv2 -> conv3 (+ residual) [-> next conv1]
+        if len(parts) > 2 and kind == 'conv1' and parts[1] == 'conv2':      # the whole bottleneck per frame (bneck_frame.hip): x in (the identity is the same tensor), y out
+            tot += hi * hi * inpl + ho * ho * planes * 4
+        elif len(parts) > 1:                                 # conv2 -> conv3 (+ residual) [-> next conv1]
             if '&downsample' in parts[1]:                        # identity branch computed from the block input: x in, y out
                 tot += hi * hi * planes + hi * hi * inpl + ho * ho * planes * 4
             else:
@@ -852,7 +854,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel') + ' %d conv launches of one %d-frame chunk, HIP events on the launch stream, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel + bneck_frame_kernel') + ' %d conv launches of one %d-frame chunk, HIP events on the launch stream, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)

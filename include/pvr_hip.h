@@ -175,21 +175,22 @@ pvr_status pvr_op_conv2d(const void *in_dev, const void *wgt_dev, const float *b
                          const void *residual_dev, void *out_dev, int32_t n, int32_t h, int32_t w,
                          int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                          int32_t relu, int32_t out_f32, int32_t dtype, void *hip_stream);
-/* Per-frame fused tail of a layer3 bottleneck (torchvision Bottleneck, reference src/embeddings.py:118-120; bneck_frame.hip): t1 (n,14,14,256) 16-bit
- * -> conv2 3x3 pad 1 (+ b2, ReLU, rounded to the storage type) -> conv3 1x1 to 1024 channels (+ b3 + residual (n,14,14,1024), ReLU) -> y (n,14,14,1024)
- * [-> the NEXT block's conv1 1x1 (1024 -> 256, + b1n, ReLU) -> t1n (n,14,14,256)].  w2: (256, 3*3*256), w3: (1024, 256), w1n: (256, 1024) in the
- * fragment-blocked layout pvr_op_pack_frag_weights makes of pvr_op_conv2d's weight layout.  phases 1: conv2 only, its output to t2_out (n,14,14,256);
- * 3: conv2 + conv3 (t2_out optional); 7: + the next conv1.  One workgroup per frame; bit-identical to the pvr_op_conv2d calls it replaces. */
+/* Per-frame fused layer3 bottleneck (torchvision Bottleneck, reference src/embeddings.py:118-120; bneck_frame.hip), one workgroup per 14 x 14 frame:
+ * [x (n,14,14,1024) -> the block's own conv1 1x1 (+ b1f, ReLU) ->] t1 (n,14,14,256) -> conv2 3x3 pad 1 (+ b2, ReLU, rounded to the storage type) -> conv3 1x1
+ * to 1024 channels (+ b3 + residual (n,14,14,1024), ReLU) -> y (n,14,14,1024) [-> the NEXT block's conv1 1x1 (+ b1n, ReLU) -> t1n (n,14,14,256)].
+ * w2: (256, 3*3*256), w3: (1024, 256), w1n / w1f: (256, 1024) in the fragment-blocked layout pvr_op_pack_frag_weights makes of pvr_op_conv2d's layout.
+ * phases 1: conv2 only, its output to t2_out; 3: conv2 + conv3 (t2_out optional); 7: + the next conv1; 3 + 8 = 11: the block's own conv1 in front (the
+ * launch reads the block input = residual_dev, t1_dev is not used).  Bit-identical to the pvr_op_conv2d calls it replaces. */
 pvr_status pvr_op_bneck_frame(const void *t1_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev, const float *b3_dev,
                               const void *residual_dev, void *y_dev, void *t2_out_dev, const void *w1n_dev, const float *b1n_dev, void *t1n_dev,
-                              int32_t n, int32_t phases, int32_t dtype, void *hip_stream);
+                              const void *w1f_dev, const float *b1f_dev, int32_t n, int32_t phases, int32_t dtype, void *hip_stream);
 /* (rows, k) 16-bit weights in pvr_op_conv2d's layout -> the MFMA-fragment-blocked layout [row tile][k / 8][16 rows][8] with the rows permuted inside
  * every 32-row block (row 16 t + 4 a + c holds output channel 8 a + 4 t + c), same size; rows % 32 == 0, k % 32 == 0.  Device to device, enqueued. */
 pvr_status pvr_op_pack_frag_weights(const void *w_dev, void *out_dev, int32_t rows, int32_t k, void *hip_stream);
 /* diagnostics: the same launch (phases 3, or 7 when w1n_dev is given) writing s_memtime stamps of workgroup 8 to stamps_dev (20 x uint64: waves 0 and 4, ten phase boundaries each) */
 pvr_status pvr_debug_bneck_frame_stamps(const void *t1_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev, const float *b3_dev,
-                                        const void *residual_dev, void *y_dev, const void *w1n_dev, const float *b1n_dev, void *t1n_dev, int32_t n,
-                                        int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
+                                        const void *residual_dev, void *y_dev, const void *w1n_dev, const float *b1n_dev, void *t1n_dev,
+                                        const void *w1f_dev, const float *b1f_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
 /* launches of that kernel so far (tests: the layer3 plan really took it) */
 int64_t pvr_debug_bneck_frame_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape

@@ -56,7 +56,7 @@ long long bneck_frame_launches();
 pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, hipStream_t stream);
 pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *res, void *y,
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
-                              const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr);
+                              const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 long long pp_persistent_launches();
 
 static void *g_zero = nullptr;
@@ -87,15 +87,18 @@ pvr_status pvr_op_pack_frag_weights(const void *w, void *out, int32_t rows, int3
 
 // single-operator entry point of the per-frame fused layer3 bottleneck tail (bneck_frame.hip), for the op-level parity tests
 pvr_status pvr_op_bneck_frame(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *residual, void *y,
-                              void *t2_out, const void *w1n, const float *b1n, void *t1n, int32_t n, int32_t phases, int32_t dtype, void *stream) {
-    PVR_REQUIRE(n > 0 && n <= 1300 && ((phases & 15) == 1 || (phases & 15) == 3 || (phases & 15) == 7), "pvr_op_bneck_frame: n must be 1..1300, phases 1 (conv2 only), 3 (conv2 + conv3) or 7 (+ the next conv1)");
-    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, t2_out, n, phases, dtype, (hipStream_t)stream, nullptr, w1n, b1n, t1n);
+                              void *t2_out, const void *w1n, const float *b1n, void *t1n, const void *w1f, const float *b1f, int32_t n, int32_t phases,
+                              int32_t dtype, void *stream) {
+    PVR_REQUIRE(n > 0 && n <= 1300, "pvr_op_bneck_frame: n must be 1..1300");
+    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, t2_out, n, phases, dtype, (hipStream_t)stream, nullptr, w1n, b1n, t1n, w1f, b1f);
 }
 // the same launch with s_memtime stamps of block 8 (20 x uint64 on the device: waves 0 and 4, ten phase boundaries each) - diagnostics only
 pvr_status pvr_debug_bneck_frame_stamps(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *residual, void *y,
-                                        const void *w1n, const float *b1n, void *t1n, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *stream) {
+                                        const void *w1n, const float *b1n, void *t1n, const void *w1f, const float *b1f, int32_t n, int32_t dtype,
+                                        uint64_t *stamps_dev, void *stream) {
     PVR_REQUIRE(stamps_dev && n > 8, "pvr_debug_bneck_frame_stamps: needs a stamp buffer and more than 8 frames");
-    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, w1n ? 7 : 3, dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev, w1n, b1n, t1n);
+    return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, (w1n ? 7 : 3) | (w1f ? 8 : 0), dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev,
+                              w1n, b1n, t1n, w1f, b1f);
 }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 

@@ -41,17 +41,19 @@ struct BFP {
     const u16 *t1, *w2, *w3, *res;  // w2 / w3: fragment-blocked (pack_frag_weights)
     const float *b2, *b3;
     u16 *y, *t2_out;               // t2_out != nullptr (tests): conv2's output also goes to HBM, NHWC
+    const u16 *w1f;                // FRONT1: this block's own conv1 weights (256, 1024), fragment-blocked, and bias: the launch then reads the block INPUT
+    const float *b1f;              //         (= the identity tensor `res`) and computes t1 itself
     const u16 *w1n;                // NEXT1: the next block's conv1 weights (256, 1024), fragment-blocked; its bias; its output (n,14,14,256)
     const float *b1n;
     u16 *t1n;
-    int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3, 7: + the next block's conv1
-    unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes, w1n_bytes, t1n_bytes;
+    int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3, 7: + the next block's conv1; + 8: the block's own conv1 in front
+    unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes, w1n_bytes, t1n_bytes, w1f_bytes;
     unsigned long long *stamps;    // diagnostics (scripts/bneck_frame_time.py): s_memtime at the phase boundaries of block 8, waves 0 and 4; nullptr in the product
 };
 
 #define BF_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
-template <bool F16, bool NEXT1>
+template <bool F16, bool NEXT1, bool FRONT1 = false>
 __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int NPIX = 196, IW = 14, CM = 256, CO = 1024, NT = 13;
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
 
     // ---- the frame's t1 image -> T: 4 slices x 26 groups of 8 rows, one 1 KB DMA each (rows >= 196: offset past num_records -> zeros)
+    if constexpr (!FRONT1)
     for (int u = wave; u < 104; u += 8) {
         const int s = u / 26, g = u % 26;
         const int row = g * 8 + (lane >> 3), lch = (lane & 7) ^ ((row >> 1) & 7);
@@ -91,22 +94,9 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
             dst_[i][ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_, wlane, (((rt0_) + i) * (KC_) + 4 * (2 * (kt_) + ks)) * 256, 0));
-    BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, 0);
+    if constexpr (!FRONT1) { BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, 0); }
 
     const int sw = (fr >> 1) & 7;
-    // border masks of conv2: bit (3 (dy+1) + (dx+1)) of vmask[j] set <=> pixel 16 j + fr exists and its (dy, dx) neighbour is inside the image
-    int vmask[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int pp = 16 * j + fr, py = pp / IW, px = pp % IW;
-        int m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-            m |= (int)(pp < NPIX && (unsigned)yy < (unsigned)IW && (unsigned)xx < (unsigned)IW) << t;
-        }
-        vmask[j] = m;
-    }
     const int zaddr = ZROW * 128 + (fq << 4);             // the zero row (its XOR-64 partner is in the row too)
 
     f32x4 acc[2][NT];
@@ -118,17 +108,18 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     // counted lgkmcnt waits (hipcc's own schedule kept every read next to its use: read, wait, 4 MFMAs - the LDS latency of every tile exposed).
     // W0_ / W1_ hold the weight fragments of slices 0, 2 / 1, 3; NEXT0_ .. NEXT3_ request the fragments of the following K tiles at the slice starts.
     V8 xs[3][2];
+    int xbase = 0;                                        // byte offset of the first slice of a pipeline run (the front conv1 alternates between the image's two halves)
 #define BF_XREAD(q_)                                                                                            \
     {                                                                                                          \
-        const int a0_ = xa[(q_) % NT] + ((q_) / NT) * SLICE;                                                    \
+        const int a0_ = xa[(q_) % NT] + xbase + ((q_) / NT) * SLICE;                                            \
         asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][0]) : "v"(a0_));                                 \
         asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][1]) : "v"(a0_ ^ 64));                            \
     }
-#define BF_STEP(q_, W_)                                                                                         \
+#define BF_STEP(q_, W_, NQ_)                                                                                    \
     {                                                                                                          \
-        if ((q_) + 2 < 4 * NT) BF_XREAD((q_) + 2);                                                              \
-        if ((q_) + 2 < 4 * NT) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));      \
-        else if ((q_) + 1 < 4 * NT) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1])); \
+        if ((q_) + 2 < (NQ_)) BF_XREAD((q_) + 2);                                                               \
+        if ((q_) + 2 < (NQ_)) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));      \
+        else if ((q_) + 1 < (NQ_)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1])); \
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         constexpr int j_ = (q_) % NT;                                                                           \
@@ -137,27 +128,127 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         acc[0][j_] = mfma16<F16>(W_[0][1], xs[(q_) % 3][1], acc[0][j_]);                                        \
         acc[1][j_] = mfma16<F16>(W_[1][1], xs[(q_) % 3][1], acc[1][j_]);                                        \
     }
-#define BF_SLICE(s_, W_)                                                                                        \
-    BF_STEP((s_) * NT + 0, W_) BF_STEP((s_) * NT + 1, W_) BF_STEP((s_) * NT + 2, W_) BF_STEP((s_) * NT + 3, W_)  \
-    BF_STEP((s_) * NT + 4, W_) BF_STEP((s_) * NT + 5, W_) BF_STEP((s_) * NT + 6, W_) BF_STEP((s_) * NT + 7, W_)  \
-    BF_STEP((s_) * NT + 8, W_) BF_STEP((s_) * NT + 9, W_) BF_STEP((s_) * NT + 10, W_) BF_STEP((s_) * NT + 11, W_) \
-    BF_STEP((s_) * NT + 12, W_)
+#define BF_SLICE(s_, W_, NQ_)                                                                                   \
+    BF_STEP((s_) * NT + 0, W_, NQ_) BF_STEP((s_) * NT + 1, W_, NQ_) BF_STEP((s_) * NT + 2, W_, NQ_) BF_STEP((s_) * NT + 3, W_, NQ_)  \
+    BF_STEP((s_) * NT + 4, W_, NQ_) BF_STEP((s_) * NT + 5, W_, NQ_) BF_STEP((s_) * NT + 6, W_, NQ_) BF_STEP((s_) * NT + 7, W_, NQ_)  \
+    BF_STEP((s_) * NT + 8, W_, NQ_) BF_STEP((s_) * NT + 9, W_, NQ_) BF_STEP((s_) * NT + 10, W_, NQ_) BF_STEP((s_) * NT + 11, W_, NQ_) \
+    BF_STEP((s_) * NT + 12, W_, NQ_)
+    // two K tiles (slices xbase / SLICE and the next one) with the fragments WA_ / WB_: the front conv1's half chunks
+#define BF_TWO_KTILES(WA_, WB_)                                                                                 \
+    {                                                                                                          \
+        BF_XREAD(0); BF_XREAD(1);                                                                               \
+        BF_SLICE(0, WA_, 2 * NT)                                                                                \
+        BF_SLICE(1, WB_, 2 * NT)                                                                                \
+    }
 #define BF_FOUR_KTILES(NEXT0_, NEXT1_, NEXT2_, NEXT3_)                                                          \
     {                                                                                                          \
         BF_XREAD(0); BF_XREAD(1);                                                                               \
-        NEXT0_; BF_SLICE(0, wa)                                                                                 \
-        NEXT1_; BF_SLICE(1, wb)                                                                                 \
-        NEXT2_; BF_SLICE(2, wa)                                                                                 \
-        NEXT3_; BF_SLICE(3, wb)                                                                                 \
+        NEXT0_; BF_SLICE(0, wa, 4 * NT)                                                                         \
+        NEXT1_; BF_SLICE(1, wb, 4 * NT)                                                                         \
+        NEXT2_; BF_SLICE(2, wa, 4 * NT)                                                                         \
+        NEXT3_; BF_SLICE(3, wb, 4 * NT)                                                                         \
     }
 
     BF_ZERO_ACC();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the image has landed (this wave's part; the first weight fragments too)
-    __syncthreads();
+#define BF_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    int xa[NT];
+    if constexpr (FRONT1) {
+        // =============================================== conv1 (1x1, 1024 -> 256) of THIS block, in front =====================================
+        // The block input x (= the identity tensor) goes through the image region in four chunks of 256 channels - the region is free until t1
+        // exists - each chunk: DMA (the t1 load's code with x's row stride), wait, barrier, four barrier-free K tiles.  The chunk's DMA latency
+        // is exposed (no second buffer: 107 KB of 160); what the launch saves is conv1's own launch (its ramp, prologue, output burst and the
+        // 51 MB t1 round trip).  The weight fragments of a chunk's first K tile are requested BEFORE its DMA (loads retire in order: a
+        // request behind the DMA could only be waited for together with it).
+        const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
+        const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1f), 0, p.w1f_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);
+        // Eight half chunks of 128 channels alternate between the two halves of the image region (slices 0-1 / 2-3): half chunk h + 1 lands while h is
+        // computed.  Loads retire in order, so the weight fragments are requested a whole half chunk ahead, right behind the DMA they will be
+        // waited for together with: W of half chunk h + 1 (wc / wd or wa / wb in turns) is in flight with its pixels.
+        V8 wc[2][2], wd[2][2];
+        auto stage_x = [&](int h) {                                // block-input channels [128 h, 128 h + 128) -> image slices 2 (h & 1), 2 (h & 1) + 1
+            int lane_c = lane;
+            asm volatile("" : "+v"(lane_c));
+            for (int u = wave; u < 52; u += 8) {
+                const int s2 = u / 26, g = u % 26;
+                const int row = g * 8 + (lane_c >> 3), lch = (lane_c & 7) ^ ((row >> 1) & 7);
+                const int vo = row < NPIX ? ((n * NPIX + row) * CO + h * 128 + s2 * 64 + lch * 8) * 2 : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * (h & 1) + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
+            }
+        };
+#define BF_CHUNK_DONE() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        BF_LOAD_W(wa, rs_w1, 2 * wave, CO / 8, 0);
+        BF_LOAD_W(wb, rs_w1, 2 * wave, CO / 8, 1);
+        stage_x(0);
+        BF_CHUNK_DONE();
+#pragma unroll 1
+        for (int hh = 0; hh < 4; ++hh) {
+            // (opaque per iteration: the fragment addresses do not change, and hipcc otherwise hoists every step's address and its XOR-64 partner out of
+            //  this loop - 55 spilled VGPRs)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(xa[j]));
+            const int h = 2 * hh;
+            stage_x(h + 1);
+            BF_LOAD_W(wc, rs_w1, 2 * wave, CO / 8, 2 * h + 2);
+            BF_LOAD_W(wd, rs_w1, 2 * wave, CO / 8, 2 * h + 3);
+            xbase = 0;
+            BF_TWO_KTILES(wa, wb);
+            BF_CHUNK_DONE();                                       // half chunk h + 1 has landed; every wave is done with half 0
+            const bool lastc = hh == 3;
+            if (!lastc) stage_x(h + 2);
+            // (the last requests: conv2's first K tile and a harmless repeat - never a branch around loads)
+            const auto rs_n = lastc ? rs_w2 : rs_w1;
+            const int kc_n = lastc ? 9 * CM / 8 : CO / 8;
+            BF_LOAD_W(wa, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 4);
+            BF_LOAD_W(wb, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 5);
+            xbase = 2 * SLICE;
+            BF_TWO_KTILES(wc, wd);
+            if (!lastc) BF_CHUNK_DONE();
+        }
+        xbase = 0;
+#undef BF_CHUNK_DONE
+        BF_BARRIER();                                             // every wave's reads of the last chunk are done
+        {
+            const int c1 = 32 * wave + 8 * fq;
+            const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b1f + c1), bh = *reinterpret_cast<const f32x4 *>(p.b1f + c1 + 4);
+            char *tbase = smem + (wave >> 1) * SLICE + (((4 * (wave & 1) + fq) ^ sw) << 4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int pp = 16 * j + fr;
+                const f32x4 lo = acc[0][j], hi = acc[1][j];
+                const float v[8] = {lo[0] + bl[0], lo[1] + bl[1], lo[2] + bl[2], lo[3] + bl[3], hi[0] + bh[0], hi[1] + bh[1], hi[2] + bh[2], hi[3] + bh[3]};
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
+                if (pp >= NPIX) o = u32x4{0u, 0u, 0u, 0u};        // padding pixels of tile 12: zeros, as the t1 load leaves them
+                *reinterpret_cast<u32x4 *>(tbase + pp * 128) = o;
+            }
+        }
+        BF_ZERO_ACC();
+        BF_BARRIER();                                             // t1 is in the image
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the image has landed (this wave's part; the first weight fragments too)
+        __syncthreads();
+    }
     BF_TS(1);
 
+    // border masks of conv2: bit (3 (dy+1) + (dx+1)) of vmask[j] set <=> pixel 16 j + fr exists and its (dy, dx) neighbour is inside the image
+    int vmask[NT];
+    int frm = fr;
+    asm volatile("" : "+v"(frm));                                  // (computed here, after the front phase: thirteen live registers less in it)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int pp = 16 * j + frm, py = pp / IW, px = pp % IW;
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            m |= (int)(pp < NPIX && (unsigned)yy < (unsigned)IW && (unsigned)xx < (unsigned)IW) << t;
+        }
+        vmask[j] = m;
+    }
     // =================================================== conv2: 9 taps x 4 slices =====================================================
-    int xa[NT];
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         // row offset and swizzle of this tap's neighbour pixel; per tile: the image row or the zero row
@@ -176,7 +267,6 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
                        BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 3), BF_LOAD_W(wa, rs_n, rt_n, kc_n, kt_n));
     }
     BF_TS(2);
-#define BF_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     BF_BARRIER();                                               // every wave's reads of the t1 image are done
     // ---- t2 = relu(conv2 + b2), rounded to the storage type, into the image: this wave's 32 channels = half of slice w >> 1
     {
@@ -360,6 +450,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #undef BF_TS
 #undef BF_BARRIER
 #undef BF_FOUR_KTILES
+#undef BF_TWO_KTILES
 #undef BF_SLICE
 #undef BF_STEP
 #undef BF_XREAD
@@ -397,33 +488,42 @@ bool bneck_frame_supported(int n, int h, int w, int cm, int cout, int stride) {
     return on && h == 14 && w == 14 && cm == 256 && cout == 1024 && stride == 1 && n >= 1 && (int64_t)n * 196 * 1024 * 2 < 0x7ffffff0ll;
 }
 
-// w2p / w3p / w1np: fragment-blocked weights (launch_pack_frag_weights of the (256, 2304) / (1024, 256) / (256, 1024) matrices)
+// w2p / w3p / w1np / w1fp: fragment-blocked weights (launch_pack_frag_weights of the (256, 2304) / (1024, 256) / (256, 1024) / (256, 1024) matrices).
+// phases: 1 conv2 only (t2_out), 3 conv2 + conv3, 7 + the NEXT block's conv1 (w1np, b1n -> t1n); + 8: the block's OWN conv1 in front (w1fp, b1f; the
+// launch reads the block input `res` instead of t1); + 16 / 32: timing knock-outs.
 pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps, const void *w1np,
-                              const float *b1n, void *t1n) {
-    PVR_REQUIRE(t1 && w2p && b2 && ((phases & 15) <= 1 || (w3p && b3 && res && y)) && ((phases & 15) > 1 || t2_out) && ((phases & 15) < 7 || (w1np && b1n && t1n)), "bneck_frame: null argument");
-    PVR_REQUIRE((phases & 15) == 1 || (phases & 15) == 3 || (phases & 15) == 7, "bneck_frame: phases must be 1, 3 or 7 (+ 16 / 32: timing knock-outs of the y stores / identity loads)");
+                              const float *b1n, void *t1n, const void *w1fp, const float *b1f) {
+    const int ph = phases & 7, front = (phases & 8) != 0;
+    PVR_REQUIRE(ph == 1 || ph == 3 || ph == 7, "bneck_frame: phases must be 1, 3 or 7 (+ 8: own conv1 in front; + 16 / 32: timing knock-outs of the y stores / identity loads)");
+    PVR_REQUIRE((t1 || front) && w2p && b2 && (ph <= 1 || (w3p && b3 && res && y)) && (ph > 1 || t2_out) && (ph < 7 || (w1np && b1n && t1n)) &&
+                (!front || (w1fp && b1f && res && ph == 3)), "bneck_frame: null argument (the front conv1 comes with phases 3 only)");
     PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "bneck_frame: 16-bit storage types only");
     BFP p;
     p.t1 = (const u16 *)t1; p.w2 = (const u16 *)w2p; p.w3 = (const u16 *)w3p; p.res = (const u16 *)res; p.b2 = b2; p.b3 = b3;
-    p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases; p.stamps = stamps;
-    p.w1n = (const u16 *)w1np; p.b1n = b1n; p.t1n = (u16 *)t1n;
+    p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases & ~8; p.stamps = stamps;
+    p.w1n = (const u16 *)w1np; p.b1n = b1n; p.t1n = (u16 *)t1n; p.w1f = (const u16 *)w1fp; p.b1f = b1f;
     p.t1_bytes = p.t2_bytes = p.t1n_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
-    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0; p.w1n_bytes = w1np ? 256u * 1024 * 2 : 0;
+    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0; p.w1n_bytes = w1np ? 256u * 1024 * 2 : 0; p.w1f_bytes = w1fp ? 256u * 1024 * 2 : 0;
     p.res_bytes = p.y_bytes = (unsigned)((size_t)n * 196 * 1024 * 2);
     constexpr int lds = 4 * 209 * 128, lds1 = lds + 2 * 208 * 128;
     static DeviceOnce attr_done;
     if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
         attr_done.mark();
     }
     ++g_bneck_frame_launches;
-    if ((phases & 15) == 7) {
+    if (ph == 7) {
         if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, true>), dim3(n), dim3(512), lds1, stream, p);
         else hipLaunchKernelGGL((bneck_frame_kernel<false, true>), dim3(n), dim3(512), lds1, stream, p);
+    } else if (front) {
+        if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false, true>), dim3(n), dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((bneck_frame_kernel<false, false, true>), dim3(n), dim3(512), lds, stream, p);
     } else {
         if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false>), dim3(n), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((bneck_frame_kernel<false, false>), dim3(n), dim3(512), lds, stream, p);

@@ -353,6 +353,33 @@ static pvr_status build_schedules(pvr_encoder *e) {
                 return -1;
             return c;
         };
+        // layer3's stride-1 bottlenecks as ONE launch per block: conv1 -> conv2 -> conv3 + identity of one 14 x 14 image per workgroup
+        // (bneck_frame.hip with the block's own conv1 in front; PVR_FRAME_FRONT1=0: conv1 keeps its launch)
+        {
+            const char *ff = getenv("PVR_FRAME_FRONT1"), *fn = getenv("PVR_FRAME_NEXT1");
+            const bool front_on = (!ff || atoi(ff) != 0) && !(fn && atoi(fn) != 0);
+            if (front_on && ends_with(op.conv, ".conv1") && op.k == 1 && op.stride == 1 && op.relu == 1 && !op.f32op && !op.out_f32 && op.tap.empty() && i + 2 < n &&
+                op.cin_real == op.cin && op.cout_real == op.cout) {
+                const ConvOp &o2 = e->ops[i + 1], &o3 = e->ops[i + 2];
+                if (ends_with(o2.conv, ".conv2") && o2.k == 3 && !o2.f32op && o2.relu == 1 && o2.cin == o2.cout && o2.cin_real == o2.cin && o2.in_buf == op.out_buf &&
+                    ends_with(o3.conv, ".conv3") && !o3.f32op && !o3.out_f32 && o3.relu == 1 && o3.res_buf == op.in_buf && o3.cout == op.cin && o3.cout_real == o3.cout &&
+                    o3.in_buf == o2.out_buf && op.cout == o2.cin && bneck_frame_supported(e->desc.chunk, o2.h, o2.w, o2.cout, o3.cout, o2.stride)) {
+                    Launch l;
+                    l.conv1 = i; l.conv2 = i + 1; l.conv3 = i + 2; l.frame = 1; l.t1_in = op.out_buf;
+                    e->sched_fused.push_back(l);
+                    for (int oi : {l.conv1, l.conv2, l.conv3}) {
+                        ConvOp &o = e->ops[oi];
+                        if (o.d_wfb) continue;
+                        const size_t K = (size_t)o.k * o.k * o.cin;
+                        PVR_HIP_TRY(hipMalloc((void **)&o.d_wfb, (size_t)o.cout * K * 2));
+                        pvr_status s = launch_pack_frag_weights(o.d_w, o.d_wfb, o.cout, (int)K, nullptr);
+                        if (s) return s;
+                    }
+                    i += 3;
+                    continue;
+                }
+            }
+        }
         // layer3's stride-1 bottlenecks: conv2 -> conv3 + residual of one 14 x 14 image per workgroup (bneck_frame.hip); with PVR_FRAME_NEXT1=1 the
         // next block's conv1 rides in the same launch (it then reads / writes the two t1 buffers in turns, as the layer1 / layer2 chains do)
         if (ends_with(op.conv, ".conv2") && op.k == 3 && !op.f32op && i + 1 < n && ends_with(e->ops[i + 1].conv, ".conv3") && !e->ops[i + 1].f32op &&
@@ -856,13 +883,18 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if (l.frame) {
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
-                if (nb >= enc->frame_min_n && !enc->low_latency) {
+                const ConvOp *cf = l.conv1 >= 0 ? &enc->ops[l.conv1] : nullptr;
+                if (nb >= enc->frame_min_n && !enc->low_latency && cf) {
+                    s = launch_bneck_frame(nullptr, c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, 3 | 8, dt, st,
+                                           nullptr, nullptr, nullptr, nullptr, cf->d_wfb, cf->d_b);
+                } else if (nb >= enc->frame_min_n && !enc->low_latency) {
                     s = launch_bneck_frame(enc->d_buf[l.t1_in], c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, c1 ? 7 : 3, dt, st,
                                            nullptr, c1 ? c1->d_wfb : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr);
                 } else {
                     // small batches (a frame per workgroup leaves most CUs idle): the member convolutions as their own launches - bit-identical.
                     // t2 goes to the t1 buffer this launch does not read.
                     const int t2b = l.t1_in == B_T1 ? B_T2 : B_T1;
+                    s = PVR_OK;
                     auto one = [&](const ConvOp &o, const void *in, const void *r_, void *out) {
                         const int ks = small_batch_ksplit(enc, o, nb);
                         if (ks) {
@@ -871,7 +903,8 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                         }
                         return launch_conv(in, o.d_w, o.d_b, r_, out, enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
                     };
-                    s = one(c2, enc->d_buf[l.t1_in], nullptr, enc->d_buf[t2b]);
+                    if (cf) s = one(*cf, enc->d_buf[cf->in_buf], nullptr, enc->d_buf[l.t1_in]);
+                    if (!s) s = one(c2, enc->d_buf[l.t1_in], nullptr, enc->d_buf[t2b]);
                     if (!s) s = one(op, enc->d_buf[t2b], res, enc->d_buf[op.out_buf]);
                     if (!s && c1) s = one(*c1, enc->d_buf[op.out_buf], nullptr, enc->d_buf[l.t1_out]);
                 }
@@ -1016,7 +1049,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
         const bool fused = enc->fuse && enc->desc.dtype != PVR_F32;
         for (const Launch &l : (fused ? enc->sched_fused : enc->sched_plain)) {
             if (i >= nl) break;
-            op_flops[i++] = flops(l.conv2) + flops(l.conv3) + flops(l.next1) + flops(l.ds);
+            op_flops[i++] = flops(l.conv1) + flops(l.conv2) + flops(l.conv3) + flops(l.next1) + flops(l.ds);
         }
         *n_ops = nl;
     }
@@ -1078,7 +1111,8 @@ int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf
         const std::vector<Launch> &sc = fused ? enc->sched_fused : enc->sched_plain;
         const int i = index - 3;
         if (i < (int)sc.size()) {
-            nm = enc->ops[sc[i].conv2].conv;
+            nm = enc->ops[sc[i].conv1 >= 0 ? sc[i].conv1 : sc[i].conv2].conv;
+            if (sc[i].conv1 >= 0) nm += "+conv2";
             if (sc[i].conv3 >= 0) nm += "+" + enc->ops[sc[i].conv3].conv.substr(enc->ops[sc[i].conv3].conv.rfind('.') + 1);
             if (sc[i].ds >= 0) nm += "&downsample";
             if (sc[i].next1 >= 0) nm += "+" + enc->ops[sc[i].next1].conv;

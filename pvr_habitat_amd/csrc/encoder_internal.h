@@ -42,7 +42,7 @@ bool bneck_frame_supported(int n, int h, int w, int cm, int cout, int stride);
 pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, hipStream_t stream);
 pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
-                              const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr);
+                              const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 
 struct HostTensor {
     std::vector<int64_t> shape;
@@ -79,6 +79,7 @@ struct Launch {
     int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
     int wave = 0;                             // chain: the wave form runs it (chain_wave.hip)
+    int conv1 = -1;                           // per-frame form: the block's own conv1 runs in front, inside the launch (the launch reads the block input)
     int frame = 0;                            // per-frame form (bneck_frame.hip, layer3): conv2 -> conv3 + residual [-> next1] of one 14 x 14 image per workgroup
     int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip)
 };

@@ -155,7 +155,7 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
     for src, dst, rows, k in ((w2n, w2, 256, 2304), (w3n, w3, 1024, 256), (w1n, w1, 256, 1024)):
         _lib.check(L.pvr_op_pack_frag_weights(vp(src), vp(dst), rows, k, _lib.stream_ptr()))
     t2 = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda')
-    _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), None, None, None, None, vp(t2), None, None, None, n, 1, cdt, _lib.stream_ptr()))
+    _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), None, None, None, None, vp(t2), None, None, None, None, None, n, 1, cdt, _lib.stream_ptr()))
     torch.cuda.synchronize()
     assert same(t2, t2_ref), diff(t2, t2_ref)
     for phases, with_t2 in ((3, False), (3, True), (7, False)):
@@ -164,7 +164,7 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
         t1n = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda') if phases == 7 else None
         before = L.pvr_debug_bneck_frame_launches()
         _lib.check(L.pvr_op_bneck_frame(vp(x), vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y), vp(t2b), vp(w1) if phases == 7 else None,
-                                        vp(b1) if phases == 7 else None, vp(t1n), n, phases, cdt, _lib.stream_ptr()))
+                                        vp(b1) if phases == 7 else None, vp(t1n), None, None, n, phases, cdt, _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert L.pvr_debug_bneck_frame_launches() == before + 1
         assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) > 0
@@ -173,6 +173,16 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
             assert same(t2b, t2_ref)
         if phases == 7:
             assert torch.isfinite(t1n.float()).all() and same(t1n, t1n_ref), diff(t1n, t1n_ref)
+    # the whole bottleneck in one launch (phases 3 + 8): the block's own conv1 in front, reading the block input (= the identity tensor) r
+    t1f_ref = _run_conv(r, w1n, b1, None, n, 14, 14, 1024, 256, 1, 1, 1, 0, 0, cdt, tdt)
+    t2f_ref = _run_conv(t1f_ref, w2n, b2, None, n, 14, 14, 256, 256, 3, 1, 1, 0, 0, cdt, tdt)
+    yf_ref = _run_conv(t2f_ref, w3n, b3, r, n, 14, 14, 256, 1024, 1, 1, 1, 0, 0, cdt, tdt)
+    y = torch.full((n, 14, 14, 1024), float('nan'), dtype=tdt, device='cuda')
+    t2b = torch.full((n, 14, 14, 256), float('nan'), dtype=tdt, device='cuda')
+    _lib.check(L.pvr_op_bneck_frame(None, vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y), vp(t2b), None, None, None, vp(w1), vp(b1), n, 3 | 8, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert same(t2b, t2f_ref), diff(t2b, t2f_ref)
+    assert torch.isfinite(y.float()).all() and same(y, yf_ref), diff(y, yf_ref)
 
 
 PP_CASES = [
@@ -806,17 +816,20 @@ def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch)
 
 @pytest.mark.parametrize('variant,dtype,n', [('conv5', 'bf16', 3), ('conv5', 'f16', 5), ('conv4', 'bf16', 2), ('conv5', 'bf16', 130)])
 def test_frame_bottleneck_plan_is_bit_identical(variant, dtype, n, monkeypatch):
-    """The layer3 plan with the per-frame fused tails (bneck_frame.hip: conv2 -> conv3 + residual of one 14 x 14 image per workgroup; with
-    PVR_FRAME_NEXT1=1 also the next block's conv1) against the plan of separate launches (PVR_FRAME_BNECK=0): layer3's output and the embedding, every
-    element, bit for bit; the launch names say which plan ran and the kernel's launch counter that it did.  n = 130: above the default batch
-    threshold; the small batches force the kernel with PVR_FRAME_MIN_N=1 and also check the below-threshold path (member convolutions)."""
+    """The layer3 plan with the per-frame fused bottlenecks (bneck_frame.hip, one 14 x 14 image per workgroup) - the default: the whole block
+    conv1 -> conv2 -> conv3 + identity in one launch; PVR_FRAME_FRONT1=0: conv2 -> conv3 + identity (conv1 keeps its launch); PVR_FRAME_NEXT1=1:
+    conv2 -> conv3 + identity -> the next block's conv1 - against the plan of separate launches (PVR_FRAME_BNECK=0): layer3's output and the
+    embedding, every element, bit for bit; the launch names say which plan ran and the kernel's launch counter that it did.  n = 130: above the
+    default batch threshold; the small batches force the kernel with PVR_FRAME_MIN_N=1 and also check the below-threshold path (member convolutions)."""
     from pvr_habitat_amd.embeddings import HipResNet50
     L = _lib.lib()
     sd = synth.resnet50_state_dict(8, variant)
     fr = torch.from_numpy(synth.smooth_frames(40 + n, n, 96, 128)).cuda()
     outs = {}
-    for key, on, next1, min_n in (('sep', '0', '0', None), ('frame', '1', '0', '1'), ('frame_next1', '1', '1', '1'), ('below', '1', '1', '100000')):
+    for key, on, front, next1, min_n in (('sep', '0', '1', '0', None), ('whole', '1', '1', '0', '1'), ('tail', '1', '0', '0', '1'), ('tail_next1', '1', '1', '1', '1'),
+                                         ('below', '1', '1', '0', '100000'), ('below_next1', '1', '1', '1', '100000')):
         monkeypatch.setenv('PVR_FRAME_BNECK', on)
+        monkeypatch.setenv('PVR_FRAME_FRONT1', front)
         monkeypatch.setenv('PVR_FRAME_NEXT1', next1)
         if min_n is None:
             monkeypatch.delenv('PVR_FRAME_MIN_N', raising=False)
@@ -837,10 +850,14 @@ def test_frame_bottleneck_plan_is_bit_identical(variant, dtype, n, monkeypatch):
             assert not any(x.startswith('layer3') and '+' in x for x in names), names
             assert ran == 0
         else:
-            assert 'layer3.1.conv2+conv3' + ('+layer3.2.conv1' if next1 == '1' else '') in names, names
-            assert 'layer3.5.conv2+conv3' in names and 'layer3.0.conv2' in names           # the stride-2 block keeps its launches; the last block has no next conv1
-            assert ran == (10 if key != 'below' else 0), ran                                # five tails per forward, two forwards
-    for key in ('frame', 'frame_next1', 'below'):
+            expect = {'whole': 'layer3.1.conv1+conv2+conv3', 'below': 'layer3.1.conv1+conv2+conv3', 'tail': 'layer3.1.conv2+conv3',
+                      'tail_next1': 'layer3.1.conv2+conv3+layer3.2.conv1', 'below_next1': 'layer3.1.conv2+conv3+layer3.2.conv1'}[key]
+            assert expect in names, names
+            assert 'layer3.0.conv2' in names and any(x.startswith('layer3.5.') and x.endswith('conv2+conv3') for x in names), names   # the stride-2 block keeps its launches
+            assert ran == (0 if key.startswith('below') else 10), ran                       # five launches per forward, two forwards
+    for key in outs:
+        if key == 'sep':
+            continue
         for a, b, what in ((outs[key][0], outs['sep'][0], 'layer3'), (outs[key][1], outs['sep'][1], 'embedding')):
             assert torch.isfinite(b).all() and float(b.abs().max()) > 0
             assert torch.equal(a, b), (key, what, int((a != b).sum()), float((a - b).abs().max()))
