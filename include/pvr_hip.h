@@ -193,14 +193,6 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1_dev, const void *w2_dev, 
                                         const void *w1f_dev, const float *b1f_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
 /* launches of that kernel so far (tests: the layer3 plan really took it) */
 int64_t pvr_debug_bneck_frame_launches(void);
-/* Per-tile fused layer2 bottleneck (torchvision Bottleneck, reference src/embeddings.py:118-120; bneck_tile.hip), one workgroup per 7-row tile of a
- * 28 x 28 image: x (n,28,28,512) -> conv1 1x1 to 128 (+ b1, ReLU) -> conv2 3x3 pad 1 (+ b2, ReLU) -> conv3 1x1 to 512 (+ b3 + x, ReLU) -> y (n,28,28,512).
- * w1: (128, 512), w2: (128, 3*3*128), w3: (512, 128) in pvr_op_pack_frag_weights' layout.  t1_out / t2_out (optional, (n,28,28,128)): conv1's / conv2's
- * outputs as well.  Bit-identical to the three pvr_op_conv2d calls it replaces. */
-pvr_status pvr_op_bneck_tile(const void *x_dev, const void *w1_dev, const float *b1_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev,
-                             const float *b3_dev, void *y_dev, void *t1_out_dev, void *t2_out_dev, int32_t n, int32_t dtype, void *hip_stream);
-/* launches of that kernel so far (tests: the layer2 plan really took it) */
-int64_t pvr_debug_bneck_tile_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */

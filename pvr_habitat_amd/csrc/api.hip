@@ -58,9 +58,6 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, c
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 long long pp_persistent_launches();
-long long bneck_tile_launches();
-pvr_status launch_bneck_tile(const void *x, const void *w1p, const float *b1, const void *w2p, const float *b2, const void *w3p, const float *b3, void *y,
-                             void *t1_out, void *t2_out, int n, int dtype, hipStream_t stream);
 
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
@@ -103,13 +100,6 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1, const void *w2, const fl
     return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, (w1n ? 7 : 3) | (w1f ? 8 : 0), dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev,
                               w1n, b1n, t1n, w1f, b1f);
 }
-// single-operator entry point of the per-tile fused layer2 bottleneck (bneck_tile.hip), for the op-level parity tests
-pvr_status pvr_op_bneck_tile(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, const void *w3, const float *b3, void *y,
-                             void *t1_out, void *t2_out, int32_t n, int32_t dtype, void *stream) {
-    PVR_REQUIRE(n > 0 && n <= 2600, "pvr_op_bneck_tile: n must be 1..2600");
-    return launch_bneck_tile(x, w1, b1, w2, b2, w3, b3, y, t1_out, t2_out, n, dtype, (hipStream_t)stream);
-}
-int64_t pvr_debug_bneck_tile_launches(void) { return (int64_t)bneck_tile_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {

@@ -44,11 +44,6 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 
-// bneck_tile.hip: the whole layer2 stride-1 bottleneck per 7-row tile of a 28 x 28 image; weights in the fragment-blocked layout
-bool bneck_tile_supported(int n, int h, int w, int cm, int cout, int stride);
-pvr_status launch_bneck_tile(const void *x, const void *w1p, const float *b1, const void *w2p, const float *b2, const void *w3p, const float *b3, void *y,
-                             void *t1_out, void *t2_out, int n, int dtype, hipStream_t stream);
-
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;

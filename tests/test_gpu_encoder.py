@@ -185,45 +185,6 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
     assert torch.isfinite(y.float()).all() and same(y, yf_ref), diff(y, yf_ref)
 
 
-@pytest.mark.parametrize('dt', ['bf16', 'f16'])
-@pytest.mark.parametrize('n', [1, 3, 67])
-def test_tile_bottleneck_op_is_bit_identical(dt, n):
-    """bneck_tile.hip (round 5): a whole layer2 stride-1 bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity + ReLU) per 7-row tile of a
-    28 x 28 image, t1 and t2 resident in LDS, against the three launches it replaces (pvr_op_conv2d): EVERY element of t1, t2 and y, bit for bit -
-    the halo rows recomputed by neighbouring tiles, the image's top / bottom padding rows and the x-border masks included."""
-    tdt, cdt = DT[dt]
-    L = _lib.lib()
-    x = torch.from_numpy(synth.normal(6, 'bt_x_%d' % n, (n, 28, 28, 512))).clamp_(min=0).to(tdt).cuda()
-    w1n = torch.from_numpy(synth.normal(6, 'bt_w1', (128, 512), std=float(np.sqrt(2.0 / 512)))).to(tdt).cuda()
-    w2n = torch.from_numpy(synth.normal(6, 'bt_w2', (128, 9 * 128), std=float(np.sqrt(2.0 / 1152)))).to(tdt).cuda()
-    w3n = torch.from_numpy(synth.normal(6, 'bt_w3', (512, 128), std=float(np.sqrt(2.0 / 128)))).to(tdt).cuda()
-    b1 = torch.from_numpy(synth.uniform(6, 'bt_b1', (128,), -0.5, 0.5)).cuda()
-    b2 = torch.from_numpy(synth.uniform(6, 'bt_b2', (128,), -0.5, 0.5)).cuda()
-    b3 = torch.from_numpy(synth.uniform(6, 'bt_b3', (512,), -0.5, 0.5)).cuda()
-    t1_ref = _run_conv(x, w1n, b1, None, n, 28, 28, 512, 128, 1, 1, 1, 0, 0, cdt, tdt)
-    t2_ref = _run_conv(t1_ref, w2n, b2, None, n, 28, 28, 128, 128, 3, 1, 1, 0, 0, cdt, tdt)
-    y_ref = _run_conv(t2_ref, w3n, b3, x, n, 28, 28, 128, 512, 1, 1, 1, 0, 0, cdt, tdt)
-    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    same = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
-    diff = lambda a, b: (int((a.view(torch.int16) != b.view(torch.int16)).sum()), float((a.float() - b.float()).abs().max()))
-    w1, w2, w3 = torch.empty_like(w1n), torch.empty_like(w2n), torch.empty_like(w3n)
-    for src, dst, rows, k in ((w1n, w1, 128, 512), (w2n, w2, 128, 1152), (w3n, w3, 512, 128)):
-        _lib.check(L.pvr_op_pack_frag_weights(vp(src), vp(dst), rows, k, _lib.stream_ptr()))
-    for with_t in (True, False):
-        y = torch.full((n, 28, 28, 512), float('nan'), dtype=tdt, device='cuda')
-        t1 = torch.full((n, 28, 28, 128), float('nan'), dtype=tdt, device='cuda') if with_t else None
-        t2 = torch.full((n, 28, 28, 128), float('nan'), dtype=tdt, device='cuda') if with_t else None
-        before = L.pvr_debug_bneck_tile_launches()
-        _lib.check(L.pvr_op_bneck_tile(vp(x), vp(w1), vp(b1), vp(w2), vp(b2), vp(w3), vp(b3), vp(y), vp(t1), vp(t2), n, cdt, _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        assert L.pvr_debug_bneck_tile_launches() == before + 1
-        if with_t:
-            assert same(t1, t1_ref), diff(t1, t1_ref)
-            assert same(t2, t2_ref), diff(t2, t2_ref)
-        assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) > 0
-        assert same(y, y_ref), diff(y, y_ref)
-
-
 PP_CASES = [
     # n, h, w, cin, cout, k, stride, act, res(0 none, 1 16-bit, 2 fp32), out_f32     -- shapes of the deep-K launches
     (64, 14, 14, 256, 256, 3, 1, 1, 0, 0),       # layer3 conv2: K = 2304
