@@ -854,7 +854,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'traffic_note': 'avg HBM bytes per conv launch; algorithmic in+out+residual bytes per launch average %.0f' % (algo_bytes / max(n_conv, 1)),
-                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel + bneck_frame_kernel') + ' %d conv launches of one %d-frame chunk, HIP events on the launch stream, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
+                         'kernel': '%s (all' % ('conv_f32_kernel' if args.dtype == 'f32' else 'implicit-GEMM conv family: conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel + bneck_frame_kernel + conv_wfrag_kernel') + ' %d conv launches of one %d-frame chunk, HIP events on the launch stream, ONE batch in flight: conv_ms_per_chunk is a one-lane measurement and may exceed ms_per_step, which is timed with %d batches in flight)' % (n_conv, chunk, lanes),
                          'avg_launch_ms': round(conv_ms / reps / max(n_conv, 1), 4),
                          # the whole step against the HBM roof: PMC bytes of the conv launches of one batch / wall time of one step
                          # (with two batches in flight the step is shorter than the sum of its launches)

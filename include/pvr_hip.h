@@ -193,6 +193,14 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1_dev, const void *w2_dev, 
                                         const void *w1f_dev, const float *b1f_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
 /* launches of that kernel so far (tests: the layer3 plan really took it) */
 int64_t pvr_debug_bneck_frame_launches(void);
+/* pvr_op_conv2d's convolution for small pixel counts and deep K (layer4 at batch 256; conv_wfrag.hip): 112-pixel x 256-cout tiles, the weight operand read
+ * from L2 as whole MFMA fragments.  wgt_packed: pvr_op_pack_frag_weights of the (cout, kh*kw*cin) matrix; cin % 64 == 0, cout % 256 == 0, kh == kw <= 3,
+ * relu 0 / 1, residual 16-bit or NULL, out_f32 0 / 1.  Bit-identical to pvr_op_conv2d. */
+pvr_status pvr_op_conv_wfrag(const void *in_dev, const void *wgt_packed_dev, const float *bias_dev, const void *residual_dev, void *out_dev, int32_t n,
+                             int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu,
+                             int32_t out_f32, int32_t dtype, void *hip_stream);
+/* launches of that kernel so far (tests: the layer4 plan really took it) */
+int64_t pvr_debug_conv_wfrag_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */

@@ -58,6 +58,9 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, c
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 long long pp_persistent_launches();
+long long conv_wfrag_launches();
+pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
+                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream);
 
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
@@ -100,6 +103,14 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1, const void *w2, const fl
     return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, (w1n ? 7 : 3) | (w1f ? 8 : 0), dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev,
                               w1n, b1n, t1n, w1f, b1f);
 }
+// single-operator entry point of the small-M implicit-GEMM kernel with weights as L2 fragments (conv_wfrag.hip), for the op-level parity tests
+pvr_status pvr_op_conv_wfrag(const void *in, const void *wgt_packed, const float *bias, const void *residual, void *out, int32_t n, int32_t h, int32_t w,
+                             int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu, int32_t out_f32, int32_t dtype,
+                             void *stream) {
+    PVR_REQUIRE(n > 0 && h > 0 && w > 0, "pvr_op_conv_wfrag: empty input");
+    return launch_conv_wfrag(in, wgt_packed, bias, residual, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, dtype, (hipStream_t)stream);
+}
+int64_t pvr_debug_conv_wfrag_launches(void) { return (int64_t)conv_wfrag_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {

@@ -416,6 +416,15 @@ static pvr_status build_schedules(pvr_encoder *e) {
         if (c3 < 0) {
             Launch l; l.conv2 = i;
             e->sched_fused.push_back(l);
+            // a stand-alone convolution with few pixels and a deep K (layer3 / layer4's 1 x 1 and 3 x 3 at 14 x 14 and 7 x 7): conv_wfrag.hip may take it at
+            // run time (conv_wfrag_preferred: by the batch) - it reads the fragment-blocked copy of the weights
+            if (op.kind == 0 && !op.f32op && !op.d_wfb && op.h == op.w && op.h <= 14 && op.cout_real == op.cout && (int64_t)op.k * op.k * op.cin >= 1024 &&
+                conv_wfrag_supported(1, 1, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
+                const size_t K = (size_t)op.k * op.k * op.cin;
+                PVR_HIP_TRY(hipMalloc((void **)&op.d_wfb, (size_t)op.cout * K * 2));
+                pvr_status s = launch_pack_frag_weights(op.d_w, op.d_wfb, op.cout, (int)K, nullptr);
+                if (s) return s;
+            }
             if (ends_with(op.conv, ".conv1")) cur_t1 = B_T1;
             ++i;
             continue;
@@ -936,6 +945,13 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
                 s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);
                 t1_blocked = true;
+            } else if (op.d_wfb && !l.frame && conv_algo() == -1 && !enc->low_latency &&
+                       conv_wfrag_preferred((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1), op.cin, op.cout, op.k, op.k) &&
+                       conv_wfrag_supported((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1),
+                                            (int64_t)nb * op.h * op.w * op.cin * 2, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
+                // few pixels, deep K (layer4 at batch 256): 112 x 256 tiles, weights as L2 fragments
+                s = launch_conv_wfrag(enc->d_buf[op.in_buf], op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, op.k, op.k,
+                                      op.stride, op.pad, op.relu, op.out_f32, dt, st);
             } else {
                 s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h, op.w,
                                 op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);

@@ -44,6 +44,12 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 
+// conv_wfrag.hip: implicit GEMM in 112-pixel x 256-cout tiles with the weights read from L2 as MFMA fragments (layer4 at batch 256)
+bool conv_wfrag_supported(int64_t M, int64_t in_bytes, int cin, int cout, int kh, int kw, int pad, int act, int out_f32);
+bool conv_wfrag_preferred(int64_t M, int cin, int cout, int kh, int kw);
+pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
+                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream);
+
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;

@@ -39,13 +39,13 @@ def pmc(fdb, wdb, out_json, out_txt=None, plan_json=None, label=None):
         dur = f[k][2] / n * 1e-9
         rows.append(dict(kernel=k[-70:], launches=n, fetch_MB=round(fetch / 1e6, 2), write_MB=round(write / 1e6, 2),
                          avg_us=round(dur * 1e6, 1), hbm_TBps=round((fetch + write) / dur / 1e12, 2)))
-    conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain', 'chain_wave', 'conv_expand', 'bneck_frame'))]
+    conv = [r for r in rows if any(t in r['kernel'] for t in ('conv_igemm', 'conv_pp256', 'bottleneck_chain', 'chain_wave', 'conv_expand', 'bneck_frame', 'conv_wfrag'))]
     tot_b = sum((r['fetch_MB'] + r['write_MB']) * r['launches'] for r in conv); tot_n = sum(r['launches'] for r in conv)
     lines = [json.dumps(r) for r in rows[:16]] + ['conv family: avg HBM traffic per launch = %.1f MB over %d launches' % (tot_b / tot_n, tot_n)]
     print('\n'.join(lines))
     if out_txt:
         open(out_txt, 'w').write('\n'.join(lines) + '\n')
-    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel + bneck_frame_kernel (all instantiations)', 'launches': tot_n,
+    out = {'kernel': 'conv_igemm_kernel + conv_pp256_kernel + bottleneck_chain_kernel + chain_wave_kernel + conv_expand_kernel + bneck_frame_kernel + conv_wfrag_kernel (all instantiations)', 'launches': tot_n,
            'avg_hbm_bytes_per_launch': tot_b / tot_n * 1e6,
            'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB units, separate --pmc passes', 'per_kernel': rows[:16]}
     if plan_json:                                           # the launch plan these counters belong to (bench.py --dump-plan): bench.py withholds them for any other plan

@@ -185,6 +185,56 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
     assert torch.isfinite(y.float()).all() and same(y, yf_ref), diff(y, yf_ref)
 
 
+WF_CASES = [
+    # n, h, w, cin, cout, k, stride, relu, res, out_f32
+    (64, 7, 7, 512, 512, 3, 1, 1, 0, 0),        # layer4.1 / .2 conv2: K = 4608, 28 x 2 tiles
+    (64, 14, 14, 512, 512, 3, 2, 1, 0, 0),      # layer4.0 conv2 (stride 2)
+    (64, 7, 7, 2048, 512, 1, 1, 1, 0, 0),       # layer4.1 / .2 conv1
+    (64, 7, 7, 512, 2048, 1, 1, 1, 1, 0),       # conv3 + identity
+    (64, 7, 7, 512, 2048, 1, 1, 1, 1, 1),       # the last conv3: fp32 out
+    (64, 14, 14, 1024, 2048, 1, 2, 0, 0, 0),    # downsample: 1 x 1, stride 2, no ReLU
+    (3, 7, 7, 512, 512, 3, 1, 1, 0, 0),         # ragged M = 147: one full and one partial pixel tile
+    (1, 7, 7, 128, 256, 3, 1, 0, 1, 0),         # M = 49 (< one tile), two K chunks per tap, residual without ReLU
+    (5, 9, 11, 64, 256, 3, 1, 1, 0, 0),         # one K chunk per tap (nch = 9), odd image
+    (2, 7, 7, 64, 256, 1, 1, 1, 0, 0),          # a single K chunk in all
+    (2, 7, 7, 128, 256, 1, 1, 1, 0, 0),         # two
+    (256, 7, 7, 512, 512, 3, 1, 1, 0, 0),       # the bench shape: 224 tiles
+]
+
+
+@pytest.mark.parametrize('case', WF_CASES)
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_conv_wfrag_is_bit_identical(case, dt):
+    """conv_wfrag.hip (round 5): 112-pixel x 256-cout tiles, weights as MFMA fragments straight from L2, taps / stride / padding in the LDS-DMA's source
+    addresses - against pvr_op_conv2d (conv_igemm / conv_pp256) on every element, bit for bit; and the same bits on a second run (hand-counted vmcnt)."""
+    n, h, w, cin, cout, k, stride, relu, res, out_f32 = case
+    tdt, cdt = DT[dt]
+    L = _lib.lib()
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x = torch.from_numpy(synth.normal(8, 'wfx%s' % (case,), (n, h, w, cin))).to(tdt).cuda()
+    wk = torch.from_numpy(synth.normal(8, 'wfw%s' % (case,), (cout, k * k * cin), std=float(np.sqrt(2.0 / (cin * k * k))))).to(tdt).cuda()
+    b = torch.from_numpy(synth.uniform(8, 'wfb%s' % (case,), (cout,), -0.5, 0.5)).cuda()
+    r = torch.from_numpy(synth.normal(8, 'wfr%s' % (case,), (n, ho, wo, cout))).to(tdt).cuda() if res else None
+    ref = _run_conv(x, wk, b, r, n, h, w, cin, cout, k, stride, relu, out_f32, 0, cdt, tdt)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    wp = torch.empty_like(wk)
+    _lib.check(L.pvr_op_pack_frag_weights(vp(wk), vp(wp), cout, k * k * cin, _lib.stream_ptr()))
+    outs = []
+    for rep in range(2):
+        y = torch.full((n, ho, wo, cout), float('nan'), dtype=torch.float32 if out_f32 else tdt, device='cuda')
+        before = L.pvr_debug_conv_wfrag_launches()
+        _lib.check(L.pvr_op_conv_wfrag(vp(x), vp(wp), vp(b), vp(r), vp(y), n, h, w, cin, cout, k, k, stride, pad, relu, out_f32, cdt, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert L.pvr_debug_conv_wfrag_launches() == before + 1
+        outs.append(y)
+    iv = torch.int32 if out_f32 else torch.int16
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
+    nd = int((outs[0].view(iv) != ref.view(iv)).sum())
+    assert nd == 0, (nd, float((outs[0].float() - ref.float()).abs().max()))
+    assert torch.equal(outs[0].view(iv), outs[1].view(iv))
+
+
 PP_CASES = [
     # n, h, w, cin, cout, k, stride, act, res(0 none, 1 16-bit, 2 fp32), out_f32     -- shapes of the deep-K launches
     (64, 14, 14, 256, 256, 3, 1, 1, 0, 0),       # layer3 conv2: K = 2304
