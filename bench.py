@@ -72,6 +72,8 @@ def conv_algorithmic_bytes(n, names=None):
             tot += hi * hi * planes + ho * ho * planes
         elif kind == 'downsample':
             tot += hi * hi * inpl + ho * ho * planes * 4
+        elif kind == 'conv3&downsample':                     # the two-operand launch (conv_pp256 DUAL): t2 and the strided pixels of the block input in, y out
+            tot += ho * ho * planes + ho * ho * inpl + ho * ho * planes * 4
         elif kind == 'conv3':
             tot += ho * ho * planes + 2 * ho * ho * planes * 4
     return tot * 2 * n

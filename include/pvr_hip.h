@@ -199,6 +199,12 @@ int64_t pvr_debug_bneck_frame_launches(void);
 pvr_status pvr_op_conv_wfrag(const void *in_dev, const void *wgt_packed_dev, const float *bias_dev, const void *residual_dev, void *out_dev, int32_t n,
                              int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu,
                              int32_t out_f32, int32_t dtype, void *hip_stream);
+/* pvr_op_conv2d with a SECOND pixel operand appended along K (conv_pp256's two-operand form): out = act(W[:, :kh*kw*cin] . in + W[:, kh*kw*cin:] . in2 +
+ * bias) - a stride-2 bottleneck's conv3 and its 1 x 1 downsample (torchvision Bottleneck.downsample, reference src/embeddings.py:118-120) in one fp32
+ * accumulation.  in2: (n,h2,w2,cin2) read at (ho*stride2, wo*stride2), (h2-1)/stride2+1 == ho; wgt: (cout_pad, kh*kw*cin + cin2); 16-bit output. */
+pvr_status pvr_op_conv2d_dual(const void *in_dev, const void *in2_dev, const void *wgt_dev, const float *bias_dev, void *out_dev, int32_t n, int32_t h,
+                              int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t h2, int32_t w2,
+                              int32_t cin2, int32_t stride2, int32_t relu, int32_t dtype, void *hip_stream);
 /* launches of that kernel so far (tests: the layer4 plan really took it) */
 int64_t pvr_debug_conv_wfrag_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape

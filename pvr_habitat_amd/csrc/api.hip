@@ -58,6 +58,9 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, c
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
 long long pp_persistent_launches();
+pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream,
+                             const void *in2 = nullptr, int h2 = 0, int w2 = 0, int cin2 = 0, int stride2 = 1);
 long long conv_wfrag_launches();
 pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
                              int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream);
@@ -109,6 +112,15 @@ pvr_status pvr_op_conv_wfrag(const void *in, const void *wgt_packed, const float
                              void *stream) {
     PVR_REQUIRE(n > 0 && h > 0 && w > 0, "pvr_op_conv_wfrag: empty input");
     return launch_conv_wfrag(in, wgt_packed, bias, residual, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32, dtype, (hipStream_t)stream);
+}
+// conv_pp256's two-operand form (conv3 & downsample in one accumulation), for the op-level parity tests
+pvr_status pvr_op_conv2d_dual(const void *in, const void *in2, const void *wgt, const float *bias, void *out, int32_t n, int32_t h, int32_t w, int32_t cin,
+                              int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t h2, int32_t w2, int32_t cin2, int32_t stride2,
+                              int32_t relu, int32_t dtype, void *stream) {
+    PVR_REQUIRE(in && in2 && wgt && bias && out && n > 0, "pvr_op_conv2d_dual: null argument");
+    PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "pvr_op_conv2d_dual: 16-bit storage types only");
+    return launch_conv_pp256(in, wgt, bias, nullptr, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, 0, 0, dtype, 224, (hipStream_t)stream, in2, h2, w2,
+                             cin2, stride2);
 }
 int64_t pvr_debug_conv_wfrag_launches(void) { return (int64_t)conv_wfrag_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }

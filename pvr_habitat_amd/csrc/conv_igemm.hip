@@ -31,7 +31,8 @@ bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_by
 pvr_status launch_conv_w4(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
                           int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, hipStream_t stream);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream);
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream,
+                             const void *in2 = nullptr, int h2 = 0, int w2 = 0, int cin2 = 0, int stride2 = 1);
 
 struct ConvP {
     const u16 *in;

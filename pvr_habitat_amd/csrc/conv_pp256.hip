@@ -49,6 +49,12 @@ struct PPP {
     int total_tiles;               // pixel tiles x cout tiles (the persistent form walks them with a stride of gridDim.x)
     int pointwise;                 // KH = KW = 1, stride 1, pad 0: pp_tile_setup needs no (n, ho, wo) decomposition
     int bias_lds;                  // the bias vector (<= 4096 floats, zero past Cout) is copied to LDS once per block: see the epilogue
+    // DUAL (round 5): a second pixel operand appended along K - out = act(W[:, :K1] . in + W[:, K1:] . in2 + bias): a bottleneck's conv3 and its
+    // 1 x 1 strided downsample (the identity branch) in ONE accumulation, the downsample's output never exists in HBM.  in2: (n, H2, W2, Cin2),
+    // read at (ho * stride2, wo * stride2), no padding; nk2 = Cin2 / 64 K tiles (0: off); K = K1 + Cin2 is the weight rows' length.
+    const u16 *in2;
+    unsigned in2_bytes;
+    int H2, W2, Cin2, stride2, nk2;
 };
 
 #define PP_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
@@ -87,7 +93,7 @@ __device__ unsigned long long pp_tstamps[2][8];
 // per-lane staging offsets of one output tile (pixel rows m0 .., couts co0 ..): see "staging" in the kernel
 template <int BM, int XI>
 __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int wave, int lane, int (&a_off)[2][XI], int (&a_mask)[2][XI],
-                                              int (&b_off)[2][2], bool natural) {
+                                              int (&b_off)[2][2], bool natural, int (*a_off2)[XI] = nullptr) {
     constexpr int XH = BM / 2, OOB = 0x7ffffff0;       // (BM = 224: 112 pixel rows per half tile in a 128-row LDS half; rows 112..127 stay zero)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -121,6 +127,11 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
                 for (int t3 = 0; t3 < 3; ++t3) mask |= ((hb >> t3) & 1) ? (wb << (t3 * p.KW)) : 0;
                 a_mask[h][i < XI ? i : 0] = mask;
                 }
+                if (a_off2) {                                           // DUAL: the second operand's pixel (1 x 1, stride2, no padding); bit 9 of the mask = row exists
+                    const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, n = t / p.Ho;
+                    a_off2[h][i < XI ? i : 0] = (((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + lch * 8) * 2;
+                    a_mask[h][i < XI ? i : 0] |= ok ? 512 : 0;
+                }
             }
             const int R = h * 128 + r;                                  // A-operand row inside the 256-cout tile
             // 16-bit outputs: rows permuted so that a lane's tile PAIR is 8 consecutive couts (one 16-byte store).  fp32 outputs with an fp32
@@ -140,7 +151,7 @@ __device__ __forceinline__ void pp_tile_setup(const PPP &p, int m0, int co0, int
 // half tiles of K tile 1) is issued between the main loop and the epilogue of the current tile, so its HBM / L2 latency runs under the
 // epilogue's stores instead of in front of the first MFMA.  LDS is free at that point (every wave has passed the barrier that follows
 // its last fragment read) and the epilogue does not touch LDS.
-template <int BM, bool F16, int RES, bool PERSIST = false>
+template <int BM, bool F16, int RES, bool PERSIST = false, bool DUAL = false>
 __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
     typedef typename HT<F16>::V8 V8;
     // BM = 224 (round 2): the BM = 256 structure with 7 of the 8 pixel tiles per wave.  50 176 pixels (batch 256 at 14 x 14) are 196 tiles of
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.wgt), 0, p.w_bytes, 0x00020000);
+    const auto rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(DUAL ? p.in2 : p.in), 0, DUAL ? p.in2_bytes : p.in_bytes, 0x00020000);
     // the bias vector -> LDS, behind the two staging buffers (read by the epilogues; the K loops' barriers order it before the first one)
     const unsigned bias_l = (unsigned)(size_t)PP_LDS_PTR(2 * BUF);
     if (p.bias_lds) {
@@ -176,16 +188,17 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 
     // ---- staging: half tile h, DMA instruction i: this lane feeds LDS row r = (8i + wave)*8 + lane/8, physical chunk lane%8
     int a_off[2][XI], a_mask[2][XI], b_off[2][2];
+    int a_off2[DUAL ? 2 : 1][XI];
     const bool natural = p.out_f32 && RES != 1;   // weight rows (= the accumulators' couts) in natural order: see pp_tile_setup
 #define PP_TILE_SETUP(v_)                                                                                        \
     {                                                                                                            \
         const int swz_ = xcd_remap((v_), PERSIST ? p.total_tiles : (int)gridDim.x);                               \
         m0 = (swz_ / p.n_tiles) * BM; co0 = (swz_ % p.n_tiles) * 256;                                             \
-        pp_tile_setup<BM, XI>(p, m0, co0, wave, lane, a_off, a_mask, b_off, natural);                             \
+        pp_tile_setup<BM, XI>(p, m0, co0, wave, lane, a_off, a_mask, b_off, natural, DUAL ? a_off2 : nullptr);     \
     }
     PP_TILE_SETUP(vb);
     const int cpt = p.Cin >> 6;                   // K tiles per filter tap
-    const int nk = p.KH * p.KW * cpt;
+    const int nk = p.KH * p.KW * cpt + (DUAL ? p.nk2 : 0);
     int xs_tap = 0, xs_kh = 0, xs_kw = 0, xs_cs = 0;   // filter position of the next X tile to stage (wave-uniform)
 
 #ifdef PP_KNOCK
@@ -195,14 +208,28 @@ __global__ __launch_bounds__(512, 1) void conv_pp256_kernel(PPP p) {
 #endif
 #define PP_STAGE_X(h_, buf_)                                                                                     \
     if constexpr (!(PP_KNOCK_ & 2)) {                                                                            \
-        const int tap_off = ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;                                     \
-        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                         \
-            const int vo = ((a_mask[h_][i] >> xs_tap) & 1) ? a_off[h_][i] + tap_off : OOB;                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * XHB + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
+        if constexpr (!DUAL) {                                                                                   \
+            const int tap_off = ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;                                 \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                     \
+                const int vo = ((a_mask[h_][i] >> xs_tap) & 1) ? a_off[h_][i] + tap_off : OOB;                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * XHB + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            /* past the first operand's last tap (xs_kh == KH) the K tiles come from the second one.  Pure ALU selects (masks), no ?: - hipcc turned */ \
+            /* the nested conditionals into EXEC-masked in-place updates of the offset registers and put s_waitcnt vmcnt(0) in front of each        */ \
+            const int s2m_ = -(int)(xs_kh >= p.KH);                                                               \
+            const int tap_off = s2m_ ? xs_cs * 128 : ((xs_kh * p.W + xs_kw) * p.Cin + xs_cs * 64) * 2;            \
+            const int bit_ = s2m_ ? 9 : xs_tap;                                                                   \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                     \
+                const int base_ = a_off[h_][i] ^ ((a_off[h_][i] ^ a_off2[DUAL ? h_ : 0][i]) & s2m_);              \
+                const int ok_ = -((a_mask[h_][i] >> bit_) & 1);                                                   \
+                const int vo = ((base_ + tap_off) & ok_) | (OOB & ~ok_);                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s2m_ ? rs_in2 : rs_in, PP_LDS_PTR((buf_) * BUF + (h_) * XHB + (i * 8 + wave) * 1024), 16, vo, 0, 0, 0); \
+            }                                                                                                    \
         }                                                                                                        \
     }
 #define PP_ADVANCE_X()                                                                                           \
-    { if (++xs_cs == cpt) { xs_cs = 0; ++xs_tap; if (++xs_kw == p.KW) { xs_kw = 0; ++xs_kh; } } }
+    { if (++xs_cs == ((DUAL && xs_kh >= p.KH) ? p.nk2 : cpt)) { xs_cs = 0; ++xs_tap; if (++xs_kw == p.KW) { xs_kw = 0; ++xs_kh; } } }
 #define PP_STAGE_W(h_, kt_, buf_)                                                                                \
     if constexpr (!(PP_KNOCK_ & 2)) {                                                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
@@ -576,6 +603,30 @@ static int pp_persist_min() {
     return v;
 }
 
+// DUAL launches (conv3 & downsample of a stride-2 bottleneck): 224-pixel tiles, no residual operand
+template <bool F16>
+static pvr_status launch_pp_dual(PPP &p, hipStream_t stream) {
+    constexpr int BM = 224, lds = 2 * (256 * 128 + 32768) + 16384;
+    static DeviceOnce attr_done;
+    if (attr_done.needed()) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)conv_pp256_kernel<BM, F16, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done.mark();
+    }
+    const int grid = ((p.M + BM - 1) / BM) * p.n_tiles;
+    p.total_tiles = grid;
+    p.pointwise = 0;
+    p.bias_lds = p.CoutPad <= 4096 ? 1 : 0;
+    if (pp_persist_min() > 0 && grid >= pp_persist_min()) {
+        ++g_pp_persistent_launches;
+        hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, 0, true, true>), dim3(256), dim3(512), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_pp256_kernel<BM, F16, 0, false, true>), dim3(grid), dim3(512), lds, stream, p);
+    }
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
 template <int BM, bool F16, int RES>
 static pvr_status launch_pp_inst(PPP &p, hipStream_t stream) {
     constexpr int lds = 2 * ((BM == 224 ? 256 : BM) * 128 + 32768) + 16384;      // two staging buffers + the bias vector (<= 4096 floats)
@@ -621,15 +672,23 @@ bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_by
 
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
                              int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm,
-                             hipStream_t stream) {
+                             hipStream_t stream, const void *in2, int h2, int w2, int cin2, int stride2) {
     PPP p;
+    p.in2 = (const u16 *)in2; p.in2_bytes = 0; p.H2 = h2; p.W2 = w2; p.Cin2 = cin2; p.stride2 = stride2; p.nk2 = 0;
     p.in = (const u16 *)in; p.wgt = (const u16 *)wgt; p.res = (const u16 *)res; p.bias = bias; p.out = out;
     p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.CoutPad = (cout + 63) / 64 * 64;
     p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
     p.Ho = (h + 2 * pad - kh) / stride + 1;
     p.Wo = (w + 2 * pad - kw) / stride + 1;
     const int64_t M = (int64_t)n * p.Ho * p.Wo;
-    p.K = kh * kw * cin;
+    p.K = kh * kw * cin + (in2 ? cin2 : 0);
+    if (in2) {
+        // wgt: (CoutPad, kh*kw*cin + cin2) - the second operand's columns behind the first's
+        PVR_REQUIRE(!res && !out_f32 && cin2 % 64 == 0 && stride2 >= 1 && (h2 - 1) / stride2 + 1 == p.Ho && (w2 - 1) / stride2 + 1 == p.Wo,
+                    "conv_pp256: the second operand must be a 1 x 1 (strided) view with the output's size, without a residual");
+        PVR_REQUIRE((int64_t)n * h2 * w2 * cin2 * 2 < 0x7ffffff0ll, "conv_pp256: second operand larger than 2 GiB");
+        p.in2_bytes = (unsigned)((int64_t)n * h2 * w2 * cin2 * 2); p.nk2 = cin2 / 64;
+    }
     const int64_t inb = (int64_t)n * h * w * cin * 2, wb = (int64_t)p.CoutPad * p.K * 2, ob = M * cout * (out_f32 ? 4 : 2),
                   rb = res ? M * cout * (res_f32 ? 4 : 2) : 0;
     PVR_REQUIRE(pp256_supported(M, cin, cout, kh, kw, inb, wb, ob, rb), "conv_pp256: unsupported shape");
@@ -638,6 +697,7 @@ pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias,
     p.act = act; p.out_f32 = out_f32;
     p.n_tiles = (cout + 255) / 256;
     const int rmode = !res ? 0 : (res_f32 ? 2 : 1);
+    if (in2) return dtype == PVR_F16 ? launch_pp_dual<true>(p, stream) : launch_pp_dual<false>(p, stream);
     if (bm == 224) return launch_pp_bm<224>(p, rmode, dtype, stream);
     return bm == 256 ? launch_pp_bm<256>(p, rmode, dtype, stream) : launch_pp_bm<128>(p, rmode, dtype, stream);
 }

@@ -414,6 +414,33 @@ static pvr_status build_schedules(pvr_encoder *e) {
         }
         const int c3 = chain_end(i);
         if (c3 < 0) {
+            // A stride-2 bottleneck outside the chains (layer3.0, layer4.0): its 1 x 1 downsample and the conv3 that adds it run as ONE two-operand
+            // launch (conv_pp256 DUAL: K = conv3's channels, then the block input's) - the identity branch is accumulated in fp32 and never exists in
+            // HBM (- 2 x 103 MB at layer3.0, - 2 x 51 MB at layer4.0 per 256 frames, one launch less).  PVR_DUAL_DS=0: separate launches.
+            const bool dual_on = [] { const char *v = getenv("PVR_DUAL_DS"); return !v || atoi(v) != 0; }();      // (read when a plan is built: A/B switch)
+            if (dual_on && ends_with(op.conv, ".downsample.0") && op.kind == 0 && !op.f32op && op.k == 1 && op.pad == 0 && !op.relu && !op.out_f32 &&
+                op.res_buf == B_NONE && op.tap.empty() && op.cin_real == op.cin && op.cout_real == op.cout && op.cin % 64 == 0 && i + 1 < n) {
+                ConvOp &o3 = e->ops[i + 1];
+                if (ends_with(o3.conv, ".conv3") && o3.kind == 0 && !o3.f32op && o3.k == 1 && o3.stride == 1 && o3.pad == 0 && o3.relu == 1 && !o3.out_f32 &&
+                    o3.res_buf == op.out_buf && o3.cout == op.cout && o3.cout_real == o3.cout && o3.cin_real == o3.cin && o3.cin % 64 == 0 &&
+                    (op.h - 1) / op.stride + 1 == o3.h && (op.w - 1) / op.stride + 1 == o3.w && o3.cout >= 256 && o3.ksplit <= 1 && op.ksplit <= 1) {
+                    const size_t K1 = (size_t)o3.cin, K2 = (size_t)op.cin, cp = ((size_t)o3.cout + 63) / 64 * 64;
+                    std::vector<u16> wc(cp * (K1 + K2), 0);
+                    for (int r = 0; r < o3.cout; ++r) {
+                        memcpy(&wc[(size_t)r * (K1 + K2)], &o3.h_w[(size_t)r * K1], K1 * 2);
+                        memcpy(&wc[(size_t)r * (K1 + K2) + K1], &op.h_w[(size_t)r * K2], K2 * 2);
+                    }
+                    std::vector<float> bs(cp, 0.f);
+                    for (int c = 0; c < o3.cout; ++c) bs[c] = o3.h_b[c] + op.h_b[c];
+                    pvr_status s = enc_upload(&o3.d_wcat, wc);
+                    if (!s) s = enc_upload(&o3.d_bsum, bs);
+                    if (s) return s;
+                    Launch l; l.conv2 = i + 1; l.ds = i;
+                    e->sched_fused.push_back(l);
+                    i += 2;
+                    continue;
+                }
+            }
             Launch l; l.conv2 = i;
             e->sched_fused.push_back(l);
             // a stand-alone convolution with few pixels and a deep K (layer3 / layer4's 1 x 1 and 3 x 3 at 14 x 14 and 7 x 7): conv_wfrag.hip may take it at
@@ -917,6 +944,24 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                     if (!s) s = one(op, enc->d_buf[t2b], res, enc->d_buf[op.out_buf]);
                     if (!s && c1) s = one(*c1, enc->d_buf[op.out_buf], nullptr, enc->d_buf[l.t1_out]);
                 }
+            } else if (l.conv3 < 0 && l.ds >= 0) {
+                // conv3 & downsample as one two-operand launch (layer3.0 / layer4.0); the low-latency plan keeps the two launches (its split-K forms)
+                const ConvOp &cd = enc->ops[l.ds];
+                if (!(enc->low_latency && nb <= 4) && conv_algo() == -1) {          // (the low-latency plan covers forwards of <= 4 frames: small_batch_ksplit)
+                    s = launch_conv_pp256(enc->d_buf[op.in_buf], op.d_wcat, op.d_bsum, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0,
+                                          op.relu, 0, 0, dt, 224, st, enc->d_buf[cd.in_buf], cd.h, cd.w, cd.cin, cd.stride);
+                } else {
+                    auto one = [&](const ConvOp &o, const void *r_) {
+                        const int ks = small_batch_ksplit(enc, o, nb);
+                        if (ks) {
+                            if (!enc->d_smallk[enc->cur_lane] && hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES) != hipSuccess) { set_error("hipMalloc failed (split-K scratch)"); return (pvr_status)PVR_ERR_HIP; }
+                            return launch_conv_splitk(enc->d_buf[o.in_buf], o.d_w, o.d_b, r_, enc->d_buf[o.out_buf], enc->d_zero, enc->d_smallk[enc->cur_lane], ks, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+                        }
+                        return launch_conv(enc->d_buf[o.in_buf], o.d_w, o.d_b, r_, enc->d_buf[o.out_buf], enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+                    };
+                    s = one(cd, nullptr);
+                    if (!s) s = one(op, res);
+                }
             } else if (l.conv3 >= 0) {
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
@@ -945,7 +990,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
                 s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);
                 t1_blocked = true;
-            } else if (op.d_wfb && !l.frame && conv_algo() == -1 && !enc->low_latency &&
+            } else if (op.d_wfb && !l.frame && conv_algo() == -1 && !(enc->low_latency && nb <= 4) &&
                        conv_wfrag_preferred((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1), op.cin, op.cout, op.k, op.k) &&
                        conv_wfrag_supported((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1),
                                             (int64_t)nb * op.h * op.w * op.cin * 2, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
@@ -1186,7 +1231,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

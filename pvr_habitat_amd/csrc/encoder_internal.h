@@ -33,7 +33,8 @@ pvr_status launch_conv_expand(const void *in, const void *wgt, const float *bias
 // conv_pp256.hip: 256x256-tile ping-pong kernel for deep-K convolutions / linear layers
 bool pp256_supported(int64_t M, int cin, int cout, int kh, int kw, int64_t in_bytes, int64_t w_bytes, int64_t out_bytes, int64_t res_bytes);
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
-                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream);
+                             int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream,
+                             const void *in2 = nullptr, int h2 = 0, int w2 = 0, int cin2 = 0, int stride2 = 1);
 int conv_algo();
 void set_conv_algo(int a);
 
@@ -73,7 +74,8 @@ struct ConvOp {
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     float *d_b = nullptr;
     std::vector<float> h_b;        // host copy of the bias (same lifetime as h_w)
-    float *d_bsum = nullptr;       // conv3 of a block whose downsample runs inside the chain: b3 + b_downsample
+    float *d_bsum = nullptr;       // conv3 of a block whose downsample runs inside the chain / the two-operand launch: b3 + b_downsample
+    u16 *d_wcat = nullptr;         // conv3 of a two-operand launch (conv_pp256 DUAL): [W3 | W_downsample] rows, (cout_pad, cin + cin_downsample)
     std::string tap;               // non-empty: output of this op is the named tap
     int ksplit = 0, ks_buf = B_NONE;   // split-K launch (conv_igemm.hip): number of K ranges, workspace buffer that is dead at this op
 };
@@ -82,7 +84,8 @@ struct ConvOp {
 // (conv2 3x3 -> conv3 1x1 + residual -> the next block's conv1 1x1; bottleneck_chain.hip)
 struct Launch {
     int conv2 = -1, conv3 = -1, next1 = -1;   // chain members (indices into ops); conv3 < 0: single launch of ops[conv2]
-    int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own)
+    int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own);
+                                              // with conv3 < 0: ops[conv2] is a conv3 that runs as conv_pp256's two-operand launch with ops[ds] (layer3.0 / layer4.0)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
     int wave = 0;                             // chain: the wave form runs it (chain_wave.hip)
     int conv1 = -1;                           // per-frame form: the block's own conv1 runs in front, inside the launch (the launch reads the block input)

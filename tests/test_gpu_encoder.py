@@ -235,6 +235,58 @@ def test_conv_wfrag_is_bit_identical(case, dt):
     assert torch.equal(outs[0].view(iv), outs[1].view(iv))
 
 
+DUAL_CASES = [
+    # n, ho (= wo), cin, cout, k, cin2, stride2
+    (64, 14, 256, 1024, 1, 512, 2),     # layer3.0: conv3 (256 -> 1024) & downsample (512 -> 1024, stride 2 on 28 x 28): 896 tiles, the persistent form
+    (64, 7, 512, 2048, 1, 1024, 2),     # layer4.0
+    (3, 7, 512, 2048, 1, 1024, 2),      # ragged M = 147, the one-tile-per-block form
+    (2, 14, 64, 256, 1, 64, 1),         # one K tile per operand, stride 1
+    (5, 9, 128, 320, 3, 192, 2),        # a 3 x 3 first operand (taps, padding) in front of the second; cout tail
+]
+
+
+@pytest.mark.parametrize('case', DUAL_CASES)
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_conv_dual_operand(case, dt):
+    """conv_pp256's two-operand form: K tiles of the first operand (all its taps), then of the second (1 x 1, strided), ONE accumulation.  For a 1 x 1
+    first operand that is exactly pvr_op_conv2d on the channel-concatenated pixels: bit-identical; with a 3 x 3 first operand: against the fp32 sum of
+    the two convolutions, to the storage type's rounding."""
+    n, ho, cin, cout, k, cin2, s2 = case
+    tdt, cdt = DT[dt]
+    L = _lib.lib()
+    pad = k // 2
+    h2 = ho * s2 - (s2 - 1)
+    x = torch.from_numpy(synth.normal(9, 'dux%s' % (case,), (n, ho, ho, cin))).clamp_(min=0).to(tdt).cuda()
+    x2 = torch.from_numpy(synth.normal(9, 'duy%s' % (case,), (n, h2, h2, cin2))).clamp_(min=0).to(tdt).cuda()
+    K1 = k * k * cin
+    cout_pad = (cout + 63) // 64 * 64
+    wk = torch.zeros((cout_pad, K1 + cin2), dtype=tdt)
+    wk[:cout] = torch.from_numpy(synth.normal(9, 'duw%s' % (case,), (cout, K1 + cin2), std=float(np.sqrt(1.0 / (K1 + cin2))))).to(tdt)
+    wk = wk.cuda()
+    b = torch.zeros(cout_pad); b[:cout] = torch.from_numpy(synth.uniform(9, 'dub%s' % (case,), (cout,), -0.5, 0.5)); b = b.cuda()
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    outs = []
+    for rep in range(2):
+        y = torch.full((n, ho, ho, cout), float('nan'), dtype=tdt, device='cuda')
+        _lib.check(L.pvr_op_conv2d_dual(vp(x), vp(x2), vp(wk), vp(b), vp(y), n, ho, ho, cin, cout, k, k, 1, pad, h2, h2, cin2, s2, 1, cdt, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if k == 1:
+        xcat = torch.cat([x, x2[:, ::s2, ::s2, :]], dim=3).contiguous()
+        ref = _run_conv(xcat, wk, b, None, n, ho, ho, cin + cin2, cout, 1, 1, 1, 0, 0, cdt, tdt)
+        nd = int((outs[0].view(torch.int16) != ref.view(torch.int16)).sum())
+        assert nd == 0, (nd, float((outs[0].float() - ref.float()).abs().max()))
+    else:
+        w1 = wk[:cout, :K1].float().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+        w2 = wk[:cout, K1:].float().reshape(cout, cin2, 1, 1)
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w1, padding=pad) + torch.nn.functional.conv2d(x2.float().permute(0, 3, 1, 2), w2, stride=s2)
+        ref = torch.relu(ref + b[:cout].view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        err = float((outs[0].float() - ref).abs().max() / ref.abs().max())
+        assert err < (2e-3 if dt == 'f16' else 1.2e-2), err
+
+
 PP_CASES = [
     # n, h, w, cin, cout, k, stride, act, res(0 none, 1 16-bit, 2 fp32), out_f32     -- shapes of the deep-K launches
     (64, 14, 14, 256, 256, 3, 1, 1, 0, 0),       # layer3 conv2: K = 2304
@@ -845,10 +897,12 @@ def test_fp32_reference_precision_mode(variant, frame):
 def test_fused_bottleneck_chain_is_bit_identical(variant, dtype, n, monkeypatch):
     """bottleneck_chain.hip (conv2 -> conv3 + residual -> next conv1 in one launch, layer1/layer2) keeps the unfused
     plan's rounding points and K order, so the two plans must agree BIT FOR BIT (n chosen so that the 128-pixel tiles
-    have tails: n*56*56 is not a multiple of 128 for odd n).  (PVR_CHAIN_DS=0: layer1.0's downsample as its own launch; inside the
-    chain it skips one 16-bit rounding, see test_downsample_inside_the_chain.)"""
+    have tails: n*56*56 is not a multiple of 128 for odd n).  (PVR_CHAIN_DS=0, PVR_DUAL_DS=0: the downsamples as their own launches; inside
+    the chain / inside conv3's accumulation they skip one 16-bit rounding, see test_downsample_inside_the_chain and
+    test_stride2_downsample_inside_conv3.)"""
     from pvr_habitat_amd.embeddings import HipResNet50
     monkeypatch.setenv('PVR_CHAIN_DS', '0')
+    monkeypatch.setenv('PVR_DUAL_DS', '0')
     sd = synth.resnet50_state_dict(8, variant)
     fr = torch.from_numpy(synth.smooth_frames(90 + n, n, 160, 200)).cuda()
     m = HipResNet50(sd, variant, compute_dtype=dtype, max_batch=8)
@@ -998,6 +1052,42 @@ def test_downsample_inside_the_chain(dtype, n):
     print('\n[%s n=%d] downsample in chain vs own launch: rel-L2 %.2e; vs fp32 oracle %.2e (in chain) / %.2e (own launch)' % (dtype, n, d, ef, ep))
     assert 0 < d < (3e-4 if dtype == 'f16' else 3e-3)
     assert ef < ep * 1.1 and ef < (1e-3 if dtype == 'f16' else 1e-2)
+
+
+@pytest.mark.parametrize('dtype,n', [('f16', 5), ('bf16', 3)])
+def test_stride2_downsample_inside_conv3(dtype, n, monkeypatch):
+    """layer3.0 / layer4.0 (round 5): the 1 x 1 stride-2 downsample and the conv3 that adds it run as ONE two-operand launch (conv_pp256 DUAL): the
+    identity branch is accumulated in fp32 behind conv3's own K and never rounded to 16 bits or written to HBM.  Against the plan with the two
+    launches (PVR_DUAL_DS=0): a few ulps of the storage type apart, at least as close to the fp32 oracle, two launches fewer."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(8, 'conv5')
+    fr_np = synth.smooth_frames(120 + n, n, 160, 200)
+    fr = torch.from_numpy(fr_np).cuda()
+    monkeypatch.setenv('PVR_DUAL_DS', '0')
+    m0 = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=8)
+    names0 = m0.op_names()
+    assert 'layer3.0.downsample.0' in names0 and 'layer3.0.conv3' in names0 and 'layer4.0.downsample.0' in names0, names0
+    plain = m0(fr).clone()
+    monkeypatch.setenv('PVR_DUAL_DS', '1')
+    m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=8)
+    names = m.op_names()
+    assert 'layer3.0.conv3&downsample' in names and 'layer4.0.conv3&downsample' in names and len(names) == len(names0) - 2, names
+    assert 'layer3.0.downsample.0' not in names and 'layer4.0.downsample.0' not in names
+    fused = m(fr).clone()
+    assert torch.equal(fused, m(fr))
+    ref = eo.embed(sd, fr_np, 'conv5', squeeze=False)
+    d = _relerr(fused.cpu().numpy(), plain.cpu().numpy())[0]
+    ef, ep = _relerr(fused.cpu().numpy(), ref)[0], _relerr(plain.cpu().numpy(), ref)[0]
+    print('\n[%s n=%d] stride-2 downsample inside conv3 vs own launch: rel-L2 %.2e; vs fp32 oracle %.2e (inside) / %.2e (own launch)' % (dtype, n, d, ef, ep))
+    assert 0 < d < (3e-4 if dtype == 'f16' else 3e-3)
+    assert ef < ep * 1.1 and ef < (1e-3 if dtype == 'f16' else 1e-2)
+    # the low-latency plan keeps the two launches (their split-K forms): same embedding as the plain plan's small-batch path, to fp32 regrouping
+    m.set_low_latency(True)
+    ll = m(fr[:2]).clone()
+    m.set_low_latency(False)
+    assert _relerr(ll.cpu().numpy(), ref[:2])[0] < (1e-3 if dtype == 'f16' else 1e-2)
 
 
 def test_low_latency_plan_for_online_embedding(monkeypatch):
