@@ -522,33 +522,53 @@ def save_obs_e2e_bench(batch, dtype, n_samples=100000, traj_len=500, hw=64, dist
             shutil.rmtree(d, ignore_errors=True)
 
 
-def uber5crop_bench(batch, dtype, n_frames=1024, frame=256):
+def uber5crop_bench(batch, dtype, n_frames=2048, frame=256):
     """BASELINE configs[4]: the paper's best PVR - moco_aug_uber_345 (three separately loaded ResNet50 trunks: l3-compressed, l4-compressed,
     conv5; src/embeddings.py:44-57,195-280) on 5 crop windows per frame (corner + centre, torchvision FiveCrop order: the build-defined
-    extension of configs[4]), 256x256 uint8 frames in pinned host memory -> H2D -> 15 trunk forwards per frame -> D2H of 31 310 floats
-    per frame, overlapped (stream_embed: "embeddings streamed to host").  frames/s and the trunks' rate against the MFMA peak
-    (115.69 GFLOP per frame)."""
+    extension of configs[4]): 15 trunk forwards and 31 310 floats per 256x256 uint8 frame.  `value` follows the headline's rule - frames
+    resident in HBM when the timed region starts, two batches in flight, results left in HBM; `streamed` is the PCIe-inclusive rate of the same
+    work through stream_embed (pinned host frames -> H2D -> forwards -> D2H, overlapped: "embeddings streamed to host").  Rates against the
+    MFMA peak use 115.69 GFLOP per frame."""
     os.environ.setdefault('PVR_SYNTHETIC_WEIGHTS', '1')
     from pvr_habitat_amd import synth
-    from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed
+    from pvr_habitat_amd.embeddings import EmbeddingNet, stream_embed, lane_streams
     net = EmbeddingNet('moco_aug_uber_345', pretrained=False, crops=5, max_batch=batch, compute_dtype=dtype)
     assert net.out_size == 5 * 6262
+    n_frames = max(2 * batch, n_frames // batch * batch)
     fr = torch.from_numpy(synth.frames(5, n_frames, frame, frame)).pin_memory()
+    dev = fr.cuda()
+    outs = [torch.empty((batch, net.out_size), device='cuda') for _ in range(2)]
+    streams = lane_streams()
+
+    def resident():
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+        for i in range(n_frames // batch):
+            with torch.cuda.stream(streams[i & 1]):
+                net.embedding.forward_into(dev[i * batch:(i + 1) * batch], outs[i & 1], lane=i & 1)
+        torch.cuda.synchronize()
+
+    resident()                                                                   # warm-up (allocations, first-use attributes, both lanes)
+    t0 = time.perf_counter(); resident(); el_res = time.perf_counter() - t0
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
     out = torch.empty((n_frames, net.out_size), dtype=torch.float32).pin_memory()
-    stream_embed(net, fr[:2 * batch], batch=batch, out=out[:2 * batch])         # warm-up (allocations, first-use attributes, both lanes)
+    stream_embed(net, fr[:2 * batch], batch=batch, out=out[:2 * batch])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     stream_embed(net, fr, batch=batch, out=out)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     assert np.isfinite(out.numpy()[::97]).all()
     net.close()
-    fps = n_frames / el
+    fps, fps_s = n_frames / el_res, n_frames / el
     gflop = 5 * 23.138
-    return {'metric': 'frames/sec embedded (5-crop moco_aug_uber_345, 256x256, streamed to host)', 'value': round(fps, 1), 'unit': 'frames/s', 'dtype': dtype,
+    return {'metric': 'frames/sec embedded (5-crop moco_aug_uber_345, 256x256)', 'value': round(fps, 1), 'unit': 'frames/s', 'dtype': dtype,
             'frames': n_frames, 'floats_per_frame': int(net.out_size), 'trunk_forwards_per_frame': 15, 'trunk_frames_per_s': round(15 * fps, 1),
-            'd2h_GBps': round(fps * net.out_size * 4 / 1e9, 3), 'tflops': round(fps * gflop / 1e3, 1),
-            'frac_of_mfma_peak': round(fps * gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
-            'note': 'algorithmic %.2f GFLOP per frame (5 windows x 23.138); in f16 the l3 / l4 members run their last stage and head in fp32 on the f32-input '
-                    'MFMA (1/16 the rate: the parity plan of the compressed PVRs, DESIGN 2), so the f16 figure is not comparable with the 16-bit peak' % gflop}
+            'tflops': round(fps * gflop / 1e3, 1), 'frac_of_mfma_peak': round(fps * gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
+            'streamed': {'value': round(fps_s, 1), 'unit': 'frames/s', 'd2h_GBps': round(fps_s * net.out_size * 4 / 1e9, 3),
+                         'frac_of_mfma_peak': round(fps_s * gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
+                         'note': 'PCIe-inclusive: pinned host frames -> H2D -> 15 trunk forwards per frame -> D2H of the fp32 rows, stream_embed (two lanes)'},
+            'note': 'frames resident in HBM, two batches in flight, results left in HBM (the headline\'s rule); algorithmic %.2f GFLOP per frame (5 windows x '
+                    '23.138); in f16 the l3 / l4 members run their last stage and head in fp32 on the f32-input MFMA (1/16 the rate: the parity plan of the '
+                    'compressed PVRs, DESIGN 2), so the f16 figure is not comparable with the 16-bit peak' % gflop}
 
 
 _ORACLE_REF = {}

@@ -37,8 +37,9 @@ def _check(line, n):
         assert 0 < ew['p50'] <= ew['p99'] <= ew['max'] and ew['n_elements'] > 1000 and ew['p50'] < bound
     if n == 1:
         assert d['png_source']['files'] == 750 and d['png_source']['value'] > 1000      # the PNG tree through the GPU decoder
-        u = d['uber5crop']                                             # BASELINE configs[4]: 5-crop uber_345 streamed to the host
+        u = d['uber5crop']                                             # BASELINE configs[4]: 5-crop uber_345, HBM-resident (value) and streamed to the host
         assert u['floats_per_frame'] == 31310 and u['value'] > 1000 and 0.05 < u['frac_of_mfma_peak'] < 1 and u['f16_parity_plan']['value'] > 300
+        assert 500 < u['streamed']['value'] <= u['value'] * 1.05 and u['streamed']['d2h_GBps'] > 0
     return d
 
 
