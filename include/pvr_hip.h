@@ -205,6 +205,11 @@ pvr_status pvr_op_conv_wfrag(const void *in_dev, const void *wgt_packed_dev, con
 pvr_status pvr_op_conv2d_dual(const void *in_dev, const void *in2_dev, const void *wgt_dev, const float *bias_dev, void *out_dev, int32_t n, int32_t h,
                               int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t h2, int32_t w2,
                               int32_t cin2, int32_t stride2, int32_t relu, int32_t dtype, void *hip_stream);
+/* The trunk's last convolution with AdaptiveAvgPool2d(1) inside (torchvision resnet.avgpool, reference src/embeddings.py:118-120): 1 x 1 convolution on
+ * (n,7,7,cin) + bias + 16-bit residual (n,7,7,cout) + ReLU, averaged over each frame's 49 pixels in fp32: pool_out[f * pool_stride + c].  The
+ * (n,7,7,cout) activation is never written.  Bit-identical to pvr_op_conv2d (fp32 output) followed by pvr_op_avgpool. */
+pvr_status pvr_op_conv_wfrag_pool(const void *in_dev, const void *wgt_packed_dev, const float *bias_dev, const void *residual_dev, float *pool_out_dev,
+                                  int64_t pool_stride, int32_t n, int32_t cin, int32_t cout, int32_t dtype, void *hip_stream);
 /* launches of that kernel so far (tests: the layer4 plan really took it) */
 int64_t pvr_debug_conv_wfrag_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape

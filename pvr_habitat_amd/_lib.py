@@ -58,6 +58,7 @@ _SIGS = {
     'pvr_debug_bneck_frame_launches': (C.c_int64, []),
     'pvr_op_conv_wfrag': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 12 + [C.c_void_p]),
     'pvr_debug_conv_wfrag_launches': (C.c_int64, []),
+    'pvr_op_conv_wfrag_pool': (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     'pvr_op_conv2d_dual': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 15 + [C.c_void_p]),
     'pvr_op_pack_frag_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'pvr_debug_bneck_frame_stamps': (C.c_int, [C.c_void_p] * 12 + [C.c_int32] * 2 + [C.c_void_p] * 2),

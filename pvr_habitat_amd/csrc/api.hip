@@ -63,7 +63,8 @@ pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias,
                              const void *in2 = nullptr, int h2 = 0, int w2 = 0, int cin2 = 0, int stride2 = 1);
 long long conv_wfrag_launches();
 pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
-                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream);
+                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream, float *pool_out = nullptr,
+                             int64_t pool_stride = 0);
 
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
@@ -121,6 +122,12 @@ pvr_status pvr_op_conv2d_dual(const void *in, const void *in2, const void *wgt, 
     PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "pvr_op_conv2d_dual: 16-bit storage types only");
     return launch_conv_pp256(in, wgt, bias, nullptr, out, n, h, w, cin, cout, kh, kw, stride, pad, relu, 0, 0, dtype, 224, (hipStream_t)stream, in2, h2, w2,
                              cin2, stride2);
+}
+// the pooled form of conv_wfrag: a 1 x 1 convolution on 7 x 7 maps + identity + ReLU whose only output is the average over each frame's 49 pixels
+pvr_status pvr_op_conv_wfrag_pool(const void *in, const void *wgt_packed, const float *bias, const void *residual, float *pool_out, int64_t pool_stride,
+                                  int32_t n, int32_t cin, int32_t cout, int32_t dtype, void *stream) {
+    PVR_REQUIRE(n > 0 && pool_out, "pvr_op_conv_wfrag_pool: empty input");
+    return launch_conv_wfrag(in, wgt_packed, bias, residual, nullptr, n, 7, 7, cin, cout, 1, 1, 1, 0, 1, 1, dtype, (hipStream_t)stream, pool_out, pool_stride);
 }
 int64_t pvr_debug_conv_wfrag_launches(void) { return (int64_t)conv_wfrag_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }

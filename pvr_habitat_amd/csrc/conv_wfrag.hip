@@ -24,15 +24,25 @@ struct WFP {
     int KC;             // K / 8: 16-byte k-chunks per weight row
     int ct_major;       // tile order inside an XCD's contiguous run: cout tile outermost (big weight matrices) or pixel tile outermost
     unsigned in_bytes, w_bytes, out_bytes, res_bytes;
+    float *pool_out;     // POOL: the average over a frame's 49 pixels, fp32, row f at pool_out + f * pool_stride (nothing else is written)
+    long long pool_stride;
+    int frames;
 };
 
 #define WF_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
 // KO (EXPERIMENTS builds, PVR_WFRAG_KO): timing knock-outs, results wrong by construction - 1 no pixel DMA, 2 no weight requests after the prologue's,
 // 4 no barriers, 8 no MFMAs, 16 no fragment reads
-template <bool F16, int RES, bool OUT32, int KO = 0>
+// POOL: the launch is the trunk's last convolution on 7 x 7 maps and only AdaptiveAvgPool2d(1) reads its output (torchvision resnet.avgpool, reference
+// src/embeddings.py:118-120): a tile is TWO whole frames (98 of its 112 rows), a wave owns every pixel of both for its 32 couts, and the epilogue
+// reduces them in registers - the (n,7,7,2048) fp32 activation (103 MB written, 103 MB read back by avgpool_kernel at batch 256) never exists.
+// The summation order is defined on the pixel index q inside a frame, not on its position in the tile: lane sums over q = 16 j' + l (j' ascending),
+// then the row_shr 1 / 2 / 4 / 8 tree over l - avgpool_kernel follows the same order, so the fused and the stand-alone pool agree bit for bit
+// and a frame's embedding does not depend on whether it sits first or second in its tile.
+template <bool F16, int RES, bool OUT32, int KO = 0, bool POOL = false>
 __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
     typedef typename HT<F16>::V8 V8;
+    constexpr int BMV = POOL ? 98 : 112;               // rows of the tile that are output pixels
     constexpr int BM = 112, NT = 7, XB = 16384;       // a ring buffer (four of them): 14 row groups of 1 KB + 2 KB nothing reads (waves 6 / 7's second, empty DMA)
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
     int mt, ct;
     if (p.ct_major) { ct = t / p.MT; mt = t - ct * p.MT; }
     else { mt = t / p.NCT; ct = t - mt * p.NCT; }
-    const int m0 = mt * BM, co0 = ct * 256;
+    const int m0 = mt * BMV, co0 = ct * 256;
 
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.in), 0, p.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w), 0, p.w_bytes, 0x00020000);
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
         const int g = wave + 8 * i, r = g * 8 + (lane >> 3);
         const int lch = (lane & 7) ^ ((r >> 1) & 7);
         const int m = m0 + r;
-        const bool ok = g < BM / 8 && m < p.M;
+        const bool ok = g < BM / 8 && r < BMV && m < p.M;
         const int mm = ok ? m : 0;
         const int wo = mm % p.Wo, tq = mm / p.Wo, ho = tq % p.Ho, n = tq / p.Ho;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
@@ -186,9 +196,14 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int m = m0 + 16 * j + fr;
-            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, m < p.M ? (m * p.Cout + c) * 2 : OOB, 0, 0));
+            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (m < p.M && 16 * j + fr < BMV) ? (m * p.Cout + c) * 2 : OOB, 0, 0));
         }
     }
+    float ps[2][8];                                       // POOL: this lane's sums over the pixel tiles, per frame of the tile
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ps[f][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int m = m0 + 16 * j + fr;
@@ -205,7 +220,14 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if constexpr (OUT32) {
+        if constexpr (POOL) {
+            const int pp = 16 * j + fr;                       // row of the tile: frame 0 = rows 0 .. 48, frame 1 = rows 49 .. 97
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ps[0][e] += pp < 49 ? v[e] : 0.f;
+                ps[1][e] += (pp >= 49 && pp < 98) ? v[e] : 0.f;
+            }
+        } else if constexpr (OUT32) {
             const int o = m < p.M ? (m * p.Cout + c) * 4 : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rs_o, o, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rs_o, o, 16, 0);
@@ -214,6 +236,30 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_h<F16>(v[2 * e]) | ((unsigned)to_h<F16>(v[2 * e + 1]) << 16);
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, m < p.M ? (m * p.Cout + c) * 2 : OOB, 0, 0);
+        }
+    }
+    if constexpr (POOL) {
+        // frame 1's pixel q = row - 49 sits one lane to the right of frame 0's pixel q (49 = 3 * 16 + 1): rotate its lane sums one lane to the left
+        // (row_ror:15) and both frames go through the same tree
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float tot[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = ps[f][e];
+                if (f == 1) t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x12f, 0xf, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x111, 0xf, 0xf, true));   // row_shr:1, missing lanes add 0
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x112, 0xf, 0xf, true));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x114, 0xf, 0xf, true));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x118, 0xf, 0xf, true));
+                tot[e] = t / 49.f;
+            }
+            const int frame = 2 * mt + f;
+            if (fr == 15 && frame < p.frames) {
+                float *o = p.pool_out + (long long)frame * p.pool_stride + c;
+                *reinterpret_cast<f32x4 *>(o) = f32x4{tot[0], tot[1], tot[2], tot[3]};
+                *reinterpret_cast<f32x4 *>(o + 4) = f32x4{tot[4], tot[5], tot[6], tot[7]};
+            }
         }
     }
 #undef WF_ITER
@@ -246,8 +292,9 @@ bool conv_wfrag_preferred(int64_t M, int cin, int cout, int kh, int kw) {
 
 // wp: the fragment-blocked copy (launch_pack_frag_weights) of the (cout, kh * kw * cin) matrix
 pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
-                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream) {
-    PVR_REQUIRE(in && wp && bias && out, "conv_wfrag: null argument");
+                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream, float *pool_out, int64_t pool_stride) {
+    // pool_out != nullptr: `out` is not written; pool_out[f * pool_stride + c] = mean over frame f's 7 x 7 outputs (fp32)
+    PVR_REQUIRE(in && wp && bias && (out || pool_out), "conv_wfrag: null argument");
     PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "conv_wfrag: 16-bit storage types only");
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     const int64_t M = (int64_t)n * ho * wo;
@@ -255,7 +302,10 @@ pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, 
     WFP p;
     p.in = (const u16 *)in; p.w = (const u16 *)wp; p.res = (const u16 *)res; p.bias = bias; p.out = out;
     p.M = (int)M; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.Ho = ho; p.Wo = wo; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad; p.act = act;
-    p.MT = (int)((M + 111) / 112); p.NCT = cout / 256;
+    p.MT = pool_out ? (n + 1) / 2 : (int)((M + 111) / 112); p.NCT = cout / 256;
+    p.pool_out = pool_out; p.pool_stride = pool_stride; p.frames = n;
+    PVR_REQUIRE(!pool_out || (ho == 7 && wo == 7 && res && act == 1 && pool_stride >= cout && ((size_t)pool_out & 15) == 0 && pool_stride % 4 == 0),
+                "conv_wfrag: the pooled form is the 7 x 7 conv3 + identity + ReLU of the trunk's last block");
     p.cpt = cin / 64; p.nch = kh * kw * p.cpt; p.KC = kh * kw * cin / 8;
     const int64_t wbytes = (int64_t)cout * kh * kw * cin * 2;
     p.ct_major = wbytes > (5 << 19) ? 1 : 0;              // > 2.5 MB of weights: an XCD's L2 (4 MB) keeps ONE cout tile's slice of them
@@ -275,6 +325,12 @@ pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, 
         return PVR_OK;
     }
 #endif
+    if (pool_out) {
+        if (f16) hipLaunchKernelGGL((conv_wfrag_kernel<true, 1, false, 0, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((conv_wfrag_kernel<false, 1, false, 0, true>), grid, block, lds, stream, p);
+        PVR_LAUNCH_CHECK();
+        return PVR_OK;
+    }
     if (f16) {
         if (res) { if (o32) WF_GO(true, 1, true); else WF_GO(true, 1, false); }
         else { if (o32) WF_GO(true, 0, true); else WF_GO(true, 0, false); }

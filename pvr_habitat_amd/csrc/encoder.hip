@@ -445,7 +445,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
             e->sched_fused.push_back(l);
             // a stand-alone convolution with few pixels and a deep K (layer3 / layer4's 1 x 1 and 3 x 3 at 14 x 14 and 7 x 7): conv_wfrag.hip may take it at
             // run time (conv_wfrag_preferred: by the batch) - it reads the fragment-blocked copy of the weights
-            if (op.kind == 0 && !op.f32op && !op.d_wfb && op.h == op.w && op.h <= 14 && op.cout_real == op.cout && (int64_t)op.k * op.k * op.cin >= 1024 &&
+            if (op.kind == 0 && !op.f32op && !op.d_wfb && op.h == op.w && op.h <= 14 && op.cout_real == op.cout && (int64_t)op.k * op.k * op.cin >= 512 &&
                 conv_wfrag_supported(1, 1, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
                 const size_t K = (size_t)op.k * op.k * op.cin;
                 PVR_HIP_TRY(hipMalloc((void **)&op.d_wfb, (size_t)op.cout * K * 2));
@@ -911,9 +911,12 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false, t1_blocked = false;   // t1_blocked: the conv1 launch in front of layer1's first tail wrote t1 in the blocked layout
+        bool pooled = false;                         // the plan's last convolution wrote the average pool itself (conv_wfrag's pooled form)
+        const std::vector<Launch> &plan_ = enc->fuse ? enc->sched_fused : enc->sched_plain;
+        const bool pool_fuse = [] { const char *v = getenv("PVR_POOL_FUSE"); return !v || atoi(v) != 0; }();   // (A/B switch, read per forward)
         int launch_idx = 0;                          // debug: stop_after = "#k" ends the forward after conv launch k of the plan
         const int stop_idx = enc->stop_after.size() > 1 && enc->stop_after[0] == '#' ? atoi(enc->stop_after.c_str() + 1) : -1;
-        for (const Launch &l : (enc->fuse ? enc->sched_fused : enc->sched_plain)) {
+        for (const Launch &l : plan_) {
             const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
             if (l.frame) {
@@ -990,6 +993,14 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
                 s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);
                 t1_blocked = true;
+            } else if (pool_fuse && &l == &plan_.back() && op.d_wfb && pooled_head(enc) && enc->final_hw == 49 && op.h == 7 && op.w == 7 && op.k == 1 &&
+                       op.stride == 1 && op.relu == 1 && (op.out_f32 & 1) && !(op.out_f32 & 2) && res && op.out_buf == B_F32 && enc->final_c == op.cout &&
+                       conv_algo() == -1 && !(enc->low_latency && nb <= 4) && enc->stop_after.empty() && out_stride % 4 == 0 &&
+                       (((size_t)(out + (size_t)f0 * out_stride)) & 15) == 0) {
+                // the trunk's last conv3 + identity + ReLU with AdaptiveAvgPool2d(1) in its epilogue: the (n,7,7,2048) fp32 activation is never written
+                s = launch_conv_wfrag(enc->d_buf[op.in_buf], op.d_wfb, op.d_b, res, nullptr, nb, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, 1, 1, dt, st,
+                                      out + (size_t)f0 * out_stride, out_stride);
+                pooled = true;
             } else if (op.d_wfb && !l.frame && conv_algo() == -1 && !(enc->low_latency && nb <= 4) &&
                        conv_wfrag_preferred((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1), op.cin, op.cout, op.k, op.k) &&
                        conv_wfrag_supported((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1),
@@ -1008,7 +1019,9 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         }
         if (stopped) return PVR_OK;
         float *o = out + (size_t)f0 * out_stride;
-        if (pooled_head(enc))
+        if (pooled)
+            s = PVR_OK;                               // (the last launch wrote the pooled rows)
+        else if (pooled_head(enc))
             s = launch_avgpool(enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c, 1, dt, st);
         else
             s = launch_nhwc_to_chw((const float *)enc->d_buf[B_F32], o, out_stride, nb, enc->final_hw, enc->final_c,

@@ -49,7 +49,8 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
 bool conv_wfrag_supported(int64_t M, int64_t in_bytes, int cin, int cout, int kh, int kw, int pad, int act, int out_f32);
 bool conv_wfrag_preferred(int64_t M, int cin, int cout, int kh, int kw);
 pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, const void *res, void *out, int n, int h, int w, int cin, int cout,
-                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream);
+                             int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream, float *pool_out = nullptr,
+                             int64_t pool_stride = 0);
 
 struct HostTensor {
     std::vector<int64_t> shape;

@@ -425,12 +425,26 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const void *__restrict__ i
     float s = 0.f;
     if constexpr (IN_F32) {
         const float *p = (const float *)in + (size_t)b * hw * c + ch;
-        if (hw == 49) {                               // the ResNet50 trunk: all 49 loads in flight at once, then the same ascending summation
+        if (hw == 49) {
+            // the ResNet50 trunk: all 49 loads in flight at once.  Summation order (round 5) = the order conv_wfrag's pooled epilogue sums in, so that
+            // a plan with the pool inside the last convolution and a plan with this launch agree bit for bit: sixteen partial sums over
+            // q = 16 j + l (j ascending), then the shift-and-add tree l += l - 1, l - 2, l - 4, l - 8 whose last element is the total
             float v[49];
 #pragma unroll
             for (int i = 0; i < 49; ++i) v[i] = p[(size_t)i * c];
+            float a[16];
 #pragma unroll
-            for (int i = 0; i < 49; ++i) s += v[i];
+            for (int l = 0; l < 16; ++l) {
+                a[l] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (16 * j + l < 49) a[l] += v[16 * j + l];
+            }
+#pragma unroll
+            for (int sh = 1; sh < 16; sh *= 2)
+#pragma unroll
+                for (int l = 15; l >= sh; --l) a[l] += a[l - sh];
+            s = a[15];
         } else {
 #pragma unroll 7
             for (int i = 0; i < hw; ++i) s += p[(size_t)i * c];  // (same summation order; the unroll only lets the loads go out together)

@@ -235,6 +235,56 @@ def test_conv_wfrag_is_bit_identical(case, dt):
     assert torch.equal(outs[0].view(iv), outs[1].view(iv))
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('n', [1, 2, 3, 64, 255])
+def test_conv_wfrag_pooled_epilogue_is_bit_identical(dt, n):
+    """conv_wfrag's pooled form (round 5): the trunk's last conv3 + identity + ReLU with AdaptiveAvgPool2d(1) in its epilogue - two whole 7 x 7 frames per
+    tile, reduced in registers - against pvr_op_conv2d (fp32 output) followed by pvr_op_avgpool: every pooled value bit for bit (avgpool_kernel sums in the
+    same order, defined on the pixel index inside the frame), for odd and even frame counts, and into a strided output."""
+    tdt, cdt = DT[dt]
+    L = _lib.lib()
+    cin, cout = 512, 2048
+    x = torch.from_numpy(synth.normal(10, 'wpx%d' % n, (n, 7, 7, cin))).clamp_(min=0).to(tdt).cuda()
+    wk = torch.from_numpy(synth.normal(10, 'wpw', (cout, cin), std=float(np.sqrt(2.0 / cin)))).to(tdt).cuda()
+    b = torch.from_numpy(synth.uniform(10, 'wpb', (cout,), -0.5, 0.5)).cuda()
+    r = torch.from_numpy(synth.normal(10, 'wpr%d' % n, (n, 7, 7, cout))).clamp_(min=0).to(tdt).cuda()
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    y32 = _run_conv(x, wk, b, r, n, 7, 7, cin, cout, 1, 1, 1, 1, 0, cdt, tdt)
+    assert y32.dtype == torch.float32
+    stride = cout + 64
+    ref = torch.full((n, stride), float('nan'), device='cuda')
+    _lib.check(L.pvr_op_avgpool(vp(y32), vp(ref), stride, n, 49, cout, 1, cdt, _lib.stream_ptr()))
+    wp = torch.empty_like(wk)
+    _lib.check(L.pvr_op_pack_frag_weights(vp(wk), vp(wp), cout, cin, _lib.stream_ptr()))
+    out = torch.full((n, stride), float('nan'), device='cuda')
+    _lib.check(L.pvr_op_conv_wfrag_pool(vp(x), vp(wp), vp(b), vp(r), vp(out), stride, n, cin, cout, cdt, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[:, :cout]).all() and torch.isnan(out[:, cout:]).all()
+    assert float((y32.mean(dim=(1, 2)) - out[:, :cout]).abs().max()) < 1e-4 * float(y32.abs().max())
+    nd = int((out[:, :cout].contiguous().view(torch.int32) != ref[:, :cout].contiguous().view(torch.int32)).sum())
+    assert nd == 0, (nd, float((out[:, :cout] - ref[:, :cout]).abs().max()))
+
+
+@pytest.mark.parametrize('dtype,n', [('f16', 5), ('bf16', 8), ('f16', 130)])
+def test_pool_inside_the_last_convolution(dtype, n, monkeypatch):
+    """the default plan writes the embedding from layer4.2.conv3's epilogue (no (n,7,7,2048) activation, no avgpool launch); PVR_POOL_FUSE=0 keeps the
+    two launches: the same embedding bit for bit, whatever the position of a frame in the batch."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(8, 'conv5')
+    fr = torch.from_numpy(synth.smooth_frames(140 + n, n, 160, 200)).cuda()
+    m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=256)
+    L = _lib.lib()
+    monkeypatch.setenv('PVR_POOL_FUSE', '1')
+    before = L.pvr_debug_conv_wfrag_launches()
+    fused = m(fr).clone()
+    assert L.pvr_debug_conv_wfrag_launches() > before
+    monkeypatch.setenv('PVR_POOL_FUSE', '0')
+    plain = m(fr).clone()
+    assert torch.equal(fused, plain), float((fused - plain).abs().max())
+    monkeypatch.setenv('PVR_POOL_FUSE', '1')
+    assert torch.equal(m(fr[1:4]), fused[1:4])               # a frame's embedding does not depend on where it sits in its pair
+
+
 DUAL_CASES = [
     # n, ho (= wo), cin, cout, k, cin2, stride2
     (64, 14, 256, 1024, 1, 512, 2),     # layer3.0: conv3 (256 -> 1024) & downsample (512 -> 1024, stride 2 on 28 x 28): 896 tiles, the persistent form
