@@ -48,6 +48,7 @@ struct BFP {
     u16 *t1n;
     int n, phases;                 // phases 1: conv2 only, 3: conv2 + conv3, 7: + the next block's conv1; + 8: the block's own conv1 in front
     unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes, w1n_bytes, t1n_bytes, w1f_bytes;
+    int stagger;                   // experiment (PVR_FRAME_STAGGER): odd workgroups start `stagger` x 8128 cycles late - de-phases the CUs' HBM and matrix phases
     unsigned long long *stamps;    // diagnostics (scripts/bneck_frame_time.py): s_memtime at the phase boundaries of block 8, waves 0 and 4; nullptr in the product
 };
 
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BF_TS(k_) { if (p.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_[k_]) :: "memory"); }
 #define BF_TS_OUT() { if (p.stamps && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) { _Pragma("unroll") for (int k = 0; k < 10; ++k) p.stamps[(wave >> 2) * 10 + k] = ts_[k]; } }
+    if (p.stagger && (blockIdx.x & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     BF_TS(0);
 
     const auto rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.t1), 0, p.t1_bytes, 0x00020000);
@@ -163,25 +167,34 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1f), 0, p.w1f_bytes, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);
-        // Eight half chunks of 128 channels alternate between the two halves of the image region (slices 0-1 / 2-3): half chunk h + 1 lands while h is
-        // computed.  Loads retire in order, so the weight fragments are requested a whole half chunk ahead, right behind the DMA they will be
-        // waited for together with: W of half chunk h + 1 (wc / wd or wa / wb in turns) is in flight with its pixels.
+        // Eight half chunks of 128 channels rotate through THREE 53 KB regions - the two halves of the image region (slices 0-1 / 2-3) and a third one
+        // behind it (slices 4-5: 160 512 B of LDS in all) - and half chunk h + 2 is requested while h is computed: a half chunk's 1664 MFMA cycles
+        // per wave do not cover an HBM round trip, and with one half chunk of prefetch the phase took 58 k cycles against an MFMA floor of 27 k
+        // whatever the other workgroups were doing (PVR_FRAME_STAGGER experiment: not a lockstep effect, a per-CU latency chain).
+        // Loads retire in order: the weight fragments of half chunk h + 1 (wc / wd or wa / wb in turns) are requested BEFORE the DMA of h + 2, so
+        // "all but the last 7 requests" = vmcnt(7) is "pixels and weights of h + 1 are here".  Every wave issues 7 DMA instructions per half chunk
+        // (52 row groups over 8 waves; the spare ones repeat the all-padding group 25 of slice 1: zeros over zeros).
         V8 wc[2][2], wd[2][2];
-        auto stage_x = [&](int h) {                                // block-input channels [128 h, 128 h + 128) -> image slices 2 (h & 1), 2 (h & 1) + 1
+        auto stage_x = [&](int h) {                                // block-input channels [128 h, 128 h + 128) -> slices 2 (h % 3), 2 (h % 3) + 1
             int lane_c = lane;
             asm volatile("" : "+v"(lane_c));
-            for (int u = wave; u < 52; u += 8) {
+            const int b3 = h % 3;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int u0 = wave + 8 * i, u = u0 < 52 ? u0 : 51;
                 const int s2 = u / 26, g = u % 26;
                 const int row = g * 8 + (lane_c >> 3), lch = (lane_c & 7) ^ ((row >> 1) & 7);
                 const int vo = row < NPIX ? ((n * NPIX + row) * CO + h * 128 + s2 * 64 + lch * 8) * 2 : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * (h & 1) + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * b3 + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
             }
         };
-#define BF_CHUNK_DONE() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define BF_CHUNK_DONE(n_) { asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        if (tid < 16) *reinterpret_cast<u32x4 *>(smem + (4 + (tid >> 3)) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};   // (the third region's unused last rows: defined)
         BF_LOAD_W(wa, rs_w1, 2 * wave, CO / 8, 0);
         BF_LOAD_W(wb, rs_w1, 2 * wave, CO / 8, 1);
         stage_x(0);
-        BF_CHUNK_DONE();
+        stage_x(1);
+        BF_CHUNK_DONE(7);                                          // half chunk 0 and its weights
 #pragma unroll 1
         for (int hh = 0; hh < 4; ++hh) {
             // (opaque per iteration: the fragment addresses do not change, and hipcc otherwise hoists every step's address and its XOR-64 partner out of
@@ -189,23 +202,26 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(xa[j]));
             const int h = 2 * hh;
-            stage_x(h + 1);
             BF_LOAD_W(wc, rs_w1, 2 * wave, CO / 8, 2 * h + 2);
             BF_LOAD_W(wd, rs_w1, 2 * wave, CO / 8, 2 * h + 3);
-            xbase = 0;
+            asm volatile("" ::: "memory");                         // (the requests stay in front of the DMA)
+            stage_x(h + 2 < 8 ? h + 2 : 7);                        // (past the last half chunk: a repeat into a region nobody reads any more)
+            xbase = 2 * (h % 3) * SLICE;
             BF_TWO_KTILES(wa, wb);
-            BF_CHUNK_DONE();                                       // half chunk h + 1 has landed; every wave is done with half 0
+            BF_CHUNK_DONE(7);                                      // half chunk h + 1 and its weights have landed; every wave is done with h's region
             const bool lastc = hh == 3;
-            if (!lastc) stage_x(h + 2);
             // (the last requests: conv2's first K tile and a harmless repeat - never a branch around loads)
             const auto rs_n = lastc ? rs_w2 : rs_w1;
             const int kc_n = lastc ? 9 * CM / 8 : CO / 8;
             BF_LOAD_W(wa, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 4);
             BF_LOAD_W(wb, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 5);
-            xbase = 2 * SLICE;
+            asm volatile("" ::: "memory");
+            stage_x(h + 3 < 8 ? h + 3 : 7);
+            xbase = 2 * ((h + 1) % 3) * SLICE;
             BF_TWO_KTILES(wc, wd);
-            if (!lastc) BF_CHUNK_DONE();
+            if (!lastc) BF_CHUNK_DONE(7);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the repeats past the last half chunk must not land in the image once t1 is written there)
         xbase = 0;
 #undef BF_CHUNK_DONE
         BF_BARRIER();                                             // every wave's reads of the last chunk are done
@@ -502,17 +518,18 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
     BFP p;
     p.t1 = (const u16 *)t1; p.w2 = (const u16 *)w2p; p.w3 = (const u16 *)w3p; p.res = (const u16 *)res; p.b2 = b2; p.b3 = b3;
     p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases & ~8; p.stamps = stamps;
+    { const char *e = getenv("PVR_FRAME_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     p.w1n = (const u16 *)w1np; p.b1n = b1n; p.t1n = (u16 *)t1n; p.w1f = (const u16 *)w1fp; p.b1f = b1f;
     p.t1_bytes = p.t2_bytes = p.t1n_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
     p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0; p.w1n_bytes = w1np ? 256u * 1024 * 2 : 0; p.w1f_bytes = w1fp ? 256u * 1024 * 2 : 0;
     p.res_bytes = p.y_bytes = (unsigned)((size_t)n * 196 * 1024 * 2);
-    constexpr int lds = 4 * 209 * 128, lds1 = lds + 2 * 208 * 128;
+    constexpr int lds = 4 * 209 * 128, lds1 = lds + 2 * 208 * 128, ldsf = 6 * 209 * 128;   // (FRONT1: a third half-chunk region behind the image)
     static DeviceOnce attr_done;
     if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
         attr_done.mark();
@@ -522,8 +539,8 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
         if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, true>), dim3(n), dim3(512), lds1, stream, p);
         else hipLaunchKernelGGL((bneck_frame_kernel<false, true>), dim3(n), dim3(512), lds1, stream, p);
     } else if (front) {
-        if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false, true>), dim3(n), dim3(512), lds, stream, p);
-        else hipLaunchKernelGGL((bneck_frame_kernel<false, false, true>), dim3(n), dim3(512), lds, stream, p);
+        if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false, true>), dim3(n), dim3(512), ldsf, stream, p);
+        else hipLaunchKernelGGL((bneck_frame_kernel<false, false, true>), dim3(n), dim3(512), ldsf, stream, p);
     } else {
         if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false>), dim3(n), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((bneck_frame_kernel<false, false>), dim3(n), dim3(512), lds, stream, p);

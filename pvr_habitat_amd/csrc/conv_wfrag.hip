@@ -95,16 +95,22 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
             nv[i] = ((a_m[i] >> s_ky) & (a_m[i] >> (3 + s_kx)) & 1) ? a_off[i] + toff_ : OOB;                   \
     }
-#define WF_STAGE(buf_)                                                                                          \
+#define WF_STAGE1(buf_, i_)                                                                                     \
     {                                                                                                          \
-        if constexpr (!(KO & 1)) { _Pragma("unroll") for (int i = 0; i < 2; ++i)                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, WF_LDS_PTR((buf_) * XB + (wave + 8 * i) * 1024), 16, nv[i], 0, 0, 0); }   \
+        if constexpr (!(KO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, WF_LDS_PTR((buf_) * XB + (wave + 8 * (i_)) * 1024), 16, nv[i_], 0, 0, 0);   \
+        asm volatile("" ::: "memory");                                                                          \
     }
+#define WF_STAGE(buf_) { WF_STAGE1(buf_, 0) WF_STAGE1(buf_, 1) }
     // weights: fragment (row tile rt, 32-deep k-step kk) = 1 KB at ((rt * KC + 4 kk) * 256) bytes, lane * 16 inside; K chunk c = k-steps 2 c, 2 c + 1
     const int wlane = lane * 16;
     const int rt0 = (co0 >> 4) + 2 * wave;
     int w_c = 0;                                         // the next K chunk to request (clamped like the staging)
     V8 w0[2][2], w1[2][2], w2[2][2], w3[2][2];
+#define WF_LOAD_W1(dst_, i_, ks_)                                                                               \
+    {                                                                                                          \
+        if constexpr (!(KO & 2)) dst_[i_][ks_] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((rt0 + (i_)) * p.KC + 4 * (2 * w_c + (ks_))) * 256, 0));   \
+        asm volatile("" ::: "memory");            /* (pins the request here: hipcc otherwise sinks it towards its first use, past a loop exit) */ \
+    }
 #define WF_LOAD_W(dst_) WF_LOAD_W_(dst_, !(KO & 2))
 #define WF_LOAD_W_(dst_, on_)                                                                                   \
     {                                                                                                          \
@@ -147,28 +153,33 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
     }
     // One K chunk c, in buffer B_ = c % 4 with weight set W_ = c % 4.  Its barrier publishes chunk c + 1 (every wave waits for its own part of that DMA
     // first) - chunk c itself was published an iteration ago, so the read pipeline runs on into the next chunk without waiting - and says every wave is
-    // done with chunk c - 1, whose buffer and weight set the requests for chunk c + 3 then take.  In front of the barrier a wave has issued, after its
-    // part of chunk c + 1's DMA: that chunk's weights (4), chunk c + 2's DMA (2) and weights (4): vmcnt(10).
+    // done with chunk c - 1, whose buffer and weight set the requests for chunk c + 3 then take.
+    // The six requests of a chunk (4 weight fragments, then 2 DMA instructions) are issued ONE PER STEP, between the MFMAs: a CU's vector-memory path
+    // takes 64 B/clk, eight waves x 6 KB issued together stall every wave at the top of the chunk for ~750 of its 896 MFMA cycles (s_memtime stamps of
+    // the frame kernel's front phase: 1480 cycles to issue 15 requests per wave).  In front of the barrier a wave has issued, after its part of
+    // chunk c + 1's DMA: chunk c + 2's weights (4) and DMA (2): vmcnt(6).
 #define WF_ITER(B_, BN_, BF_, W_, WF_)                                                                          \
     {                                                                                                          \
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                       \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                        \
         if constexpr (!(KO & 4)) __builtin_amdgcn_s_barrier();                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        WF_STAGE(BF_);                                                                                          \
-        WF_LOAD_W(WF_);                                                                                         \
-        asm volatile("" ::: "memory");            /* (pins the requests here: hipcc otherwise sinks them towards their first use, past a loop exit) */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        WF_LOAD_W1(WF_, 0, 0) WF_STEP(0, B_, BN_, W_)                                                           \
+        WF_LOAD_W1(WF_, 0, 1) WF_STEP(1, B_, BN_, W_)                                                           \
+        WF_LOAD_W1(WF_, 1, 0) WF_STEP(2, B_, BN_, W_)                                                           \
+        WF_LOAD_W1(WF_, 1, 1) WF_STEP(3, B_, BN_, W_)                                                           \
+        if (w_c + 1 < p.nch) ++w_c;                                                                             \
+        WF_STAGE1(BF_, 0) WF_STEP(4, B_, BN_, W_)                                                               \
+        WF_STAGE1(BF_, 1) WF_STEP(5, B_, BN_, W_)                                                               \
         WF_STAGE_NEXT(1);                                                                                       \
-        WF_STEP(0, B_, BN_, W_) WF_STEP(1, B_, BN_, W_) WF_STEP(2, B_, BN_, W_) WF_STEP(3, B_, BN_, W_)           \
-        WF_STEP(4, B_, BN_, W_) WF_STEP(5, B_, BN_, W_) WF_STEP(6, B_, BN_, W_)                                   \
+        WF_STEP(6, B_, BN_, W_)                                                                                 \
     }
 
-    WF_STAGE_NEXT(0); WF_STAGE(0); WF_LOAD_W_(w0, true);
-    WF_STAGE_NEXT(1); WF_STAGE(1); WF_LOAD_W_(w1, true);
-    WF_STAGE_NEXT(1); WF_STAGE(2); WF_LOAD_W_(w2, true);
+    WF_STAGE_NEXT(0); WF_LOAD_W_(w0, true); WF_STAGE(0);
+    WF_STAGE_NEXT(1); WF_LOAD_W_(w1, true); WF_STAGE(1);
+    WF_STAGE_NEXT(1); WF_LOAD_W_(w2, true); WF_STAGE(2);
     if constexpr ((KO & 2) != 0) WF_LOAD_W_(w3, true);
     WF_STAGE_NEXT(1);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // my part of chunk 0 (behind it: 4 + 2 + 4 + 2 + 4 requests)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // my part of chunk 0 (behind it: 4 + 2 + 4 + 2 requests)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     WF_XREAD(0, 0); WF_XREAD(1, 0); WF_XREAD(2, 0);
@@ -265,9 +276,11 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
 #undef WF_ITER
 #undef WF_STEP
 #undef WF_XREAD
+#undef WF_LOAD_W1
 #undef WF_LOAD_W_
 #undef WF_LOAD_W
 #undef WF_STAGE
+#undef WF_STAGE1
 #undef WF_STAGE_NEXT
 }
 
