@@ -119,8 +119,10 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][0]) : "v"(a0_));                                 \
         asm volatile("ds_read_b128 %0, %1" : "=v"(xs[(q_) % 3][1]) : "v"(a0_ ^ 64));                            \
     }
+#define BF_HOOK(q_)                                     /* (a phase may hang one more request on a step: conv3's identity loads) */
 #define BF_STEP(q_, W_, NQ_)                                                                                    \
     {                                                                                                          \
+        BF_HOOK(q_)                                                                                             \
         if ((q_) + 2 < (NQ_)) BF_XREAD((q_) + 2);                                                               \
         if ((q_) + 2 < (NQ_)) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1]));      \
         else if ((q_) + 1 < (NQ_)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xs[(q_) % 3][0]), "+v"(xs[(q_) % 3][1])); \
@@ -144,13 +146,29 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         BF_SLICE(0, WA_, 2 * NT)                                                                                \
         BF_SLICE(1, WB_, 2 * NT)                                                                                \
     }
-#define BF_FOUR_KTILES(NEXT0_, NEXT1_, NEXT2_, NEXT3_)                                                          \
+    // a slice whose first four steps each request ONE fragment of the K tile after the next (set DST_: row tile RT_ + (j >> 1), k-step j & 1 of K tile KT_):
+    // four requests per wave at the slice start made the eight waves issue 32 KB together (see the front conv1's note)
+#define BF_STEP_L(q_, W_, NQ_, DST_, RS_, RT_, KC_, KT_)                                                         \
+    {                                                                                                          \
+        if constexpr (((q_) % NT) < 4) {                                                                        \
+            DST_[((q_) % NT) >> 1][((q_) % NT) & 1] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(RS_, wlane, (((RT_) + (((q_) % NT) >> 1)) * (KC_) + 4 * (2 * (KT_) + (((q_) % NT) & 1))) * 256, 0)); \
+            asm volatile("" ::: "memory");                                                                      \
+        }                                                                                                       \
+        BF_STEP(q_, W_, NQ_)                                                                                    \
+    }
+#define BF_SLICE_L(s_, W_, NQ_, DST_, RS_, RT_, KC_, KT_)                                                        \
+    BF_STEP_L((s_) * NT + 0, W_, NQ_, DST_, RS_, RT_, KC_, KT_) BF_STEP_L((s_) * NT + 1, W_, NQ_, DST_, RS_, RT_, KC_, KT_) BF_STEP_L((s_) * NT + 2, W_, NQ_, DST_, RS_, RT_, KC_, KT_) \
+    BF_STEP_L((s_) * NT + 3, W_, NQ_, DST_, RS_, RT_, KC_, KT_) BF_STEP((s_) * NT + 4, W_, NQ_) BF_STEP((s_) * NT + 5, W_, NQ_) BF_STEP((s_) * NT + 6, W_, NQ_)        \
+    BF_STEP((s_) * NT + 7, W_, NQ_) BF_STEP((s_) * NT + 8, W_, NQ_) BF_STEP((s_) * NT + 9, W_, NQ_) BF_STEP((s_) * NT + 10, W_, NQ_) BF_STEP((s_) * NT + 11, W_, NQ_)  \
+    BF_STEP((s_) * NT + 12, W_, NQ_)
+    // four K tiles (slices 0..3 with wa / wb in turns); (RSk_, RTk_, KCk_, KTk_): the K tile requested during slice k into the set slice k + 1 (k + 2) uses
+#define BF_FOUR_KTILES(RS0_, RT0_, KC0_, KT0_, RS1_, RT1_, KC1_, KT1_, RS2_, RT2_, KC2_, KT2_, RS3_, RT3_, KC3_, KT3_)   \
     {                                                                                                          \
         BF_XREAD(0); BF_XREAD(1);                                                                               \
-        NEXT0_; BF_SLICE(0, wa, 4 * NT)                                                                         \
-        NEXT1_; BF_SLICE(1, wb, 4 * NT)                                                                         \
-        NEXT2_; BF_SLICE(2, wa, 4 * NT)                                                                         \
-        NEXT3_; BF_SLICE(3, wb, 4 * NT)                                                                         \
+        BF_SLICE_L(0, wa, 4 * NT, wb, RS0_, RT0_, KC0_, KT0_)                                                   \
+        BF_SLICE_L(1, wb, 4 * NT, wa, RS1_, RT1_, KC1_, KT1_)                                                   \
+        BF_SLICE_L(2, wa, 4 * NT, wb, RS2_, RT2_, KC2_, KT2_)                                                   \
+        BF_SLICE_L(3, wb, 4 * NT, wa, RS3_, RT3_, KC3_, KT3_)                                                   \
     }
 
     BF_ZERO_ACC();
@@ -175,19 +193,46 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         // "all but the last 7 requests" = vmcnt(7) is "pixels and weights of h + 1 are here".  Every wave issues 7 DMA instructions per half chunk
         // (52 row groups over 8 waves; the spare ones repeat the all-padding group 25 of slice 1: zeros over zeros).
         V8 wc[2][2], wd[2][2];
-        auto stage_x = [&](int h) {                                // block-input channels [128 h, 128 h + 128) -> slices 2 (h % 3), 2 (h % 3) + 1
+        auto stage_x1 = [&](int h, int i) {                        // DMA instruction i (0..6) of half chunk h: block-input channels [128 h, 128 h + 128) -> slices 2 (h % 3), + 1
             int lane_c = lane;
             asm volatile("" : "+v"(lane_c));
             const int b3 = h % 3;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int u0 = wave + 8 * i, u = u0 < 52 ? u0 : 51;
-                const int s2 = u / 26, g = u % 26;
-                const int row = g * 8 + (lane_c >> 3), lch = (lane_c & 7) ^ ((row >> 1) & 7);
-                const int vo = row < NPIX ? ((n * NPIX + row) * CO + h * 128 + s2 * 64 + lch * 8) * 2 : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * b3 + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
-            }
+            const int u0 = wave + 8 * i, u = u0 < 52 ? u0 : 51;
+            const int s2 = u / 26, g = u % 26;
+            const int row = g * 8 + (lane_c >> 3), lch = (lane_c & 7) ^ ((row >> 1) & 7);
+            const int vo = row < NPIX ? ((n * NPIX + row) * CO + h * 128 + s2 * 64 + lch * 8) * 2 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * b3 + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
+            asm volatile("" ::: "memory");
         };
+        auto stage_x = [&](int h) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) stage_x1(h, i);
+        };
+        // The 15 requests of a half chunk - the NEXT half chunk's 8 weight fragments, then the 7 DMA instructions of the one after it - go out ONE PER
+        // STEP between the MFMAs of the current one: issued together at its top they stalled every wave for ~1480 cycles (s_memtime stamps: a CU's
+        // vector-memory path takes 64 B/clk and the eight waves of the workgroup issue 120 KB of requests at the same moment)
+#define BF_ISSUE(q_, N0_, N1_, RS_, KC_, KT_, H_)                                                                \
+        {                                                                                                      \
+            if constexpr ((q_) < 4)                                                                             \
+                N0_[(q_) >> 1][(q_) & 1] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(RS_, wlane, ((2 * wave + ((q_) >> 1)) * (KC_) + 4 * (2 * (KT_) + ((q_) & 1))) * 256, 0)); \
+            else if constexpr ((q_) < 8)                                                                        \
+                N1_[((q_) - 4) >> 1][(q_) & 1] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(RS_, wlane, ((2 * wave + (((q_) - 4) >> 1)) * (KC_) + 4 * (2 * ((KT_) + 1) + ((q_) & 1))) * 256, 0)); \
+            else if constexpr ((q_) < 15) stage_x1(H_, (q_) - 8);                                               \
+            if constexpr ((q_) < 8) asm volatile("" ::: "memory");                                              \
+        }
+#define BF_STEP_I(q_, W_, N0_, N1_, RS_, KC_, KT_, H_) { BF_ISSUE(q_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP(q_, W_, 2 * NT) }
+#define BF_SLICE_I(s_, W_, N0_, N1_, RS_, KC_, KT_, H_)                                                          \
+        BF_STEP_I((s_) * NT + 0, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 1, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 2, W_, N0_, N1_, RS_, KC_, KT_, H_)   \
+        BF_STEP_I((s_) * NT + 3, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 4, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 5, W_, N0_, N1_, RS_, KC_, KT_, H_)   \
+        BF_STEP_I((s_) * NT + 6, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 7, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 8, W_, N0_, N1_, RS_, KC_, KT_, H_)   \
+        BF_STEP_I((s_) * NT + 9, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 10, W_, N0_, N1_, RS_, KC_, KT_, H_) BF_STEP_I((s_) * NT + 11, W_, N0_, N1_, RS_, KC_, KT_, H_) \
+        BF_STEP_I((s_) * NT + 12, W_, N0_, N1_, RS_, KC_, KT_, H_)
+#define BF_TWO_KTILES_I(WA_, WB_, N0_, N1_, RS_, KC_, KT_, H_)                                                   \
+        {                                                                                                      \
+            BF_XREAD(0); BF_XREAD(1);                                                                           \
+            BF_SLICE_I(0, WA_, N0_, N1_, RS_, KC_, KT_, H_)                                                     \
+            BF_SLICE_I(1, WB_, N0_, N1_, RS_, KC_, KT_, H_)                                                     \
+        }
 #define BF_CHUNK_DONE(n_) { asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         if (tid < 16) *reinterpret_cast<u32x4 *>(smem + (4 + (tid >> 3)) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};   // (the third region's unused last rows: defined)
         BF_LOAD_W(wa, rs_w1, 2 * wave, CO / 8, 0);
@@ -202,28 +247,27 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(xa[j]));
             const int h = 2 * hh;
-            BF_LOAD_W(wc, rs_w1, 2 * wave, CO / 8, 2 * h + 2);
-            BF_LOAD_W(wd, rs_w1, 2 * wave, CO / 8, 2 * h + 3);
-            asm volatile("" ::: "memory");                         // (the requests stay in front of the DMA)
-            stage_x(h + 2 < 8 ? h + 2 : 7);                        // (past the last half chunk: a repeat into a region nobody reads any more)
+            const int hn0 = h + 2 < 8 ? h + 2 : 7;                 // (past the last half chunk: a repeat into a region nobody reads any more)
             xbase = 2 * (h % 3) * SLICE;
-            BF_TWO_KTILES(wa, wb);
+            BF_TWO_KTILES_I(wa, wb, wc, wd, rs_w1, CO / 8, 2 * h + 2, hn0);
             BF_CHUNK_DONE(7);                                      // half chunk h + 1 and its weights have landed; every wave is done with h's region
             const bool lastc = hh == 3;
-            // (the last requests: conv2's first K tile and a harmless repeat - never a branch around loads)
+            // (the last requests: conv2's first K tiles - never a branch around loads)
             const auto rs_n = lastc ? rs_w2 : rs_w1;
             const int kc_n = lastc ? 9 * CM / 8 : CO / 8;
-            BF_LOAD_W(wa, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 4);
-            BF_LOAD_W(wb, rs_n, 2 * wave, kc_n, lastc ? 0 : 2 * h + 5);
-            asm volatile("" ::: "memory");
-            stage_x(h + 3 < 8 ? h + 3 : 7);
+            const int hn1 = h + 3 < 8 ? h + 3 : 7;
+            const int kt_n = lastc ? 0 : 2 * h + 4;                // (lastc: conv2's K tiles 0 and 1; conv2 requests tile 1 again itself - harmless)
             xbase = 2 * ((h + 1) % 3) * SLICE;
-            BF_TWO_KTILES(wc, wd);
+            BF_TWO_KTILES_I(wc, wd, wa, wb, rs_n, kc_n, kt_n, hn1);
             if (!lastc) BF_CHUNK_DONE(7);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the repeats past the last half chunk must not land in the image once t1 is written there)
         xbase = 0;
 #undef BF_CHUNK_DONE
+#undef BF_TWO_KTILES_I
+#undef BF_SLICE_I
+#undef BF_STEP_I
+#undef BF_ISSUE
         BF_BARRIER();                                             // every wave's reads of the last chunk are done
         {
             const int c1 = 32 * wave + 8 * fq;
@@ -279,8 +323,8 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         const bool last = tap == 8;
         const auto rs_n = (last && (p.phases & 15) > 1) ? rs_w3 : rs_w2;
         const int rt_n = (NEXT1 && last) ? 2 * (wave & 3) : 2 * wave, kc_n = (last && (p.phases & 15) > 1) ? CM / 8 : 9 * CM / 8, kt_n = last ? 0 : kt + 4;
-        BF_FOUR_KTILES(BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 1), BF_LOAD_W(wa, rs_w2, 2 * wave, 9 * CM / 8, kt + 2),
-                       BF_LOAD_W(wb, rs_w2, 2 * wave, 9 * CM / 8, kt + 3), BF_LOAD_W(wa, rs_n, rt_n, kc_n, kt_n));
+        BF_FOUR_KTILES(rs_w2, 2 * wave, 9 * CM / 8, kt + 1, rs_w2, 2 * wave, 9 * CM / 8, kt + 2,
+                       rs_w2, 2 * wave, 9 * CM / 8, kt + 3, rs_n, rt_n, kc_n, kt_n);
     }
     BF_TS(2);
     BF_BARRIER();                                               // every wave's reads of the t1 image are done
@@ -421,23 +465,39 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);     // centre tap (padding pixels read zero-filled rows; their columns are never stored)
     BF_TS(4);
+    // The chunk's thirteen identity loads go out one per step inside its K loop (steps 17 .. 25 and 30 .. 33: behind the weight requests of slices 1 and 2),
+    // so that they have landed when the epilogue starts: issued at the top of the epilogue their HBM latency was exposed once per chunk and wave, and the
+    // eight waves' 104 KB of requests stalled each other in the vector-memory path.  (They are behind the previous chunk's stores in the one in-order
+    // vmcnt queue: those have a whole K loop to drain.)
+#undef BF_HOOK
+#ifndef BF_LATE_RES
+#define BF_LATE_RES 0           // (A/B builds: 1 = the identity loads at the top of the epilogue, as until round 5's last kernel commit)
+#endif
+#define BF_HOOK(q_)                                                                                             \
+    if constexpr (!BF_LATE_RES && (((q_) >= 17 && (q_) < 26) || ((q_) >= 30 && (q_) < 34))) {                                     \
+        constexpr int r_ = (q_) < 26 ? (q_) - 17 : (q_) - 30 + 9;                                               \
+        const int pp_ = 16 * r_ + fr;                                                                           \
+        rr[r_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp_ < NPIX && !(p.phases & 32)) ? ((n * NPIX + pp_) * CO + cc) * 2 : OOB, 0, PVR_NT_AUX(512))); \
+        asm volatile("" ::: "memory");                                                                          \
+    }
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
         BF_ZERO_ACC();
         const int rt0 = 16 * ch + 2 * wave;
         const int rt_n = ch < 3 ? rt0 + 16 : rt0;              // (after the last chunk: a harmless repeat, see conv2)
-        BF_FOUR_KTILES(BF_LOAD_W(wb, rs_w3, rt0, CM / 8, 1), BF_LOAD_W(wa, rs_w3, rt0, CM / 8, 2), BF_LOAD_W(wb, rs_w3, rt0, CM / 8, 3),
-                       BF_LOAD_W(wa, rs_w3, rt_n, CM / 8, 0));
+        const int cc = 256 * ch + 32 * wave + 8 * fq;
+        u32x4 rr[NT];
+        BF_FOUR_KTILES(rs_w3, rt0, CM / 8, 1, rs_w3, rt0, CM / 8, 2, rs_w3, rt0, CM / 8, 3, rs_w3, rt_n, CM / 8, 0);
         if (ch == 0) BF_TS(5);
         // ---- y = relu(conv3 + b3 + identity), rounded, NHWC; a lane's tile pair = 8 consecutive couts of one pixel
-        const int c = 256 * ch + 32 * wave + 8 * fq;
+        const int c = cc;
         const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b3 + c), bh = *reinterpret_cast<const f32x4 *>(p.b3 + c + 4);
-        // (all thirteen identity loads first, then the stores: a load issued behind a store can only be waited for together with that store)
-        u32x4 rr[NT];
+        if constexpr (BF_LATE_RES != 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int pp = 16 * j + fr;
-            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp < NPIX && !(p.phases & 32)) ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(512)));
+            for (int j = 0; j < NT; ++j) {
+                const int pp = 16 * j + fr;
+                rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp < NPIX && !(p.phases & 32)) ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(512)));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -457,6 +517,8 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         if (ch == 0) BF_TS(6);
         if (ch == 2) BF_TS(7);
     }
+#undef BF_HOOK
+#define BF_HOOK(q_)
     }
     BF_TS(8);
     if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -466,9 +528,12 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #undef BF_TS
 #undef BF_BARRIER
 #undef BF_FOUR_KTILES
+#undef BF_SLICE_L
+#undef BF_STEP_L
 #undef BF_TWO_KTILES
 #undef BF_SLICE
 #undef BF_STEP
+#undef BF_HOOK
 #undef BF_XREAD
 #undef BF_ZERO_ACC
 #undef BF_LOAD_W
