@@ -174,6 +174,20 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
         WF_STEP(6, B_, BN_, W_)                                                                                 \
     }
 
+    // RES: the tile's identity values are requested FIRST - the oldest entries of the in-order vmcnt queue, so the K loop's counted waits never see
+    // them - and have landed long before the epilogue wants them (requested at its top their HBM latency was exposed once per tile, and a tile of a
+    // short-K launch - conv3: 8 chunks - is mostly epilogue)
+    const int c = co0 + 32 * wave + 8 * fq;
+    u32x4 rr[NT];
+    if constexpr (RES == 1) {
+        const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int m = m0 + 16 * j + fr;
+            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (m < p.M && 16 * j + fr < BMV) ? (m * p.Cout + c) * 2 : OOB, 0, 0));
+        }
+        asm volatile("" ::: "memory");
+    }
     WF_STAGE_NEXT(0); WF_LOAD_W_(w0, true); WF_STAGE(0);
     WF_STAGE_NEXT(1); WF_LOAD_W_(w1, true); WF_STAGE(1);
     WF_STAGE_NEXT(1); WF_LOAD_W_(w2, true); WF_STAGE(2);
@@ -198,18 +212,8 @@ __global__ __launch_bounds__(512, 1) void conv_wfrag_kernel(WFP p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: + bias (+ residual) (ReLU), a lane's two row tiles = 8 consecutive couts of one pixel (the packed weights' row permutation)
-    const int c = co0 + 32 * wave + 8 * fq;
     const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.bias + c), bh = *reinterpret_cast<const f32x4 *>(p.bias + c + 4);
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-    u32x4 rr[NT];
-    if constexpr (RES == 1) {
-        const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int m = m0 + 16 * j + fr;
-            rr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (m < p.M && 16 * j + fr < BMV) ? (m * p.Cout + c) * 2 : OOB, 0, 0));
-        }
-    }
     float ps[2][8];                                       // POOL: this lane's sums over the pixel tiles, per frame of the tile
 #pragma unroll
     for (int f = 0; f < 2; ++f)
