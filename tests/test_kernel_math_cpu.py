@@ -49,3 +49,27 @@ def test_deflate_tables_in_closed_form():
     lo = 16 | (17 << 5) | (18 << 10) | (0 << 15) | (8 << 20) | (7 << 25) | (9 << 30) | (6 << 35) | (10 << 40) | (5 << 45) | (11 << 50) | (4 << 55)
     hi = 12 | (3 << 5) | (13 << 10) | (2 << 15) | (14 << 20) | (1 << 25) | (15 << 30)
     assert [((lo >> (5 * i)) & 31) if i < 12 else ((hi >> (5 * (i - 12))) & 31) for i in range(19)] == order
+
+
+def test_bench_byte_model_covers_every_launch_name_of_the_round5_plan():
+    """bench.py prices `roofline.stages` / `two_roof` with conv_algorithmic_bytes(names): every launch name the round-5 ResNet50 plan produces must be
+    understood (a name the model does not know silently contributes zero bytes), and the fused forms must be cheaper than what they replace."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = ['layer1.0.conv1', 'layer1.0.conv2+conv3&downsample+layer1.1.conv1', 'layer1.1.conv2+conv3+layer1.2.conv1', 'layer1.2.conv2+conv3+layer2.0.conv1',
+            'layer2.0.downsample.0', 'layer2.0.conv2+conv3+layer2.1.conv1', 'layer2.1.conv2+conv3+layer2.2.conv1', 'layer2.2.conv2+conv3+layer2.3.conv1',
+            'layer2.3.conv2+conv3', 'layer3.0.conv1', 'layer3.0.conv2', 'layer3.0.conv3&downsample'] + \
+           ['layer3.%d.conv1+conv2+conv3' % k for k in range(1, 6)] + \
+           ['layer4.0.conv1', 'layer4.0.conv2', 'layer4.0.conv3&downsample', 'layer4.1.conv1', 'layer4.1.conv2', 'layer4.1.conv3',
+            'layer4.2.conv1', 'layer4.2.conv2', 'layer4.2.conv3']
+    assert len(plan) == 26
+    per = [bench.conv_algorithmic_bytes(1, [nm]) for nm in plan]
+    assert all(b > 0 for b in per), [nm for nm, b in zip(plan, per) if b <= 0]
+    assert sum(per) == bench.conv_algorithmic_bytes(1, plan)
+    one = lambda *names: bench.conv_algorithmic_bytes(1, list(names))
+    assert one('layer3.0.conv3&downsample') < one('layer3.0.downsample.0', 'layer3.0.conv3')
+    assert one('layer3.1.conv1+conv2+conv3') < one('layer3.1.conv1', 'layer3.1.conv2', 'layer3.1.conv3')
+    # one launch per convolution (names=None) is the 53-convolution plan minus the stem
+    assert bench.conv_algorithmic_bytes(1) > bench.conv_algorithmic_bytes(1, plan)
