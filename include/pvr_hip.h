@@ -150,6 +150,14 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames_dev, int3
  * pvr_encoder_profile serialise the dispatcher for a few microseconds each, which this figure does not contain. */
 pvr_status pvr_encoder_profile_span(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, float *out_dev,
                                     int64_t out_stride, void *hip_stream, int32_t first_op, int32_t last_op, float *span_ms);
+/* Debug / A-B: the run-time switches of a finalized encoder - "pool_fuse" (the trunk's last convolution writes the average pool itself), "stem_u8" (the
+ * fused stem reads uint8 frames that need no resize), "frame_min_n" (frames per forward from which layer3 runs one workgroup per frame).  Every other
+ * PVR_* switch shapes the plan and is read from the environment ONCE, in pvr_encoder_create; nothing reads the environment on the forward path. */
+pvr_status pvr_encoder_debug_set_switch(pvr_encoder *enc, const char *name, int32_t value);
+/* Which kernel family launch `index` (pvr_encoder_launch_name's indices) runs as in a forward of n frames, e.g. "bneck_frame(front1)", "conv_wfrag(pool)",
+ * "conv_pp256(dual)", "chain", "conv_split16", "conv" (the shape-dispatched implicit GEMMs).  The choice is tabulated per batch size when the encoder is
+ * finalized; returns the name's length, 0 past the end of the plan. */
+int32_t pvr_encoder_launch_kernel(const pvr_encoder *enc, int32_t n, int32_t index, char *buf, int32_t cap);
 void pvr_encoder_destroy(pvr_encoder *enc);
 
 /* ---------------------------------------------------------------------------------------------
@@ -212,6 +220,18 @@ pvr_status pvr_op_conv_wfrag_pool(const void *in_dev, const void *wgt_packed_dev
                                   int64_t pool_stride, int32_t n, int32_t cin, int32_t cout, int32_t dtype, void *hip_stream);
 /* launches of that kernel so far (tests: the layer4 plan really took it) */
 int64_t pvr_debug_conv_wfrag_launches(void);
+/* fp32 convolution on the 16-bit matrix pipe (conv_split16.hip): every fp32 operand as an exact (hi, lo) pair of f16 values, three MFMAs per fragment
+ * pair, fp32 accumulation: the last trunk stage and the compression head of the `*_l3` / `*_l4` PVRs' parity plan (reference src/vision_models/moco.py:29-113
+ * through src/embeddings.py:195-280), ~4e-7 relative per term against an fp32 dot product.  in / residual / out: fp32 NHWC, (n,h,w,cin) / (n,ho,wo,cout);
+ * wgt_split: pvr_op_split16_pack_weights of the fp32 (cout_pad, k*k*cin) matrix (K index = (kh*k+kw)*cin + c; cout_pad = cout rounded up to 64, zero rows),
+ * same byte size; cin % 32 == 0, cout % 16 == 0, k in 1..3; bias: cout_pad floats. */
+pvr_status pvr_op_split16_pack_weights(const float *w_dev, void *out_dev, int32_t rows, int32_t k, void *hip_stream);
+pvr_status pvr_op_conv2d_split16(const float *in_dev, const void *wgt_split_dev, const float *bias_dev, const float *residual_dev, float *out_dev, int32_t n,
+                                 int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t relu, void *hip_stream);
+/* the same convolution on the f32-input MFMA (conv_f32.hip, the PVR_F32 reference-precision mode's kernel): wgt fp32 (cout_pad, k*k*cin) */
+pvr_status pvr_op_conv2d_f32(const float *in_dev, const float *wgt_dev, const float *bias_dev, const float *residual_dev, float *out_dev, int32_t n,
+                             int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t relu, void *hip_stream);
+int64_t pvr_debug_conv_split16_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */

@@ -66,6 +66,12 @@ pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, 
                              int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream, float *pool_out = nullptr,
                              int64_t pool_stride = 0);
 
+long long conv_split16_launches();
+pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
+pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
+                               int cout, int k, int stride, int pad, int relu, hipStream_t stream);
+pvr_status launch_conv_f32(const float *, const float *, const float *, const float *, float *, int, int, int, int, int, int, int, int, int, hipStream_t);
+
 static void *g_zero = nullptr;
 static pvr_status zero_page(void **out) {
     if (!g_zero) {
@@ -130,6 +136,22 @@ pvr_status pvr_op_conv_wfrag_pool(const void *in, const void *wgt_packed, const 
     return launch_conv_wfrag(in, wgt_packed, bias, residual, nullptr, n, 7, 7, cin, cout, 1, 1, 1, 0, 1, 1, dtype, (hipStream_t)stream, pool_out, pool_stride);
 }
 int64_t pvr_debug_conv_wfrag_launches(void) { return (int64_t)conv_wfrag_launches(); }
+// fp32 convolution on the 16-bit matrix pipe (conv_split16.hip): weights packed once, fp32 NHWC activations in and out
+pvr_status pvr_op_split16_pack_weights(const float *w, void *out, int32_t rows, int32_t k, void *stream) {
+    return launch_split16_pack(w, out, rows, k, (hipStream_t)stream);
+}
+pvr_status pvr_op_conv2d_split16(const float *in, const void *wgt_split, const float *bias, const float *residual, float *out, int32_t n, int32_t h,
+                                 int32_t w, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t relu, void *stream) {
+    PVR_REQUIRE(n > 0 && h > 0 && w > 0, "pvr_op_conv2d_split16: empty input");
+    return launch_conv_split16(in, wgt_split, bias, residual, out, n, h, w, cin, cout, k, stride, pad, relu, (hipStream_t)stream);
+}
+// the same convolution on the f32-input MFMA (conv_f32.hip: the kernel of the PVR_F32 reference-precision mode), fp32 weights (cout_pad, k*k*cin)
+pvr_status pvr_op_conv2d_f32(const float *in, const float *wgt, const float *bias, const float *residual, float *out, int32_t n, int32_t h, int32_t w,
+                             int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t relu, void *stream) {
+    PVR_REQUIRE(in && wgt && bias && out && n > 0, "pvr_op_conv2d_f32: null argument");
+    return launch_conv_f32(in, wgt, bias, residual, out, n, h, w, cin, cout, k, stride, pad, relu, (hipStream_t)stream);
+}
+int64_t pvr_debug_conv_split16_launches(void) { return (int64_t)conv_split16_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {

@@ -583,7 +583,10 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
     BFP p;
     p.t1 = (const u16 *)t1; p.w2 = (const u16 *)w2p; p.w3 = (const u16 *)w3p; p.res = (const u16 *)res; p.b2 = b2; p.b3 = b3;
     p.y = (u16 *)y; p.t2_out = (u16 *)t2_out; p.n = n; p.phases = phases & ~8; p.stamps = stamps;
-    { const char *e = getenv("PVR_FRAME_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    p.stagger = 0;
+#ifdef PVR_EXPERIMENTS
+    { static const int stg = [] { const char *e = getenv("PVR_FRAME_STAGGER"); return e ? atoi(e) : 0; }(); p.stagger = stg; }   // (negative result of round 5; read once)
+#endif
     p.w1n = (const u16 *)w1np; p.b1n = b1n; p.t1n = (u16 *)t1n; p.w1f = (const u16 *)w1fp; p.b1f = b1f;
     p.t1_bytes = p.t2_bytes = p.t1n_bytes = (unsigned)((size_t)n * 196 * 256 * 2);
     p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = w3p ? 1024u * 256 * 2 : 0; p.w1n_bytes = w1np ? 256u * 1024 * 2 : 0; p.w1f_bytes = w1fp ? 256u * 1024 * 2 : 0;

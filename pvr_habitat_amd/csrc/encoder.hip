@@ -13,6 +13,38 @@
 
 namespace pvr {
 
+pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
+bool conv_split16_supported(int cin, int cout, int k);
+pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
+                               int cout, int k, int stride, int pad, int relu, hipStream_t stream);
+
+// every environment switch of the encoder plans, read ONCE per encoder in pvr_encoder_create (never on the forward path)
+static void read_switches(PlanSwitches &sw) {
+    auto get = [](const char *name, int def) { const char *v = getenv(name); return v ? atoi(v) : def; };
+    sw.pool_fuse = get("PVR_POOL_FUSE", 1);
+    sw.stem_u8 = get("PVR_STEM_U8", 1);
+    sw.stem_lds = get("PVR_STEM_LDS", 1);
+    sw.frame_front1 = get("PVR_FRAME_FRONT1", 1);
+    sw.frame_next1 = get("PVR_FRAME_NEXT1", 0);
+    sw.dual_ds = get("PVR_DUAL_DS", 1);
+    sw.chain_ds = get("PVR_CHAIN_DS", 1);
+    sw.chain_blocked = get("PVR_CHAIN_BLOCKED", 1);
+    sw.splitk = get("PVR_SPLITK", 1);
+    sw.smallk_div = get("PVR_SMALLK_DIV", 4);
+    if (sw.smallk_div < 1) sw.smallk_div = 1;
+    sw.frame_min_n = get("PVR_FRAME_MIN_N", 128);
+    sw.split16 = get("PVR_SPLIT16", 1);
+    sw.resid32 = get("PVR_RESID32", 1);
+    sw.tail_f32 = get("PVR_TAIL_F32", 1);
+    sw.fuse = get("PVR_FUSE", 1);
+}
+
+const char *launch_kind_name(int k) {
+    static const char *nm[] = {"conv", "bneck_frame(front1)", "bneck_frame", "frame_members", "conv_pp256(dual)", "dual_members", "chain", "cast",
+                               "conv_f32", "conv_split16", "splitk(small)", "splitk", "conv_expand(blocked)", "conv_wfrag(pool)", "conv_wfrag"};
+    return k >= 0 && k < (int)(sizeof nm / sizeof nm[0]) ? nm[k] : "?";
+}
+
 static void add_conv(pvr_encoder *e, const std::string &conv, const std::string &bn, int in_buf, int out_buf,
                      int res_buf, int h, int w, int cin, int cin_real, int cout, int cout_real, int k, int stride,
                      int relu, int out_f32 = 0) {
@@ -43,8 +75,7 @@ static void build_resnet50(pvr_encoder *e) {
     const int arch = e->desc.arch;
     const int stages = arch == PVR_ARCH_RESNET50_L3 ? 3 : 4;
     const int nblk[4] = {3, 4, 6, 3};
-    e->resid32 = e->desc.dtype == PVR_F16 && arch != PVR_ARCH_RESNET50;
-    if (const char *f = getenv("PVR_RESID32")) if (atoi(f) == 0) e->resid32 = false;
+    e->resid32 = e->desc.dtype == PVR_F16 && arch != PVR_ARCH_RESNET50 && e->sw.resid32 != 0;
     // Round 3: the fp32 residual stream alone left *_l3 at 9.75e-4 of a 1e-3 bound, and CPU emulation over three weight seeds
     // (scripts/emulate_l3_rounding.py) puts that plan at 8.6e-4 ... 1.01e-3: one seed from red.  What gives real margin is the LAST
     // trunk stage entirely in fp32 (fp32 weights, fp32 operands: conv_f32.hip, the kernels of the PVR_F32 mode) with the fp32
@@ -52,8 +83,7 @@ static void build_resnet50(pvr_encoder *e) {
     // at layer3, whatever the activations do).  That stage is 36 % (layer3) / 20 % (layer4) of the trunk's FLOPs at the f32-MFMA
     // rate: the parity mode of the compressed PVRs pays for its margin in throughput (DESIGN.md section 2 has the numbers);
     // PVR_TAIL_F32=0 restores round 2's plan, bf16 (the throughput mode) never uses either.
-    e->tail32 = e->resid32;
-    if (const char *f = getenv("PVR_TAIL_F32")) if (atoi(f) == 0) e->tail32 = false;
+    e->tail32 = e->resid32 && e->sw.tail_f32 != 0;
     const int r32_from = e->tail32 ? 1 : 2;             // fp32 residual stream from layer2 on (emulated: *_l3 5.6e-4 ... 6.4e-4, *_l4 6.3e-4 ... 6.7e-4)
     int hw = 56, inpl = 64, x = B_X0, x32 = B_NONE;
     for (int li = 0; li < stages; ++li) {
@@ -289,6 +319,13 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
                     for (int b = 0; b < k; ++b)
                         hf[co * K + ((size_t)a * k + b) * op.cin + ci] = w->data[(((size_t)co * cr + ci) * k + a) * k + b] * scale[co];
         if ((s = enc_upload(&op.d_wf, hf))) return s;
+        if (op.f32op && e->desc.dtype == PVR_F16 && e->sw.split16 && conv_split16_supported(op.cin, op.cout, op.k)) {
+            // the fp32 stage / head of the parity plan on the 16-bit matrix pipe: (hi, lo) f16 pairs of the same fp32 weights (conv_split16.hip)
+            PVR_HIP_TRY(hipMalloc((void **)&op.d_wsp, (size_t)cout_pad * K * 4));
+            if ((s = launch_split16_pack(op.d_wf, op.d_wsp, cout_pad, (int)K, nullptr))) return s;
+            PVR_HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(op.d_wf); op.d_wf = nullptr;
+        }
         return enc_upload(&op.d_b, hb);
     }
     if ((s = enc_upload(&op.d_w, hw))) return s;
@@ -307,8 +344,7 @@ static bool ends_with(const std::string &s, const char *suf) {
 // measured) get 8 K ranges and, as scratch for the fp32 partial planes, a 16-bit ping-pong buffer that is
 // dead at that point of the plan (not read by this or any later op before it is overwritten).  PVR_SPLITK=0 turns it off.
 static void plan_splitk(pvr_encoder *e) {
-    if (const char *f = getenv("PVR_SPLITK")) if (atoi(f) == 0) return;
-    if (e->desc.dtype == PVR_F32) return;
+    if (!e->sw.splitk || e->desc.dtype == PVR_F32) return;
     const int n = (int)e->ops.size();
     for (int i = 0; i < n; ++i) {
         ConvOp &op = e->ops[i];
@@ -356,8 +392,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
         // layer3's stride-1 bottlenecks as ONE launch per block: conv1 -> conv2 -> conv3 + identity of one 14 x 14 image per workgroup
         // (bneck_frame.hip with the block's own conv1 in front; PVR_FRAME_FRONT1=0: conv1 keeps its launch)
         {
-            const char *ff = getenv("PVR_FRAME_FRONT1"), *fn = getenv("PVR_FRAME_NEXT1");
-            const bool front_on = (!ff || atoi(ff) != 0) && !(fn && atoi(fn) != 0);
+            const bool front_on = e->sw.frame_front1 && !e->sw.frame_next1;
             if (front_on && ends_with(op.conv, ".conv1") && op.k == 1 && op.stride == 1 && op.relu == 1 && !op.f32op && !op.out_f32 && op.tap.empty() && i + 2 < n &&
                 op.cin_real == op.cin && op.cout_real == op.cout) {
                 const ConvOp &o2 = e->ops[i + 1], &o3 = e->ops[i + 2];
@@ -388,8 +423,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
             Launch l;
             l.conv2 = i; l.conv3 = i + 1; l.frame = 1; l.t1_in = conv1_frame_out >= 0 ? conv1_frame_out : op.in_buf;
             conv1_frame_out = -1;
-            const char *f1 = getenv("PVR_FRAME_NEXT1");         // (read when the plan is built)
-            const bool next1_on = f1 && atoi(f1) != 0;
+            const bool next1_on = e->sw.frame_next1 != 0;
             const int nx = i + 2;
             if (next1_on && nx + 2 < n && ends_with(e->ops[nx].conv, ".conv1") && e->ops[nx].k == 1 && e->ops[nx].stride == 1 && e->ops[nx].relu == 1 && !e->ops[nx].f32op &&
                 e->ops[nx].cin == e->ops[i + 1].cout && e->ops[nx].cout == op.cout && e->ops[nx].in_buf == e->ops[i + 1].out_buf && e->ops[nx].cout_real == e->ops[nx].cout &&
@@ -417,7 +451,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
             // A stride-2 bottleneck outside the chains (layer3.0, layer4.0): its 1 x 1 downsample and the conv3 that adds it run as ONE two-operand
             // launch (conv_pp256 DUAL: K = conv3's channels, then the block input's) - the identity branch is accumulated in fp32 and never exists in
             // HBM (- 2 x 103 MB at layer3.0, - 2 x 51 MB at layer4.0 per 256 frames, one launch less).  PVR_DUAL_DS=0: separate launches.
-            const bool dual_on = [] { const char *v = getenv("PVR_DUAL_DS"); return !v || atoi(v) != 0; }();      // (read when a plan is built: A/B switch)
+            const bool dual_on = e->sw.dual_ds != 0;
             if (dual_on && ends_with(op.conv, ".downsample.0") && op.kind == 0 && !op.f32op && op.k == 1 && op.pad == 0 && !op.relu && !op.out_f32 &&
                 op.res_buf == B_NONE && op.tap.empty() && op.cin_real == op.cin && op.cout_real == op.cout && op.cin % 64 == 0 && i + 1 < n) {
                 ConvOp &o3 = e->ops[i + 1];
@@ -460,8 +494,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
         l.conv2 = i; l.conv3 = c3; l.t1_in = cur_t1;
         const int nx = c3 + 1;
         // layer1's block 0: its 64-channel stride-1 downsample is accumulated inside the chain's conv3 (PVR_CHAIN_DS=0: own launch)
-        const char *ds_env = getenv("PVR_CHAIN_DS");
-        const bool ds_on = !ds_env || atoi(ds_env) != 0;
+        const bool ds_on = e->sw.chain_ds != 0;
         if (c3 == i + 2 && ds_on && nx < n) {
             const ConvOp &d = e->ops[i + 1];
             if (d.k == 1 && d.pad == 0 && !d.relu && !d.out_f32 && !d.f32op && d.cin_real == d.cin && d.cout == 4 * op.cout &&
@@ -526,8 +559,7 @@ static pvr_status build_schedules(pvr_encoder *e) {
         if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0 || A.frame || B.frame) continue;
         const ConvOp &a2 = e->ops[A.conv2], &a3 = e->ops[A.conv3], &b2 = e->ops[B.conv2], &b3 = e->ops[B.conv3];
         const int a_cmn = e->ops[A.next1].cout;
-        const char *env = getenv("PVR_CHAIN_BLOCKED");
-        if (env && atoi(env) == 0) continue;
+        if (!e->sw.chain_blocked) continue;
         if (B.t1_in != A.t1_out || b3.res_buf != a3.out_buf || !a3.tap.empty() || b2.h != a2.h / a2.stride || b2.w != a2.w / a2.stride || b2.stride != 1) continue;
         if (!A.wave && !B.wave) {
             // two block-form tails (layer2): y = the next residual travels blocked (16-byte accesses of a lane land in 512-byte runs);
@@ -621,6 +653,91 @@ static pvr_status finalize_attnpool(pvr_encoder *e) {
 
 }  // namespace pvr
 
+static bool pooled_head(const pvr_encoder *enc) {   // global average pool of the fp32 last activation (vs C-major flatten of the compression heads)
+    return enc->desc.arch == PVR_ARCH_RESNET50 || enc->desc.arch == PVR_ARCH_RESNET18 || enc->desc.arch == PVR_ARCH_RESNET34;
+}
+
+static void *bufp(pvr_encoder *enc, int id) { return id == B_STEM ? (void *)enc->d_stem : enc->d_buf[id]; }
+
+// Low-latency plan (pvr_encoder_set_low_latency; the online pattern of EmbeddingWrapper: N = 2 frames per environment step).
+// A forward of <= 4 frames has 1-7 pixel tiles in layer3 / layer4, so every deep convolution is a handful of blocks each
+// walking its whole K range alone: 21 such launches x 27 us were 65 % of a 0.88 ms N = 2 forward (rocprofv3,
+// profiles/r02_small_batch_kernel_stats.csv).  Here K is cut into ranges of ~4 slices over blockIdx.y (conv_igemm split-K: fp32
+// partial planes + a fixed-order reduce with bias / residual / ReLU).  The split depends on the layer's K only, so results do
+// not depend on N within the plan; against the unsplit plan they differ by fp32 regrouping (<= 1 ulp of the storage type), which
+// is why the plan is opt-in and batch-size independence of the default plan stays bit-exact.
+constexpr size_t SMALLK_BYTES = (size_t)32 << 20;
+static int small_batch_ksplit(const pvr_encoder *enc, const ConvOp &op, int nb) {
+    if (!enc->low_latency || nb > 4 || op.kind != 0 || op.f32op || op.ksplit > 1 || op.relu > 1 || (op.out_f32 & 2)) return 0;
+    const int K = op.k * op.k * op.cin, nk = K / 64;
+    if (nk < 8) return 0;                                        // K < 512: nothing to share
+    const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
+    const long long M = (long long)nb * ho * ho, blocks = ((M + 127) / 128) * ((op.cout + 127) / 128);
+    if (blocks > 64) return 0;
+    const int div = enc->sw.smallk_div;                          // K slices per block (PVR_SMALLK_DIV, read at create)
+    int ks = nk / div;
+    if (ks > (div >= 4 ? 16 : 32)) ks = div >= 4 ? 16 : 32;
+    if ((size_t)ks * M * op.cout * sizeof(float) > SMALLK_BYTES) return 0;
+    return ks;
+}
+
+// The low-latency plan's scratch, for every lane that has a workspace: allocated when the plan is switched on (pvr_encoder_set_low_latency), at
+// finalize when it was switched on before, and when a lane's workspace is first made - never inside a forward (no allocation on the
+// forward path after finalize).
+static pvr_status ensure_smallk(pvr_encoder *enc) {
+    if (!enc->low_latency || enc->vit || enc->rnd || enc->host) return PVR_OK;
+    for (int l = 0; l < PVR_MAX_LANES; ++l)
+        if (enc->lane_ws[l].valid && !enc->d_smallk[l]) PVR_HIP_TRY(hipMalloc((void **)&enc->d_smallk[l], SMALLK_BYTES));
+    return PVR_OK;
+}
+
+// Which kernel launch `li` of the plan runs as for a forward of nb frames (allow_pool = false: the caller's output rows cannot take the
+// pooled epilogue's 16-byte stores).  A pure function of the plan, the switches and nb: tabulated by resolve_kinds, off the hot path.
+static uint8_t resolve_kind(const pvr_encoder *enc, const std::vector<Launch> &plan, size_t li, int nb, bool allow_pool = true) {
+    const Launch &l = plan[li];
+    const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
+    const bool ll = enc->low_latency && nb <= 4;                 // (the low-latency plan covers forwards of <= 4 frames: small_batch_ksplit)
+    const bool autoalgo = conv_algo() == -1;
+    if (l.frame) {
+        // small batches (a frame per workgroup leaves most CUs idle): the member convolutions as their own launches - bit-identical
+        if (nb >= enc->sw.frame_min_n && !enc->low_latency) return l.conv1 >= 0 ? LK_FRAME_FRONT1 : LK_FRAME;
+        return LK_FRAME_MEMBERS;
+    }
+    if (l.conv3 < 0 && l.ds >= 0) return (!ll && autoalgo) ? LK_DUAL : LK_DUAL_MEMBERS;
+    if (l.conv3 >= 0) return LK_CHAIN;
+    if (op.kind == 2) return LK_CAST;
+    if (op.f32op) return op.d_wsp ? LK_SPLIT16 : LK_F32;
+    if (small_batch_ksplit(enc, op, nb)) return LK_SPLITK_SMALL;
+    if (op.ksplit > 1) return LK_SPLITK;
+    const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1, wo = (op.w + 2 * op.pad - op.k) / op.stride + 1;
+    if (l.out_blk && autoalgo && op.cin == 64 &&                 // (blocked output: the cin = 64 instances of conv_expand only)
+        conv_expand_supported((int64_t)nb * op.h * op.w, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, op.relu, 0, false))
+        return LK_EXPAND_BLOCKED;
+    if (allow_pool && enc->sw.pool_fuse && li + 1 == plan.size() && op.d_wfb && pooled_head(enc) && enc->final_hw == 49 && op.h == 7 && op.w == 7 && op.k == 1 &&
+        op.stride == 1 && op.relu == 1 && (op.out_f32 & 1) && !(op.out_f32 & 2) && op.res_buf != B_NONE && op.out_buf == B_F32 && enc->final_c == op.cout &&
+        autoalgo && !ll)
+        return LK_WFRAG_POOL;
+    if (op.d_wfb && autoalgo && !ll && conv_wfrag_preferred((int64_t)nb * ho * wo, op.cin, op.cout, op.k, op.k) &&
+        conv_wfrag_supported((int64_t)nb * ho * wo, (int64_t)nb * op.h * op.w * op.cin * 2, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32))
+        return LK_WFRAG;
+    return LK_CONV;
+}
+
+static const std::vector<Launch> &cur_plan(const pvr_encoder *enc) { return enc->fuse ? enc->sched_fused : enc->sched_plain; }
+
+// kinds[(nb - 1) * launches + i] for nb = 1 .. chunk: rebuilt whenever something it depends on changes (finalize, set_low_latency,
+// debug_set_fusion, debug_set_switch; pvr_debug_set_conv_algo is process-wide, so the forward compares kinds_algo first)
+static void resolve_kinds(pvr_encoder *enc) {
+    const std::vector<Launch> &plan = cur_plan(enc);
+    const int chunk = enc->desc.chunk;
+    enc->kinds_stride = plan.size();
+    enc->kinds.assign((size_t)chunk * plan.size(), LK_CONV);
+    if (enc->desc.dtype == PVR_F32 || enc->desc.arch == PVR_ARCH_CLIP_RN50 || enc->vit || enc->rnd || enc->host) { enc->kinds_algo = conv_algo(); return; }
+    for (int nb = 1; nb <= chunk; ++nb)
+        for (size_t i = 0; i < plan.size(); ++i) enc->kinds[(size_t)(nb - 1) * plan.size() + i] = resolve_kind(enc, plan, i, nb);
+    enc->kinds_algo = conv_algo();
+}
+
 // activation workspace of the current lane (ResNet50 family)
 static pvr_status alloc_workspace(pvr_encoder *enc) {
     const int C = enc->desc.chunk, crop = enc->desc.crop;
@@ -667,7 +784,7 @@ static pvr_status use_lane(pvr_encoder *enc, int lane) {
             return s;
         }
         save_lane(enc, lane);
-        return PVR_OK;
+        return ensure_smallk(enc);
     }
     const auto &l = enc->lane_ws[lane];
     enc->d_img = l.d_img; enc->d_stem = l.d_stem; enc->d_imgf = l.d_imgf;
@@ -688,6 +805,7 @@ pvr_status pvr_encoder_create(const pvr_encoder_desc *desc, pvr_encoder **out) {
     PVR_REQUIRE(desc->resize >= desc->crop, "resize must be >= crop");
     pvr_encoder *e = new pvr_encoder();
     e->desc = *desc;
+    read_switches(e->sw);
     if (e->desc.chunk <= 0 || e->desc.chunk > e->desc.max_batch) e->desc.chunk = e->desc.max_batch;
     if (e->desc.arch == PVR_ARCH_RANDOM5) {
         random5_create(e);
@@ -744,14 +862,15 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
         if (op.kind == 0 && (s = finalize_conv(enc, op))) return s;
     if ((s = build_schedules(enc))) return s;
     for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); op.h_b.clear(); op.h_b.shrink_to_fit(); }
-    if (const char *f = getenv("PVR_FUSE")) enc->fuse = atoi(f) != 0;
-    if (const char *f = getenv("PVR_FRAME_MIN_N")) enc->frame_min_n = atoi(f);
+    enc->fuse = enc->sw.fuse != 0;
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
     plan_splitk(enc);
     PVR_HIP_TRY(hipMalloc((void **)&enc->d_zero, PVR_ZERO_BYTES));      // zero page: padding rows, and the all-zero bias of split-K launches
     PVR_HIP_TRY(hipMemset(enc->d_zero, 0, PVR_ZERO_BYTES));
     save_lane(enc, 0);
+    if ((s = ensure_smallk(enc))) return s;
+    resolve_kinds(enc);
     // the memsets above run on the null stream; forwards run on the caller's stream (torch's current
     // stream need not be ordered against it), so drain the device once here, off the hot path
     PVR_HIP_TRY(hipDeviceSynchronize());
@@ -766,11 +885,6 @@ int32_t pvr_encoder_out_size(const pvr_encoder *enc) { return enc ? enc->out_siz
 
 // One chunk of the CLIP RN50 tower: Resize(224, bicubic, antialias) + CenterCrop -> stem image -> conv1 (stem kernel) -> plan
 // (convolutions and 2x2 average pools) -> attention pool (tokens, fused q/k/v GEMM, attention core, c_proj of token 0).
-static bool pooled_head(const pvr_encoder *enc) {   // global average pool of the fp32 last activation (vs C-major flatten of the compression heads)
-    return enc->desc.arch == PVR_ARCH_RESNET50 || enc->desc.arch == PVR_ARCH_RESNET18 || enc->desc.arch == PVR_ARCH_RESNET34;
-}
-
-static void *bufp(pvr_encoder *enc, int id) { return id == B_STEM ? (void *)enc->d_stem : enc->d_buf[id]; }
 
 static pvr_status clip_rn50_chunk(pvr_encoder *enc, const uint8_t *fr, int nb, int h, int w, float *out, int64_t out_stride, hipStream_t st) {
     const int dt = enc->desc.dtype, crop = enc->desc.crop;
@@ -799,28 +913,6 @@ static pvr_status clip_rn50_chunk(pvr_encoder *enc, const uint8_t *fr, int nb, i
     if ((s = launch_conv(enc->d_buf[B_T2], enc->ap_wc, enc->ap_bc, nullptr, dense, enc->d_zero, nb, T, 1, C, 1024, 1, 1, T, 0, 0, 1, dt, st))) return s;
     PVR_HIP_TRY(hipMemcpy2DAsync(out, (size_t)out_stride * 4, dense, 1024 * 4, 1024 * 4, nb, hipMemcpyDeviceToDevice, st));
     return PVR_OK;
-}
-
-// Low-latency plan (pvr_encoder_set_low_latency; the online pattern of EmbeddingWrapper: N = 2 frames per environment step).
-// A forward of <= 4 frames has 1-7 pixel tiles in layer3 / layer4, so every deep convolution is a handful of blocks each
-// walking its whole K range alone: 21 such launches x 27 us were 65 % of a 0.88 ms N = 2 forward (rocprofv3,
-// profiles/r02_small_batch_kernel_stats.csv).  Here K is cut into ranges of ~4 slices over blockIdx.y (conv_igemm split-K: fp32
-// partial planes + a fixed-order reduce with bias / residual / ReLU).  The split depends on the layer's K only, so results do
-// not depend on N within the plan; against the unsplit plan they differ by fp32 regrouping (<= 1 ulp of the storage type), which
-// is why the plan is opt-in and batch-size independence of the default plan stays bit-exact.
-constexpr size_t SMALLK_BYTES = (size_t)32 << 20;
-static int small_batch_ksplit(const pvr_encoder *enc, const ConvOp &op, int nb) {
-    if (!enc->low_latency || nb > 4 || op.kind != 0 || op.f32op || op.ksplit > 1 || op.relu > 1 || (op.out_f32 & 2)) return 0;
-    const int K = op.k * op.k * op.cin, nk = K / 64;
-    if (nk < 8) return 0;                                        // K < 512: nothing to share
-    const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
-    const long long M = (long long)nb * ho * ho, blocks = ((M + 127) / 128) * ((op.cout + 127) / 128);
-    if (blocks > 64) return 0;
-    static const int div = [] { const char *e = getenv("PVR_SMALLK_DIV"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();   // K slices per block (A/B)
-    int ks = nk / div;
-    if (ks > (div >= 4 ? 16 : 32)) ks = div >= 4 ? 16 : 32;
-    if ((size_t)ks * M * op.cout * sizeof(float) > SMALLK_BYTES) return 0;
-    return ks;
 }
 
 // ev != nullptr: record one event before the first launch and one after every launch of the FIRST chunk
@@ -886,7 +978,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         // frames that need no resize (the bench configuration: 256 x 256 frames, Resize(256) is the identity): the fused stem reads the
         // uint8 frames itself - no preprocess launch, no padded 16-bit image in HBM
         int fused_u8 = 0;
-        if (enc->stop_after.empty() && enc->desc.crop == 224 && enc->crop_pos >= 0 && enc->crop_pos <= 4) {
+        if (enc->sw.stem_u8 && enc->sw.stem_lds && enc->stop_after.empty() && enc->desc.crop == 224 && enc->crop_pos >= 0 && enc->crop_pos <= 4) {
             int rn = 1, top = 0, left = 0;
             preprocess_geometry(h, w, enc->desc.resize, enc->desc.crop, enc->crop_pos, &rn, &top, &left);
             if (!rn && stem_pool_u8_ok(fr, h, w, top, left)) {
@@ -912,60 +1004,69 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false, t1_blocked = false;   // t1_blocked: the conv1 launch in front of layer1's first tail wrote t1 in the blocked layout
         bool pooled = false;                         // the plan's last convolution wrote the average pool itself (conv_wfrag's pooled form)
-        const std::vector<Launch> &plan_ = enc->fuse ? enc->sched_fused : enc->sched_plain;
-        const bool pool_fuse = [] { const char *v = getenv("PVR_POOL_FUSE"); return !v || atoi(v) != 0; }();   // (A/B switch, read per forward)
+        const std::vector<Launch> &plan_ = cur_plan(enc);
+        if (enc->kinds_algo != conv_algo() || enc->kinds_stride != plan_.size()) resolve_kinds(enc);   // (pvr_debug_set_conv_algo is process-wide; same size: no allocation)
+        const uint8_t *kinds = enc->kinds.data() + (size_t)(nb - 1) * plan_.size();
+        float *smallk = enc->d_smallk[enc->cur_lane];
+        // the pooled epilogue stores 16-byte pieces of the caller's rows: a property of this call's arguments, not of the plan
+        const bool pool_args_ok = enc->stop_after.empty() && out_stride % 4 == 0 && (((size_t)(out + (size_t)f0 * out_stride)) & 15) == 0;
         int launch_idx = 0;                          // debug: stop_after = "#k" ends the forward after conv launch k of the plan
         const int stop_idx = enc->stop_after.size() > 1 && enc->stop_after[0] == '#' ? atoi(enc->stop_after.c_str() + 1) : -1;
-        for (const Launch &l : plan_) {
+        // a member convolution of a launch that runs as its members (small forwards): split-K in the low-latency plan, else the shape's kernel
+        auto member = [&](const ConvOp &o, const void *in, const void *r_, void *out_) -> pvr_status {
+            if (const int ks = small_batch_ksplit(enc, o, nb)) {
+                if (!smallk) { set_error("low-latency plan without its scratch (pvr_encoder_set_low_latency allocates it)"); return PVR_ERR_STATE; }
+                return launch_conv_splitk(in, o.d_w, o.d_b, r_, out_, enc->d_zero, smallk, ks, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+            }
+            return launch_conv(in, o.d_w, o.d_b, r_, out_, enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
+        };
+        for (size_t li = 0; li < plan_.size(); ++li) {
+            const Launch &l = plan_[li];
             const ConvOp &op = enc->ops[l.conv3 >= 0 ? l.conv3 : l.conv2];
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
-            if (l.frame) {
+            int kind = kinds[li];
+            if (kind == LK_WFRAG_POOL && !pool_args_ok) kind = resolve_kind(enc, plan_, li, nb, false);
+            switch (kind) {
+            case LK_FRAME_FRONT1: {
+                const ConvOp &c2 = enc->ops[l.conv2], &cf = enc->ops[l.conv1];
+                s = launch_bneck_frame(nullptr, c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, 3 | 8, dt, st,
+                                       nullptr, nullptr, nullptr, nullptr, cf.d_wfb, cf.d_b);
+                break;
+            }
+            case LK_FRAME: {
+                const ConvOp &c2 = enc->ops[l.conv2];
+                const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
+                s = launch_bneck_frame(enc->d_buf[l.t1_in], c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, c1 ? 7 : 3, dt, st,
+                                       nullptr, c1 ? c1->d_wfb : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr);
+                break;
+            }
+            case LK_FRAME_MEMBERS: {
+                // t2 goes to the t1 buffer this launch does not read
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
                 const ConvOp *cf = l.conv1 >= 0 ? &enc->ops[l.conv1] : nullptr;
-                if (nb >= enc->frame_min_n && !enc->low_latency && cf) {
-                    s = launch_bneck_frame(nullptr, c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, 3 | 8, dt, st,
-                                           nullptr, nullptr, nullptr, nullptr, cf->d_wfb, cf->d_b);
-                } else if (nb >= enc->frame_min_n && !enc->low_latency) {
-                    s = launch_bneck_frame(enc->d_buf[l.t1_in], c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, c1 ? 7 : 3, dt, st,
-                                           nullptr, c1 ? c1->d_wfb : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr);
-                } else {
-                    // small batches (a frame per workgroup leaves most CUs idle): the member convolutions as their own launches - bit-identical.
-                    // t2 goes to the t1 buffer this launch does not read.
-                    const int t2b = l.t1_in == B_T1 ? B_T2 : B_T1;
-                    s = PVR_OK;
-                    auto one = [&](const ConvOp &o, const void *in, const void *r_, void *out) {
-                        const int ks = small_batch_ksplit(enc, o, nb);
-                        if (ks) {
-                            if (!enc->d_smallk[enc->cur_lane] && hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES) != hipSuccess) { set_error("hipMalloc failed (split-K scratch)"); return (pvr_status)PVR_ERR_HIP; }
-                            return launch_conv_splitk(in, o.d_w, o.d_b, r_, out, enc->d_zero, enc->d_smallk[enc->cur_lane], ks, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
-                        }
-                        return launch_conv(in, o.d_w, o.d_b, r_, out, enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
-                    };
-                    if (cf) s = one(*cf, enc->d_buf[cf->in_buf], nullptr, enc->d_buf[l.t1_in]);
-                    if (!s) s = one(c2, enc->d_buf[l.t1_in], nullptr, enc->d_buf[t2b]);
-                    if (!s) s = one(op, enc->d_buf[t2b], res, enc->d_buf[op.out_buf]);
-                    if (!s && c1) s = one(*c1, enc->d_buf[op.out_buf], nullptr, enc->d_buf[l.t1_out]);
-                }
-            } else if (l.conv3 < 0 && l.ds >= 0) {
-                // conv3 & downsample as one two-operand launch (layer3.0 / layer4.0); the low-latency plan keeps the two launches (its split-K forms)
+                const int t2b = l.t1_in == B_T1 ? B_T2 : B_T1;
+                s = PVR_OK;
+                if (cf) s = member(*cf, enc->d_buf[cf->in_buf], nullptr, enc->d_buf[l.t1_in]);
+                if (!s) s = member(c2, enc->d_buf[l.t1_in], nullptr, enc->d_buf[t2b]);
+                if (!s) s = member(op, enc->d_buf[t2b], res, enc->d_buf[op.out_buf]);
+                if (!s && c1) s = member(*c1, enc->d_buf[op.out_buf], nullptr, enc->d_buf[l.t1_out]);
+                break;
+            }
+            case LK_DUAL: {
+                // conv3 & downsample as one two-operand launch (layer3.0 / layer4.0)
                 const ConvOp &cd = enc->ops[l.ds];
-                if (!(enc->low_latency && nb <= 4) && conv_algo() == -1) {          // (the low-latency plan covers forwards of <= 4 frames: small_batch_ksplit)
-                    s = launch_conv_pp256(enc->d_buf[op.in_buf], op.d_wcat, op.d_bsum, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0,
-                                          op.relu, 0, 0, dt, 224, st, enc->d_buf[cd.in_buf], cd.h, cd.w, cd.cin, cd.stride);
-                } else {
-                    auto one = [&](const ConvOp &o, const void *r_) {
-                        const int ks = small_batch_ksplit(enc, o, nb);
-                        if (ks) {
-                            if (!enc->d_smallk[enc->cur_lane] && hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES) != hipSuccess) { set_error("hipMalloc failed (split-K scratch)"); return (pvr_status)PVR_ERR_HIP; }
-                            return launch_conv_splitk(enc->d_buf[o.in_buf], o.d_w, o.d_b, r_, enc->d_buf[o.out_buf], enc->d_zero, enc->d_smallk[enc->cur_lane], ks, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
-                        }
-                        return launch_conv(enc->d_buf[o.in_buf], o.d_w, o.d_b, r_, enc->d_buf[o.out_buf], enc->d_zero, nb, o.h, o.w, o.cin, o.cout, o.k, o.k, o.stride, o.pad, o.relu, o.out_f32, dt, st);
-                    };
-                    s = one(cd, nullptr);
-                    if (!s) s = one(op, res);
-                }
-            } else if (l.conv3 >= 0) {
+                s = launch_conv_pp256(enc->d_buf[op.in_buf], op.d_wcat, op.d_bsum, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0,
+                                      op.relu, 0, 0, dt, 224, st, enc->d_buf[cd.in_buf], cd.h, cd.w, cd.cin, cd.stride);
+                break;
+            }
+            case LK_DUAL_MEMBERS: {
+                const ConvOp &cd = enc->ops[l.ds];
+                s = member(cd, enc->d_buf[cd.in_buf], nullptr, enc->d_buf[cd.out_buf]);
+                if (!s) s = member(op, enc->d_buf[op.in_buf], res, enc->d_buf[op.out_buf]);
+                break;
+            }
+            case LK_CHAIN: {
                 const ConvOp &c2 = enc->ops[l.conv2];
                 const ConvOp *c1 = l.next1 >= 0 ? &enc->ops[l.next1] : nullptr;
                 const ConvOp *cd = l.ds >= 0 ? &enc->ops[l.ds] : nullptr;
@@ -975,40 +1076,44 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                             cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr, op.d_wpb, cd ? cd->d_wpb : nullptr,
                                             l.wave, cd ? (l.in_blk && t1_blocked) : l.in_blk, l.out_blk);
                 t1_blocked = false;
-            } else if (op.kind == 2) {
+                break;
+            }
+            case LK_CAST:
                 s = launch_f32_to_h((const float *)enc->d_buf[op.in_buf], enc->d_buf[op.out_buf], (size_t)nb * op.h * op.w * op.cin, dt, st);
-            } else if (op.f32op) {
+                break;
+            case LK_F32:
                 s = launch_conv_f32((const float *)enc->d_buf[op.in_buf], op.d_wf, op.d_b, (const float *)res, (float *)enc->d_buf[op.out_buf], nb,
                                     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st);
-            } else if (int ks = small_batch_ksplit(enc, op, nb)) {
+                break;
+            case LK_SPLIT16:
+                s = launch_conv_split16((const float *)enc->d_buf[op.in_buf], op.d_wsp, op.d_b, (const float *)res, (float *)enc->d_buf[op.out_buf], nb,
+                                        op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st);
+                break;
+            case LK_SPLITK_SMALL:
                 // low-latency plan: the few pixel tiles of a <= 4-frame forward share each K loop between `ks` blocks
-                if (!enc->d_smallk[enc->cur_lane]) PVR_HIP_TRY(hipMalloc((void **)&enc->d_smallk[enc->cur_lane], SMALLK_BYTES));
-                s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, enc->d_smallk[enc->cur_lane],
-                                       ks, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
-            } else if (op.ksplit > 1) {
+                s = member(op, enc->d_buf[op.in_buf], res, enc->d_buf[op.out_buf]);
+                break;
+            case LK_SPLITK:
                 s = launch_conv_splitk(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, (float *)enc->d_buf[op.ks_buf],
                                        op.ksplit, nb, op.h, op.w, op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
-            } else if (l.out_blk && conv_algo() == -1 && op.cin == 64 &&    // (blocked output: the cin = 64 instances of conv_expand only)
-                       conv_expand_supported((int64_t)nb * op.h * op.w, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, op.relu, 0, false)) {
+                break;
+            case LK_EXPAND_BLOCKED:
                 // layer1.0.conv1 in front of a wave-form tail: t1 in the blocked layout
                 s = launch_conv_expand(enc->d_buf[op.in_buf], op.d_w, op.d_b, nullptr, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, 1, op.relu, dt, st, 1);
                 t1_blocked = true;
-            } else if (pool_fuse && &l == &plan_.back() && op.d_wfb && pooled_head(enc) && enc->final_hw == 49 && op.h == 7 && op.w == 7 && op.k == 1 &&
-                       op.stride == 1 && op.relu == 1 && (op.out_f32 & 1) && !(op.out_f32 & 2) && res && op.out_buf == B_F32 && enc->final_c == op.cout &&
-                       conv_algo() == -1 && !(enc->low_latency && nb <= 4) && enc->stop_after.empty() && out_stride % 4 == 0 &&
-                       (((size_t)(out + (size_t)f0 * out_stride)) & 15) == 0) {
+                break;
+            case LK_WFRAG_POOL:
                 // the trunk's last conv3 + identity + ReLU with AdaptiveAvgPool2d(1) in its epilogue: the (n,7,7,2048) fp32 activation is never written
                 s = launch_conv_wfrag(enc->d_buf[op.in_buf], op.d_wfb, op.d_b, res, nullptr, nb, op.h, op.w, op.cin, op.cout, 1, 1, 1, 0, 1, 1, dt, st,
                                       out + (size_t)f0 * out_stride, out_stride);
                 pooled = true;
-            } else if (op.d_wfb && !l.frame && conv_algo() == -1 && !(enc->low_latency && nb <= 4) &&
-                       conv_wfrag_preferred((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1), op.cin, op.cout, op.k, op.k) &&
-                       conv_wfrag_supported((int64_t)nb * ((op.h + 2 * op.pad - op.k) / op.stride + 1) * ((op.w + 2 * op.pad - op.k) / op.stride + 1),
-                                            (int64_t)nb * op.h * op.w * op.cin * 2, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
+                break;
+            case LK_WFRAG:
                 // few pixels, deep K (layer4 at batch 256): 112 x 256 tiles, weights as L2 fragments
                 s = launch_conv_wfrag(enc->d_buf[op.in_buf], op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin, op.cout, op.k, op.k,
                                       op.stride, op.pad, op.relu, op.out_f32, dt, st);
-            } else {
+                break;
+            default:
                 s = launch_conv(enc->d_buf[op.in_buf], op.d_w, op.d_b, res, enc->d_buf[op.out_buf], enc->d_zero, nb, op.h, op.w,
                                 op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
             }
@@ -1017,6 +1122,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             if (!enc->stop_after.empty() && op.tap == enc->stop_after) { stopped = true; break; }
             if (launch_idx++ == stop_idx) { stopped = true; break; }
         }
+        enc->last_pooled = pooled;
         if (stopped) return PVR_OK;
         float *o = out + (size_t)f0 * out_stride;
         if (pooled)
@@ -1165,13 +1271,43 @@ pvr_status pvr_encoder_set_crop_position(pvr_encoder *enc, int32_t pos) {
 pvr_status pvr_encoder_set_low_latency(pvr_encoder *enc, int32_t on) {
     PVR_REQUIRE(enc, "null encoder");
     enc->low_latency = on != 0;
+    if (!enc->finalized || enc->vit || enc->rnd || enc->host) return PVR_OK;      // (finalize allocates / resolves when the plan was asked for earlier)
+    pvr_status s = ensure_smallk(enc);                          // the plan's split-K scratch, here and not in a forward
+    if (s) return s;
+    resolve_kinds(enc);
     return PVR_OK;
 }
 
 pvr_status pvr_encoder_debug_set_fusion(pvr_encoder *enc, int32_t on) {
     PVR_REQUIRE(enc, "null encoder");
     enc->fuse = on != 0;
+    if (enc->finalized && !enc->vit && !enc->rnd && !enc->host) resolve_kinds(enc);
     return PVR_OK;
+}
+
+// The switches of a finalized encoder that do not shape its plan (PlanSwitches, "live"): pool_fuse, stem_u8, frame_min_n.  The A/B tests flip them
+// between two forwards of ONE handle; everything else is fixed by the environment at pvr_encoder_create.
+pvr_status pvr_encoder_debug_set_switch(pvr_encoder *enc, const char *name, int32_t value) {
+    PVR_REQUIRE(enc && name, "pvr_encoder_debug_set_switch: null argument");
+    const std::string nm = name;
+    if (nm == "pool_fuse") enc->sw.pool_fuse = value;
+    else if (nm == "stem_u8") enc->sw.stem_u8 = value;
+    else if (nm == "frame_min_n") enc->sw.frame_min_n = value;
+    else { set_error("pvr_encoder_debug_set_switch: '%s' is not a live switch (pool_fuse, stem_u8, frame_min_n); plan switches are read from the environment at create", name); return PVR_ERR_INVALID; }
+    if (enc->finalized && !enc->vit && !enc->rnd && !enc->host) resolve_kinds(enc);
+    return PVR_OK;
+}
+
+// name of the kernel family launch `index` (the order pvr_encoder_profile reports) runs as in a forward of n frames; returns its length, 0 past the end
+int32_t pvr_encoder_launch_kernel(const pvr_encoder *enc, int32_t n, int32_t index, char *buf, int32_t cap) {
+    if (!enc || !buf || cap <= 0 || index < 3 || !enc->finalized || enc->vit || enc->rnd || enc->host || n < 1) return 0;
+    const std::vector<Launch> &plan = cur_plan(enc);
+    const int i = index - 3;
+    if (i >= (int)plan.size()) return 0;
+    const int nb = n < enc->desc.chunk ? n : enc->desc.chunk;
+    const char *nm = enc->desc.dtype == PVR_F32 ? "conv_f32" : launch_kind_name(resolve_kind(enc, plan, (size_t)i, nb));
+    snprintf(buf, (size_t)cap, "%s", nm);
+    return (int32_t)strlen(nm);
 }
 
 // name of launch `index` of the current plan (the order pvr_encoder_profile reports); returns the name's length, 0 past the end
@@ -1223,8 +1359,14 @@ pvr_status pvr_encoder_tap(pvr_encoder *enc, const char *name, float *out, int64
     } else {
         auto it = enc->taps.find(nm);
         PVR_REQUIRE(it != enc->taps.end(), "unknown tap %s", name);
-        // taps alias ping-pong buffers: only the LAST layer's tap is guaranteed intact after a full forward
+        // taps alias ping-pong buffers: only the LAST layer's tap is guaranteed intact after a full forward - and not even that one when
+        // the forward pooled inside its last convolution (conv_wfrag's pooled form: the (n,7,7,2048) activation was never written)
         const auto &g = it->second.second;
+        if (it->second.first == B_F32 && enc->last_pooled) {
+            set_error("tap %s: the last forward averaged inside its last convolution and never wrote this activation; run the forward with "
+                      "pvr_encoder_debug_stop_after(enc, \"%s\") or pvr_encoder_debug_set_switch(enc, \"pool_fuse\", 0) first", name, name);
+            return PVR_ERR_STATE;
+        }
         src = enc->d_buf[it->second.first];
         elems = (size_t)n * g[0] * g[1] * g[2];
         f32 = g[3];
@@ -1244,7 +1386,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

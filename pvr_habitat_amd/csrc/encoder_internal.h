@@ -13,7 +13,7 @@ pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, i
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
 pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
-bool stem_pool_u8_ok(const void *, int, int, int, int);
+bool stem_pool_u8_ok(const void *, int, int, int, int);   // geometry only; the PVR_STEM_U8 / PVR_STEM_LDS switches live in PlanSwitches
 pvr_status launch_stem_pool_u8(const uint8_t *, int, int, int, int, int, const void *, const float *, void *, int, hipStream_t);
 void preprocess_geometry(int h, int w, int resize, int crop, int crop_pos, int *resize_needed, int *top, int *left);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
@@ -73,6 +73,7 @@ struct ConvOp {
     u16 *d_wpb = nullptr;          // ... and that copy in the blocked layout [row >> 4][cin >> 3][row & 15][8] (chain_wave.hip reads W3 / Wd pieces from L2)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
+    u16 *d_wsp = nullptr;          // fp32 weights as (hi, lo) f16 fragment pairs (conv_split16.hip: the f32op convolutions of an f16 plan)
     float *d_b = nullptr;
     std::vector<float> h_b;        // host copy of the bias (same lifetime as h_w)
     float *d_bsum = nullptr;       // conv3 of a block whose downsample runs inside the chain / the two-operand launch: b3 + b_downsample
@@ -94,6 +95,47 @@ struct Launch {
     int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip)
 };
 
+// What one launch of the plan runs as for a forward of nb frames: resolved off the hot path (resolve_kinds: finalize, set_low_latency,
+// debug_set_fusion, debug_set_switch), one byte per (nb, launch); the forward is a switch over these.
+enum LaunchKind : uint8_t {
+    LK_CONV = 0,          // launch_conv (conv_igemm.hip picks igemm / pp256 / expand / halo by shape)
+    LK_FRAME_FRONT1,      // bneck_frame: conv1 -> conv2 -> conv3 + identity of one 14 x 14 image per workgroup
+    LK_FRAME,             // bneck_frame: conv2 -> conv3 + identity [-> next conv1]
+    LK_FRAME_MEMBERS,     // the member convolutions of a per-frame launch as their own launches (small forwards)
+    LK_DUAL,              // conv_pp256 two-operand launch: conv3 & the stride-2 downsample
+    LK_DUAL_MEMBERS,      // ... as two launches (low-latency plan, PVR_CONV_ALGO)
+    LK_CHAIN,             // bottleneck_chain / chain_wave: conv2 -> conv3 (+ residual / downsample) -> next conv1
+    LK_CAST,              // fp32 -> 16-bit copy
+    LK_F32,               // conv_f32: fp32 operands on the f32-input MFMA
+    LK_SPLIT16,           // conv_split16: fp32 operands as 16-bit (hi, lo) pairs on the 16-bit MFMA
+    LK_SPLITK_SMALL,      // low-latency plan: split-K over the lane's scratch
+    LK_SPLITK,            // planned split-K (the *_l4 compression head)
+    LK_EXPAND_BLOCKED,    // conv_expand writing the blocked layout in front of a wave-form tail
+    LK_WFRAG_POOL,        // conv_wfrag with AdaptiveAvgPool2d(1) in the epilogue
+    LK_WFRAG,             // conv_wfrag
+};
+const char *launch_kind_name(int k);
+
+// A/B switches of the plan, read from the environment ONCE per encoder (pvr_encoder_create) - never on the forward path.  The ones marked
+// (live) can be changed on a finalized encoder with pvr_encoder_debug_set_switch; the others shape the plan and are fixed at finalize.
+struct PlanSwitches {
+    int pool_fuse = 1;        // PVR_POOL_FUSE (live): the pooled form of conv_wfrag for the trunk's last launch
+    int stem_u8 = 1;          // PVR_STEM_U8 (live): the fused stem reads uint8 frames itself when no resize is needed
+    int stem_lds = 1;         // PVR_STEM_LDS
+    int frame_front1 = 1;     // PVR_FRAME_FRONT1: layer3's per-frame launches carry their own conv1
+    int frame_next1 = 0;      // PVR_FRAME_NEXT1: ... carry the NEXT block's conv1 instead (measured slower)
+    int dual_ds = 1;          // PVR_DUAL_DS: conv3 & downsample of layer3.0 / layer4.0 as one two-operand launch
+    int chain_ds = 1;         // PVR_CHAIN_DS: layer1.0's downsample inside the chain
+    int chain_blocked = 1;    // PVR_CHAIN_BLOCKED: blocked hand-off between consecutive tails
+    int splitk = 1;           // PVR_SPLITK: planned split-K of the *_l4 head
+    int smallk_div = 4;       // PVR_SMALLK_DIV: K slices per block of the low-latency plan
+    int frame_min_n = 128;    // PVR_FRAME_MIN_N (live): frames per forward from which layer3's per-frame launches run as such
+    int split16 = 1;          // PVR_SPLIT16: the fp32 stage / head of the compressed PVRs' parity plan on the 16-bit MFMA (0: f32-input MFMA)
+    int resid32 = 1;          // PVR_RESID32: fp32 residual stream of that plan (0: all-16-bit plan)
+    int tail_f32 = 1;         // PVR_TAIL_F32: its last trunk stage entirely in fp32
+    int fuse = 1;             // PVR_FUSE: the fused schedule (0: one launch per convolution; also pvr_encoder_debug_set_fusion)
+};
+
 }  // namespace pvr
 
 using namespace pvr;
@@ -107,8 +149,12 @@ struct pvr_encoder {
     std::vector<Launch> sched_plain, sched_fused;   // one launch per op / with the layer1-layer2 bottleneck tails fused
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
     bool low_latency = false;                       // pvr_encoder_set_low_latency: split-K plan for forwards of <= 4 frames
-    int frame_min_n = 128;                          // frames per forward from which layer3's per-frame tails run as such (PVR_FRAME_MIN_N; smaller forwards: the member convolutions)
-    float *d_smallk[PVR_MAX_LANES] = {nullptr};     // its fp32 partial planes, per lane (allocated on first use)
+    PlanSwitches sw;                                // environment switches, read once in pvr_encoder_create
+    std::vector<uint8_t> kinds;                     // LaunchKind of launch i for a forward of nb frames: kinds[(nb - 1) * plan.size() + i] (resolve_kinds)
+    size_t kinds_stride = 0;
+    int kinds_algo = -2;                            // conv_algo() the table was resolved under
+    bool last_pooled = false;                       // the last forward wrote the pooled rows from the last convolution: the B_F32 tap does not exist
+    float *d_smallk[PVR_MAX_LANES] = {nullptr};     // the low-latency plan's fp32 partial planes, per lane (pvr_encoder_set_low_latency / first use of a lane: never in a forward)
     bool tail32 = false;                            // round 3: + the last trunk stage entirely in fp32 (conv_f32.hip), fp32 stream one stage earlier
     bool resid32 = false;                           // compressed PVRs, f16: fp32 residual stream from layer3 on + fp32 compression head
     bool finalized = false;

@@ -513,12 +513,10 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
 }
 
 // Fused form for frames that need no resize: uint8 NHWC frames [n][h][w][3] in, pooled stem output out; (top, left) = crop origin.
-// stem_pool_u8_ok: the geometry fits the kernel's 16-byte row DMA (and PVR_STEM_U8 / PVR_STEM_LDS are not 0).
+// stem_pool_u8_ok: the geometry fits the kernel's 16-byte row DMA (the PVR_STEM_U8 / PVR_STEM_LDS switches are the encoder's: PlanSwitches).
 bool stem_pool_u8_ok(const void *frames, int h, int w, int top, int left) {
-    const char *e = getenv("PVR_STEM_U8"), *l = getenv("PVR_STEM_LDS");          // (read per call: the A/B test flips it inside one process)
-    const bool enabled = (!e || atoi(e) != 0) && (!l || atoi(l) != 0);
     // 16-byte row DMA: every source chunk aligned; the crop window inside the frame (an out-of-frame window would read wrong rows, not fail)
-    return enabled && ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&
+    return ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&
            top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w && (long long)h * w * 3 < 0x7ffffff0ll;
 }
 pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int top, int left, const void *wgt, const float *bias, void *out,

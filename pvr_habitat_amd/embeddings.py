@@ -289,6 +289,24 @@ class HipResNet50(_Node):
             i += 1
         return [n for n in names if n != 'pool/flatten']
 
+    def kernel_names(self, n=None):
+        """the kernel family each conv launch of the plan runs as in a forward of n frames (default: max_batch), in launch order:
+        'bneck_frame(front1)', 'conv_wfrag(pool)', 'conv_pp256(dual)', 'chain', 'conv_split16', 'conv' ... (pvr_encoder_launch_kernel)"""
+        if self._handle is None:
+            self._build()
+        names, buf, i = [], C.create_string_buffer(64), 3
+        while _lib.lib().pvr_encoder_launch_kernel(self._handle, int(n or self._max_batch), i, buf, 64) > 0:
+            names.append(buf.value.decode())
+            i += 1
+        return names
+
+    def set_switch(self, name, value):
+        """run-time A/B switches of the built plan: 'pool_fuse', 'stem_u8', 'frame_min_n' (pvr_encoder_debug_set_switch); every other PVR_*
+        switch is read from the environment when the handle is created"""
+        if self._handle is None:
+            self._build()
+        _lib.check(_lib.lib().pvr_encoder_debug_set_switch(self._handle, name.encode(), int(value)))
+
     def set_crop(self, pos):
         """0 = centre crop (reference), 1..4 = tl / tr / bl / br corner windows (pvr_encoder_set_crop_position)"""
         if self._handle is None:

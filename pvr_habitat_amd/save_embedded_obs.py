@@ -375,23 +375,43 @@ def stitch_shards(save_name, world, keys, copy_bytes=256 << 20):
 
 def _weights_fingerprint(model):
     """identity of the embedding's weights for the shard-resume check: a shard left by a run with other weights must not be reused.  EVERY
-    tensor of the state_dict is hashed in full (name, shape, bytes): a checkpoint that differs only in its last layers - a fine-tuned
-    layer4, another compression head - must get another fingerprint.  ~100 MB of sha1 for a ResNet50, a fraction of a second next to the
-    embedding pass it guards."""
+    tensor is hashed in full (name, shape, dtype, bytes): a checkpoint that differs only in its last layers - a fine-tuned layer4, another
+    compression head - must get another fingerprint.  state_dict() alone does not see every weight: UberModel keeps its members in a plain
+    list (as the reference does, src/embeddings.py:44-57), FiveCrop wraps its model the same way - so those containers are walked
+    explicitly (`models` / `model`), member by member, under an index prefix.  numpy values are hashed by their bytes too.  ~100 MB of sha1
+    for a ResNet50, a fraction of a second next to the embedding pass it guards."""
     import hashlib
     h = hashlib.sha1()
-    try:
-        sd = model.state_dict()
-    except Exception:
-        return None
-    for k in sorted(sd):
-        v = sd[k]
-        h.update(k.encode())
-        if hasattr(v, 'detach'):
-            t = v.detach().cpu().contiguous()
-            h.update(str(tuple(t.shape)).encode() + str(t.dtype).encode())
-            h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b'')
-    return h.hexdigest()[:16]
+
+    def feed(prefix, mod, depth=0):
+        try:
+            sd = mod.state_dict()
+        except Exception:
+            return False
+        for k in sorted(sd):
+            v = sd[k]
+            h.update((prefix + k).encode())
+            if hasattr(v, 'detach'):
+                v = v.detach().cpu().contiguous().numpy() if v.numel() else np.zeros(0, np.uint8)
+            if isinstance(v, np.ndarray):
+                a = np.ascontiguousarray(v)
+                h.update(str(tuple(a.shape)).encode() + str(a.dtype).encode())
+                h.update(a.tobytes())
+            else:
+                h.update(repr(v).encode())
+        if depth < 4:
+            # containers whose members are not registered sub-modules: plain lists named `models` (UberModel) / `model` (FiveCrop)
+            subs = [mod] + [m for m in mod.modules() if m is not mod] if hasattr(mod, 'modules') else [mod]
+            for sm in subs:
+                for attr in ('models', 'model'):
+                    members = sm.__dict__.get(attr)
+                    if isinstance(members, (list, tuple)):
+                        for i, mem in enumerate(members):
+                            if hasattr(mem, 'state_dict'):
+                                feed('%s%s[%d].' % (prefix, attr, i), mem, depth + 1)
+        return True
+
+    return h.hexdigest()[:16] if feed('', model) else None
 
 
 class BlockRing(object):

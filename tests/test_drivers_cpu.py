@@ -568,3 +568,45 @@ def test_weights_fingerprint_covers_every_tensor():
         assert _weights_fingerprint(_M(sd2)) != base, key
     sd3 = dict(sd); sd3['bn.num_batches_tracked'] = torch.tensor(8)
     assert _weights_fingerprint(_M(sd3)) != base
+
+
+def test_weights_fingerprint_sees_the_members_of_an_uber_model():
+    """UberModel keeps its member encoders in a plain list (reference src/embeddings.py:44-57): their weights are not in state_dict(), so a
+    fingerprint of state_dict() alone is a constant for every `*_uber_*` PVR.  Members are walked explicitly: two uber models
+    whose members differ in one weight - also under the 5-crop wrapper and inside an EmbeddingNet-like holder - get different fingerprints."""
+    import torch.nn as nn
+    from pvr_habitat_amd.embeddings import UberModel, FiveCrop
+    from pvr_habitat_amd.save_embedded_obs import _weights_fingerprint
+
+    class _Member(nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            self.w = nn.Parameter(torch.randn(8, 8, generator=g), requires_grad=False)
+            self.register_buffer('running_mean', torch.zeros(8))
+            self.out_size = 8
+
+    class _Net(nn.Module):                      # EmbeddingNet's shape: the (wrapped) model is a registered sub-module named `embedding`
+        def __init__(self, emb):
+            super().__init__()
+            self.embedding = emb
+
+    def uber(seeds, bump=None, crops=1):
+        ms = [_Member(s) for s in seeds]
+        if bump is not None:
+            ms[bump].w.data.view(-1)[3] += 1e-3
+        u = UberModel(ms)
+        return _Net(FiveCrop(u) if crops == 5 else u)
+
+    for crops in (1, 5):
+        base = _weights_fingerprint(uber((1, 2, 3), crops=crops))
+        assert base is not None and base == _weights_fingerprint(uber((1, 2, 3), crops=crops))
+        assert len(uber((1, 2, 3), crops=crops).state_dict()) == 0                      # the reference's blind spot, kept
+        for i in range(3):
+            assert _weights_fingerprint(uber((1, 2, 3), bump=i, crops=crops)) != base, (crops, i)
+        assert _weights_fingerprint(uber((1, 3, 2), crops=crops)) != base                # member order matters (column order of the concat)
+    # numpy values are hashed by content, not by name only
+    class _NP:
+        def __init__(self, a): self.a = a
+        def state_dict(self): return {'w': self.a}
+    assert _weights_fingerprint(_NP(np.arange(6.0))) != _weights_fingerprint(_NP(np.arange(6.0) + 1))

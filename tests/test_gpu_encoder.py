@@ -274,15 +274,25 @@ def test_pool_inside_the_last_convolution(dtype, n, monkeypatch):
     fr = torch.from_numpy(synth.smooth_frames(140 + n, n, 160, 200)).cuda()
     m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=256)
     L = _lib.lib()
-    monkeypatch.setenv('PVR_POOL_FUSE', '1')
+    m.set_switch('pool_fuse', 1)
+    assert m.kernel_names(n)[-1] == 'conv_wfrag(pool)'
     before = L.pvr_debug_conv_wfrag_launches()
     fused = m(fr).clone()
     assert L.pvr_debug_conv_wfrag_launches() > before
-    monkeypatch.setenv('PVR_POOL_FUSE', '0')
+    # the pooled forward never wrote the (n,7,7,2048) activation: tapping it must refuse, not hand out stale workspace
+    with pytest.raises(RuntimeError, match='never wrote this activation'):
+        m.tap('layer4', n * 49 * 2048)
+    m.set_switch('pool_fuse', 0)
+    assert m.kernel_names(n)[-1] != 'conv_wfrag(pool)'
     plain = m(fr).clone()
     assert torch.equal(fused, plain), float((fused - plain).abs().max())
-    monkeypatch.setenv('PVR_POOL_FUSE', '1')
+    # ... and after the two-launch plan the tap exists and averages to the embedding
+    t4 = m.tap('layer4', n * 49 * 2048).view(n, 49, 2048)
+    assert float((t4.mean(dim=1) - plain).abs().max()) < 1e-4 * float(plain.abs().max())
+    m.set_switch('pool_fuse', 1)
     assert torch.equal(m(fr[1:4]), fused[1:4])               # a frame's embedding does not depend on where it sits in its pair
+    with pytest.raises(RuntimeError, match='not a live switch'):
+        m.set_switch('dual_ds', 0)
 
 
 DUAL_CASES = [
@@ -490,8 +500,8 @@ def test_stem_reading_uint8_frames_is_bit_identical_to_preprocess_then_stem(monk
         for pos in ((0,) if n not in (3, 31) else (0, 1, 2, 3, 4)):
             m.set_crop(pos)
             outs = []
-            for u8 in ('1', '0'):
-                monkeypatch.setenv('PVR_STEM_U8', u8)
+            for u8 in (1, 0):
+                m.set_switch('stem_u8', u8)
                 outs.append(m(d).clone())
             assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
             assert torch.equal(outs[0], outs[1]), (n, pos, int((outs[0] != outs[1]).sum()))
@@ -502,13 +512,13 @@ def test_stem_reading_uint8_frames_is_bit_identical_to_preprocess_then_stem(monk
         for pos in (0, 2, 3):
             m.set_crop(pos)
             outs = []
-            for u8 in ('1', '0'):
-                monkeypatch.setenv('PVR_STEM_U8', u8)
+            for u8 in (1, 0):
+                m.set_switch('stem_u8', u8)
                 outs.append(m(d).clone())
             assert torch.equal(outs[0], outs[1]), (hh, ww, pos, int((outs[0] != outs[1]).sum()))
     m.set_crop(0)
     # frames that do not start on a 16-byte boundary cannot use the 16-byte row DMA: the library takes the preprocess path by itself
-    monkeypatch.setenv('PVR_STEM_U8', '1')
+    m.set_switch('stem_u8', 1)
     src = torch.from_numpy(synth.frames(9, 3, 256, 256)).cuda()
     buf = torch.zeros(src.numel() + 32, dtype=torch.uint8, device='cuda')
     off = 3 + (-buf.data_ptr()) % 16                                    # data_ptr + off = 3 (mod 16)
@@ -1175,3 +1185,125 @@ def test_low_latency_plan_for_online_embedding(monkeypatch):
             torch.cuda.synchronize(); t[name] = (time.perf_counter() - t0) / 100 * 1e3
         print('\n[%s] N=2 device-resident forward: default %.3f ms, low-latency plan %.3f ms (plans differ by rel-L2 %.1e)' % (dt, t['default'], t['low-latency'], l2))
         assert t['low-latency'] < t['default']
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: fp32 convolutions on the 16-bit matrix pipe (conv_split16.hip) - the fp32 stage / head of the compressed PVRs' parity plan
+# ------------------------------------------------------------------------------------------------
+SPLIT16_CASES = [
+    # n, h (= w), cin, cout, k, stride, relu, residual
+    (3, 14, 1024, 256, 1, 1, 1, False),      # layer3 conv1
+    (2, 28, 256, 256, 3, 2, 1, False),       # layer3.0 conv2: taps, padding, stride 2
+    (3, 14, 256, 1024, 1, 1, 1, True),       # conv3 + fp32 identity
+    (2, 28, 512, 1024, 1, 2, 0, False),      # stride-2 downsample, no activation
+    (5, 7, 2048, 64, 3, 1, 1, False),        # *_l4 compression head (64-cout tiles, ragged M = 245)
+    (2, 14, 64, 64, 3, 1, 1, True),          # head conv2 (cin = 64: two K steps per tap)
+    (40, 14, 256, 1024, 1, 1, 1, True),      # enough tiles for the 128 x 128 form
+    (170, 14, 64, 64, 3, 1, 0, False),       # ... and for the 128 x 64 form
+]
+
+
+@pytest.mark.parametrize('case', SPLIT16_CASES)
+def test_conv_split16_is_an_fp32_convolution(case):
+    """pvr_op_conv2d_split16: fp32 operands as (hi, lo) f16 pairs, three 16x16x32 MFMAs per fragment pair.  Against the same convolution in
+    float64: ~1e-6 (the dropped lo x lo term and the rounding of the low parts are 2^-22 relative per term) - three orders of magnitude inside
+    f16 storage rounding and as close as the f32-input MFMA kernel it replaces in the plan (pvr_op_conv2d_f32, compared on the same inputs)."""
+    n, hh, cin, cout, k, stride, relu, has_res = case
+    L = _lib.lib()
+    pad = k // 2
+    ho = (hh + 2 * pad - k) // stride + 1
+    x = torch.from_numpy(synth.normal(11, 's16x%s' % (case,), (n, hh, hh, cin))).clamp_(min=0)
+    # a few tiny and a few large activations: the low parts must survive f16's subnormal range, the high parts its 65504
+    x.view(-1)[::997] *= 1e-6
+    x.view(-1)[5::1013] *= 3e3
+    K = k * k * cin
+    cout_pad = (cout + 63) // 64 * 64
+    w4 = torch.from_numpy(synth.normal(11, 's16w%s' % (case,), (cout, cin, k, k), std=float(np.sqrt(2.0 / K))))
+    wk = torch.zeros((cout_pad, K)); wk[:cout] = w4.permute(0, 2, 3, 1).reshape(cout, K)
+    b = torch.zeros(cout_pad); b[:cout] = torch.from_numpy(synth.uniform(11, 's16b%s' % (case,), (cout,), -0.5, 0.5))
+    r = torch.from_numpy(synth.normal(11, 's16r%s' % (case,), (n, ho, ho, cout))) if has_res else None
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w4.double(), b[:cout].double(), stride, pad).permute(0, 2, 3, 1)
+    if has_res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_(min=0)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    xd, wd, bd = x.cuda(), wk.cuda(), b.cuda()
+    rd = r.cuda() if has_res else None
+    wsp = torch.empty((cout_pad, K, 2), dtype=torch.float16, device='cuda')
+    _lib.check(L.pvr_op_split16_pack_weights(vp(wd), vp(wsp), cout_pad, K, _lib.stream_ptr()))
+    before = L.pvr_debug_conv_split16_launches()
+    y = torch.full((n, ho, ho, cout), float('nan'), device='cuda')
+    _lib.check(L.pvr_op_conv2d_split16(vp(xd), vp(wsp), vp(bd), vp(rd), vp(y), n, hh, hh, cin, cout, k, stride, pad, relu, _lib.stream_ptr()))
+    y32 = torch.full((n, ho, ho, cout), float('nan'), device='cuda')
+    _lib.check(L.pvr_op_conv2d_f32(vp(xd), vp(wd), vp(bd), vp(rd), vp(y32), n, hh, hh, cin, cout, k, stride, pad, relu, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert L.pvr_debug_conv_split16_launches() == before + 1
+    assert torch.isfinite(y).all()
+    l2, mx = _relerr(y.cpu().numpy(), ref.numpy())
+    l2f, mxf = _relerr(y32.cpu().numpy(), ref.numpy())
+    print('\n[split16 %s] rel-L2 %.2e max-norm %.2e   (f32-input MFMA: %.2e / %.2e)' % (case, l2, mx, l2f, mxf))
+    assert l2 < 2e-6 and mx < 5e-6, (l2, mx)
+    # run to run: bit-identical (no atomics, fixed K order)
+    y2 = torch.empty_like(y)
+    _lib.check(L.pvr_op_conv2d_split16(vp(xd), vp(wsp), vp(bd), vp(rd), vp(y2), n, hh, hh, cin, cout, k, stride, pad, relu, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('variant,osz', [('conv3', 2156), ('conv4', 2058)])
+def test_parity_plan_of_the_compressed_pvrs_runs_on_the_16_bit_pipe(variant, osz, monkeypatch):
+    """The f16 parity plan's fp32 stage + head as conv_split16 launches (default) against the same plan on the f32-input MFMA (PVR_SPLIT16=0):
+    both are fp32 convolutions of the same fp32 tensors, so the embeddings agree to ~1e-6 - far inside the 8e-4 bound test_compressed_variants
+    holds the default plan to - and the plan's kernel names say which one ran."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(3, variant)
+    fr = torch.from_numpy(synth.smooth_frames(77, 5, 128, 160)).cuda()
+    L = _lib.lib()
+    m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=8)
+    kn = m.kernel_names(5)
+    assert 'conv_split16' in kn and 'conv_f32' not in kn, kn
+    before = L.pvr_debug_conv_split16_launches()
+    a = m(fr).clone()
+    assert L.pvr_debug_conv_split16_launches() - before == kn.count('conv_split16')
+    assert a.shape == (5, osz) and torch.isfinite(a).all()
+    assert torch.equal(m(fr[1:3]), a[1:3])                     # batch-size invariance, bit-exact
+    monkeypatch.setenv('PVR_SPLIT16', '0')
+    m0 = HipResNet50(sd, variant, compute_dtype='f16', max_batch=8)
+    kn0 = m0.kernel_names(5)
+    assert 'conv_f32' in kn0 and 'conv_split16' not in kn0, kn0
+    b = m0(fr)
+    l2, mx = _relerr(a.cpu().numpy(), b.cpu().numpy())
+    print('\n[%s] split16 vs f32-input MFMA plan: rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
+    assert l2 < 5e-6 and mx < 2e-5, (l2, mx)
+    m.close(); m0.close()
+
+
+def test_default_plan_at_the_bench_batch_against_the_oracle():
+    """the kernels the plan selects only for big forwards (bneck_frame with its own conv1, conv_wfrag incl. the pooled
+    epilogue, conv_pp256's two-operand form) met the oracle only through bit-identity chains against older HIP kernels.  Here: the DEFAULT plan, batch
+    256, f16 - the plan's own table says those kernels run at this size, their launch counters say they did - and 8 of the 256 embeddings
+    against encoder_oracle.embed at the north-star bound."""
+    from oracle import encoder_oracle as eo
+    from pvr_habitat_amd.embeddings import HipResNet50
+    torch.set_num_threads(8)
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    fr_np = synth.frames(33, 256, 256, 256)
+    m = HipResNet50(sd, 'conv5', compute_dtype='f16', max_batch=256)
+    kn = m.kernel_names(256)
+    assert kn.count('bneck_frame(front1)') == 5 and kn.count('conv_pp256(dual)') == 2 and kn[-1] == 'conv_wfrag(pool)' and kn.count('conv_wfrag') >= 4, kn
+    assert len(kn) == len(m.op_names())
+    L = _lib.lib()
+    c0 = (L.pvr_debug_bneck_frame_launches(), L.pvr_debug_conv_wfrag_launches(), L.pvr_debug_pp_persistent_launches())
+    out = m(torch.from_numpy(fr_np).cuda()).cpu().numpy()
+    assert L.pvr_debug_bneck_frame_launches() - c0[0] == 5 and L.pvr_debug_conv_wfrag_launches() - c0[1] >= 5
+    idx = [0, 1, 37, 100, 128, 201, 254, 255]
+    ref = eo.embed(sd, fr_np[idx], 'conv5', squeeze=False)
+    l2, mx = _relerr(out[idx], ref)
+    print('\n[default plan, batch 256, f16] 8 of 256 embeddings vs the fp32 oracle: rel-L2 %.2e max-norm %.2e' % (l2, mx))
+    assert l2 < 1e-3 and mx < 2e-3, (l2, mx)
+    # the small-forward plan of the same handle (none of those kernels) gives the same rows bit for bit
+    small = m(torch.from_numpy(fr_np[idx[:3]]).cuda()).cpu().numpy()
+    assert 'bneck_frame(front1)' not in m.kernel_names(3)
+    assert np.array_equal(small, out[idx[:3]])
+    m.close()
