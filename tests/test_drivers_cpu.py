@@ -1,5 +1,6 @@
 """CPU tests of the host logic around the hot path: flags, batch assembly, row sharding (gloo, world size 2),
 save_embedded_obs split/concat order with a stand-in embedder."""
+import json
 import os
 import pickle
 import subprocess
@@ -610,3 +611,42 @@ def test_weights_fingerprint_sees_the_members_of_an_uber_model():
         def __init__(self, a): self.a = a
         def state_dict(self): return {'w': self.a}
     assert _weights_fingerprint(_NP(np.arange(6.0))) != _weights_fingerprint(_NP(np.arange(6.0) + 1))
+
+
+_GUARD_WORKER = r'''
+import json, os, sys, time, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', rank=rank, world_size=2)
+import bench
+line = {'metric': 'headline', 'value': 1.0}
+guard = bench.LegGuard(dist, rank, lambda: line)
+guard.enter('host_leg', 600.0)
+try:
+    if rank == 1:
+        raise MemoryError('pin_memory failed on this rank only')
+    dist.barrier()                      # rank 0: blocked in the leg's collective - rank 1 never arrives
+    print('rank 0 passed the barrier?!', flush=True)
+except Exception as e:
+    guard.failed('host_leg', e)
+'''
+
+
+def test_bench_leg_guard_ends_a_one_sided_failure_promptly(tmp_path):
+    """bench.py, N > 1 (ADVICE round 5): a rank that raises inside a host-fed leg used to leave the other ranks blocked in the leg's collectives
+    until the launcher's 3000 s time-out - and no JSON line.  With LegGuard the failing rank posts its error to the rendezvous store, rank 0's
+    watcher prints the line so far with the error in it and every rank exits non-zero within seconds."""
+    script = tmp_path / 'guard_worker.py'
+    script.write_text(_GUARD_WORKER % dict(root=ROOT))
+    procs = []
+    t0 = time.time()
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29747')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], [p.returncode for p in procs]
+    assert time.time() - t0 < 90
+    lines = [l for l in outs[0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith('{')]
+    d = json.loads(lines[0])
+    assert d['value'] == 1.0 and 'rank 1, leg host_leg: MemoryError' in d['aborted']

@@ -37,9 +37,17 @@ def _check(line, n):
         assert 0 < ew['p50'] <= ew['p99'] <= ew['max'] and ew['n_elements'] > 1000 and ew['p50'] < bound
     if n == 1:
         assert d['png_source']['files'] == 750 and d['png_source']['value'] > 1000      # the PNG tree through the GPU decoder
-        u = d['uber5crop']                                             # BASELINE configs[4]: 5-crop uber_345, HBM-resident (value) and streamed to the host
-        assert u['floats_per_frame'] == 31310 and u['value'] > 1000 and 0.05 < u['frac_of_mfma_peak'] < 1 and u['f16_parity_plan']['value'] > 300
-        assert 500 < u['streamed']['value'] <= u['value'] * 1.05 and u['streamed']['d2h_GBps'] > 0
+    # BASELINE configs[4] at every N (round 6): 5-crop uber_345, `value` = the compliant f16 plan (HBM-resident) with the bf16 throughput plan beside it,
+    # both also streamed to the host
+    u = d['uber5crop']
+    assert 'error' not in u, u
+    assert u['dtype'] == 'f16' and u['floats_per_frame'] == 31310 and u['value'] > 800 * n and 0.03 < u['frac_of_mfma_peak'] < 1
+    assert u['bf16_throughput_plan']['dtype'] == 'bf16' and u['bf16_throughput_plan']['value'] > u['value']
+    assert 300 < u['streamed']['value'] <= u['value'] * 1.05 and u['streamed']['d2h_GBps'] > 0
+    pr = d['per_rank_ms_per_step']                                     # a straggler shows as max >> min; value uses the slowest rank
+    assert 0 < pr['min'] <= pr['max'] and abs(pr['max'] - d['ms_per_step']) < 1e-6
+    if n > 1:
+        assert u['n_gpus'] == n and u['frames'] % n == 0 and 0 < u['per_rank_s']['streamed']['min'] <= u['per_rank_s']['streamed']['max']
     return d
 
 
@@ -54,9 +62,10 @@ def test_bench_line_single_gpu():
 def test_bench_line_two_ranks_on_one_gpu():
     """N = 2 (two ranks sharing the one test GPU): the headline, the data-parallel finetune leg AND - round 5 - the host-fed legs run by all ranks
     concurrently: the PCIe-inclusive stream of every rank's own pool and ONE scene embedded by save_embedded_obs.run in per-rank shards
-    that rank 0 stitches.  These are the keys the multi-GPU driver line carries beside the HBM-resident `value`."""
+    that rank 0 stitches - and, round 6, configs[4] (5-crop uber, resident + streamed) and configs[2] (ViT-B/16) with per-rank min / max times.
+    These are the keys the multi-GPU driver line carries beside the HBM-resident `value`."""
     env = dict(os.environ, PVR_BENCH_ONE_GPU='1')
-    flags = [f for f in FAST if f != '--no-pcie'] + ['--e2e-samples', '3000', '--pool', '1024']
+    flags = [f for f in FAST if f not in ('--no-pcie', '--no-vit')] + ['--e2e-samples', '3000', '--pool', '1024']
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + flags
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -71,6 +80,10 @@ def test_bench_line_two_ranks_on_one_gpu():
     pc, e2e = d['pcie_inclusive'], d['save_embedded_obs_e2e']
     assert 'error' not in pc and pc['n_gpus'] == 2 and pc['frames'] == 2 * 2 * 1024 and pc['pageable_source']['value'] > 2000 and pc['pinned_source']['value'] > 2000
     assert 'error' not in e2e and e2e['n_gpus'] == 2 and e2e['samples'] == 3000 and e2e['value'] > 1000 and len(e2e['runs_frames_per_s']) == 3
+    # round 6: configs[2] (ViT-B/16) runs on every rank at once too: aggregate + the slowest / fastest rank
+    v = d['vit']
+    assert len(v) == 1 and v[0]['n_gpus'] == 2 and v[0]['value'] > 2000 and 0 < v[0]['per_rank_ms_per_step']['min'] <= v[0]['per_rank_ms_per_step']['max']
+    assert 'aborted' not in d
 
 
 def test_bench_launches_its_own_ranks():
