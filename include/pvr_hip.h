@@ -155,7 +155,7 @@ pvr_status pvr_encoder_profile_span(pvr_encoder *enc, const uint8_t *frames_dev,
  * PVR_* switch shapes the plan and is read from the environment ONCE, in pvr_encoder_create; nothing reads the environment on the forward path. */
 pvr_status pvr_encoder_debug_set_switch(pvr_encoder *enc, const char *name, int32_t value);
 /* Which kernel family launch `index` (pvr_encoder_launch_name's indices) runs as in a forward of n frames, e.g. "bneck_frame(front1)", "conv_wfrag(pool)",
- * "conv_pp256(dual)", "chain", "conv_split16", "conv" (the shape-dispatched implicit GEMMs).  The choice is tabulated per batch size when the encoder is
+ * "conv_pp256(dual)", "chain_wave" / "chain_wave128" / "bottleneck_chain" (the three forms of the fused bottleneck tail), "conv_split16", "conv" (the shape-dispatched implicit GEMMs).  The choice is tabulated per batch size when the encoder is
  * finalized; returns the name's length, 0 past the end of the plan. */
 int32_t pvr_encoder_launch_kernel(const pvr_encoder *enc, int32_t n, int32_t index, char *buf, int32_t cap);
 void pvr_encoder_destroy(pvr_encoder *enc);
@@ -232,6 +232,9 @@ pvr_status pvr_op_conv2d_split16(const float *in_dev, const void *wgt_split_dev,
 pvr_status pvr_op_conv2d_f32(const float *in_dev, const float *wgt_dev, const float *bias_dev, const float *residual_dev, float *out_dev, int32_t n,
                              int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t relu, void *hip_stream);
 int64_t pvr_debug_conv_split16_launches(void);
+/* launches of the layer2 wave-form tail (chain_wave128.hip: torchvision Bottleneck conv2 -> conv3 + identity -> the next conv1 at Cm = 128, reference
+ * src/embeddings.py:118-120) so far (tests: the layer2 plan really took it; PVR_CHAIN_WAVE_L2=0 keeps the block form) */
+int64_t pvr_debug_chain_wave128_launches(void);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */

@@ -67,6 +67,7 @@ pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, 
                              int64_t pool_stride = 0);
 
 long long conv_split16_launches();
+long long chain_wave128_launches();
 pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
 pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
                                int cout, int k, int stride, int pad, int relu, hipStream_t stream);
@@ -152,6 +153,7 @@ pvr_status pvr_op_conv2d_f32(const float *in, const float *wgt, const float *bia
     return launch_conv_f32(in, wgt, bias, residual, out, n, h, w, cin, cout, k, stride, pad, relu, (hipStream_t)stream);
 }
 int64_t pvr_debug_conv_split16_launches(void) { return (int64_t)conv_split16_launches(); }
+int64_t pvr_debug_chain_wave128_launches(void) { return (int64_t)chain_wave128_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 
 size_t pvr_last_error(char *buf, size_t cap) {

@@ -197,10 +197,14 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
     const int y_blkd = ((m0 >> 4) + wm * 4) * (C4 * 32) + (wn * 4 + fq) * 256 + fr * 16;
     const int y_off0 = p.y_blk ? y_blkd : y_nhwc, y_js = p.y_blk ? C4 * 32 : 16 * C4 * 2, y_gs = p.y_blk ? 2048 : 128;
     const int r_off0 = p.res_blk ? y_blkd : y_nhwc, r_js = p.res_blk ? C4 * 32 : 16 * C4 * 2, r_gs = p.res_blk ? 2048 : 128;
-    const int t_off0 = ((m0 + wm * 64 + fr) * CMN + wn * (CMN / 2) + fq * 8) * 2;
+    // t1' NHWC, or blocked for the layer2 wave form that follows (chain_wave128.hip): pixel tile j = 16 rows = one block of 16 x CMN x 2 bytes, the lane's
+    // 8 couts of tile pair q are chunk wn * CMN / 16 + 4 q + fq of it
+    const int t_nhwc = ((m0 + wm * 64 + fr) * CMN + wn * (CMN / 2) + fq * 8) * 2;
+    const int t_blkd = ((m0 >> 4) + wm * 4) * (CMN * 32) + (wn * (CMN / 16) + fq) * 256 + fr * 16;
+    const int t_off0 = p.t_blk ? t_blkd : t_nhwc, t_js = p.t_blk ? CMN * 32 : 16 * CMN * 2;
 #define Y_OFF(j_) (y_off0 + (j_) * y_js)
 #define R_OFF(j_) (r_off0 + (j_) * r_js)
-#define T_OFF(j_) (t_off0 + (j_) * (16 * CMN * 2))
+#define T_OFF(j_) (t_off0 + (j_) * t_js)
     // W3 group / W1' slice staging: thread q = tid + 256 i moves chunk (q & 7) of row r; r advances by 32 per i (the swizzle term
     // (r >> 1) & 7 does not change), so every offset is ONE per-thread base + a compile-time constant (keeps the arrays out of VGPRs)
     const int st_r = tid >> 3, st_c = ((tid & 7) ^ ((st_r >> 1) & 7)) * 16;
@@ -546,7 +550,8 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_chain_kernel(ChainP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = pack2_h<F16>(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
-                store_b128_imm<PVR_NT_AUX(8)>(o, rs_t, T_OFF(j), q * 64);
+                if (p.t_blk) store_b128_imm<0>(o, rs_t, T_OFF(j) + q * 1024, 0);
+                else store_b128_imm<PVR_NT_AUX(8)>(o, rs_t, T_OFF(j), q * 64);
             }
         }
     }
@@ -666,6 +671,8 @@ static bool chain_wave_enabled() {
 
 bool chain_uses_wave_form(int cm, int cmn, int stride, bool ds) { return chain_wave_enabled() && chain_wave_supported(cm, cmn, stride, ds); }
 
+bool chain_uses_wave128(int cm, int cmn, int stride, int64_t M) { return chain_wave_enabled() && chain_wave128_supported(cm, cmn, stride, M); }
+
 bool chain_ds_supported(int cm, int cmn, int cin, int stride) { return cm == 64 && cmn == 64 && cin == 64 && stride == 1; }
 bool chain_supported(int cm, int cmn) { return (cm == 64 && (cmn == 0 || cmn == 64 || cmn == 128)) || (cm == 128 && (cmn == 0 || cmn == 128)); }
 
@@ -675,9 +682,10 @@ int chain_row_source(int row) { return (row & ~31) + 8 * ((row >> 2) & 3) + 4 * 
 pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
                                    void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
                                    int stride, int dtype, hipStream_t stream, const void *xds, const void *wdsp, const void *w3pb, const void *wdspb,
-                                   int wave, int in_blk, int out_blk) {
-    // wave: run the wave form (chain_wave.hip; the plan decided with chain_uses_wave_form); w3pb / wdspb: blocked copies of w3p / wdsp for
-    // it; in_blk / out_blk: blocked activations between two wave-form launches
+                                   int wave, int in_blk, int out_blk, const void *wpk) {
+    // wave: 1 run the wave form (chain_wave.hip; the plan decided with chain_uses_wave_form), 2 the layer2 wave form (chain_wave128.hip; wpk: its packed
+    // weights); w3pb / wdspb: blocked copies of w3p / wdsp for the former; in_blk / out_blk: blocked activations between two wave-form launches
+    // (block form: out_blk bit 1 = t1' blocked too, for a layer2 wave-form launch that follows)
     // xds != null: `res` is unused; the identity branch is Wd . x (x = xds: [pixels][64], wdsp: [4Cm][64] row-permuted) and b3 = b3 + bd
     PVR_REQUIRE(chain_supported(cm, cmn), "bottleneck chain: unsupported widths Cm=%d next=%d", cm, cmn);
     PVR_REQUIRE(t1 && w2 && b2 && w3p && b3 && (res || xds) && y && (cmn == 0 || (w1np && b1n && t1n)), "bottleneck chain: null argument");
@@ -694,13 +702,19 @@ pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *
     p.xds = (const u16 *)xds; p.wds = (const u16 *)wdsp;
     p.xds_bytes = xds ? (unsigned)(M * 64 * 2) : 0; p.wds_bytes = xds ? (unsigned)(4 * cm * 64 * 2) : 0;
     p.w2_bytes = (unsigned)(cm * 9 * cm * 2); p.w3_bytes = (unsigned)(4 * cm * cm * 2); p.w1n_bytes = (unsigned)(cmn * 4 * cm * 2);
+    if (wave == 2) {
+        PVR_REQUIRE(chain_wave128_supported(cm, cmn, stride, M) && !xds, "bottleneck chain: no layer2 wave form for Cm=%d next=%d stride=%d", cm, cmn, stride);
+        p.wpk = (const u16 *)wpk; p.in_blk = in_blk; p.out_blk = out_blk & 1;
+        return launch_chain_wave128(p, cmn, dtype, stream);
+    }
     if (wave) {
         PVR_REQUIRE(chain_wave_supported(cm, cmn, stride, xds != nullptr), "bottleneck chain: no wave form for Cm=%d next=%d stride=%d", cm, cmn, stride);
         p.w3b = (const u16 *)w3pb; p.wdsb = (const u16 *)wdspb; p.in_blk = in_blk; p.out_blk = out_blk;
         return launch_chain_wave(p, cmn, dtype, stream);
     }
     PVR_REQUIRE(!(in_blk || out_blk) || M % 16 == 0, "bottleneck chain: the blocked layout needs a multiple of 16 pixels");
-    p.res_blk = xds ? 0 : in_blk; p.y_blk = out_blk;           // block form: only y / the residual travel blocked (t1 and t1' stay NHWC)
+    p.res_blk = xds ? 0 : in_blk; p.y_blk = out_blk & 1;       // block form: y / the residual travel blocked; t1 stays NHWC, t1' too unless a layer2 wave form follows
+    p.t_blk = (out_blk & 2) && cmn > 0;
     return dtype == PVR_F16 ? launch_chain_dt<true>(p, cm, cmn, stream) : launch_chain_dt<false>(p, cm, cmn, stream);
 }
 

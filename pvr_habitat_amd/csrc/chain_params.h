@@ -19,6 +19,10 @@ struct ChainP {
     int res_blk = 0, y_blk = 0;                    // block form: the residual / y in that layout (t1 and t1' stay NHWC)
     // ... and the row-permuted W3 / Wd in that layout ([row >> 4][channel >> 3][row & 15][8]) for the instances that read them from L2
     const u16 *w3b = nullptr, *wdsb = nullptr;
+    // layer2 wave form (chain_wave128.hip): the launch's 17 weight units as LDS images (launch_chain_wave128_pack); t_blk: the block form writes t1' blocked for it
+    const u16 *wpk = nullptr;
+    unsigned wpk_bytes = 0;
+    int t_blk = 0;
 };
 
 bool chain_supported(int cm, int cmn);
@@ -28,7 +32,8 @@ int chain_row_source(int row);
 pvr_status launch_bottleneck_chain(const void *t1, const void *w2, const float *b2, const void *w3p, const float *b3, const void *res,
                                    void *y, const void *w1np, const float *b1n, void *t1n, int n, int h, int w, int cm, int cmn,
                                    int stride, int dtype, hipStream_t stream, const void *xds = nullptr, const void *wdsp = nullptr,
-                                   const void *w3pb = nullptr, const void *wdspb = nullptr, int wave = 0, int in_blk = 0, int out_blk = 0);
+                                   const void *w3pb = nullptr, const void *wdspb = nullptr, int wave = 0, int in_blk = 0, int out_blk = 0,
+                                   const void *wpk = nullptr);
 
 
 // chain_wave.hip: the barrier-free form (stride-1 blocks with Cm = 64)
@@ -36,5 +41,12 @@ bool chain_wave_supported(int cm, int cmn, int stride, bool ds);
 bool chain_wave_blocked_ok(int cmn_first, int h, int w);
 bool chain_wave_halo_enabled();                    // PVR_CHAIN_WAVE_HALO != 0
 pvr_status launch_chain_wave(ChainP &p, int cmn, int dtype, hipStream_t stream);
+
+// chain_wave128.hip: the wave form of layer2's stride-1 tails (Cm = 128): wave-owned pixels, weights streamed through an LDS ring
+bool chain_wave128_supported(int cm, int cmn, int stride, int64_t M);
+bool chain_uses_wave128(int cm, int cmn, int stride, int64_t M);     // ... and PVR_CHAIN_WAVE != 0 (the all-block-form A/B baseline); read when a plan is built
+size_t chain_wave128_pack_bytes();
+pvr_status launch_chain_wave128_pack(const void *w2, const void *w3p, const void *w1np, void *out, hipStream_t stream);
+pvr_status launch_chain_wave128(ChainP &p, int cmn, int dtype, hipStream_t stream);
 
 }  // namespace pvr

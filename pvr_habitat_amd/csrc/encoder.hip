@@ -554,6 +554,40 @@ static pvr_status build_schedules(pvr_encoder *e) {
             const ConvOp &c2 = e->ops[l.conv2];
             l.wave = chain_uses_wave_form(c2.cout, l.next1 >= 0 ? e->ops[l.next1].cout : 0, c2.stride, l.ds >= 0);
         }
+    // layer2's stride-1 tails on their wave form (chain_wave128.hip, round 6).  That kernel reads t1 and the residual blocked and writes t1' blocked, so a
+    // launch can take it only if (i) the launch in front is a chain that carries this block's conv1 and hands y and t1' over untapped - the block form (it can
+    // write both blocked: out_blk 1 | 2) or another launch of this form - and (ii) the launch behind it, if it carries the next conv1 here, takes this form too.
+    {
+        std::vector<Launch> &sc = e->sched_fused;
+        const int ns = (int)sc.size();
+        auto linked = [&](int a, int b) {               // sc[a] hands y (as the residual) and t1' straight to sc[b]
+            if (a < 0 || b >= ns) return false;
+            const Launch &A = sc[a], &B = sc[b];
+            if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || A.frame || B.frame || B.ds >= 0) return false;
+            const ConvOp &a2 = e->ops[A.conv2], &a3 = e->ops[A.conv3], &b2 = e->ops[B.conv2], &b3 = e->ops[B.conv3];
+            return B.t1_in == A.t1_out && b3.res_buf == a3.out_buf && a3.tap.empty() && b2.h == a2.h / a2.stride && b2.w == a2.w / a2.stride && A.next1 + 1 == B.conv2;
+        };
+        auto eligible = [&](int b) {
+            const Launch &B = sc[b];
+            if (B.conv3 < 0 || B.frame || B.ds >= 0 || B.wave) return false;
+            const ConvOp &b2 = e->ops[B.conv2];
+            return (b2.h * b2.w) % 16 == 0 && e->sw.chain_blocked && chain_uses_wave128(b2.cout, B.next1 >= 0 ? e->ops[B.next1].cout : 0, b2.stride, (int64_t)b2.h * b2.w);
+        };
+        std::vector<char> can(ns, 0);
+        for (int b = ns - 1; b >= 1; --b)
+            can[b] = eligible(b) && linked(b - 1, b) && (sc[b].next1 < 0 || (b + 1 < ns && can[b + 1] && linked(b, b + 1)));
+        for (int b = 1; b < ns; ++b) {
+            if (!can[b] || !(sc[b - 1].wave == 0 || sc[b - 1].wave == 2)) continue;
+            Launch &B = sc[b];
+            B.wave = 2;
+            ConvOp &c2 = e->ops[B.conv2];
+            if (!c2.d_wpk) {
+                PVR_HIP_TRY(hipMalloc((void **)&c2.d_wpk, chain_wave128_pack_bytes()));
+                pvr_status s = launch_chain_wave128_pack(c2.d_w, e->ops[B.conv3].d_wp, B.next1 >= 0 ? e->ops[B.next1].d_wp : nullptr, c2.d_wpk, nullptr);
+                if (s) return s;
+            }
+        }
+    }
     for (size_t a = 0; a + 1 < e->sched_fused.size(); ++a) {
         Launch &A = e->sched_fused[a], &B = e->sched_fused[a + 1];
         if (A.conv3 < 0 || B.conv3 < 0 || A.next1 < 0 || B.ds >= 0 || A.frame || B.frame) continue;
@@ -561,6 +595,10 @@ static pvr_status build_schedules(pvr_encoder *e) {
         const int a_cmn = e->ops[A.next1].cout;
         if (!e->sw.chain_blocked) continue;
         if (B.t1_in != A.t1_out || b3.res_buf != a3.out_buf || !a3.tap.empty() || b2.h != a2.h / a2.stride || b2.w != a2.w / a2.stride || b2.stride != 1) continue;
+        if (B.wave == 2) {                            // a layer2 wave-form tail: everything it reads arrives blocked (its producer: block form or this form)
+            A.out_blk = A.wave == 2 ? 1 : 3; B.in_blk = 1;
+            continue;
+        }
         if (!A.wave && !B.wave) {
             // two block-form tails (layer2): y = the next residual travels blocked (16-byte accesses of a lane land in 512-byte runs);
             // t1' stays NHWC (the halo DMA wants contiguous pixel rows)
@@ -1074,7 +1112,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                             c1 ? c1->d_wp : nullptr, c1 ? c1->d_b : nullptr, c1 ? enc->d_buf[l.t1_out] : nullptr, nb,
                                             c2.h, c2.w, c2.cout, c1 ? c1->cout : 0, c2.stride, dt, st,
                                             cd ? enc->d_buf[cd->in_buf] : nullptr, cd ? cd->d_wp : nullptr, op.d_wpb, cd ? cd->d_wpb : nullptr,
-                                            l.wave, cd ? (l.in_blk && t1_blocked) : l.in_blk, l.out_blk);
+                                            l.wave, cd ? (l.in_blk && t1_blocked) : l.in_blk, l.out_blk, c2.d_wpk);
                 t1_blocked = false;
                 break;
             }
@@ -1305,7 +1343,9 @@ int32_t pvr_encoder_launch_kernel(const pvr_encoder *enc, int32_t n, int32_t ind
     const int i = index - 3;
     if (i >= (int)plan.size()) return 0;
     const int nb = n < enc->desc.chunk ? n : enc->desc.chunk;
-    const char *nm = enc->desc.dtype == PVR_F32 ? "conv_f32" : launch_kind_name(resolve_kind(enc, plan, (size_t)i, nb));
+    const int kind = resolve_kind(enc, plan, (size_t)i, nb);
+    const char *nm = enc->desc.dtype == PVR_F32 ? "conv_f32" : launch_kind_name(kind);
+    if (enc->desc.dtype != PVR_F32 && kind == LK_CHAIN) nm = plan[i].wave == 2 ? "chain_wave128" : plan[i].wave == 1 ? "chain_wave" : "bottleneck_chain";
     snprintf(buf, (size_t)cap, "%s", nm);
     return (int32_t)strlen(nm);
 }
@@ -1386,7 +1426,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_wpk) (void)hipFree(op.d_wpk); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

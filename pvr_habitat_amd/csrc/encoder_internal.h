@@ -73,6 +73,7 @@ struct ConvOp {
     u16 *d_wpb = nullptr;          // ... and that copy in the blocked layout [row >> 4][cin >> 3][row & 15][8] (chain_wave.hip reads W3 / Wd pieces from L2)
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
+    u16 *d_wpk = nullptr;          // conv2 of a layer2 wave-form tail: the launch's 17 weight units as LDS images (chain_wave128.hip: launch_chain_wave128_pack)
     u16 *d_wsp = nullptr;          // fp32 weights as (hi, lo) f16 fragment pairs (conv_split16.hip: the f32op convolutions of an f16 plan)
     float *d_b = nullptr;
     std::vector<float> h_b;        // host copy of the bias (same lifetime as h_w)
@@ -89,10 +90,11 @@ struct Launch {
     int ds = -1;                              // chain: the block's downsample convolution, accumulated inside conv3 (no launch of its own);
                                               // with conv3 < 0: ops[conv2] is a conv3 that runs as conv_pp256's two-operand launch with ops[ds] (layer3.0 / layer4.0)
     int t1_in = B_NONE, t1_out = B_NONE;      // chain: buffer holding conv2's input / receiving the next block's conv1 output
-    int wave = 0;                             // chain: the wave form runs it (chain_wave.hip)
+    int wave = 0;                             // chain: 1 the wave form runs it (chain_wave.hip), 2 the layer2 wave form (chain_wave128.hip)
     int conv1 = -1;                           // per-frame form: the block's own conv1 runs in front, inside the launch (the launch reads the block input)
     int frame = 0;                            // per-frame form (bneck_frame.hip, layer3): conv2 -> conv3 + residual [-> next1] of one 14 x 14 image per workgroup
-    int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip)
+    int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip);
+                                              // block form: out_blk 1 = y blocked, 3 = y and t1' blocked (a layer2 wave-form launch follows)
 };
 
 // What one launch of the plan runs as for a forward of nb frames: resolved off the hot path (resolve_kinds: finalize, set_low_latency,

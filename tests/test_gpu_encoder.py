@@ -1293,6 +1293,7 @@ def test_default_plan_at_the_bench_batch_against_the_oracle():
     kn = m.kernel_names(256)
     assert kn.count('bneck_frame(front1)') == 5 and kn.count('conv_pp256(dual)') == 2 and kn[-1] == 'conv_wfrag(pool)' and kn.count('conv_wfrag') >= 4, kn
     assert len(kn) == len(m.op_names())
+    assert kn.count('chain_wave') == 3 and kn.count('chain_wave128') == 3 and kn.count('bottleneck_chain') == 1, kn      # layer1 | layer2.1-2.3 | layer2.0 (stride 2)
     L = _lib.lib()
     c0 = (L.pvr_debug_bneck_frame_launches(), L.pvr_debug_conv_wfrag_launches(), L.pvr_debug_pp_persistent_launches())
     out = m(torch.from_numpy(fr_np).cuda()).cpu().numpy()
@@ -1307,3 +1308,36 @@ def test_default_plan_at_the_bench_batch_against_the_oracle():
     assert 'bneck_frame(front1)' not in m.kernel_names(3)
     assert np.array_equal(small, out[idx[:3]])
     m.close()
+
+
+@pytest.mark.parametrize('dtype,n', [('f16', 1), ('bf16', 3), ('f16', 6), ('bf16', 40), ('f16', 41)])
+def test_layer2_wave_form_equals_block_form(dtype, n, monkeypatch):
+    """chain_wave128.hip (round 6): layer2's stride-1 tails with wave-owned pixels and the 544 KB of weights streamed through a two-slot LDS ring,
+    against the block form (bottleneck_chain.hip) - same rounding points, same K order per accumulator: layer2's output and the embedding bit for
+    bit.  Odd n: the last 32-pixel tile holds a single 16-pixel block; n = 40 / 41: several rounds per workgroup and workgroups with idle waves in
+    the last round.  The plan's launch list is unchanged (the form is a property of the launch); the launch counter says which form ran."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    L = _lib.lib()
+    L.pvr_debug_chain_wave128_launches.restype = C.c_int64
+    sd = synth.resnet50_state_dict(8, 'conv5')
+    fr = torch.from_numpy(synth.smooth_frames(170 + n, n, 160, 200)).cuda()
+    got = {}
+    for key, on in (('block', '0'), ('wave', '1')):
+        monkeypatch.setenv('PVR_CHAIN_WAVE_L2', on)
+        m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=max(8, n))
+        names = m.op_names()
+        before = L.pvr_debug_chain_wave128_launches()
+        m.debug_stop_after('layer2')
+        m(fr)
+        t2 = m.tap('layer2', n * 28 * 28 * 512).clone()
+        m.debug_stop_after('')
+        emb = m(fr).clone()
+        assert torch.equal(emb, m(fr))
+        ran = L.pvr_debug_chain_wave128_launches() - before
+        assert ran == (9 if on == '1' else 0), ran                  # layer2.1 / 2.2 / 2.3, three forwards
+        m.close()
+        got[key] = (t2, emb, names)
+    assert got['wave'][2] == got['block'][2]
+    assert torch.isfinite(got['block'][0]).all() and float(got['block'][0].abs().max()) > 0
+    for a, b, what in ((got['wave'][0], got['block'][0], 'layer2'), (got['wave'][1], got['block'][1], 'embedding')):
+        assert torch.equal(a, b), (what, int((a != b).sum()), float((a - b).abs().max()))
