@@ -1293,7 +1293,7 @@ def test_default_plan_at_the_bench_batch_against_the_oracle():
     kn = m.kernel_names(256)
     assert kn.count('bneck_frame(front1)') == 5 and kn.count('conv_pp256(dual)') == 2 and kn[-1] == 'conv_wfrag(pool)' and kn.count('conv_wfrag') >= 4, kn
     assert len(kn) == len(m.op_names())
-    assert kn.count('chain_wave') == 3 and kn.count('chain_wave128') == 3 and kn.count('bottleneck_chain') == 1, kn      # layer1 | layer2.1-2.3 | layer2.0 (stride 2)
+    assert kn.count('chain_wave') == 3 and kn.count('bottleneck_chain') == 4 and kn.count('chain_wave128') == 0, kn      # layer1 | layer2 (its wave form is opt-in: r06_chain_wave128.txt)
     L = _lib.lib()
     c0 = (L.pvr_debug_bneck_frame_launches(), L.pvr_debug_conv_wfrag_launches(), L.pvr_debug_pp_persistent_launches())
     out = m(torch.from_numpy(fr_np).cuda()).cpu().numpy()
@@ -1314,7 +1314,7 @@ def test_default_plan_at_the_bench_batch_against_the_oracle():
 def test_layer2_wave_form_equals_block_form(dtype, n, monkeypatch):
     """chain_wave128.hip (round 6): layer2's stride-1 tails with wave-owned pixels and the 544 KB of weights streamed through a two-slot LDS ring,
     against the block form (bottleneck_chain.hip) - same rounding points, same K order per accumulator: layer2's output and the embedding bit for
-    bit.  Odd n: the last 32-pixel tile holds a single 16-pixel block; n = 40 / 41: several rounds per workgroup and workgroups with idle waves in
+    bit.  (Opt-in since the end of round 6: measured no faster than the block form, profiles/experiments/r06_chain_wave128.txt; PVR_CHAIN_WAVE_L2=1 selects it.)  Odd n: the last 32-pixel tile holds a single 16-pixel block; n = 40 / 41: several rounds per workgroup and workgroups with idle waves in
     the last round.  The plan's launch list is unchanged (the form is a property of the launch); the launch counter says which form ran."""
     from pvr_habitat_amd.embeddings import HipResNet50
     L = _lib.lib()
