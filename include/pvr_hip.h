@@ -235,6 +235,10 @@ int64_t pvr_debug_conv_split16_launches(void);
 /* launches of the layer2 wave-form tail (chain_wave128.hip: torchvision Bottleneck conv2 -> conv3 + identity -> the next conv1 at Cm = 128, reference
  * src/embeddings.py:118-120) so far (tests: the layer2 plan really took it; PVR_CHAIN_WAVE_L2=0 keeps the block form) */
 int64_t pvr_debug_chain_wave128_launches(void);
+/* debug / A-B: which form of the fused stem (conv1 7x7/2 + bn1 + relu + maxpool, torchvision ResNet stem reached from reference src/embeddings.py:118-120)
+ * runs: 1 the max pool in registers straight from the MFMA accumulators (stem_pool_reg_kernel, default since round 6), 0 the pooling pass over an LDS tile
+ * of rounds 3-5, -1 back to the environment (PVR_STEM_REGPOOL).  Both forms give the same bits.  Process-global. */
+pvr_status pvr_debug_set_stem_regpool(int32_t mode);
 /* debug / A-B: which implicit-GEMM kernel pvr_op_conv2d and the encoder plans use.  -1 = automatic choice by shape
  * (default), 0 = conv_igemm (128x128 tiles) only, 1 / 2 / 3 = conv_pp256 (ping-pong kernel, 256x256 / 128x256 / 224x256 tiles) whenever it
  * accepts the shape.  All kernels accumulate every output in the same K order and give bit-identical results. Process-global. */

@@ -68,6 +68,8 @@ _SIGS = {
     'pvr_op_conv2d_split16': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
     'pvr_op_conv2d_f32': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
     'pvr_debug_conv_split16_launches': (C.c_int64, []),
+    'pvr_debug_set_stem_regpool': (C.c_int, [C.c_int32]),
+    'pvr_debug_chain_wave128_launches': (C.c_int64, []),
     'pvr_op_nonfinite_flag': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 

@@ -66,6 +66,7 @@ pvr_status launch_conv_wfrag(const void *in, const void *wp, const float *bias, 
                              int kh, int kw, int stride, int pad, int act, int out_f32, int dtype, hipStream_t stream, float *pool_out = nullptr,
                              int64_t pool_stride = 0);
 
+void set_stem_regpool(int v);
 long long conv_split16_launches();
 long long chain_wave128_launches();
 pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
@@ -153,6 +154,11 @@ pvr_status pvr_op_conv2d_f32(const float *in, const float *wgt, const float *bia
     return launch_conv_f32(in, wgt, bias, residual, out, n, h, w, cin, cout, k, stride, pad, relu, (hipStream_t)stream);
 }
 int64_t pvr_debug_conv_split16_launches(void) { return (int64_t)conv_split16_launches(); }
+pvr_status pvr_debug_set_stem_regpool(int32_t mode) {
+    PVR_REQUIRE(mode >= -1 && mode <= 1, "pvr_debug_set_stem_regpool: -1 (environment: PVR_STEM_REGPOOL, default on), 0 (LDS-tile pooling) or 1 (register pooling)");
+    set_stem_regpool(mode);
+    return PVR_OK;
+}
 int64_t pvr_debug_chain_wave128_launches(void) { return (int64_t)chain_wave128_launches(); }
 int64_t pvr_debug_pp_persistent_launches(void) { return (int64_t)pp_persistent_launches(); }
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const u16 *__restrict__ 
 // Rows above the image (cr0 = -1 for the first row pair) have a negative source offset: the buffer range check returns zeros; the conv
 // rows they would feed are outside the image and never pooled, as before.
 #ifdef STEM_STAMP
-__device__ long long stem_stamps[8][64][5];
+__device__ long long stem_stamps[8][64][6];
 #define ST_T(i_) { if (blockIdx.x == 13 && blockIdx.y == 1 && lane == 0 && n - n0 < 64) stem_stamps[wave][n - n0][i_] = __builtin_amdgcn_s_memtime(); }
 #else
 #define ST_T(i_)
@@ -377,6 +377,231 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
     }
 }
 
+// Round 6 form of the fused stem: the 3 x 3 / 2 max pool runs IN REGISTERS, straight from the MFMA accumulators.
+//
+// stem_pool_lds_kernel above writes a block's five conv rows (5 x 112 pixels x 64 channels, 70 KB) to LDS, meets a barrier and pools them with all 512 threads:
+// 182 us per 256 frames at 0.13 of BOTH roofs, LDS bank conflicts 0.40 of the LDS cycles, 41 M vector instructions against 7 M MFMAs, one of eight waves idle
+// in the matrix phase (seven 16-column tiles), the matrix phase and the pooling phase strictly one after the other (profiles/r05_sq_counters_conv.txt).
+// Here a wave's 16-column conv tile is cut so that it holds every conv column its pooled columns need: wave w owns pooled columns 7 w .. 7 w + 6 = conv columns
+// 14 w - 1 .. 14 w + 13 (15 of the tile's 16 columns; 8 waves x 7 = the row's 56 pooled columns, all eight waves in the matrix phase).  Then
+//   * vertical max: the three conv rows of a pooled row are the same lane's accumulators of three consecutive row iterations (running max, fp32);
+//   * horizontal max: the neighbouring conv columns are the neighbouring LANES of the 16-lane MFMA row: two DPP row shifts (row_shr:1 / row_shl:1, lanes
+//     without a source keep -inf) - the pooled column 7 w + k sits in lane 2 k + 1;
+//   * bias, ReLU and the 16-bit rounding are applied ONCE, to the maximum: x -> round(relu(x + b)) is monotone, so round(relu(max(acc) + b)) is the element
+//     the old kernel picks among the rounded taps, bit for bit (a -0 is cleared as there); columns / rows outside the image are -inf / skipped;
+//   * the 14 KB of pooled values cross a small LDS tile only to leave as whole 128-byte lines.
+// No conv tile, no pooling pass over it, one quarter of the epilogue conversions.  Same fragments and MFMA order per output pixel as stem_kernel: bit-identical
+// (test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool, test_stem_reading_uint8_frames_...).  PVR_STEM_REGPOOL=0 keeps the LDS-tile form (A/B).
+template <bool F16, bool U8 = false>
+__global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
+                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb, U8Geo u8g = U8Geo{}) {
+    typedef typename HT<F16>::V8 V8;
+    constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
+    constexpr int ROWB = PW * 8;                                     // bytes of one image row (4 channels x 16 bit)
+    constexpr int INB = U8 ? 28672 : 32768;                          // one input-row buffer (15 rows = 27 840 B, copied as 32 x 1 KB)
+    constexpr int RAWROW = 224 * 3, RAWB = 10240;                    // U8: raw crop rows [15][672] uint8 (10 x 1 KB of DMA), three buffers
+    constexpr int PAD = 1024;                                        // (conv column -1 of wave 0 reads 16 bytes in front of a row: keep that inside the allocation)
+    constexpr int IN0 = PAD, RAW0 = IN0 + 2 * INB, OT0 = RAW0 + (U8 ? 3 * RAWB : 0);   // [pad | rows buffer 0 | rows buffer 1 (| raw 0 | raw 1 | raw 2) | pooled tile [2][56][128 B]]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pr0 = blockIdx.x * 2;                                  // pooled rows pr0, pr0+1
+    const int cr0 = 2 * pr0 - 1;                                     // first conv row held (may be -1: above the image)
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    V8 wf[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+            wf[i][s] = *reinterpret_cast<const V8 *>(wgt + (size_t)(i * 16 + px) * STEM_K + s * 32 + g * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4 *>(bias + i * 16 + g * 4);
+    const int n0 = blockIdx.y * ipb, n1 = n0 + ipb < nimg ? n0 + ipb : nimg;
+    auto stage_rows = [&](int n_, int b_) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(img) + (size_t)n_ * PH * PW * 4, 0, (unsigned)(PH * ROWB), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int flat = (wave * 4 + k) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + IN0 + b_ * INB + flat), 16,
+                                                     2 * cr0 * ROWB + flat + lane * 16, 0, 0, 0);
+        }
+    };
+    auto stage_raw = [&](int n_) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(u8g.src) + (size_t)n_ * u8g.img_bytes, 0, (unsigned)u8g.img_bytes, 0x00020000);
+        char *rb = smem + RAW0 + ((n_ - n0) % 3) * RAWB;
+        for (int i = wave; i < 10; i += 8) {
+            const int q = i * 64 + lane, r = q / 42, c = q % 42;
+            const int yi = 2 * cr0 - 3 + r;                               // crop row of padded row 2 cr0 + r
+            const bool ok = q < 630 && yi >= 0 && yi < 224;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(rb + i * 1024), 16,
+                                                     ok ? u8g.off0 + yi * u8g.pitch + c * 16 : 0x7ffffff0, 0, 0, 0);
+        }
+    };
+    auto convert_rows = [&](int n_, int zb_) {
+        const char *rb = smem + RAW0 + ((n_ - n0) % 3) * RAWB;
+        char *zb = smem + IN0 + zb_ * INB;
+        for (int i = tid; i < 15 * 56; i += 512) {
+            const int r = i / 56, k = i - r * 56, yi = 2 * cr0 - 3 + r;
+            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 w = u32x3{0u, 0u, 0u};
+            const bool ok = yi >= 0 && yi < 224;
+            if (ok) w = *reinterpret_cast<const u32x3 *>(rb + r * RAWROW + k * 12);
+            const float one = ok ? 1.0f : 0.f, off = ok ? 128.f : 0.f;
+            float f[12];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                f[4 * d] = (float)(w[d] & 0xffu); f[4 * d + 1] = (float)((w[d] >> 8) & 0xffu);
+                f[4 * d + 2] = (float)((w[d] >> 16) & 0xffu); f[4 * d + 3] = (float)(w[d] >> 24);
+            }
+            char *dst = zb + r * ROWB + (4 * k + 3) * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 o = {pack2_h<F16>(f[3 * q] - off, f[3 * q + 1] - off), pack2_h<F16>(f[3 * q + 2] - off, one)};
+                *reinterpret_cast<uint2 *>(dst + q * 8) = o;
+            }
+        }
+        if (tid < 15 * 8) {                                           // the zero border: padded columns 0..2 and 227..231 of every row
+            const int r = tid >> 3, e = tid & 7, pc = e < 3 ? e : 224 + e;
+            *reinterpret_cast<ushort4 *>(zb + r * ROWB + pc * 8) = make_ushort4(0, 0, 0, 0);
+        }
+    };
+    if constexpr (U8) {
+        for (int k = 0; k < 3; ++k) if (n0 + k < n1) stage_raw(n0 + k);
+    } else {
+        if (n0 < n1) stage_rows(n0, 0);
+        if (n0 + 1 < n1) stage_rows(n0 + 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (U8) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (n0 < n1) convert_rows(n0, 0);
+    }
+    // this lane's conv column and its pooled slot
+    const int col = 14 * wave - 1 + px;                              // conv column of MFMA column px of this wave's tile
+    const bool col_ok = (unsigned)col < (unsigned)OW && px < 15;
+    const bool owner = (px & 1) && px < 15;                          // lane 2 k + 1 holds pooled column 7 w + k
+    const int pc = 7 * wave + (px >> 1);
+    const float NEG = -__builtin_huge_valf();
+    const bool border = wave == 0 || wave == 7;                       // the only tiles with a conv column outside the image (-1 / 112)
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // v_max_f32 as it is: fmaxf() makes hipcc canonicalise both operands first (a v_max x, x each: 96 more vector instructions per image in a kernel that
+    // is bound by vector issue); MFMA results and -inf need no quieting
+    auto vmax = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto vmax3 = [](float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    for (int n = n0; n < n1; ++n) {
+        const int b = (n - n0) & 1;
+        ST_T(0);
+        if constexpr (U8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // convert_rows' LDS stores (previous copy-out phase / prologue)
+        __builtin_amdgcn_s_barrier();                                    // rows buffer b complete; everyone has copied the previous image's pooled tile out
+        __builtin_amdgcn_sched_barrier(0);
+        ST_T(1);
+        // U8: the next image's rows are converted inside this image's matrix phase - by waves 0-3 in front of their MFMAs, by waves 4-7 behind them, so that
+        // each SIMD's two waves (w, w + 4) have vector work and matrix work at different times (raw rows of image n + 1: waited for before barrier 2 of image
+        // n - 1; rows buffer 1 - b: free since that barrier)
+        if constexpr (U8) { if (wave < 4 && n + 1 < n1) convert_rows(n + 1, 1 - b); }
+        const char *rows = smem + IN0 + b * INB;
+        const char *fb = rows + (2 * col + 2 * g) * 8;                   // lane (px, g), filter row s: pixels 2 col + 2 g, + 1 of LDS row 2 lr + s
+        V8 xa[7], xb[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) xa[s] = *reinterpret_cast<const V8 *>(fb + s * ROWB);
+        // The five conv rows of the block: rows 0-2 make pooled row pr0, rows 2-4 pooled row pr0 + 1 (one v_max3 per value and pooled row).  Rows 1-3 are
+        // always inside the image; row 0 is above it in the first block row, row 4 below it in the last (block-uniform).
+        const bool top_ok = cr0 >= 0, bot_ok = cr0 + 4 < OW;
+        f32x4 ra[4], rb[4], rc[4], v0[4], v1[4];
+#define STEM_ROW(dst_, lr_)                                                                                             \
+        {                                                                                                               \
+            V8 (&xc)[7] = ((lr_) & 1) ? xb : xa;                                                                        \
+            V8 (&xnx)[7] = ((lr_) & 1) ? xa : xb;                                                                       \
+            if ((lr_) + 1 < 5) {                                                                                        \
+                _Pragma("unroll") for (int s = 0; s < 7; ++s) xnx[s] = *reinterpret_cast<const V8 *>(fb + (2 * ((lr_) + 1) + s) * ROWB); \
+            }                                                                                                           \
+            _Pragma("unroll") for (int s = 0; s < 7; ++s)                                                               \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) dst_[i] = mfma16<F16>(wf[i][s], xc[s], s == 0 ? zero : dst_[i]); \
+            if (border) {                              /* (wave-uniform) columns outside the image never win */         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) dst_[i][e] = col_ok ? dst_[i][e] : NEG;               \
+            }                                                                                                           \
+        }
+        if (top_ok) STEM_ROW(ra, 0)
+        else {                                                           // (keeps the fragment double-buffering in step: row 1 reads the other set)
+#pragma unroll
+            for (int s = 0; s < 7; ++s) xb[s] = *reinterpret_cast<const V8 *>(fb + (2 + s) * ROWB);
+        }
+        STEM_ROW(rb, 1)
+        STEM_ROW(rc, 2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v0[i][e] = top_ok ? vmax3(ra[i][e], rb[i][e], rc[i][e]) : vmax(rb[i][e], rc[i][e]);
+        STEM_ROW(ra, 3)
+        if (bot_ok) {
+            STEM_ROW(rb, 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v1[i][e] = vmax3(rc[i][e], ra[i][e], rb[i][e]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v1[i][e] = vmax(rc[i][e], ra[i][e]);
+        }
+#undef STEM_ROW
+        // horizontal max over conv columns col - 1, col, col + 1 = lanes px - 1, px, px + 1 of the 16-lane row (the DPP shift rides in the max instruction);
+        // then bias, ReLU, rounding - once
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ve = pr ? v1[i][e] : v0[i][e];
+                    float t;
+                    // (lanes 0 / 15 of a row have no left / right source: the instruction leaves their result undefined - the owners of a pooled column are lanes 1, 3 .. 13)
+                    asm("v_max_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(ve), "v"(ve));      // max(lane px - 1, lane px)
+                    asm("v_max_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(h[e]) : "v"(ve), "v"(t));    // max(lane px + 1, that)
+                }
+                if (owner) {
+                    const uint2 o = {pack2_h<F16>(vmax(h[0] + bv[i].x, 0.f), vmax(h[1] + bv[i].y, 0.f)) & 0x7fff7fffu,
+                                     pack2_h<F16>(vmax(h[2] + bv[i].z, 0.f), vmax(h[3] + bv[i].w, 0.f)) & 0x7fff7fffu};
+                    const int c16 = i * 2 + (g >> 1);                    // 16-byte chunk of channels 16 i + 4 g .. + 3
+                    *reinterpret_cast<uint2 *>(smem + OT0 + (pr * PO + pc) * 128 + ((c16 ^ (pc & 7)) << 4) + (g & 1) * 8) = o;
+                }
+            }
+        }
+        if constexpr (U8) { if (wave >= 4 && n + 1 < n1) convert_rows(n + 1, 1 - b); }
+        ST_T(2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the rows of image n + 1 (and this wave's older stores) have landed; the pooled tile is written
+        ST_T(3);
+        __builtin_amdgcn_s_barrier();                                    // pooled tile complete; every wave has finished with rows buffer b
+        __builtin_amdgcn_sched_barrier(0);
+        ST_T(4);
+        if constexpr (U8) {
+            if (n + 3 < n1) stage_raw(n + 3);
+        } else {
+            if (n + 2 < n1) stage_rows(n + 2, b);                        // (travels under the copy-out and the next image's MFMAs)
+        }
+        // the pooled tile leaves as whole 128-byte lines: 2 rows x 56 columns x 8 chunks of 16 bytes
+        for (int o = tid; o < 2 * PO * 8; o += 512) {
+            const int k = o & 7, pcc = (o >> 3) % PO, pr = o / (8 * PO);
+            const u32x4 vv = *reinterpret_cast<const u32x4 *>(smem + OT0 + (pr * PO + pcc) * 128 + ((k ^ (pcc & 7)) << 4));
+            u32x4 *const dst = reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pcc) * STEM_CO + k * 8);
+            if constexpr (PVR_NT & 128) __builtin_nontemporal_store(vv, dst);
+            else *dst = vv;
+        }
+        ST_T(5);
+    }
+}
+#ifdef STEM_STAMP
+}  // namespace pvr
+extern "C" int pvr_debug_stem_stamps(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pvr::stem_stamps), sizeof(pvr::stem_stamps)); }
+namespace pvr {
+#endif
+
 // maxpool 3x3 stride 2 pad 1, NHWC, 8 channels (16 B) per thread.  Inputs are post-ReLU but the
 // kernel is general: out-of-range taps are skipped (-inf padding as torch does).
 template <bool F16>
@@ -514,6 +739,14 @@ pvr_status launch_stem(const void *img, const void *wgt, const float *bias, void
 
 // Fused form for frames that need no resize: uint8 NHWC frames [n][h][w][3] in, pooled stem output out; (top, left) = crop origin.
 // stem_pool_u8_ok: the geometry fits the kernel's 16-byte row DMA (the PVR_STEM_U8 / PVR_STEM_LDS switches are the encoder's: PlanSwitches).
+// PVR_STEM_REGPOOL=0: the LDS-tile pooling of rounds 3-5 (A/B; both forms are bit-identical).  Process-wide, read once.
+static bool stem_regpool() {
+    static const bool on = [] { const char *e = getenv("PVR_STEM_REGPOOL"); return !e || atoi(e) != 0; }();
+    return on;
+}
+static int g_stem_regpool_override = -1;                         // pvr_debug_set_stem_regpool: -1 environment, 0 / 1 forced (the A/B test flips it inside one process)
+void set_stem_regpool(int v) { g_stem_regpool_override = v; }
+static bool stem_regpool_now() { return g_stem_regpool_override >= 0 ? g_stem_regpool_override != 0 : stem_regpool(); }
 bool stem_pool_u8_ok(const void *frames, int h, int w, int top, int left) {
     // 16-byte row DMA: every source chunk aligned; the crop window inside the frame (an out-of-frame window would read wrong rows, not fail)
     return ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&
@@ -527,15 +760,25 @@ pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int t
     const int ipb_fit = (n + yb - 1) / yb;
     const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
-    const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240;
+    const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240, lds_reg = 1024 + 2 * 28672 + 3 * 10240 + 2 * 56 * 128;
     static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
     if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_reg_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_reg_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg));
         attr_done.mark();
     }
     U8Geo g;
     g.src = frames; g.pitch = w * 3; g.img_bytes = h * w * 3; g.off0 = (top * w + left) * 3;
+    if (stem_regpool_now()) {                                    // round 6: the max pool in registers (stem_pool_reg_kernel)
+        if (dtype == PVR_F16)
+            hipLaunchKernelGGL((stem_pool_reg_kernel<true, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
+        else
+            hipLaunchKernelGGL((stem_pool_reg_kernel<false, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
+        PVR_LAUNCH_CHECK();
+        return PVR_OK;
+    }
     if (dtype == PVR_F16)
         hipLaunchKernelGGL((stem_pool_lds_kernel<true, true>), grid, dim3(512), lds, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
     else
@@ -556,6 +799,21 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
     const int ipb_fit = (n + yb - 1) / yb;
     const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB && use_lds ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
+    if (use_lds && stem_regpool_now()) {                         // round 6: the max pool in registers (stem_pool_reg_kernel), padded 16-bit image in
+        const size_t lds_reg = 1024 + 2 * 32768 + 2 * 56 * 128;
+        static DeviceOnce attr3_done;
+        if (attr3_done.needed()) {
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_reg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg));
+            PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_reg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg));
+            attr3_done.mark();
+        }
+        if (dtype == PVR_F16)
+            hipLaunchKernelGGL(stem_pool_reg_kernel<true>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+        else
+            hipLaunchKernelGGL(stem_pool_reg_kernel<false>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+        PVR_LAUNCH_CHECK();
+        return PVR_OK;
+    }
     if (use_lds) {
         const size_t lds = 5 * 112 * 128 + 2 * 32768;
         static bool attr2_done = false;

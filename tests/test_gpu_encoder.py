@@ -1341,3 +1341,34 @@ def test_layer2_wave_form_equals_block_form(dtype, n, monkeypatch):
     assert torch.isfinite(got['block'][0]).all() and float(got['block'][0].abs().max()) > 0
     for a, b, what in ((got['wave'][0], got['block'][0], 'layer2'), (got['wave'][1], got['block'][1], 'embedding')):
         assert torch.equal(a, b), (what, int((a != b).sum()), float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize('dt,n', [('f16', 3), ('bf16', 9), ('f16', 33)])
+def test_stem_register_pooling_equals_the_lds_tile_form(dt, n):
+    """stem_pool_reg_kernel (round 6: the 3 x 3 / 2 max pool taken in registers from the MFMA accumulators - running max over the conv rows, DPP row shifts
+    over the conv columns, bias / ReLU / rounding applied once to the maximum) against stem_pool_lds_kernel (conv rows to an LDS tile, pooling pass over it):
+    the pooled stem output and the embedding bit for bit, for the uint8-reading form (256 x 256 frames, every crop window) and the padded-image form
+    (frames that are resized first).  x -> round(relu(x + b)) is monotone, so the maximum commutes with it."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    L = _lib.lib()
+    sd = synth.resnet50_state_dict(1, 'conv5')
+    m = HipResNet50(sd, 'conv5', compute_dtype=dt, max_batch=max(8, n))
+    cases = [(torch.from_numpy(synth.frames(90 + n, n, 256, 256)).cuda(), pos) for pos in (0, 1, 4)]          # uint8 form: no resize
+    cases += [(torch.from_numpy(synth.smooth_frames(91 + n, n, 128, 160)).cuda(), 0)]                          # padded-image form: Resize(256) first
+    try:
+        for fr, pos in cases:
+            m.set_crop(pos)
+            got = {}
+            for mode in (1, 0):
+                _lib.check(L.pvr_debug_set_stem_regpool(mode))
+                m.debug_stop_after('pool'); m(fr)
+                pool = m.tap('pool', n * 56 * 56 * 64).clone()
+                m.debug_stop_after('')
+                got[mode] = (pool, m(fr).clone())
+            assert torch.isfinite(got[0][0]).all() and float(got[0][0].abs().max()) > 0
+            assert torch.equal(got[1][0], got[0][0]), ('pool', pos, int((got[1][0] != got[0][0]).sum()))
+            assert torch.equal(got[1][1], got[0][1]), ('embedding', pos, int((got[1][1] != got[0][1]).sum()))
+    finally:
+        _lib.check(L.pvr_debug_set_stem_regpool(-1))
+        m.set_crop(0)
+        m.close()
