@@ -150,6 +150,13 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames_dev, int3
  * pvr_encoder_profile serialise the dispatcher for a few microseconds each, which this figure does not contain. */
 pvr_status pvr_encoder_profile_span(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, float *out_dev,
                                     int64_t out_stride, void *hip_stream, int32_t first_op, int32_t last_op, float *span_ms);
+/* Load-time range validation of the 16-bit storage types (the reference computes in fp32, src/embeddings.py:386-402; f16 has 5 exponent bits): one forward of
+ * the UNFUSED plan with every launch's output checked for inf / NaN.  An overflow inside the network does not always reach the embedding (+inf x a negative
+ * weight = -inf, and ReLU maps -inf and NaN to 0), so a finite check of the output alone can miss it.  *first_bad = index of the first launch whose output is
+ * non-finite (pvr_encoder_launch_name numbering of the unfused plan; its name says which convolution) or -1.  n <= chunk frames; synchronises; the embeddings of
+ * this forward are written to out_dev as usual.  ResNet family, 16-bit plans. */
+pvr_status pvr_encoder_check_range(pvr_encoder *enc, const uint8_t *frames_dev, int32_t n, int32_t h, int32_t w, float *out_dev, int64_t out_stride,
+                                   void *hip_stream, int32_t *first_bad);
 /* Debug / A-B: the run-time switches of a finalized encoder - "pool_fuse" (the trunk's last convolution writes the average pool itself), "stem_u8" (the
  * fused stem reads uint8 frames that need no resize), "frame_min_n" (frames per forward from which layer3 runs one workgroup per frame).  Every other
  * PVR_* switch shapes the plan and is read from the environment ONCE, in pvr_encoder_create; nothing reads the environment on the forward path. */

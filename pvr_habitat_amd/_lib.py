@@ -62,6 +62,7 @@ _SIGS = {
     'pvr_op_conv2d_dual': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 15 + [C.c_void_p]),
     'pvr_op_pack_frag_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'pvr_debug_bneck_frame_stamps': (C.c_int, [C.c_void_p] * 12 + [C.c_int32] * 2 + [C.c_void_p] * 2),
+    'pvr_encoder_check_range': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]),
     'pvr_encoder_debug_set_switch': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     'pvr_encoder_launch_kernel': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
     'pvr_op_split16_pack_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

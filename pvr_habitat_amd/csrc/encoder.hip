@@ -39,6 +39,25 @@ static void read_switches(PlanSwitches &sw) {
     sw.fuse = get("PVR_FUSE", 1);
 }
 
+// f16 range validation (pvr_encoder_check_range): any inf / NaN among the first `n` 16-bit (or fp32) values of a launch's output -> flags[idx] = 1
+template <bool F32>
+__global__ __launch_bounds__(256) void range_flag_kernel(const void *x, size_t n8, int dtype, int *flags, int idx) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        if constexpr (F32) {
+            const u32x4 a = reinterpret_cast<const u32x4 *>(x)[2 * i], b = reinterpret_cast<const u32x4 *>(x)[2 * i + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (a[e] & 0x7f800000u) == 0x7f800000u || (b[e] & 0x7f800000u) == 0x7f800000u;
+        } else {
+            const u32x4 a = reinterpret_cast<const u32x4 *>(x)[i];
+            const unsigned em = dtype == PVR_F16 ? 0x7c00u : 0x7f80u;          // exponent field all ones: inf or NaN
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= ((a[e] & em) == em) || (((a[e] >> 16) & em) == em);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flags + idx, 1);
+}
+
 const char *launch_kind_name(int k) {
     static const char *nm[] = {"conv", "bneck_frame(front1)", "bneck_frame", "frame_members", "conv_pp256(dual)", "dual_members", "chain", "cast",
                                "conv_f32", "conv_split16", "splitk(small)", "splitk", "conv_expand(blocked)", "conv_wfrag(pool)", "conv_wfrag"};
@@ -1037,6 +1056,10 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         }
         // conv1 + bn1 + relu + maxpool fused: the 112x112x64 activation stays in LDS
         if (!fused_u8 && (s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st))) return s;
+        if (enc->range_flags) {                      // pvr_encoder_check_range: the pooled stem output (flag slot behind the plan's launches)
+            const size_t n8 = (size_t)nb * 56 * 56 * 64 / 8;
+            hipLaunchKernelGGL(range_flag_kernel<false>, dim3(2048), dim3(256), 0, st, enc->d_buf[B_X0], n8, dt, enc->range_flags, (int)cur_plan(enc).size());
+        }
         if ((s = mark())) return s;
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
@@ -1156,6 +1179,13 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                                 op.cin, op.cout, op.k, op.k, op.stride, op.pad, op.relu, op.out_f32, dt, st);
             }
             if (s) return s;
+            if (enc->range_flags && kind != LK_WFRAG_POOL) {         // pvr_encoder_check_range: the launch's output, all of it
+                const int ho_ = (op.h + 2 * op.pad - op.k) / op.stride + 1, wo_ = (op.w + 2 * op.pad - op.k) / op.stride + 1;
+                const size_t n8 = (size_t)nb * ho_ * wo_ * op.cout / 8;
+                const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+                if (op.out_f32 & 1) hipLaunchKernelGGL(range_flag_kernel<true>, dim3(blocks), dim3(256), 0, st, enc->d_buf[op.out_buf], n8, dt, enc->range_flags, (int)li);
+                else hipLaunchKernelGGL(range_flag_kernel<false>, dim3(blocks), dim3(256), 0, st, enc->d_buf[op.out_buf], n8, dt, enc->range_flags, (int)li);
+            }
             if ((s = mark())) return s;
             if (!enc->stop_after.empty() && op.tap == enc->stop_after) { stopped = true; break; }
             if (launch_idx++ == stop_idx) { stopped = true; break; }
@@ -1334,6 +1364,42 @@ pvr_status pvr_encoder_debug_set_switch(pvr_encoder *enc, const char *name, int3
     else { set_error("pvr_encoder_debug_set_switch: '%s' is not a live switch (pool_fuse, stem_u8, frame_min_n); plan switches are read from the environment at create", name); return PVR_ERR_INVALID; }
     if (enc->finalized && !enc->vit && !enc->rnd && !enc->host) resolve_kinds(enc);
     return PVR_OK;
+}
+
+// Range validation of the 16-bit storage types (f16: 5 exponent bits).  A non-finite EMBEDDING is caught by the callers' finite check, but an activation that
+// overflows INSIDE the network need not reach the output: +inf times a negative weight is -inf, -inf or NaN through fmaxf(v, 0) is 0 - a wrong, finite
+// embedding.  This runs ONE forward of the unfused plan (every convolution's output exists in HBM and is bit-identical to what the fused launches compute
+// internally) and checks every launch's output for inf / NaN; *first_bad = index of the first such launch (pvr_encoder_launch_name's numbering of the
+// UNFUSED plan, 3 = the first convolution) or -1.  Synchronises; allocates and frees its flag buffer: a load-time check, not part of the forward path.
+pvr_status pvr_encoder_check_range(pvr_encoder *enc, const uint8_t *frames, int32_t n, int32_t h, int32_t w, float *out, int64_t out_stride, void *hip_stream,
+                                   int32_t *first_bad) {
+    PVR_REQUIRE(enc && frames && out && first_bad, "pvr_encoder_check_range: null argument");
+    PVR_NO_HOST(enc, "pvr_encoder_check_range");
+    PVR_REQUIRE(enc->finalized && !enc->vit && !enc->rnd && enc->desc.arch != PVR_ARCH_CLIP_RN50 && enc->desc.dtype != PVR_F32,
+                "pvr_encoder_check_range: built for the 16-bit plans of the torchvision ResNet family");
+    PVR_REQUIRE(n > 0 && n <= enc->desc.chunk, "pvr_encoder_check_range: n=%d must fit one chunk (%d)", n, enc->desc.chunk);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t nl = enc->sched_plain.size();
+    pvr_status s = use_lane(enc, 0);
+    if (!s) s = lane_wait(enc, 0, hip_stream);
+    if (s) return s;
+    int *flags = nullptr;
+    PVR_HIP_TRY(hipMalloc((void **)&flags, (nl + 1) * sizeof(int)));
+    if (hipMemsetAsync(flags, 0, (nl + 1) * sizeof(int), st) != hipSuccess) { (void)hipFree(flags); set_error("check_range: memset failed"); return PVR_ERR_HIP; }
+    const bool fuse0 = enc->fuse;
+    enc->fuse = false; resolve_kinds(enc);
+    enc->range_flags = flags;
+    s = forward_impl(enc, frames, n, h, w, out, out_stride, hip_stream, nullptr);
+    enc->range_flags = nullptr;
+    enc->fuse = fuse0; resolve_kinds(enc);
+    std::vector<int> hf(nl + 1, 0);
+    if (!s && hipMemcpyAsync(hf.data(), flags, (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("check_range: copy failed"); s = PVR_ERR_HIP; }
+    if (!s && hipStreamSynchronize(st) != hipSuccess) { set_error("check_range: sync failed"); s = PVR_ERR_HIP; }
+    (void)hipFree(flags);
+    if (s) return s;
+    *first_bad = hf[nl] ? 1 : -1;                               // 1 = "stem" (conv1 + bn1 + relu + maxpool)
+    for (size_t i = 0; i < nl && *first_bad < 0; ++i) if (hf[i]) *first_bad = (int32_t)i + 3;
+    return lane_mark(enc, 0, hip_stream);
 }
 
 // name of the kernel family launch `index` (the order pvr_encoder_profile reports) runs as in a forward of n frames; returns its length, 0 past the end

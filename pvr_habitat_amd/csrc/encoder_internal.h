@@ -155,6 +155,7 @@ struct pvr_encoder {
     std::vector<uint8_t> kinds;                     // LaunchKind of launch i for a forward of nb frames: kinds[(nb - 1) * plan.size() + i] (resolve_kinds)
     size_t kinds_stride = 0;
     int kinds_algo = -2;                            // conv_algo() the table was resolved under
+    int *range_flags = nullptr;                     // pvr_encoder_check_range: per-launch "output holds inf / NaN" flags of the forward in progress (else null)
     bool last_pooled = false;                       // the last forward wrote the pooled rows from the last convolution: the B_F32 tap does not exist
     float *d_smallk[PVR_MAX_LANES] = {nullptr};     // the low-latency plan's fp32 partial planes, per lane (pvr_encoder_set_low_latency / first use of a lane: never in a forward)
     bool tail32 = false;                            // round 3: + the last trunk stage entirely in fp32 (conv_f32.hip), fp32 stream one stage earlier

@@ -79,7 +79,9 @@ _CLIP = {'clip_vit': ('clip_b32', 'ViT-B-32.pt', 32), 'clip_vit_b16': ('clip_b16
 def _dtype_from_env(compute_dtype=None):
     # Default f16 (round 5): the reference is fp32 and the north star asks for embeddings within 1e-3 of it; f16 storage (11-bit significand)
     # measures 4e-4 at the same rate as bf16 (8-bit significand, 3e-3).  A checkpoint whose activations leave f16's range raises
-    # FloatingPointError (_checked) naming compute_dtype='bf16' as the way out - nothing is clipped silently.
+    # FloatingPointError naming compute_dtype='bf16' as the way out: every output batch is checked for non-finite values (_checked / the device flag of
+    # stream_embed), and - because an overflow INSIDE the network can be turned into a finite value by the next ReLU - the first frames a net embeds run
+    # once through pvr_encoder_check_range, which checks every convolution's output (EmbeddingNet.validate_range).  Later batches rely on the output check.
     d = (compute_dtype or os.environ.get('PVR_DTYPE', 'f16')).lower()
     if d in ('bf16', 'bfloat16'):
         return _lib.PVR_BF16
@@ -306,6 +308,30 @@ class HipResNet50(_Node):
         if self._handle is None:
             self._build()
         _lib.check(_lib.lib().pvr_encoder_debug_set_switch(self._handle, name.encode(), int(value)))
+
+    def check_range(self, frames_u8):
+        """Load-time validation of the 16-bit storage range on real frames (pvr_encoder_check_range): one forward of the UNFUSED plan with every launch's
+        output checked for inf / NaN - an overflow inside the network can be turned into a finite, wrong embedding by the next ReLU, which the finite check of
+        the output cannot see.  Returns the name of the first convolution whose output is non-finite, or None.  ResNet family, 16-bit plans."""
+        if self._handle is None:
+            self._build()
+        n = min(int(frames_u8.shape[0]), self._chunk or self._max_batch)
+        fr = frames_u8[:n].contiguous()
+        out = torch.empty((n, self.out_size), dtype=torch.float32, device=fr.device)
+        bad = C.c_int32(-1)
+        _lib.check(_lib.lib().pvr_encoder_check_range(self._handle, C.c_void_p(fr.data_ptr()), n, fr.shape[1], fr.shape[2], C.c_void_p(out.data_ptr()),
+                                                      out.stride(0), _lib.stream_ptr(), C.byref(bad)))
+        if bad.value < 0:
+            return None
+        if bad.value < 3:
+            return 'conv1+bn1+relu+maxpool'
+        fused = None
+        try:                                      # names of the unfused plan
+            self.set_fusion(False)
+            names = self.op_names()
+        finally:
+            self.set_fusion(True)
+        return names[bad.value - 3] if bad.value - 3 < len(names) else 'launch %d' % bad.value
 
     def set_crop(self, pos):
         """0 = centre crop (reference), 1..4 = tl / tr / bl / br corner windows (pvr_encoder_set_crop_position)"""
@@ -569,7 +595,27 @@ class EmbeddingNet(nn.Module):
         if not self._host:
             _lib.require_gpu()
         observation = observation.to(device=self.device, non_blocking=True).contiguous()
+        if not self._host and not getattr(self, '_range_checked', False):
+            self._range_checked = True
+            self.validate_range(observation)
         return self._forward(observation)
+
+    def validate_range(self, observation_dev, max_frames=8):
+        """ONE-OFF, on the first frames this net embeds (PVR_RANGE_CHECK=0 skips it): every f16 ResNet member runs pvr_encoder_check_range on up to
+        `max_frames` of them.  The reference is fp32 (src/embeddings.py:386-402); f16 storage has 5 exponent bits, and an activation that overflows inside the
+        network can come out as a finite, wrong embedding (ReLU maps -inf and NaN to 0) - this names the convolution instead.  It validates THESE frames with
+        THIS checkpoint, not every later batch; the per-batch finite check of the outputs stays."""
+        if os.environ.get('PVR_RANGE_CHECK', '1') == '0':
+            return
+        members = []
+        for m in [self.embedding] + [x for x in getattr(self.embedding, 'model', [])]:
+            members += list(getattr(m, 'models', [m]))
+        for m in members:
+            if isinstance(m, HipResNet50) and m._dtype == _lib.PVR_F16 and m.variant in ('conv5', 'conv4', 'conv3', 'r18', 'r34'):
+                bad = m.check_range(observation_dev[:max_frames])
+                if bad is not None:
+                    raise FloatingPointError("activations of '%s' leave the f16 range on these frames (first non-finite output: %s): "
+                                             "use compute_dtype='bf16' (8 exponent bits) or 'f32' for this checkpoint" % (self.embedding_name, bad))
 
     def forward(self, observation):
         if self.embedding_name == 'true_state':
@@ -673,6 +719,9 @@ def stream_embed(net, frames_u8, batch=256, out=None, depth=4, stage_threads=Non
     for s_ in (h2d, d2h, *comps):
         s_.wait_stream(torch.cuda.current_stream())          # whatever the caller queued (e.g. a forward on the default stream) comes first
     model = net.embedding
+    if hasattr(net, 'validate_range') and not getattr(net, '_range_checked', False) and not getattr(net, '_host', False) and n > 0:
+        net._range_checked = True                           # the one-off f16 range validation on the first frames of the stream (EmbeddingNet.validate_range)
+        net.validate_range(x[:8, :, :, :3].to(device=dev).contiguous())
     two_lanes = getattr(model, 'lanes', 1) >= 2 and os.environ.get('PVR_STREAM_LANES', '2') != '1'
     depth = max(2, min(int(depth), (n + batch - 1) // batch + 1))
     device_src = x.is_cuda                                  # frames already in HBM (PNG source decoded on the GPU): no upload at all

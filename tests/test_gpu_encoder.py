@@ -639,6 +639,18 @@ def test_f16_activation_range(monkeypatch):
     from pvr_habitat_amd.embeddings import stream_embed
     with pytest.raises(FloatingPointError):                    # the streaming path checks every batch on the device (pvr_op_nonfinite_flag)
         stream_embed(net, torch.from_numpy(np.concatenate([fr, fr, fr])), batch=4)
+    # round 6: the load-time validation names WHERE the range is left (pvr_encoder_check_range: every launch's output of the unfused plan), because an overflow
+    # inside the network need not reach the embedding - ReLU maps -inf and NaN to 0
+    assert m.check_range(torch.from_numpy(fr).cuda()) is None                      # the in-range checkpoint: clean
+    assert torch.equal(m(torch.from_numpy(fr).cuda()), torch.from_numpy(out).cuda())   # ... and the fused plan is back afterwards
+    mo = HipResNet50(scaled(16 * S), 'conv5', compute_dtype='f16', max_batch=4)
+    where = mo.check_range(torch.from_numpy(fr).cuda())
+    print('[f16 range] 16x larger: first non-finite launch output: %s' % where)
+    assert where is not None and (where.startswith('layer') or where.startswith('conv1'))
+    net2 = EmbeddingNet('resnet50', pretrained=False, compute_dtype='f16', max_batch=4)
+    net2.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
+    with pytest.raises(FloatingPointError, match='first non-finite output: ' + where.split('+')[0].replace('.', r'\.')):
+        net2(torch.from_numpy(fr))
     netb = EmbeddingNet('resnet50', pretrained=False, compute_dtype='bf16', max_batch=4)
     netb.embedding.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scaled(16 * S).items()})
     ob = netb(torch.from_numpy(fr))
