@@ -71,7 +71,8 @@ long long conv_split16_launches();
 long long chain_wave128_launches();
 pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
 pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
-                               int cout, int k, int stride, int pad, int relu, hipStream_t stream);
+                               int cout, int k, int stride, int pad, int relu, hipStream_t stream, float *out2 = nullptr, int n1 = 0, void *out16 = nullptr,
+                               int terms = 3);
 pvr_status launch_conv_f32(const float *, const float *, const float *, const float *, float *, int, int, int, int, int, int, int, int, int, hipStream_t);
 
 static void *g_zero = nullptr;

@@ -29,13 +29,20 @@ struct ConvS {
     const float *in, *bias, *res;
     const u16 *w;
     float *out;
+    // pair form (two convolutions of the SAME input in one launch: the compression head's conv1 and downsample): couts < n1 go to `out` (row stride n1, with
+    // the activation), couts >= n1 to out2 (row stride Cout - n1, no activation); out16: 16-bit output (f16, row stride Cout) instead of fp32
+    float *out2 = nullptr;
+    int n1 = 0;
+    u16 *out16 = nullptr;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, M, relu, n_ctiles, nsteps;
     unsigned in_bytes, w_bytes;
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN>
+// TERMS = 3: the exact split product above.  TERMS = 1: a_hi w_hi only - an ordinary 16-bit convolution that reads its fp32 input itself (the rounding of the
+// operand to f16 happens in the staging pass: the fp32 -> 16-bit copy launch of the residual stream is gone) with the 16-bit plan's own weights (w_hi = f16(w)).
+template <int BM, int BN, int TERMS = 3>
 __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
     constexpr int NWC = BN / 16, NWP = 8 / NWC, WP = BM / NWP, JT = WP / 16, RPT = BM / 64;
     static_assert(NWC * NWP == 8 && WP % 16 == 0 && RPT >= 1, "tile shape");
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0));           \
         }                                                                                                        \
         n_hi = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off, (ks_) * 2048, 0));   \
-        n_lo = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off + 1024, (ks_) * 2048, 0)); \
+        if constexpr (TERMS == 3) n_lo = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off + 1024, (ks_) * 2048, 0)); \
         if (++cs == cpt) { cs = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }                                  \
     }
 #define PVR_S_STORE(buf_)                                                                                        \
@@ -93,10 +100,12 @@ __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
         _Pragma("unroll") for (int i = 0; i < RPT; ++i) {                                                        \
             const unsigned h01 = pack2_h<true>(ra[i][0], ra[i][1]), h23 = pack2_h<true>(ra[i][2], ra[i][3]);     \
             const pk_f16x2 q01 = __builtin_bit_cast(pk_f16x2, h01), q23 = __builtin_bit_cast(pk_f16x2, h23);     \
-            const unsigned l01 = pack2_h<true>((ra[i][0] - (float)q01[0]) * 2048.f, (ra[i][1] - (float)q01[1]) * 2048.f); \
-            const unsigned l23 = pack2_h<true>((ra[i][2] - (float)q23[0]) * 2048.f, (ra[i][3] - (float)q23[1]) * 2048.f); \
             *reinterpret_cast<uint2 *>(&sm[buf_][0][s_off[i]]) = make_uint2(h01, h23);                           \
-            *reinterpret_cast<uint2 *>(&sm[buf_][1][s_off[i]]) = make_uint2(l01, l23);                           \
+            if constexpr (TERMS == 3) {                                                                          \
+                const unsigned l01 = pack2_h<true>((ra[i][0] - (float)q01[0]) * 2048.f, (ra[i][1] - (float)q01[1]) * 2048.f); \
+                const unsigned l23 = pack2_h<true>((ra[i][2] - (float)q23[0]) * 2048.f, (ra[i][3] - (float)q23[1]) * 2048.f); \
+                *reinterpret_cast<uint2 *>(&sm[buf_][1][s_off[i]]) = make_uint2(l01, l23);                       \
+            }                                                                                                    \
         }                                                                                                        \
     }
     f32x4 acc0[JT], acc1[JT];
@@ -116,10 +125,12 @@ __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const f16x8 bh = *reinterpret_cast<const f16x8 *>(Bh + j * 128);
-            const f16x8 bl = *reinterpret_cast<const f16x8 *>(Bl + j * 128);
             acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh, acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl, acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh, acc1[j], 0, 0, 0);
+            if constexpr (TERMS == 3) {
+                const f16x8 bl = *reinterpret_cast<const f16x8 *>(Bl + j * 128);
+                acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl, acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh, acc1[j], 0, 0, 0);
+            }
         }
         if (more) { PVR_S_STORE(cur ^ 1); a_hi = n_hi; a_lo = n_lo; }
         __syncthreads();
@@ -131,23 +142,29 @@ __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
     const int co = n0 + wc * 16 + fq * 4;
     if (co >= p.Cout) return;
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    // pair form: this wave's 16 couts belong to one of the two outputs (n1 is a multiple of 16)
+    const bool second = p.out2 && co >= p.n1;
+    float *const obase = second ? p.out2 : p.out;
+    const int ostride = p.out2 ? (second ? p.Cout - p.n1 : p.n1) : p.Cout, oc = second ? co - p.n1 : co;
+    const bool relu = p.relu && !second;
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int m = m0 + wp * WP + j * 16 + fr;
         if (m >= p.M) continue;
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc0[j][r] + acc1[j][r] * (1.f / 2048.f) + bv[r];
+        for (int r = 0; r < 4; ++r) v[r] = (TERMS == 3 ? acc0[j][r] + acc1[j][r] * (1.f / 2048.f) : acc0[j][r]) + bv[r];
         if (p.res) {
             const f32x4 rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.Cout + co);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
-        if (p.relu) {
+        if (relu) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.Cout + co) = v;
+        if (p.out16) *reinterpret_cast<uint2 *>(p.out16 + (size_t)m * p.Cout + co) = make_uint2(pack2_h<true>(v[0], v[1]), pack2_h<true>(v[2], v[3]));
+        else *reinterpret_cast<f32x4 *>(obase + (size_t)m * ostride + oc) = v;
     }
 }
 
@@ -183,13 +200,16 @@ bool conv_split16_supported(int cin, int cout, int k) { return cin % 32 == 0 && 
 static long long g_split16_launches = 0;
 long long conv_split16_launches() { return g_split16_launches; }
 
-// in / res / out: fp32 NHWC (out and res with row stride cout); wsp: launch_split16_pack of the (cout rounded up to 64, k k cin) fp32 weights
+// in / res / out: fp32 NHWC (out and res with row stride cout); wsp: launch_split16_pack of the (cout rounded up to 64, k k cin) fp32 weights.
+// out2 / n1: the pair form (see ConvS); out16: 16-bit output instead of `out`; terms: 3 = the exact split product, 1 = a 16-bit convolution of an fp32 input
 pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
-                               int cout, int k, int stride, int pad, int relu, hipStream_t stream) {
-    PVR_REQUIRE(in && wsp && bias && out, "conv_split16: null argument");
+                               int cout, int k, int stride, int pad, int relu, hipStream_t stream, float *out2, int n1, void *out16, int terms) {
+    PVR_REQUIRE(in && wsp && bias && (out || out16), "conv_split16: null argument");
     PVR_REQUIRE(conv_split16_supported(cin, cout, k), "conv_split16: cin %d must be a multiple of 32, cout %d of 16, k %d in 1..3", cin, cout, k);
+    PVR_REQUIRE(terms == 3 || terms == 1, "conv_split16: terms must be 3 or 1");
+    PVR_REQUIRE(!out2 || (n1 > 0 && n1 < cout && n1 % 16 == 0 && !res && !out16), "conv_split16 (pair form): n1 must split the couts at a multiple of 16, no residual");
     ConvS p;
-    p.in = in; p.w = (const u16 *)wsp; p.bias = bias; p.res = res; p.out = out;
+    p.in = in; p.w = (const u16 *)wsp; p.bias = bias; p.res = res; p.out = out; p.out2 = out2; p.n1 = n1; p.out16 = (u16 *)out16;
     p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.KH = k; p.KW = k; p.stride = stride; p.pad = pad;
     p.Ho = (h + 2 * pad - k) / stride + 1; p.Wo = (w + 2 * pad - k) / stride + 1;
     const int cout_pad = (cout + 63) / 64 * 64;
@@ -198,17 +218,23 @@ pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bi
     p.M = (int)M; p.relu = relu; p.in_bytes = (unsigned)inb; p.w_bytes = (unsigned)wb; p.nsteps = k * k * cin / 32;
     static const int cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
     ++g_split16_launches;
+#define PVR_S16_LAUNCH(BM_, BN_, grid_)                                                                                              \
+    {                                                                                                                                \
+        if (terms == 3) hipLaunchKernelGGL((conv_split16_kernel<BM_, BN_, 3>), dim3((unsigned)(grid_)), dim3(512), 0, stream, p);    \
+        else hipLaunchKernelGGL((conv_split16_kernel<BM_, BN_, 1>), dim3((unsigned)(grid_)), dim3(512), 0, stream, p);               \
+    }
     if (cout_pad % 128 == 0) {
         p.n_ctiles = cout_pad / 128;
         const int64_t t128 = ((M + 127) / 128) * p.n_ctiles;
-        if (t128 >= cus) hipLaunchKernelGGL((conv_split16_kernel<128, 128>), dim3((unsigned)t128), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((conv_split16_kernel<64, 128>), dim3((unsigned)(((M + 63) / 64) * p.n_ctiles)), dim3(512), 0, stream, p);
+        if (t128 >= cus) PVR_S16_LAUNCH(128, 128, t128)
+        else PVR_S16_LAUNCH(64, 128, ((M + 63) / 64) * p.n_ctiles)
     } else {
         p.n_ctiles = cout_pad / 64;
         const int64_t t128 = ((M + 127) / 128) * p.n_ctiles;
-        if (t128 >= cus) hipLaunchKernelGGL((conv_split16_kernel<128, 64>), dim3((unsigned)t128), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((conv_split16_kernel<64, 64>), dim3((unsigned)(((M + 63) / 64) * p.n_ctiles)), dim3(512), 0, stream, p);
+        if (t128 >= cus) PVR_S16_LAUNCH(128, 64, t128)
+        else PVR_S16_LAUNCH(64, 64, ((M + 63) / 64) * p.n_ctiles)
     }
+#undef PVR_S16_LAUNCH
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }

@@ -16,7 +16,8 @@ namespace pvr {
 pvr_status launch_split16_pack(const float *w, void *out, int rows, int K, hipStream_t stream);
 bool conv_split16_supported(int cin, int cout, int k);
 pvr_status launch_conv_split16(const float *in, const void *wsp, const float *bias, const float *res, float *out, int n, int h, int w, int cin,
-                               int cout, int k, int stride, int pad, int relu, hipStream_t stream);
+                               int cout, int k, int stride, int pad, int relu, hipStream_t stream, float *out2 = nullptr, int n1 = 0, void *out16 = nullptr,
+                               int terms = 3);
 
 // every environment switch of the encoder plans, read ONCE per encoder in pvr_encoder_create (never on the forward path)
 static void read_switches(PlanSwitches &sw) {
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void range_flag_kernel(const void *x, size_t n
 
 const char *launch_kind_name(int k) {
     static const char *nm[] = {"conv", "bneck_frame(front1)", "bneck_frame", "frame_members", "conv_pp256(dual)", "dual_members", "chain", "cast",
-                               "conv_f32", "conv_split16", "splitk(small)", "splitk", "conv_expand(blocked)", "conv_wfrag(pool)", "conv_wfrag"};
+                               "conv_f32", "conv_split16", "conv_split16(pair)", "conv_split16(in32)", "splitk(small)", "splitk", "conv_expand(blocked)",
+                               "conv_wfrag(pool)", "conv_wfrag"};
     return k >= 0 && k < (int)(sizeof nm / sizeof nm[0]) ? nm[k] : "?";
 }
 
@@ -104,6 +106,10 @@ static void build_resnet50(pvr_encoder *e) {
     // PVR_TAIL_F32=0 restores round 2's plan, bf16 (the throughput mode) never uses either.
     e->tail32 = e->resid32 && e->sw.tail_f32 != 0;
     const int r32_from = e->tail32 ? 1 : 2;             // fp32 residual stream from layer2 on (emulated: *_l3 5.6e-4 ... 6.4e-4, *_l4 6.3e-4 ... 6.7e-4)
+    // Round 6: with conv_split16 the convolutions that consume the fp32 stream as a 16-bit operand (the next block's conv1, a stage's downsample) read it
+    // themselves and round it in their staging pass (ConvOp::from32): no fp32 -> 16-bit copy launches (3 x 0.11 ms in *_l3, 4 x 0.11 + 5 x 0.05 ms in *_l4)
+    const bool in32 = e->resid32 && e->sw.split16 != 0;
+    bool x_is_32 = false;                               // the block input exists as fp32 only (the previous block wrote y32 and no 16-bit copy)
     int hw = 56, inpl = 64, x = B_X0, x32 = B_NONE;
     for (int li = 0; li < stages; ++li) {
         const int planes = 64 << li;
@@ -141,12 +147,14 @@ static void build_resnet50(pvr_encoder *e) {
                 x32 = y32; hw = ohw; inpl = planes * 4;
                 continue;
             }
-            add_conv(e, p + ".conv1", p + ".bn1", x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
+            add_conv(e, p + ".conv1", p + ".bn1", x_is_32 ? x32 : x, B_T1, B_NONE, hw, hw, inpl, inpl, planes, planes, 1, 1, 1);
+            e->ops.back().from32 = x_is_32;
             add_conv(e, p + ".conv2", p + ".bn2", B_T1, B_T2, B_NONE, hw, hw, planes, planes, planes, planes, 3, stride, 1);
             int res = r32 ? x32 : x;
             if (bi == 0) {
-                add_conv(e, p + ".downsample.0", p + ".downsample.1", x, B_DS, B_NONE, hw, hw, inpl, inpl, planes * 4,
+                add_conv(e, p + ".downsample.0", p + ".downsample.1", x_is_32 ? x32 : x, B_DS, B_NONE, hw, hw, inpl, inpl, planes * 4,
                          planes * 4, 1, stride, 0, r32 ? 1 : 0);
+                e->ops.back().from32 = x_is_32;
                 res = B_DS;
             }
             if (r32) {
@@ -154,12 +162,13 @@ static void build_resnet50(pvr_encoder *e) {
                 add_conv(e, p + ".conv3", p + ".bn3", B_T2, y32, res, ohw, ohw, planes, planes, planes * 4, planes * 4, 1, 1, 1, 1 | 2);
                 // the 16-bit copy feeds the next block's convolutions - unless that block is fp32 (it reads the stream itself), as the head does
                 const bool next_f32 = e->tail32 && li == stages - 2 && bi == nblk[li] - 1;
-                if (!last && !next_f32) add_cast(e, y32, y, ohw, planes * 4);
+                if (!last && !next_f32 && !in32) add_cast(e, y32, y, ohw, planes * 4);
                 if (bi == nblk[li] - 1) {
                     e->ops.back().tap = tn;
                     e->taps[tn] = {y32, {ohw, ohw, planes * 4, 1}};
                 }
                 x32 = y32; x = y; hw = ohw; inpl = planes * 4;
+                x_is_32 = in32;
                 continue;
             }
             // the trunk's last block feeds avgpool: keep fp32 (conv5 variant only)
@@ -330,7 +339,7 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
                 }
     std::vector<float> hb(cout_pad, 0.f);
     for (int co = 0; co < cor; ++co) hb[co] = shift[co];
-    if (e->desc.dtype == PVR_F32 || op.f32op) {   // reference-precision mode / fp32 head of a 16-bit plan: same layout, fp32 values
+    if (e->desc.dtype == PVR_F32 || op.f32op || op.from32) {   // reference-precision mode / fp32 head of a 16-bit plan / a 16-bit conv reading fp32: same layout, fp32 values
         std::vector<float> hf(cout_pad * K, 0.f);
         for (int co = 0; co < cor; ++co)
             for (int ci = 0; ci < cr; ++ci)
@@ -338,13 +347,14 @@ static pvr_status finalize_conv(pvr_encoder *e, ConvOp &op) {
                     for (int b = 0; b < k; ++b)
                         hf[co * K + ((size_t)a * k + b) * op.cin + ci] = w->data[(((size_t)co * cr + ci) * k + a) * k + b] * scale[co];
         if ((s = enc_upload(&op.d_wf, hf))) return s;
-        if (op.f32op && e->desc.dtype == PVR_F16 && e->sw.split16 && conv_split16_supported(op.cin, op.cout, op.k)) {
-            // the fp32 stage / head of the parity plan on the 16-bit matrix pipe: (hi, lo) f16 pairs of the same fp32 weights (conv_split16.hip)
+        if ((op.f32op || op.from32) && e->desc.dtype == PVR_F16 && e->sw.split16 && conv_split16_supported(op.cin, op.cout, op.k)) {
+            // the fp32 stage / head of the parity plan on the 16-bit matrix pipe: (hi, lo) f16 pairs of the same fp32 weights (conv_split16.hip); for a from32
+            // convolution only the hi half is used: f16(w), the 16-bit plan's own weight.  (d_wf stays until the schedules are built: the head's pair image)
             PVR_HIP_TRY(hipMalloc((void **)&op.d_wsp, (size_t)cout_pad * K * 4));
             if ((s = launch_split16_pack(op.d_wf, op.d_wsp, cout_pad, (int)K, nullptr))) return s;
-            PVR_HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(op.d_wf); op.d_wf = nullptr;
         }
+        if (op.from32 && !op.d_wsp) { set_error("%s: a convolution that reads the fp32 stream needs the conv_split16 weight image (cin %d, cout %d)", op.conv.c_str(), op.cin, op.cout); return PVR_ERR_INVALID; }
+        op.h_b = hb;
         return enc_upload(&op.d_b, hb);
     }
     if ((s = enc_upload(&op.d_w, hw))) return s;
@@ -367,7 +377,7 @@ static void plan_splitk(pvr_encoder *e) {
     const int n = (int)e->ops.size();
     for (int i = 0; i < n; ++i) {
         ConvOp &op = e->ops[i];
-        if (op.kind != 0 || op.f32op || op.cout > 64 || op.k * op.k * op.cin < 16384 || (op.out_f32 & 2)) continue;
+        if (op.kind != 0 || op.f32op || op.from32 || op.cout > 64 || op.k * op.k * op.cin < 16384 || (op.out_f32 & 2)) continue;
         const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
         const size_t need = (size_t)8 * e->desc.chunk * ho * ho * op.cout * sizeof(float);
         if (need > e->buf_elems * 2) continue;
@@ -494,11 +504,37 @@ static pvr_status build_schedules(pvr_encoder *e) {
                     continue;
                 }
             }
+            // the compression head: conv1 (+ ReLU) and the downsample convolution read the SAME fp32 tensor with the same geometry: one conv_split16 launch over
+            // [W1 ; Wd] (128 couts), two outputs - the 205 / 103 MB input is read once
+            if (op.f32op && op.d_wsp && op.d_wf && i + 1 < n) {
+                ConvOp &od = e->ops[i + 1];
+                if (od.f32op && od.d_wsp && od.d_wf && od.in_buf == op.in_buf && od.k == op.k && od.stride == op.stride && od.pad == op.pad && od.cin == op.cin && od.h == op.h &&
+                    op.cout == 64 && od.cout == 64 && op.relu == 1 && od.relu == 0 && op.res_buf == B_NONE && od.res_buf == B_NONE && op.tap.empty() && od.tap.empty() &&
+                    ends_with(op.conv, ".conv1") && ends_with(od.conv, ".downsample.0")) {
+                    const size_t K = (size_t)op.k * op.k * op.cin;
+                    float *cat = nullptr;
+                    PVR_HIP_TRY(hipMalloc((void **)&cat, 128 * K * 4));
+                    PVR_HIP_TRY(hipMemcpy(cat, op.d_wf, 64 * K * 4, hipMemcpyDeviceToDevice));
+                    PVR_HIP_TRY(hipMemcpy(cat + 64 * K, od.d_wf, 64 * K * 4, hipMemcpyDeviceToDevice));
+                    PVR_HIP_TRY(hipMalloc((void **)&op.d_wsp_pair, 128 * K * 4));
+                    pvr_status s = launch_split16_pack(cat, op.d_wsp_pair, 128, (int)K, nullptr);
+                    PVR_HIP_TRY(hipDeviceSynchronize());
+                    (void)hipFree(cat);
+                    if (s) return s;
+                    std::vector<float> bb(128, 0.f);
+                    for (int c = 0; c < 64; ++c) { bb[c] = op.h_b[c]; bb[64 + c] = od.h_b[c]; }
+                    if ((s = enc_upload(&op.d_b_pair, bb))) return s;
+                    Launch l; l.conv2 = i; l.pair = i + 1;
+                    e->sched_fused.push_back(l);
+                    i += 2;
+                    continue;
+                }
+            }
             Launch l; l.conv2 = i;
             e->sched_fused.push_back(l);
             // a stand-alone convolution with few pixels and a deep K (layer3 / layer4's 1 x 1 and 3 x 3 at 14 x 14 and 7 x 7): conv_wfrag.hip may take it at
             // run time (conv_wfrag_preferred: by the batch) - it reads the fragment-blocked copy of the weights
-            if (op.kind == 0 && !op.f32op && !op.d_wfb && op.h == op.w && op.h <= 14 && op.cout_real == op.cout && (int64_t)op.k * op.k * op.cin >= 512 &&
+            if (op.kind == 0 && !op.f32op && !op.from32 && !op.d_wfb && op.h == op.w && op.h <= 14 && op.cout_real == op.cout && (int64_t)op.k * op.k * op.cin >= 512 &&
                 conv_wfrag_supported(1, 1, op.cin, op.cout, op.k, op.k, op.pad, op.relu, op.out_f32)) {
                 const size_t K = (size_t)op.k * op.k * op.cin;
                 PVR_HIP_TRY(hipMalloc((void **)&op.d_wfb, (size_t)op.cout * K * 2));
@@ -725,7 +761,7 @@ static void *bufp(pvr_encoder *enc, int id) { return id == B_STEM ? (void *)enc-
 // is why the plan is opt-in and batch-size independence of the default plan stays bit-exact.
 constexpr size_t SMALLK_BYTES = (size_t)32 << 20;
 static int small_batch_ksplit(const pvr_encoder *enc, const ConvOp &op, int nb) {
-    if (!enc->low_latency || nb > 4 || op.kind != 0 || op.f32op || op.ksplit > 1 || op.relu > 1 || (op.out_f32 & 2)) return 0;
+    if (!enc->low_latency || nb > 4 || op.kind != 0 || op.f32op || op.from32 || op.ksplit > 1 || op.relu > 1 || (op.out_f32 & 2)) return 0;
     const int K = op.k * op.k * op.cin, nk = K / 64;
     if (nk < 8) return 0;                                        // K < 512: nothing to share
     const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1;
@@ -763,7 +799,9 @@ static uint8_t resolve_kind(const pvr_encoder *enc, const std::vector<Launch> &p
     if (l.conv3 < 0 && l.ds >= 0) return (!ll && autoalgo) ? LK_DUAL : LK_DUAL_MEMBERS;
     if (l.conv3 >= 0) return LK_CHAIN;
     if (op.kind == 2) return LK_CAST;
+    if (l.pair >= 0) return LK_SPLIT16_PAIR;
     if (op.f32op) return op.d_wsp ? LK_SPLIT16 : LK_F32;
+    if (op.from32) return LK_SPLIT16_IN32;
     if (small_batch_ksplit(enc, op, nb)) return LK_SPLITK_SMALL;
     if (op.ksplit > 1) return LK_SPLITK;
     const int ho = (op.h + 2 * op.pad - op.k) / op.stride + 1, wo = (op.w + 2 * op.pad - op.k) / op.stride + 1;
@@ -918,7 +956,11 @@ pvr_status pvr_encoder_finalize(pvr_encoder *enc) {
     for (auto &op : enc->ops)
         if (op.kind == 0 && (s = finalize_conv(enc, op))) return s;
     if ((s = build_schedules(enc))) return s;
-    for (auto &op : enc->ops) { op.h_w.clear(); op.h_w.shrink_to_fit(); op.h_b.clear(); op.h_b.shrink_to_fit(); }
+    PVR_HIP_TRY(hipDeviceSynchronize());                        // (the weight-packing launches above)
+    for (auto &op : enc->ops) {
+        op.h_w.clear(); op.h_w.shrink_to_fit(); op.h_b.clear(); op.h_b.shrink_to_fit();
+        if (op.d_wsp && op.d_wf) { (void)hipFree(op.d_wf); op.d_wf = nullptr; }     // fp32 weights that were only the source of a split image
+    }
     enc->fuse = enc->sw.fuse != 0;
     pvr_status ws = alloc_workspace(enc);
     if (ws) return ws;
@@ -1150,6 +1192,17 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 s = launch_conv_split16((const float *)enc->d_buf[op.in_buf], op.d_wsp, op.d_b, (const float *)res, (float *)enc->d_buf[op.out_buf], nb,
                                         op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st);
                 break;
+            case LK_SPLIT16_PAIR: {
+                const ConvOp &od = enc->ops[l.pair];
+                s = launch_conv_split16((const float *)enc->d_buf[op.in_buf], op.d_wsp_pair, op.d_b_pair, nullptr, (float *)enc->d_buf[op.out_buf], nb, op.h, op.w, op.cin,
+                                        128, op.k, op.stride, op.pad, 1, st, (float *)enc->d_buf[od.out_buf], 64);
+                break;
+            }
+            case LK_SPLIT16_IN32:
+                // a 16-bit convolution whose operand is the fp32 residual stream (rounded to f16 in the kernel's staging pass): t1 leaves 16-bit, a downsample fp32
+                s = launch_conv_split16((const float *)enc->d_buf[op.in_buf], op.d_wsp, op.d_b, nullptr, (op.out_f32 & 1) ? (float *)enc->d_buf[op.out_buf] : nullptr, nb,
+                                        op.h, op.w, op.cin, op.cout, op.k, op.stride, op.pad, op.relu, st, nullptr, 0, (op.out_f32 & 1) ? nullptr : enc->d_buf[op.out_buf], 1);
+                break;
             case LK_SPLITK_SMALL:
                 // low-latency plan: the few pixel tiles of a <= 4-frame forward share each K loop between `ks` blocks
                 s = member(op, enc->d_buf[op.in_buf], res, enc->d_buf[op.out_buf]);
@@ -1183,7 +1236,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
                 const int ho_ = (op.h + 2 * op.pad - op.k) / op.stride + 1, wo_ = (op.w + 2 * op.pad - op.k) / op.stride + 1;
                 const size_t n8 = (size_t)nb * ho_ * wo_ * op.cout / 8;
                 const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
-                if (op.out_f32 & 1) hipLaunchKernelGGL(range_flag_kernel<true>, dim3(blocks), dim3(256), 0, st, enc->d_buf[op.out_buf], n8, dt, enc->range_flags, (int)li);
+                if ((op.out_f32 & 1) || op.f32op) hipLaunchKernelGGL(range_flag_kernel<true>, dim3(blocks), dim3(256), 0, st, enc->d_buf[op.out_buf], n8, dt, enc->range_flags, (int)li);
                 else hipLaunchKernelGGL(range_flag_kernel<false>, dim3(blocks), dim3(256), 0, st, enc->d_buf[op.out_buf], n8, dt, enc->range_flags, (int)li);
             }
             if ((s = mark())) return s;
@@ -1297,7 +1350,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
         const bool fused = enc->fuse && enc->desc.dtype != PVR_F32;
         for (const Launch &l : (fused ? enc->sched_fused : enc->sched_plain)) {
             if (i >= nl) break;
-            op_flops[i++] = flops(l.conv1) + flops(l.conv2) + flops(l.conv3) + flops(l.next1) + flops(l.ds);
+            op_flops[i++] = flops(l.conv1) + flops(l.conv2) + flops(l.conv3) + flops(l.next1) + flops(l.ds) + flops(l.pair);
         }
         *n_ops = nl;
     }
@@ -1430,7 +1483,7 @@ int32_t pvr_encoder_launch_name(const pvr_encoder *enc, int32_t index, char *buf
             nm = enc->ops[sc[i].conv1 >= 0 ? sc[i].conv1 : sc[i].conv2].conv;
             if (sc[i].conv1 >= 0) nm += "+conv2";
             if (sc[i].conv3 >= 0) nm += "+" + enc->ops[sc[i].conv3].conv.substr(enc->ops[sc[i].conv3].conv.rfind('.') + 1);
-            if (sc[i].ds >= 0) nm += "&downsample";
+            if (sc[i].ds >= 0 || sc[i].pair >= 0) nm += "&downsample";
             if (sc[i].next1 >= 0) nm += "+" + enc->ops[sc[i].next1].conv;
         } else if (i == (int)sc.size() && !enc->vit && !enc->rnd) nm = "pool/flatten";
     }
@@ -1492,7 +1545,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->hplan) host_destroy(enc);
     if (enc->vit) vit_destroy(enc);
     if (enc->rnd) random5_destroy(enc);
-    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_wpk) (void)hipFree(op.d_wpk); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
+    for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_wsp_pair) (void)hipFree(op.d_wsp_pair); if (op.d_b_pair) (void)hipFree(op.d_b_pair); if (op.d_wpk) (void)hipFree(op.d_wpk); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {

@@ -67,6 +67,8 @@ struct ConvOp {
     int h, w, cin, cin_real, cout, cout_real, k, stride, pad, relu, out_f32;
     int kind = 0;                  // 0 convolution, 1 AvgPool2d(2) on NHWC 16-bit (CLIP ModifiedResNet; cin = channels), 2 fp32 -> 16-bit copy
     bool f32op = false;            // convolution on fp32 buffers with fp32 weights on the f32-input MFMA (conv_f32.hip) inside a 16-bit plan
+    bool from32 = false;           // a 16-bit convolution (16-bit weights, one MFMA per product) whose INPUT is the fp32 residual stream: conv_split16's single-term
+                                   // form rounds the operand in its staging pass - the fp32 -> 16-bit copy launch of the stream is gone (round 6)
     u16 *d_w = nullptr;
     u16 *d_wp = nullptr;           // row-permuted copy for the fused bottleneck chain (bottleneck_chain.hip)
     u16 *d_wfb = nullptr;          // fragment-blocked copy of d_w for the per-frame layer3 tail (bneck_frame.hip: launch_pack_frag_weights)
@@ -74,6 +76,8 @@ struct ConvOp {
     std::vector<u16> h_w;          // host copy, kept until finalize has built the chain copies
     float *d_wf = nullptr;         // fp32 weights (PVR_F32 mode)
     u16 *d_wpk = nullptr;          // conv2 of a layer2 wave-form tail: the launch's 17 weight units as LDS images (chain_wave128.hip: launch_chain_wave128_pack)
+    u16 *d_wsp_pair = nullptr;     // compression head: [conv1 ; downsample] rows as ONE split weight image (both read the same fp32 input: one launch, round 6)
+    float *d_b_pair = nullptr;
     u16 *d_wsp = nullptr;          // fp32 weights as (hi, lo) f16 fragment pairs (conv_split16.hip: the f32op convolutions of an f16 plan)
     float *d_b = nullptr;
     std::vector<float> h_b;        // host copy of the bias (same lifetime as h_w)
@@ -93,6 +97,7 @@ struct Launch {
     int wave = 0;                             // chain: 1 the wave form runs it (chain_wave.hip), 2 the layer2 wave form (chain_wave128.hip)
     int conv1 = -1;                           // per-frame form: the block's own conv1 runs in front, inside the launch (the launch reads the block input)
     int frame = 0;                            // per-frame form (bneck_frame.hip, layer3): conv2 -> conv3 + residual [-> next1] of one 14 x 14 image per workgroup
+    int pair = -1;                            // conv_split16 pair form: ops[conv2] and ops[pair] read the same fp32 input and run as one launch (the compression head)
     int in_blk = 0, out_blk = 0;              // chain, wave form: t1 + residual / y + t1' travel in the blocked layout between two such launches (chain_wave.hip);
                                               // block form: out_blk 1 = y blocked, 3 = y and t1' blocked (a layer2 wave-form launch follows)
 };
@@ -110,6 +115,8 @@ enum LaunchKind : uint8_t {
     LK_CAST,              // fp32 -> 16-bit copy
     LK_F32,               // conv_f32: fp32 operands on the f32-input MFMA
     LK_SPLIT16,           // conv_split16: fp32 operands as 16-bit (hi, lo) pairs on the 16-bit MFMA
+    LK_SPLIT16_PAIR,      // ... two convolutions of the same input in one launch (the compression head's conv1 & downsample)
+    LK_SPLIT16_IN32,      // ... single-term form: a 16-bit convolution that reads the fp32 residual stream itself
     LK_SPLITK_SMALL,      // low-latency plan: split-K over the lane's scratch
     LK_SPLITK,            // planned split-K (the *_l4 compression head)
     LK_EXPAND_BLOCKED,    // conv_expand writing the blocked layout in front of a wave-form tail

@@ -1275,15 +1275,17 @@ def test_parity_plan_of_the_compressed_pvrs_runs_on_the_16_bit_pipe(variant, osz
     m = HipResNet50(sd, variant, compute_dtype='f16', max_batch=8)
     kn = m.kernel_names(5)
     assert 'conv_split16' in kn and 'conv_f32' not in kn, kn
+    # ... the head's conv1 & downsample as ONE launch, and no fp32 -> 16-bit copy of the residual stream: its consumers read it themselves (single-term form)
+    assert kn.count('conv_split16(pair)') == 1 and 'conv_split16(in32)' in kn and 'cast' not in kn, kn
     before = L.pvr_debug_conv_split16_launches()
     a = m(fr).clone()
-    assert L.pvr_debug_conv_split16_launches() - before == kn.count('conv_split16')
+    assert L.pvr_debug_conv_split16_launches() - before == sum(k.startswith('conv_split16') for k in kn)
     assert a.shape == (5, osz) and torch.isfinite(a).all()
     assert torch.equal(m(fr[1:3]), a[1:3])                     # batch-size invariance, bit-exact
     monkeypatch.setenv('PVR_SPLIT16', '0')
     m0 = HipResNet50(sd, variant, compute_dtype='f16', max_batch=8)
     kn0 = m0.kernel_names(5)
-    assert 'conv_f32' in kn0 and 'conv_split16' not in kn0, kn0
+    assert 'conv_f32' in kn0 and 'cast' in kn0 and not any(k.startswith('conv_split16') for k in kn0), kn0
     b = m0(fr)
     l2, mx = _relerr(a.cpu().numpy(), b.cpu().numpy())
     print('\n[%s] split16 vs f32-input MFMA plan: rel-L2 %.2e max-norm %.2e' % (variant, l2, mx))
