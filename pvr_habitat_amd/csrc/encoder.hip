@@ -35,6 +35,7 @@ static void read_switches(PlanSwitches &sw) {
     if (sw.smallk_div < 1) sw.smallk_div = 1;
     sw.frame_min_n = get("PVR_FRAME_MIN_N", 128);
     sw.split16 = get("PVR_SPLIT16", 1);
+    sw.stem_conv1 = get("PVR_STEM_CONV1", 1);
     sw.resid32 = get("PVR_RESID32", 1);
     sw.tail_f32 = get("PVR_TAIL_F32", 1);
     sw.fuse = get("PVR_FUSE", 1);
@@ -674,6 +675,23 @@ static pvr_status build_schedules(pvr_encoder *e) {
             }
         }
     }
+    // layer1.0.conv1 (1 x 1, 64 -> 64 on the pooled stem output) inside the fused stem (stem.hip, StemC1; round 6): the launch leaves the fused schedule; the
+    // forward hands the stem its weights, or - where the stem's register-pooling form does not run - launches the convolution itself in front of the plan
+    if (e->sw.stem_conv1 && !e->sched_fused.empty() && (e->desc.arch == PVR_ARCH_RESNET50 || e->desc.arch == PVR_ARCH_RESNET50_L3 || e->desc.arch == PVR_ARCH_RESNET50_L4)) {
+        const Launch &L0 = e->sched_fused[0];
+        if (L0.conv3 < 0 && L0.ds < 0 && L0.pair < 0 && !L0.frame && L0.conv2 == 0) {
+            const ConvOp &c1 = e->ops[0];
+            if (c1.kind == 0 && !c1.f32op && !c1.from32 && c1.k == 1 && c1.stride == 1 && c1.cin == 64 && c1.cout == 64 && c1.cin_real == 64 && c1.cout_real == 64 && c1.relu == 1 &&
+                c1.in_buf == B_X0 && c1.out_buf == B_T1 && c1.res_buf == B_NONE && !c1.out_f32 && c1.tap.empty() && c1.ksplit <= 1 && c1.h == 56 && (int)c1.h_w.size() == 64 * 64) {
+                std::vector<u16> img(64 * 64);
+                stem_c1_pack(c1.h_w.data(), img.data());
+                pvr_status s = enc_upload(&e->d_stem_c1w, img);
+                if (s) return s;
+                e->stem_c1 = 0; e->stem_c1_blk = L0.out_blk;
+                e->sched_fused.erase(e->sched_fused.begin());
+            }
+        }
+    }
     return PVR_OK;
 }
 
@@ -1077,12 +1095,16 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         // frames that need no resize (the bench configuration: 256 x 256 frames, Resize(256) is the identity): the fused stem reads the
         // uint8 frames itself - no preprocess launch, no padded 16-bit image in HBM
         int fused_u8 = 0;
+        // layer1.0.conv1 has no launch in the fused schedule (build_schedules): the stem's register-pooling form runs it
+        const bool c1_pending = enc->fuse && enc->stem_c1 >= 0;
+        const bool c1_in_stem = c1_pending && enc->stop_after.empty() && stem_conv1_capable();
         if (enc->sw.stem_u8 && enc->sw.stem_lds && enc->stop_after.empty() && enc->desc.crop == 224 && enc->crop_pos >= 0 && enc->crop_pos <= 4) {
             int rn = 1, top = 0, left = 0;
             preprocess_geometry(h, w, enc->desc.resize, enc->desc.crop, enc->crop_pos, &rn, &top, &left);
             if (!rn && stem_pool_u8_ok(fr, h, w, top, left)) {
                 if ((s = mark())) return s;                  // (launch index of the preprocess stays: pvr_encoder_profile)
-                if ((s = launch_stem_pool_u8(fr, nb, h, w, top, left, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], dt, st))) return s;
+                if ((s = launch_stem_pool_u8(fr, nb, h, w, top, left, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], dt, st, c1_in_stem ? enc->d_stem_c1w : nullptr,
+                                             c1_in_stem ? enc->ops[enc->stem_c1].d_b : nullptr, c1_in_stem ? enc->d_buf[B_T1] : nullptr, enc->stem_c1_blk))) return s;
                 fused_u8 = 1;
             }
         }
@@ -1097,7 +1119,8 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             return PVR_OK;
         }
         // conv1 + bn1 + relu + maxpool fused: the 112x112x64 activation stays in LDS
-        if (!fused_u8 && (s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st))) return s;
+        if (!fused_u8 && (s = launch_stem_pool(enc->d_img, enc->d_stem_w, enc->d_stem_b, enc->d_buf[B_X0], nb, enc->desc.crop, dt, st, c1_in_stem ? enc->d_stem_c1w : nullptr,
+                                               c1_in_stem ? enc->ops[enc->stem_c1].d_b : nullptr, c1_in_stem ? enc->d_buf[B_T1] : nullptr, enc->stem_c1_blk))) return s;
         if (enc->range_flags) {                      // pvr_encoder_check_range: the pooled stem output (flag slot behind the plan's launches)
             const size_t n8 = (size_t)nb * 56 * 56 * 64 / 8;
             hipLaunchKernelGGL(range_flag_kernel<false>, dim3(2048), dim3(256), 0, st, enc->d_buf[B_X0], n8, dt, enc->range_flags, (int)cur_plan(enc).size());
@@ -1106,6 +1129,17 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         if ((s = mark())) return s;                  // (keeps the launch indices of pvr_encoder_profile stable)
         if (enc->stop_after == "pool") return PVR_OK;
         bool stopped = false, t1_blocked = false;   // t1_blocked: the conv1 launch in front of layer1's first tail wrote t1 in the blocked layout
+        if (c1_in_stem) t1_blocked = enc->stem_c1_blk != 0;
+        else if (c1_pending && enc->stop_after != "pool") {
+            // ... or, where that stem form did not run (debug stops, PVR_STEM_REGPOOL=0), as its own launch in front of the plan - blocked t1 when the tail wants it
+            const ConvOp &c1 = enc->ops[enc->stem_c1];
+            if (enc->stem_c1_blk && conv_algo() == -1 && conv_expand_supported((int64_t)nb * c1.h * c1.w, c1.h, c1.w, c1.cin, c1.cout, 1, 1, 1, 0, c1.relu, 0, false)) {
+                s = launch_conv_expand(enc->d_buf[c1.in_buf], c1.d_w, c1.d_b, nullptr, enc->d_buf[c1.out_buf], nb, c1.h, c1.w, c1.cin, c1.cout, 1, c1.relu, dt, st, 1);
+                t1_blocked = true;
+            } else
+                s = launch_conv(enc->d_buf[c1.in_buf], c1.d_w, c1.d_b, nullptr, enc->d_buf[c1.out_buf], enc->d_zero, nb, c1.h, c1.w, c1.cin, c1.cout, 1, 1, 1, 0, c1.relu, 0, dt, st);
+            if (s) return s;
+        }
         bool pooled = false;                         // the plan's last convolution wrote the average pool itself (conv_wfrag's pooled form)
         const std::vector<Launch> &plan_ = cur_plan(enc);
         if (enc->kinds_algo != conv_algo() || enc->kinds_stride != plan_.size()) resolve_kinds(enc);   // (pvr_debug_set_conv_algo is process-wide; same size: no allocation)
@@ -1340,6 +1374,7 @@ pvr_status pvr_encoder_profile(pvr_encoder *enc, const uint8_t *frames, int32_t 
         }
         // stem: 118.0 MMAC/frame = 112*112*64*147
         if (nl > 1) op_flops[1] = 2.0 * n * 112.0 * 112.0 * 64.0 * 147.0;
+        if (nl > 1 && enc->fuse && enc->stem_c1 >= 0 && enc->desc.dtype != PVR_F32) op_flops[1] += 2.0 * n * 56.0 * 56.0 * 64.0 * 64.0;   // layer1.0.conv1 runs inside the stem
         int i = 3;
         auto flops = [&](int oi) {
             if (oi < 0) return 0.0;
@@ -1547,6 +1582,7 @@ void pvr_encoder_destroy(pvr_encoder *enc) {
     if (enc->rnd) random5_destroy(enc);
     for (auto &op : enc->ops) { if (op.d_w) (void)hipFree(op.d_w); if (op.d_wp) (void)hipFree(op.d_wp); if (op.d_wpb) (void)hipFree(op.d_wpb); if (op.d_wfb) (void)hipFree(op.d_wfb); if (op.d_wcat) (void)hipFree(op.d_wcat); if (op.d_wf) (void)hipFree(op.d_wf); if (op.d_wsp) (void)hipFree(op.d_wsp); if (op.d_wsp_pair) (void)hipFree(op.d_wsp_pair); if (op.d_b_pair) (void)hipFree(op.d_b_pair); if (op.d_wpk) (void)hipFree(op.d_wpk); if (op.d_b) (void)hipFree(op.d_b); if (op.d_bsum) (void)hipFree(op.d_bsum); }
     if (enc->d_stem_wf) (void)hipFree(enc->d_stem_wf);
+    if (enc->d_stem_c1w) (void)hipFree(enc->d_stem_c1w);
     bool any_lane = false;
     for (auto &l : enc->lane_ws) {
         if (!l.valid) continue;

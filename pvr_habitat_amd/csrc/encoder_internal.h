@@ -12,9 +12,14 @@ namespace pvr {
 pvr_status launch_preprocess(const uint8_t *, int, int, int, int, int, void *, int, hipStream_t, int crop_pos = 0);
 pvr_status launch_stem(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
 pvr_status launch_maxpool(const void *, void *, int, int, int, int, int, hipStream_t);
-pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t);
+// (c1_*: layer1.0.conv1 inside the stem - stem.hip, StemC1; only when stem_conv1_capable())
+pvr_status launch_stem_pool(const void *, const void *, const float *, void *, int, int, int, hipStream_t, const void *c1_w = nullptr, const float *c1_b = nullptr,
+                            void *c1_t1 = nullptr, int c1_blk = 0);
 bool stem_pool_u8_ok(const void *, int, int, int, int);   // geometry only; the PVR_STEM_U8 / PVR_STEM_LDS switches live in PlanSwitches
-pvr_status launch_stem_pool_u8(const uint8_t *, int, int, int, int, int, const void *, const float *, void *, int, hipStream_t);
+pvr_status launch_stem_pool_u8(const uint8_t *, int, int, int, int, int, const void *, const float *, void *, int, hipStream_t, const void *c1_w = nullptr,
+                               const float *c1_b = nullptr, void *c1_t1 = nullptr, int c1_blk = 0);
+bool stem_conv1_capable();
+void stem_c1_pack(const u16 *w, u16 *img);
 void preprocess_geometry(int h, int w, int resize, int crop, int crop_pos, int *resize_needed, int *top, int *left);
 pvr_status launch_avgpool(const void *, float *, int64_t, int, int, int, int, int, hipStream_t);
 pvr_status launch_nhwc_to_chw(const float *, float *, int64_t, int, int, int, int, hipStream_t);
@@ -139,6 +144,7 @@ struct PlanSwitches {
     int splitk = 1;           // PVR_SPLITK: planned split-K of the *_l4 head
     int smallk_div = 4;       // PVR_SMALLK_DIV: K slices per block of the low-latency plan
     int frame_min_n = 128;    // PVR_FRAME_MIN_N (live): frames per forward from which layer3's per-frame launches run as such
+    int stem_conv1 = 1;       // PVR_STEM_CONV1: layer1.0.conv1 runs inside the fused stem (no launch of its own; round 6)
     int split16 = 1;          // PVR_SPLIT16: the fp32 stage / head of the compressed PVRs' parity plan on the 16-bit MFMA (0: f32-input MFMA)
     int resid32 = 1;          // PVR_RESID32: fp32 residual stream of that plan (0: all-16-bit plan)
     int tail_f32 = 1;         // PVR_TAIL_F32: its last trunk stage entirely in fp32
@@ -159,6 +165,9 @@ struct pvr_encoder {
     bool fuse = true;                               // PVR_FUSE=0 or pvr_encoder_debug_set_fusion(enc, 0) selects sched_plain
     bool low_latency = false;                       // pvr_encoder_set_low_latency: split-K plan for forwards of <= 4 frames
     PlanSwitches sw;                                // environment switches, read once in pvr_encoder_create
+    int stem_c1 = -1;                               // fused schedule: ops[stem_c1] = layer1.0.conv1 has no launch - the stem runs it (stem.hip, StemC1) or, where that
+    int stem_c1_blk = 0;                            // form does not apply, the forward launches it in front of the plan; _blk: the tail behind it reads t1 blocked
+    u16 *d_stem_c1w = nullptr;                      // its weights as the stem's fragment image (stem_c1_pack)
     std::vector<uint8_t> kinds;                     // LaunchKind of launch i for a forward of nb frames: kinds[(nb - 1) * plan.size() + i] (resolve_kinds)
     size_t kinds_stride = 0;
     int kinds_algo = -2;                            // conv_algo() the table was resolved under

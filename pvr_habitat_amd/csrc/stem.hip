@@ -192,6 +192,9 @@ __device__ long long stem_stamps[8][64][6];
 // converted (x - 128 exactly, 4th channel 1, zero border: what preprocess_kernel writes) into the two row buffers by all 512 threads
 // at the start of the previous image's pooling phase.  u8s: the frames, geometry in U8Geo.
 struct U8Geo { const uint8_t *src; int pitch, img_bytes, off0; };     // bytes per source row, bytes per frame, byte offset of the crop's first pixel
+// layer1.0.conv1 inside the fused stem (stem_pool_reg_kernel): w = the 64 x 64 weights as eight MFMA A fragments (launch_stem_c1_pack), b = bias, t1 = output
+// (n, 56, 56, 64) NHWC or in the blocked layout of the wave-form tails (blk)
+struct StemC1 { const u16 *w = nullptr; const float *b = nullptr; u16 *t1 = nullptr; int blk = 0; };
 template <bool F16, bool U8 = false>
 __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
                                                                const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb, U8Geo u8g = U8Geo{}) {
@@ -394,14 +397,17 @@ __global__ __launch_bounds__(512, 1) void stem_pool_lds_kernel(const u16 *__rest
 // (test_fused_stem_pool_is_bit_identical_to_stem_then_maxpool, test_stem_reading_uint8_frames_...).  PVR_STEM_REGPOOL=0 keeps the LDS-tile form (A/B).
 template <bool F16, bool U8 = false>
 __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__restrict__ img, const u16 *__restrict__ wgt,
-                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb, U8Geo u8g = U8Geo{}) {
+                                                               const float *__restrict__ bias, u16 *__restrict__ out, int nimg, int ipb, U8Geo u8g = U8Geo{},
+                                                               StemC1 c1 = StemC1{}) {
     typedef typename HT<F16>::V8 V8;
     constexpr int PW = 232, PH = 230, OW = 112, PO = 56;
     constexpr int ROWB = PW * 8;                                     // bytes of one image row (4 channels x 16 bit)
     constexpr int INB = U8 ? 28672 : 32768;                          // one input-row buffer (15 rows = 27 840 B, copied as 32 x 1 KB)
     constexpr int RAWROW = 224 * 3, RAWB = 10240;                    // U8: raw crop rows [15][672] uint8 (10 x 1 KB of DMA), three buffers
     constexpr int PAD = 1024;                                        // (conv column -1 of wave 0 reads 16 bytes in front of a row: keep that inside the allocation)
-    constexpr int IN0 = PAD, RAW0 = IN0 + 2 * INB, OT0 = RAW0 + (U8 ? 3 * RAWB : 0);   // [pad | rows buffer 0 | rows buffer 1 (| raw 0 | raw 1 | raw 2) | pooled tile [2][56][128 B]]
+    constexpr int IN0 = PAD, RAW0 = IN0 + 2 * INB, OT0 = RAW0 + (U8 ? 3 * RAWB : 0);   // [pad | rows buffer 0 | rows buffer 1 (| raw 0 | raw 1 | raw 2) | pooled tile [2][56][128 B] | W1 image]
+    constexpr int OTB = 2 * PO * 128;                                // one pooled tile; TWO of them: image n's is copied out (and convolved) during image n + 1's matrix phase
+    constexpr int W1L = OT0 + 2 * OTB;                               // layer1.0.conv1's weights (8 KB: eight MFMA A fragments), when that convolution runs here
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pr0 = blockIdx.x * 2;                                  // pooled rows pr0, pr0+1
     const int cr0 = 2 * pr0 - 1;                                     // first conv row held (may be -1: above the image)
@@ -465,6 +471,10 @@ __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__rest
             *reinterpret_cast<ushort4 *>(zb + r * ROWB + pc * 8) = make_ushort4(0, 0, 0, 0);
         }
     };
+    if (c1.w) {                                                      // (visible after the prologue's barrier)
+        *reinterpret_cast<u32x4 *>(smem + W1L + tid * 16) = *reinterpret_cast<const u32x4 *>(c1.w + tid * 8);
+        if (tid < 64) *reinterpret_cast<float *>(smem + W1L + 8192 + tid * 4) = c1.b[tid];
+    }
     if constexpr (U8) {
         for (int k = 0; k < 3; ++k) if (n0 + k < n1) stage_raw(n0 + k);
     } else {
@@ -491,17 +501,59 @@ __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__rest
     // is bound by vector issue); MFMA results and -inf need no quieting
     auto vmax = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto vmax3 = [](float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    // What happens to a finished pooled tile (image m, tile m & 1), INSIDE the next image's matrix phase - or, for the block's last image, behind the loop:
+    //   copy-out (waves 0-3, in front of their MFMAs): the tile leaves as whole 128-byte lines, 2 rows x 56 columns x 8 chunks of 16 bytes;
+    //   layer1.0.conv1 (waves 4-7, behind their MFMAs; 1 x 1, 64 -> 64, + bn1 + ReLU: torchvision Bottleneck.conv1 of the first block) on the tile's 112 pixels:
+    //   seven 16-pixel MFMA tiles (the block's two pooled rows are seven ALIGNED 16-pixel blocks of the tensor), two per wave, weights as A fragments from the LDS
+    //   image, rows permuted so that a tile pair gives a lane 8 consecutive output channels (chain_row_source) = 16-byte stores in either layout.  The launch of
+    //   that convolution and its read of the pooled tensor (103 MB per 256 frames) are gone; same K order and rounding.
+    // so that each SIMD's two waves (w, w + 4) have vector work and matrix work at different times.
+    auto copy_out = [&](int m, int first, int step) {
+        const char *ot = smem + OT0 + ((m - n0) & 1) * OTB;
+        for (int o = first; o < 2 * PO * 8; o += step) {
+            const int k = o & 7, pcc = (o >> 3) % PO, pr = o / (8 * PO);
+            const u32x4 vv = *reinterpret_cast<const u32x4 *>(ot + (pr * PO + pcc) * 128 + ((k ^ (pcc & 7)) << 4));
+            u32x4 *const dst = reinterpret_cast<u32x4 *>(out + (((size_t)m * PO + pr0 + pr) * PO + pcc) * STEM_CO + k * 8);
+            if constexpr (PVR_NT & 128) __builtin_nontemporal_store(vv, dst);
+            else *dst = vv;
+        }
+    };
+    auto conv1_tile = [&](int m, int tile) {
+        const char *ot = smem + OT0 + ((m - n0) & 1) * OTB;
+        const int pixl = tile * 16 + px, pr = pixl / PO, pcc = pixl - pr * PO;
+        f32x4 a1[4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const V8 xf = *reinterpret_cast<const V8 *>(ot + (pr * PO + pcc) * 128 + (((ks * 4 + g) ^ (pcc & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a1[i] = mfma16<F16>(*reinterpret_cast<const V8 *>(smem + W1L + (i * 2 + ks) * 1024 + lane * 16), xf, ks == 0 ? zero : a1[i]);
+        }
+        const long long m0 = ((long long)m * PO + pr0) * PO;                                  // first pixel of the block's two rows: a multiple of 16
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bA = *reinterpret_cast<const float4 *>(smem + W1L + 8192 + (32 * q + 8 * g) * 4), bB = *reinterpret_cast<const float4 *>(smem + W1L + 8192 + (32 * q + 8 * g + 4) * 4);
+            const f32x4 lo = a1[2 * q], hi = a1[2 * q + 1];
+            u32x4 o;
+            o[0] = pack2_h<F16>(vmax(lo[0] + bA.x, 0.f), vmax(lo[1] + bA.y, 0.f)); o[1] = pack2_h<F16>(vmax(lo[2] + bA.z, 0.f), vmax(lo[3] + bA.w, 0.f));
+            o[2] = pack2_h<F16>(vmax(hi[0] + bB.x, 0.f), vmax(hi[1] + bB.y, 0.f)); o[3] = pack2_h<F16>(vmax(hi[2] + bB.z, 0.f), vmax(hi[3] + bB.w, 0.f));
+            u16 *dst = c1.blk ? c1.t1 + ((m0 >> 4) + tile) * 1024 + (q * 4 + g) * 128 + px * 8                 // [pixel >> 4][channel >> 3][pixel & 15][8]
+                              : c1.t1 + (m0 + pixl) * 64 + q * 32 + g * 8;
+            *reinterpret_cast<u32x4 *>(dst) = o;
+        }
+    };
     for (int n = n0; n < n1; ++n) {
         const int b = (n - n0) & 1;
         ST_T(0);
         if constexpr (U8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // convert_rows' LDS stores (previous copy-out phase / prologue)
-        __builtin_amdgcn_s_barrier();                                    // rows buffer b complete; everyone has copied the previous image's pooled tile out
+        __builtin_amdgcn_s_barrier();                                    // rows buffer b complete
         __builtin_amdgcn_sched_barrier(0);
         ST_T(1);
         // U8: the next image's rows are converted inside this image's matrix phase - by waves 0-3 in front of their MFMAs, by waves 4-7 behind them, so that
         // each SIMD's two waves (w, w + 4) have vector work and matrix work at different times (raw rows of image n + 1: waited for before barrier 2 of image
         // n - 1; rows buffer 1 - b: free since that barrier)
         if constexpr (U8) { if (wave < 4 && n + 1 < n1) convert_rows(n + 1, 1 - b); }
+        if (wave < 4 && n > n0) copy_out(n - 1, tid, 256);
         const char *rows = smem + IN0 + b * INB;
         const char *fb = rows + (2 * col + 2 * g) * 8;                   // lane (px, g), filter row s: pixels 2 col + 2 g, + 1 of LDS row 2 lr + s
         V8 xa[7], xb[7];
@@ -569,11 +621,15 @@ __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__rest
                     const uint2 o = {pack2_h<F16>(vmax(h[0] + bv[i].x, 0.f), vmax(h[1] + bv[i].y, 0.f)) & 0x7fff7fffu,
                                      pack2_h<F16>(vmax(h[2] + bv[i].z, 0.f), vmax(h[3] + bv[i].w, 0.f)) & 0x7fff7fffu};
                     const int c16 = i * 2 + (g >> 1);                    // 16-byte chunk of channels 16 i + 4 g .. + 3
-                    *reinterpret_cast<uint2 *>(smem + OT0 + (pr * PO + pc) * 128 + ((c16 ^ (pc & 7)) << 4) + (g & 1) * 8) = o;
+                    *reinterpret_cast<uint2 *>(smem + OT0 + b * OTB + (pr * PO + pc) * 128 + ((c16 ^ (pc & 7)) << 4) + (g & 1) * 8) = o;
                 }
             }
         }
         if constexpr (U8) { if (wave >= 4 && n + 1 < n1) convert_rows(n + 1, 1 - b); }
+        if (c1.w && wave >= 4 && n > n0) {
+            conv1_tile(n - 1, 2 * (wave - 4));
+            if (wave < 7) conv1_tile(n - 1, 2 * (wave - 4) + 1);
+        }
         ST_T(2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the rows of image n + 1 (and this wave's older stores) have landed; the pooled tile is written
         ST_T(3);
@@ -585,15 +641,12 @@ __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__rest
         } else {
             if (n + 2 < n1) stage_rows(n + 2, b);                        // (travels under the copy-out and the next image's MFMAs)
         }
-        // the pooled tile leaves as whole 128-byte lines: 2 rows x 56 columns x 8 chunks of 16 bytes
-        for (int o = tid; o < 2 * PO * 8; o += 512) {
-            const int k = o & 7, pcc = (o >> 3) % PO, pr = o / (8 * PO);
-            const u32x4 vv = *reinterpret_cast<const u32x4 *>(smem + OT0 + (pr * PO + pcc) * 128 + ((k ^ (pcc & 7)) << 4));
-            u32x4 *const dst = reinterpret_cast<u32x4 *>(out + (((size_t)n * PO + pr0 + pr) * PO + pcc) * STEM_CO + k * 8);
-            if constexpr (PVR_NT & 128) __builtin_nontemporal_store(vv, dst);
-            else *dst = vv;
-        }
         ST_T(5);
+    }
+    // the block's last image: its pooled tile is complete behind the loop's last barrier
+    if (n1 > n0) {
+        copy_out(n1 - 1, tid, 512);
+        if (c1.w && wave < 7) conv1_tile(n1 - 1, wave);
     }
 }
 #ifdef STEM_STAMP
@@ -752,15 +805,32 @@ bool stem_pool_u8_ok(const void *frames, int h, int w, int top, int left) {
     return ((uintptr_t)frames & 15) == 0 && ((long long)h * w * 3) % 16 == 0 && (w * 3) % 16 == 0 && (left * 3) % 16 == 0 &&
            top >= 0 && left >= 0 && top + 224 <= h && left + 224 <= w && (long long)h * w * 3 < 0x7ffffff0ll;
 }
+// The stem can run layer1.0.conv1 itself (register-pooling form only): callers ask first
+bool stem_conv1_capable() { return stem_regpool_now(); }
+
+// (64, 64) 16-bit weights of a 1 x 1 convolution in pvr_op_conv2d's layout -> the 8 KB image stem_pool_reg_kernel reads: fragment (cout tile i, K step ks) =
+// [k chunk][row & 15][8], rows permuted inside the two 32-row blocks (row 16 t + 4 a + c holds cout 8 a + 4 t + c); host side, once per plan
+void stem_c1_pack(const u16 *w, u16 *img) {
+    for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int c = 0; c < 4; ++c)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 16 * i + r, src = (row & ~31) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3);
+                    for (int e = 0; e < 8; ++e) img[(((i * 2 + ks) * 4 + c) * 16 + r) * 8 + e] = w[src * 64 + ks * 32 + c * 8 + e];
+                }
+}
+
 pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int top, int left, const void *wgt, const float *bias, void *out,
-                               int dtype, hipStream_t stream) {
+                               int dtype, hipStream_t stream, const void *c1_w, const float *c1_b, void *c1_t1, int c1_blk) {
     PVR_REQUIRE(stem_pool_u8_ok(frames, h, w, top, left), "stem (uint8 form): geometry h=%d w=%d top=%d left=%d not supported", h, w, top, left);
     static const int cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
     const int yb = cus / 28 > 0 ? cus / 28 : 1;
     const int ipb_fit = (n + yb - 1) / yb;
     const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
-    const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240, lds_reg = 1024 + 2 * 28672 + 3 * 10240 + 2 * 56 * 128;
+    const size_t lds = 5 * 112 * 128 + 2 * 28672 + 3 * 10240, lds_reg = 1024 + 2 * 28672 + 3 * 10240 + 2 * 2 * 56 * 128 + 8192 + 256;
+    PVR_REQUIRE(!c1_w || (stem_regpool_now() && c1_b && c1_t1), "stem: layer1.0.conv1 inside the stem needs the register-pooling form");
+    StemC1 c1; c1.w = (const u16 *)c1_w; c1.b = c1_b; c1.t1 = (u16 *)c1_t1; c1.blk = c1_blk;
     static DeviceOnce attr_done;          // per device: a second GPU of the process needs the attribute too
     if (attr_done.needed()) {
         PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -773,9 +843,9 @@ pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int t
     g.src = frames; g.pitch = w * 3; g.img_bytes = h * w * 3; g.off0 = (top * w + left) * 3;
     if (stem_regpool_now()) {                                    // round 6: the max pool in registers (stem_pool_reg_kernel)
         if (dtype == PVR_F16)
-            hipLaunchKernelGGL((stem_pool_reg_kernel<true, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
+            hipLaunchKernelGGL((stem_pool_reg_kernel<true, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g, c1);
         else
-            hipLaunchKernelGGL((stem_pool_reg_kernel<false, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g);
+            hipLaunchKernelGGL((stem_pool_reg_kernel<false, true>), grid, dim3(512), lds_reg, stream, (const u16 *)nullptr, (const u16 *)wgt, bias, (u16 *)out, n, ipb, g, c1);
         PVR_LAUNCH_CHECK();
         return PVR_OK;
     }
@@ -788,8 +858,10 @@ pvr_status launch_stem_pool_u8(const uint8_t *frames, int n, int h, int w, int t
 }
 
 pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias, void *out, int n, int crop, int dtype,
-                            hipStream_t stream) {
+                            hipStream_t stream, const void *c1_w, const float *c1_b, void *c1_t1, int c1_blk) {
     PVR_REQUIRE(crop == 224, "stem: crop must be 224 (got %d)", crop);
+    PVR_REQUIRE(!c1_w || (stem_regpool_now() && c1_b && c1_t1), "stem: layer1.0.conv1 inside the stem needs the register-pooling form");
+    StemC1 c1; c1.w = (const u16 *)c1_w; c1.b = c1_b; c1.t1 = (u16 *)c1_t1; c1.blk = c1_blk;
     static const bool use_lds = [] { const char *e = getenv("PVR_STEM_LDS"); return !e || atoi(e) != 0; }();
     // images per block: a handful of frames (online embedding) -> one image per block (28 n blocks); else as many as it takes for the
     // 28 x ceil(n / ipb) blocks to fit the chip in ONE round (n = 256 on 256 CUs: 9 block rows of 29 images = 252 blocks), never fewer
@@ -800,7 +872,7 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
     const int ipb = n <= 8 ? 1 : (ipb_fit > STEM_IPB && use_lds ? ipb_fit : STEM_IPB);
     dim3 grid(28, (n + ipb - 1) / ipb);
     if (use_lds && stem_regpool_now()) {                         // round 6: the max pool in registers (stem_pool_reg_kernel), padded 16-bit image in
-        const size_t lds_reg = 1024 + 2 * 32768 + 2 * 56 * 128;
+        const size_t lds_reg = 1024 + 2 * 32768 + 2 * 2 * 56 * 128 + 8192 + 256;
         static DeviceOnce attr3_done;
         if (attr3_done.needed()) {
             PVR_HIP_TRY(hipFuncSetAttribute((const void *)stem_pool_reg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg));
@@ -808,9 +880,9 @@ pvr_status launch_stem_pool(const void *img, const void *wgt, const float *bias,
             attr3_done.mark();
         }
         if (dtype == PVR_F16)
-            hipLaunchKernelGGL(stem_pool_reg_kernel<true>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+            hipLaunchKernelGGL(stem_pool_reg_kernel<true>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb, U8Geo{}, c1);
         else
-            hipLaunchKernelGGL(stem_pool_reg_kernel<false>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb);
+            hipLaunchKernelGGL(stem_pool_reg_kernel<false>, grid, dim3(512), lds_reg, stream, (const u16 *)img, (const u16 *)wgt, bias, (u16 *)out, n, ipb, U8Geo{}, c1);
         PVR_LAUNCH_CHECK();
         return PVR_OK;
     }

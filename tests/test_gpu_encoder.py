@@ -1386,3 +1386,31 @@ def test_stem_register_pooling_equals_the_lds_tile_form(dt, n):
         _lib.check(L.pvr_debug_set_stem_regpool(-1))
         m.set_crop(0)
         m.close()
+
+
+@pytest.mark.parametrize('variant,dt,n', [('conv5', 'f16', 3), ('conv5', 'bf16', 40), ('conv4', 'f16', 5)])
+def test_layer1_conv1_inside_the_stem(variant, dt, n, monkeypatch):
+    """Round 6: layer1.0.conv1 (1 x 1, 64 -> 64 on the pooled stem output) runs inside the fused stem - seven waves take one 16-pixel MFMA tile each of the block's
+    pooled tile in LDS - instead of as a launch of its own: one launch and one read of the pooled tensor fewer, t1 in the layout the tail behind it reads (blocked).
+    Against the plan with the separate launch (PVR_STEM_CONV1=0): layer1's output and the embedding bit for bit (same K order, same rounding), for frames the stem
+    reads as uint8 and for frames that are resized first; with a debug stop (the stem form that cannot carry the convolution) the forward launches it itself."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    sd = synth.resnet50_state_dict(4, variant)
+    frames = [torch.from_numpy(synth.frames(60 + n, n, 256, 256)).cuda(), torch.from_numpy(synth.smooth_frames(61 + n, n, 120, 160)).cuda()]
+    got = {}
+    for key, on in (('inside', '1'), ('launch', '0')):
+        monkeypatch.setenv('PVR_STEM_CONV1', on)
+        m = HipResNet50(sd, variant, compute_dtype=dt, max_batch=max(8, n))
+        names = m.op_names()
+        res = []
+        for fr in frames:
+            m.debug_stop_after('layer1'); m(fr)
+            res.append(m.tap('layer1', n * 56 * 56 * 256).clone())
+            m.debug_stop_after('')
+            res.append(m(fr).clone())
+        m.close()
+        got[key] = (names, res)
+    assert 'layer1.0.conv1' in got['launch'][0] and 'layer1.0.conv1' not in got['inside'][0] and len(got['inside'][0]) == len(got['launch'][0]) - 1
+    for a, b in zip(got['inside'][1], got['launch'][1]):
+        assert torch.isfinite(b).all() and float(b.abs().max()) > 0
+        assert torch.equal(a, b), (int((a != b).sum()), float((a - b).abs().max()))
