@@ -926,8 +926,12 @@ def main():
     op_ms = (C.c_float * cap)(); op_fl = (C.c_double * cap)(); n_ops = C.c_int32()
     conv_ms, conv_fl, other_ms, bound_ms = 0.0, 0.0, 0.0, 0.0
     plan_names = [nm for nm in model.op_names()]
+    # which kernel each entry runs as at this chunk size: entries '(in the run)' have no launch of their own (round 6: layer3.1 .. 3.5 are ONE launch),
+    # so the identity of the plan the PMC file is tied to carries the kinds, and launches are counted without them
+    plan_kinds = model.kernel_names(chunk) if args.dtype != 'f32' and hasattr(model, 'kernel_names') else [''] * len(plan_names)
+    plan_id = ['%s [%s]' % (nm, k) if k in ('bneck_frame(run)', '(in the run)') else nm for nm, k in zip(plan_names, plan_kinds)]
     if args.dump_plan and rank == 0:
-        json.dump({'plan_launches': plan_names, 'dtype': args.dtype, 'chunk': chunk}, open(args.dump_plan, 'w'))
+        json.dump({'plan_launches': plan_id, 'dtype': args.dtype, 'chunk': chunk}, open(args.dump_plan, 'w'))
     algo_bytes = conv_algorithmic_bytes(chunk, plan_names if args.dtype != 'f32' else None)
     grp = {}                                                 # per ResNet stage: [ms, flops, algorithmic bytes] of its conv launches
     reps = 5
@@ -952,18 +956,18 @@ def main():
                   'frac_mfma': round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 3),
                   'algorithmic_GBps': round(v[2] / (v[0] * 1e-3) / 1e9, 1), 'frac_hbm': round(v[2] / (v[0] * 1e-3) / 8e12, 3)}
               for k, v in sorted(grp.items())}
-    n_conv = n_ops.value - 4
+    n_conv = n_ops.value - 4 - sum(1 for k in plan_kinds if k == '(in the run)')
     traffic, traffic_source = None, None
     tf = os.path.join(ROOT, 'profiles', 'pmc_conv_traffic.json')
     if os.path.isfile(tf) and args.dtype != 'f32':           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bf16 kernels)
         tj = json.load(open(tf))
-        if tj.get('plan_launches') == plan_names:
+        if tj.get('plan_launches') == plan_id:
             traffic = round(tj['avg_hbm_bytes_per_launch'])
             traffic_source = 'committed rocprofv3 PMC passes of this command (%s), NOT measured in this run: profiles/pmc_conv_traffic.json' % tj.get('captured', 'round 1 build')
         else:
             # the committed counters describe another plan (different fusions / launch list): a stale number is worse than none
             traffic_source = ('profiles/pmc_conv_traffic.json was captured for a different launch plan (%d launches recorded, %d in this run): '
-                              'traffic withheld; re-run the --pmc passes (scripts/pmc_summary.py)' % (len(tj.get('plan_launches') or []), len(plan_names)))
+                              'traffic withheld; re-run the --pmc passes (scripts/pmc_summary.py)' % (len(tj.get('plan_launches') or []), len(plan_id)))
     if args.per_op and rank == 0:
         names = ['preprocess', 'stem', 'maxpool'] + [op for op in model.op_names()] + ['pool/flatten']
         for i in range(n_ops.value):

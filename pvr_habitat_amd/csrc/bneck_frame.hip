@@ -34,6 +34,8 @@
 // 32-deep MFMA steps per slice) and rounding points (t2 and y rounded to the 16-bit storage type after bias + ReLU) as the separate conv_pp256 /
 // conv_expand launches: bit-identical to them (tests/test_gpu_encoder.py::test_frame_bottleneck_op_is_bit_identical).
 #include "common.h"
+#include "encoder_internal.h"
+#include <cstddef>
 
 namespace pvr {
 
@@ -50,11 +52,18 @@ struct BFP {
     unsigned t1_bytes, w2_bytes, w3_bytes, res_bytes, y_bytes, t2_bytes, w1n_bytes, t1n_bytes, w1f_bytes;
     int stagger;                   // experiment (PVR_FRAME_STAGGER): odd workgroups start `stagger` x 8128 cycles late - de-phases the CUs' HBM and matrix phases
     unsigned long long *stamps;    // diagnostics (scripts/bneck_frame_time.py): s_memtime at the phase boundaries of block 8, waves 0 and 4; nullptr in the product
+    int nblk;                      // RUN: consecutive bottlenecks of the stage this launch runs per frame (blk[0 .. nblk))
+    BFBlk blk[6];
 };
 
 #define BF_LDS_PTR(off_) ((__attribute__((address_space(3))) void *)(smem + (off_)))
 
-template <bool F16, bool NEXT1, bool FRONT1 = false>
+// RUN (round 6): the launch takes every frame through `nblk` CONSECUTIVE bottlenecks (layer3.1 .. 3.5) - a frame's next bottleneck needs nothing but that
+// frame's own output, so the workgroup that wrote y reads it back as the next x (and identity) without a launch boundary in between: the CUs stop moving in
+// step (every launch boundary re-aligned all 256 of them: all in their HBM-bound front phase together, all in the traffic-free conv2 together), y is re-read
+// while it is still in the Infinity Cache, and four launches' ramps go.  Between two bottlenecks: this wave's stores retired (vmcnt(0)) and a workgroup
+// barrier.
+template <bool F16, bool NEXT1, bool FRONT1 = false, bool RUN = false>
 __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     typedef typename HT<F16>::V8 V8;
     constexpr int NPIX = 196, IW = 14, CM = 256, CO = 1024, NT = 13;
@@ -63,21 +72,42 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int n = blockIdx.x;
     unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BF_TS(k_) { if (p.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_[k_]) :: "memory"); }
-#define BF_TS_OUT() { if (p.stamps && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) { _Pragma("unroll") for (int k = 0; k < 10; ++k) p.stamps[(wave >> 2) * 10 + k] = ts_[k]; } }
-    if (p.stagger && (blockIdx.x & 1)) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#define BF_TS_OUT() { if (p.stamps && blockIdx.x == 8 && lane0 == 0 && (wave0 & 3) == 0) { _Pragma("unroll") for (int k = 0; k < 10; ++k) p.stamps[(wave0 >> 2) * 10 + k] = ts_[k]; } }
+    if (p.stagger) {
+        // start delay in units of 8128 cycles: (stagger & 255) for the last of G groups, the others spread evenly below it; pattern = stagger >> 8:
+        // 0: odd / even workgroups (= odd / even XCDs), 1: two groups inside every XCD, 2: four, 3: eight
+        const int pat = p.stagger >> 8, units = p.stagger & 255;
+        const int G = pat <= 1 ? 2 : pat == 2 ? 4 : 8;
+        const int g = pat == 0 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & (G - 1));
+        const int d = units * g / (G - 1);
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
     }
     BF_TS(0);
+    const int nblk = RUN ? p.nblk : 1;
+    int blk = 0;
+    do {                                                          // (non-RUN: `while (false)` - no loop at all; a one-trip `for` changed hipcc's hoisting decisions: 109 spilled VGPRs)
+    int tid = tid0;
+    if constexpr (RUN) asm volatile("" : "+v"(tid));              // (opaque per bottleneck: nothing derived from the lane index is hoisted out of the loop and kept alive across it)
+    const int lane = tid & 63;
+    const int wave = RUN ? __builtin_amdgcn_readfirstlane(tid >> 6) : wave0;
+    const int fr = lane & 15, fq = lane >> 4;
+    // (the table is read from the kernel-argument segment with a scalar load at a run-time offset: indexing the by-value struct itself makes hipcc copy it to scratch)
+    typedef const __attribute__((address_space(4))) BFBlk *BlkPtr;
+    typedef const __attribute__((address_space(4))) char *KaPtr;
+    const BlkPtr bt = (BlkPtr)((KaPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(BFP, blk)) + blk;
+    const u16 *P_w1f = p.w1f, *P_w2 = p.w2, *P_w3 = p.w3, *P_res = p.res;
+    const float *P_b1f = p.b1f, *P_b2 = p.b2, *P_b3 = p.b3;
+    u16 *P_y = p.y;
+    if constexpr (RUN) { P_w1f = bt->w1f; P_w2 = bt->w2; P_w3 = bt->w3; P_res = bt->res; P_b1f = bt->b1f; P_b2 = bt->b2; P_b3 = bt->b3; P_y = bt->y; }
 
     const auto rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.t1), 0, p.t1_bytes, 0x00020000);
-    const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w2), 0, p.w2_bytes, 0x00020000);
-    const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w3), 0, p.w3_bytes, 0x00020000);
+    const auto rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(P_w2), 0, p.w2_bytes, 0x00020000);
+    const auto rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(P_w3), 0, p.w3_bytes, 0x00020000);
 
     // ---- the frame's t1 image -> T: 4 slices x 26 groups of 8 rows, one 1 KB DMA each (rows >= 196: offset past num_records -> zeros)
     if constexpr (!FRONT1)
@@ -181,8 +211,8 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         // is exposed (no second buffer: 107 KB of 160); what the launch saves is conv1's own launch (its ramp, prologue, output burst and the
         // 51 MB t1 round trip).  The weight fragments of a chunk's first K tile are requested BEFORE its DMA (loads retire in order: a
         // request behind the DMA could only be waited for together with it).
-        const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
-        const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.w1f), 0, p.w1f_bytes, 0x00020000);
+        const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(P_res), 0, p.res_bytes, 0x00020000);
+        const auto rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(P_w1f), 0, p.w1f_bytes, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NT; ++j) xa[j] = (16 * j + fr) * 128 + ((fq ^ sw) << 4);
         // Eight half chunks of 128 channels rotate through THREE 53 KB regions - the two halves of the image region (slices 0-1 / 2-3) and a third one
@@ -271,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         BF_BARRIER();                                             // every wave's reads of the last chunk are done
         {
             const int c1 = 32 * wave + 8 * fq;
-            const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b1f + c1), bh = *reinterpret_cast<const f32x4 *>(p.b1f + c1 + 4);
+            const f32x4 bl = *reinterpret_cast<const f32x4 *>(P_b1f + c1), bh = *reinterpret_cast<const f32x4 *>(P_b1f + c1 + 4);
             char *tbase = smem + (wave >> 1) * SLICE + (((4 * (wave & 1) + fq) ^ sw) << 4);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     {
         const auto rs_t2 = __builtin_amdgcn_make_buffer_rsrc(p.t2_out, 0, p.t2_out ? p.t2_bytes : 0, 0x00020000);
         const int c = 32 * wave + 8 * fq;
-        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b2 + c), bh = *reinterpret_cast<const f32x4 *>(p.b2 + c + 4);
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(P_b2 + c), bh = *reinterpret_cast<const f32x4 *>(P_b2 + c + 4);
         char *tbase = smem + (wave >> 1) * SLICE + (((4 * (wave & 1) + fq) ^ sw) << 4);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -353,8 +383,8 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     BF_BARRIER();                                               // every wave's part of t2 is in the image
 
     // =================================================== conv3: 4 chunks of 256 couts x 4 slices ========================================
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(p.res), 0, p.res_bytes, 0x00020000);
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(P_res), 0, p.res_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(P_y, 0, p.y_bytes, 0x00020000);
     if constexpr (NEXT1) {
     // ---- form 3: conv3 in eight rounds of 128 couts + the next block's conv1 over each round's y image
     const int wr = wave >> 2, wc = wave & 3;
@@ -418,7 +448,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         f32x4 acc3[2][4];
         const int rt3 = 8 * r + 2 * wc;                         // W3 row tiles of this wave and round (shared with wave w ^ 4)
         const int c = 128 * r + 32 * wc + 8 * fq;
-        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b3 + c), bh = *reinterpret_cast<const f32x4 *>(p.b3 + c + 4);
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(P_b3 + c), bh = *reinterpret_cast<const f32x4 *>(P_b3 + c + 4);
         BF_ZERO3();
         BF_LOAD_W(wb, rs_w3, rt3, CM / 8, 1); BF_KT3(0, 0, wa);
         BF_LOAD_W(wa, rs_w3, rt3, CM / 8, 2); BF_KT3(1, 0, wb);
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
         if (ch == 0) BF_TS(5);
         // ---- y = relu(conv3 + b3 + identity), rounded, NHWC; a lane's tile pair = 8 consecutive couts of one pixel
         const int c = cc;
-        const f32x4 bl = *reinterpret_cast<const f32x4 *>(p.b3 + c), bh = *reinterpret_cast<const f32x4 *>(p.b3 + c + 4);
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(P_b3 + c), bh = *reinterpret_cast<const f32x4 *>(P_b3 + c + 4);
         if constexpr (BF_LATE_RES != 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -520,6 +550,17 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
 #undef BF_HOOK
 #define BF_HOOK(q_)
     }
+    if constexpr (RUN) {
+        if (blk + 1 < nblk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's y stores have reached L2 ...
+            __builtin_amdgcn_s_barrier();                         // ... every wave's have, and every wave is done with the t2 image
+            // (no cache invalidate: a frame's region of the ping-pong buffers is written by THIS workgroup only, and a CU's vector L1 is coherent with
+            //  that CU's own stores - workgroup scope needs no invalidate outside threadgroup-split mode.  `buffer_inv sc1` here cost 14 us per
+            //  bottleneck: at agent scope it also drops the XCD's L2 lines, i.e. the weight fragments all 32 CUs of the XCD are reading.)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    } while (RUN && ++blk < nblk);                                // (the bottlenecks of a RUN launch)
     BF_TS(8);
     if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BF_TS(9);
@@ -613,6 +654,35 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
         if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false>), dim3(n), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((bneck_frame_kernel<false, false>), dim3(n), dim3(512), lds, stream, p);
     }
+    PVR_LAUNCH_CHECK();
+    return PVR_OK;
+}
+
+// RUN launch: `nblk` consecutive whole bottlenecks (own conv1 in front) per frame; blocks[k].res = bottleneck k's input, blocks[k].y its output (blocks[k + 1].res
+// == blocks[k].y).  stagger: odd workgroups start `stagger` x 8128 cycles late.
+pvr_status launch_bneck_frame_run(const BFBlk *blocks, int nblk, int n, int dtype, hipStream_t stream, int stagger) {
+    PVR_REQUIRE(blocks && nblk >= 1 && nblk <= 6 && n >= 1, "bneck_frame_run: 1 .. 6 bottlenecks");
+    PVR_REQUIRE(dtype == PVR_BF16 || dtype == PVR_F16, "bneck_frame_run: 16-bit storage types only");
+    BFP p = {};
+    p.n = n; p.phases = 3; p.nblk = nblk; p.stagger = stagger;
+    for (int k = 0; k < nblk; ++k) {
+        const BFBlk &b = blocks[k];
+        PVR_REQUIRE(b.w1f && b.w2 && b.w3 && b.b1f && b.b2 && b.b3 && b.res && b.y && b.res != b.y && (k == 0 || b.res == blocks[k - 1].y),
+                    "bneck_frame_run: null argument or a bottleneck that does not read its predecessor's output");
+        p.blk[k] = b;
+    }
+    p.w2_bytes = 256u * 9 * 256 * 2; p.w3_bytes = 1024u * 256 * 2; p.w1f_bytes = 256u * 1024 * 2;
+    p.res_bytes = p.y_bytes = (unsigned)((size_t)n * 196 * 1024 * 2);
+    constexpr int ldsf = 6 * 209 * 128;
+    static DeviceOnce attr_done;
+    if (attr_done.needed()) {
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        PVR_HIP_TRY(hipFuncSetAttribute((const void *)bneck_frame_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        attr_done.mark();
+    }
+    ++g_bneck_frame_launches;
+    if (dtype == PVR_F16) hipLaunchKernelGGL((bneck_frame_kernel<true, false, true, true>), dim3(n), dim3(512), ldsf, stream, p);
+    else hipLaunchKernelGGL((bneck_frame_kernel<false, false, true, true>), dim3(n), dim3(512), ldsf, stream, p);
     PVR_LAUNCH_CHECK();
     return PVR_OK;
 }

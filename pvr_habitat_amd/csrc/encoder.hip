@@ -34,6 +34,8 @@ static void read_switches(PlanSwitches &sw) {
     sw.smallk_div = get("PVR_SMALLK_DIV", 4);
     if (sw.smallk_div < 1) sw.smallk_div = 1;
     sw.frame_min_n = get("PVR_FRAME_MIN_N", 128);
+    sw.frame_run = get("PVR_FRAME_RUN", 0);       // (measured equal to one launch per bottleneck: opt-in, profiles/experiments/r06_bneck_frame_run.txt)
+    sw.frame_stagger = get("PVR_FRAME_RUN_STAGGER", 0);
     sw.split16 = get("PVR_SPLIT16", 1);
     sw.stem_conv1 = get("PVR_STEM_CONV1", 1);
     sw.resid32 = get("PVR_RESID32", 1);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void range_flag_kernel(const void *x, size_t n
 }
 
 const char *launch_kind_name(int k) {
-    static const char *nm[] = {"conv", "bneck_frame(front1)", "bneck_frame", "frame_members", "conv_pp256(dual)", "dual_members", "chain", "cast",
+    static const char *nm[] = {"conv", "bneck_frame(front1)", "bneck_frame", "bneck_frame(run)", "(in the run)", "frame_members", "conv_pp256(dual)", "dual_members", "chain", "cast",
                                "conv_f32", "conv_split16", "conv_split16(pair)", "conv_split16(in32)", "splitk(small)", "splitk", "conv_expand(blocked)",
                                "conv_wfrag(pool)", "conv_wfrag"};
     return k >= 0 && k < (int)(sizeof nm / sizeof nm[0]) ? nm[k] : "?";
@@ -848,6 +850,19 @@ static void resolve_kinds(pvr_encoder *enc) {
     if (enc->desc.dtype == PVR_F32 || enc->desc.arch == PVR_ARCH_CLIP_RN50 || enc->vit || enc->rnd || enc->host) { enc->kinds_algo = conv_algo(); return; }
     for (int nb = 1; nb <= chunk; ++nb)
         for (size_t i = 0; i < plan.size(); ++i) enc->kinds[(size_t)(nb - 1) * plan.size() + i] = resolve_kind(enc, plan, i, nb);
+    // consecutive whole-bottleneck frame launches, each reading its predecessor's output (layer3.1 .. 3.5): one launch for the run (bneck_frame.hip RUN)
+    if (enc->sw.frame_run)
+        for (int nb = 1; nb <= chunk; ++nb) {
+            uint8_t *k = enc->kinds.data() + (size_t)(nb - 1) * plan.size();
+            for (size_t i = 0; i + 1 < plan.size(); ++i) {
+                if (k[i] != LK_FRAME_FRONT1) continue;
+                size_t j = i;
+                while (j + 1 < plan.size() && j + 1 - i < 6 && k[j + 1] == LK_FRAME_FRONT1 &&
+                       enc->ops[plan[j + 1].conv3].res_buf == enc->ops[plan[j].conv3].out_buf && enc->ops[plan[j + 1].conv1].in_buf == enc->ops[plan[j].conv3].out_buf) ++j;
+                if (j > i) { k[i] = LK_FRAME_RUN; for (size_t t = i + 1; t <= j; ++t) k[t] = LK_FRAME_RUN_TAIL; }
+                i = j;
+            }
+        }
     enc->kinds_algo = conv_algo();
 }
 
@@ -1148,6 +1163,7 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
         // the pooled epilogue stores 16-byte pieces of the caller's rows: a property of this call's arguments, not of the plan
         const bool pool_args_ok = enc->stop_after.empty() && out_stride % 4 == 0 && (((size_t)(out + (size_t)f0 * out_stride)) & 15) == 0;
         int launch_idx = 0;                          // debug: stop_after = "#k" ends the forward after conv launch k of the plan
+        const bool run_ok = enc->stop_after.empty() && !enc->range_flags;
         const int stop_idx = enc->stop_after.size() > 1 && enc->stop_after[0] == '#' ? atoi(enc->stop_after.c_str() + 1) : -1;
         // a member convolution of a launch that runs as its members (small forwards): split-K in the low-latency plan, else the shape's kernel
         auto member = [&](const ConvOp &o, const void *in, const void *r_, void *out_) -> pvr_status {
@@ -1163,7 +1179,23 @@ static pvr_status forward_impl(pvr_encoder *enc, const uint8_t *frames, int32_t 
             const void *res = op.res_buf == B_NONE ? nullptr : enc->d_buf[op.res_buf];
             int kind = kinds[li];
             if (kind == LK_WFRAG_POOL && !pool_args_ok) kind = resolve_kind(enc, plan_, li, nb, false);
+            if ((kind == LK_FRAME_RUN || kind == LK_FRAME_RUN_TAIL) && !run_ok) kind = LK_FRAME_FRONT1;     // (taps, debug stops, range validation: one launch per bottleneck)
             switch (kind) {
+            case LK_FRAME_RUN: {
+                BFBlk blks[6];
+                int nblk = 0;
+                for (size_t t = li; t < plan_.size() && nblk < 6 && (t == li || kinds[t] == LK_FRAME_RUN_TAIL); ++t, ++nblk) {
+                    const Launch &lt = plan_[t];
+                    const ConvOp &o3 = enc->ops[lt.conv3], &o2 = enc->ops[lt.conv2], &o1 = enc->ops[lt.conv1];
+                    blks[nblk] = BFBlk{(const u16 *)o1.d_wfb, (const u16 *)o2.d_wfb, (const u16 *)o3.d_wfb, (const u16 *)enc->d_buf[o3.res_buf], o1.d_b, o2.d_b, o3.d_b,
+                                       (u16 *)enc->d_buf[o3.out_buf]};
+                }
+                s = launch_bneck_frame_run(blks, nblk, nb, dt, st, enc->sw.frame_stagger);
+                break;
+            }
+            case LK_FRAME_RUN_TAIL:
+                s = PVR_OK;                                   // (inside the run's launch)
+                break;
             case LK_FRAME_FRONT1: {
                 const ConvOp &c2 = enc->ops[l.conv2], &cf = enc->ops[l.conv1];
                 s = launch_bneck_frame(nullptr, c2.d_wfb, c2.d_b, op.d_wfb, op.d_b, res, enc->d_buf[op.out_buf], nullptr, nb, 3 | 8, dt, st,
@@ -1449,7 +1481,9 @@ pvr_status pvr_encoder_debug_set_switch(pvr_encoder *enc, const char *name, int3
     if (nm == "pool_fuse") enc->sw.pool_fuse = value;
     else if (nm == "stem_u8") enc->sw.stem_u8 = value;
     else if (nm == "frame_min_n") enc->sw.frame_min_n = value;
-    else { set_error("pvr_encoder_debug_set_switch: '%s' is not a live switch (pool_fuse, stem_u8, frame_min_n); plan switches are read from the environment at create", name); return PVR_ERR_INVALID; }
+    else if (nm == "frame_run") enc->sw.frame_run = value;
+    else if (nm == "frame_stagger") enc->sw.frame_stagger = value;
+    else { set_error("pvr_encoder_debug_set_switch: '%s' is not a live switch (pool_fuse, stem_u8, frame_min_n, frame_run, frame_stagger); plan switches are read from the environment at create", name); return PVR_ERR_INVALID; }
     if (enc->finalized && !enc->vit && !enc->rnd && !enc->host) resolve_kinds(enc);
     return PVR_OK;
 }
@@ -1497,7 +1531,9 @@ int32_t pvr_encoder_launch_kernel(const pvr_encoder *enc, int32_t n, int32_t ind
     const int i = index - 3;
     if (i >= (int)plan.size()) return 0;
     const int nb = n < enc->desc.chunk ? n : enc->desc.chunk;
-    const int kind = resolve_kind(enc, plan, (size_t)i, nb);
+    // the forward's own table when it is current (it knows the runs: several plan entries in one launch), else the per-entry rule
+    const bool tab = enc->kinds_stride == plan.size() && enc->kinds.size() == (size_t)enc->desc.chunk * plan.size() && enc->kinds_algo == conv_algo();
+    const int kind = tab ? enc->kinds[(size_t)(nb - 1) * plan.size() + i] : resolve_kind(enc, plan, (size_t)i, nb);
     const char *nm = enc->desc.dtype == PVR_F32 ? "conv_f32" : launch_kind_name(kind);
     if (enc->desc.dtype != PVR_F32 && kind == LK_CHAIN) nm = plan[i].wave == 2 ? "chain_wave128" : plan[i].wave == 1 ? "chain_wave" : "bottleneck_chain";
     snprintf(buf, (size_t)cap, "%s", nm);

@@ -49,6 +49,13 @@ pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, h
 pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *res, void *y,
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
+// round 6: consecutive whole bottlenecks of the stage per frame in ONE launch (blocks[k + 1].res == blocks[k].y); odd workgroups start `stagger` x 8128 cycles late
+struct BFBlk {
+    const unsigned short *w1f, *w2, *w3, *res;
+    const float *b1f, *b2, *b3;
+    unsigned short *y;
+};
+pvr_status launch_bneck_frame_run(const BFBlk *blocks, int nblk, int n, int dtype, hipStream_t stream, int stagger);
 
 // conv_wfrag.hip: implicit GEMM in 112-pixel x 256-cout tiles with the weights read from L2 as MFMA fragments (layer4 at batch 256)
 bool conv_wfrag_supported(int64_t M, int64_t in_bytes, int cin, int cout, int kh, int kw, int pad, int act, int out_f32);
@@ -113,6 +120,8 @@ enum LaunchKind : uint8_t {
     LK_CONV = 0,          // launch_conv (conv_igemm.hip picks igemm / pp256 / expand / halo by shape)
     LK_FRAME_FRONT1,      // bneck_frame: conv1 -> conv2 -> conv3 + identity of one 14 x 14 image per workgroup
     LK_FRAME,             // bneck_frame: conv2 -> conv3 + identity [-> next conv1]
+    LK_FRAME_RUN,         // round 6: the first of >= 2 consecutive LK_FRAME_FRONT1 launches - ONE launch takes every frame through all of them
+    LK_FRAME_RUN_TAIL,    //          ... and the others (no launch of their own)
     LK_FRAME_MEMBERS,     // the member convolutions of a per-frame launch as their own launches (small forwards)
     LK_DUAL,              // conv_pp256 two-operand launch: conv3 & the stride-2 downsample
     LK_DUAL_MEMBERS,      // ... as two launches (low-latency plan, PVR_CONV_ALGO)
@@ -143,6 +152,8 @@ struct PlanSwitches {
     int chain_blocked = 1;    // PVR_CHAIN_BLOCKED: blocked hand-off between consecutive tails
     int splitk = 1;           // PVR_SPLITK: planned split-K of the *_l4 head
     int smallk_div = 4;       // PVR_SMALLK_DIV: K slices per block of the low-latency plan
+    int frame_run = 0;        // PVR_FRAME_RUN (live, opt-in: measured equal): consecutive whole-bottleneck frame launches (layer3.1 .. 3.5) as one launch
+    int frame_stagger = 0;    // PVR_FRAME_RUN_STAGGER: odd workgroups of that launch start this many x 8128 cycles late
     int frame_min_n = 128;    // PVR_FRAME_MIN_N (live): frames per forward from which layer3's per-frame launches run as such
     int stem_conv1 = 1;       // PVR_STEM_CONV1: layer1.0.conv1 runs inside the fused stem (no launch of its own; round 6)
     int split16 = 1;          // PVR_SPLIT16: the fp32 stage / head of the compressed PVRs' parity plan on the 16-bit MFMA (0: f32-input MFMA)

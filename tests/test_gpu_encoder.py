@@ -1039,6 +1039,37 @@ def test_frame_bottleneck_plan_is_bit_identical(variant, dtype, n, monkeypatch):
             assert torch.equal(a, b), (key, what, int((a != b).sum()), float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_frame_run_is_bit_identical_at_the_bench_batch(dtype):
+    """Round 6 (opt-in, PVR_FRAME_RUN=1: measured equal to the default): layer3.1 .. 3.5 as ONE launch that takes every frame through the five bottlenecks (bneck_frame.hip RUN: the workgroup that wrote a frame's y
+    reads it back as the next x and identity; between two bottlenecks: stores retired + a workgroup barrier) against one launch per
+    bottleneck, at the bench batch (256 frames = one workgroup per CU) and a ragged one, with and without the start stagger of the odd workgroups: every
+    element of the embedding, bit for bit, five times in a row (a stale cache line would be a sporadic difference)."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    L = _lib.lib()
+    sd = synth.resnet50_state_dict(11)
+    m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=256)
+    try:
+        for n in (256, 131):
+            fr = torch.from_numpy(synth.smooth_frames(70 + n, n, 64, 64)).cuda()
+            m.set_switch('frame_run', 0)
+            assert 'bneck_frame(run)' not in m.kernel_names(n)
+            ref = m(fr).clone()
+            for stagger in (0, 6):
+                m.set_switch('frame_run', 1)
+                m.set_switch('frame_stagger', stagger)
+                names = m.kernel_names(n)
+                assert names.count('bneck_frame(run)') == 1 and names.count('(in the run)') == 4, names
+                before = L.pvr_debug_bneck_frame_launches()
+                for _ in range(5):
+                    out = m(fr)
+                    assert torch.equal(out, ref)
+                assert L.pvr_debug_bneck_frame_launches() - before == 5
+        m.set_switch('frame_stagger', 0)
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize('variant,dtype,n,ds,w128', [('conv5', 'bf16', 3, '1', '0'), ('conv5', 'f16', 5, '0', '1'), ('conv3', 'f16', 2, '1', '0'), ('conv5', 'bf16', 1, '1', '1'),
                                                      ('conv5', 'bf16', 40, '1', '0')])
 def test_chain_wave_equals_block_form(variant, dtype, n, ds, w128, monkeypatch):
@@ -1319,7 +1350,7 @@ def test_default_plan_at_the_bench_batch_against_the_oracle():
     assert l2 < 1e-3 and mx < 2e-3, (l2, mx)
     # the small-forward plan of the same handle (none of those kernels) gives the same rows bit for bit
     small = m(torch.from_numpy(fr_np[idx[:3]]).cuda()).cpu().numpy()
-    assert 'bneck_frame(front1)' not in m.kernel_names(3)
+    assert 'bneck_frame(front1)' not in m.kernel_names(3) and 'bneck_frame(run)' not in m.kernel_names(3)
     assert np.array_equal(small, out[idx[:3]])
     m.close()
 
