@@ -63,6 +63,17 @@ struct BFP {
 // step (every launch boundary re-aligned all 256 of them: all in their HBM-bound front phase together, all in the traffic-free conv2 together), y is re-read
 // while it is still in the Infinity Cache, and four launches' ramps go.  Between two bottlenecks: this wave's stores retired (vmcnt(0)) and a workgroup
 // barrier.
+// byte offset of channel c_ of pixel p_ of this frame in the block input / identity / output.  BF_LAYOUT_KO (timing experiments only: WRONG results against NHWC
+// tensors): bit 0 / 1 / 2 = the front conv1's x reads / conv3's identity reads / the y stores address a frame as [channel >> 7][pixel][channel & 127] - every
+// 128-channel half chunk of a frame one contiguous 50 KB block instead of 196 pieces of 256 B at a 2 KB stride
+#ifndef BF_LAYOUT_KO
+#define BF_LAYOUT_KO 0
+#endif
+#define BF_NHWC_(p_, c_) (((n * NPIX + (p_)) * CO + (c_)) * 2)
+#define BF_BLK_(p_, c_) ((((n * 8 + ((c_) >> 7)) * NPIX + (p_)) * 128 + ((c_) & 127)) * 2)
+#define BF_XADDR(p_, c_) ((BF_LAYOUT_KO & 1) ? BF_BLK_(p_, c_) : BF_NHWC_(p_, c_))
+#define BF_RADDR(p_, c_) ((BF_LAYOUT_KO & 2) ? BF_BLK_(p_, c_) : BF_NHWC_(p_, c_))
+#define BF_YADDR(p_, c_) ((BF_LAYOUT_KO & 4) ? BF_BLK_(p_, c_) : BF_NHWC_(p_, c_))
 template <bool F16, bool NEXT1, bool FRONT1 = false, bool RUN = false>
 __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     typedef typename HT<F16>::V8 V8;
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
             const int u0 = wave + 8 * i, u = u0 < 52 ? u0 : 51;
             const int s2 = u / 26, g = u % 26;
             const int row = g * 8 + (lane_c >> 3), lch = (lane_c & 7) ^ ((row >> 1) & 7);
-            const int vo = row < NPIX ? ((n * NPIX + row) * CO + h * 128 + s2 * 64 + lch * 8) * 2 : OOB;
+            const int vo = row < NPIX ? BF_XADDR(row, h * 128 + s2 * 64 + lch * 8) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, BF_LDS_PTR((2 * b3 + s2) * SLICE + g * 1024), 16, vo, 0, 0, 0);
             asm volatile("" ::: "memory");
         };
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     if constexpr (!BF_LATE_RES && (((q_) >= 17 && (q_) < 26) || ((q_) >= 30 && (q_) < 34))) {                                     \
         constexpr int r_ = (q_) < 26 ? (q_) - 17 : (q_) - 30 + 9;                                               \
         const int pp_ = 16 * r_ + fr;                                                                           \
-        rr[r_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp_ < NPIX && !(p.phases & 32)) ? ((n * NPIX + pp_) * CO + cc) * 2 : OOB, 0, PVR_NT_AUX(512))); \
+        rr[r_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pp_ < NPIX && !(p.phases & 32)) ? BF_RADDR(pp_, cc) : OOB, 0, PVR_NT_AUX(512))); \
         asm volatile("" ::: "memory");                                                                          \
     }
 #pragma unroll 1
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
                 v[2 * e + 1] += from_h<F16>((u16)(rr[j][e] >> 16));
                 o[e] = (unsigned)to_h<F16>(fmaxf(v[2 * e], 0.f)) | ((unsigned)to_h<F16>(fmaxf(v[2 * e + 1], 0.f)) << 16);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, (pp < NPIX && !(p.phases & 16)) ? ((n * NPIX + pp) * CO + c) * 2 : OOB, 0, PVR_NT_AUX(256));
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, (pp < NPIX && !(p.phases & 16)) ? BF_YADDR(pp, c) : OOB, 0, PVR_NT_AUX(256));
         }
         if (ch == 0) BF_TS(6);
         if (ch == 2) BF_TS(7);
