@@ -59,7 +59,7 @@ const std::string &last_error();
 // first to leave L2), so that the rows a kernel re-reads (3x3 halos, the resident weights) stay.  PVR_NT is a build-time mask for
 // A/B runs (profiles/experiments/r04_nt_streams.txt): 1 chain_wave stores, 2 chain_wave residual loads, 4 / 8 bottleneck_chain y /
 // t1' stores, 16 its residual loads, 32 / 64 conv_expand stores / residual loads, 128 stem stores, 256 / 512 conv_pp256 stores /
-// residual loads.
+// residual loads, 1024 the register-pooling stem's uint8 frame reads (round 6).
 #ifndef PVR_NT
 #define PVR_NT 119  // 1+2 wave stores / residual, 4+16 block-form y stores / residual, 32+64 conv_expand with a residual (layer3 / layer4 conv3)
 #endif

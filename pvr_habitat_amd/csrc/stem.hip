@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 1) void stem_pool_reg_kernel(const u16 *__rest
             const int yi = 2 * cr0 - 3 + r;                               // crop row of padded row 2 cr0 + r
             const bool ok = q < 630 && yi >= 0 && yi < 224;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(rb + i * 1024), 16,
-                                                     ok ? u8g.off0 + yi * u8g.pitch + c * 16 : 0x7ffffff0, 0, 0, 0);
+                                                     ok ? u8g.off0 + yi * u8g.pitch + c * 16 : 0x7ffffff0, 0, 0, PVR_NT_AUX(1024));
         }
     };
     auto convert_rows = [&](int n_, int zb_) {
