@@ -208,6 +208,14 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1_dev, const void *w2_dev, 
                                         const void *w1f_dev, const float *b1f_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
 /* launches of that kernel so far (tests: the layer3 plan really took it) */
 int64_t pvr_debug_bneck_frame_launches(void);
+/* round 6: which kernel runs the whole-bottleneck form (w1f given; torchvision Bottleneck conv1 -> conv2 -> conv3 + identity reached from reference
+ * src/embeddings.py:118-120): 1 bneck_frame64.hip (one wave per SIMD, 64 output channels x 13 pixel tiles per wave: half the LDS reads per MFMA), 0 the
+ * 32-channel tiling of round 5, -1 back to the environment (PVR_FRAME64, default 0: bit-identical, measured slower).  Both give the same bits.  Process-global. */
+pvr_status pvr_debug_set_frame64(int32_t mode);
+int64_t pvr_debug_bneck_frame64_launches(void);
+/* the 64-channel tiling with s_memtime stamps of workgroup 8, wave 0 (8 x uint64 on the device) - diagnostics only */
+pvr_status pvr_debug_bneck_frame64_stamps(const void *w1f_dev, const float *b1f_dev, const void *w2_dev, const float *b2_dev, const void *w3_dev, const float *b3_dev,
+                                          const void *x_dev, void *y_dev, int32_t n, int32_t dtype, uint64_t *stamps_dev, void *hip_stream);
 /* pvr_op_conv2d's convolution for small pixel counts and deep K (layer4 at batch 256; conv_wfrag.hip): 112-pixel x 256-cout tiles, the weight operand read
  * from L2 as whole MFMA fragments.  wgt_packed: pvr_op_pack_frag_weights of the (cout, kh*kw*cin) matrix; cin % 64 == 0, cout % 256 == 0, kh == kw <= 3,
  * relu 0 / 1, residual 16-bit or NULL, out_f32 0 / 1.  Bit-identical to pvr_op_conv2d. */

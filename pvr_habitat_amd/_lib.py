@@ -56,6 +56,9 @@ _SIGS = {
     'pvr_debug_convert': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'pvr_op_bneck_frame': (C.c_int, [C.c_void_p] * 13 + [C.c_int32] * 3 + [C.c_void_p]),
     'pvr_debug_bneck_frame_launches': (C.c_int64, []),
+    'pvr_debug_set_frame64': (C.c_int, [C.c_int32]),
+    'pvr_debug_bneck_frame64_launches': (C.c_int64, []),
+    'pvr_debug_bneck_frame64_stamps': (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 2 + [C.c_void_p] * 2),
     'pvr_op_conv_wfrag': (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 12 + [C.c_void_p]),
     'pvr_debug_conv_wfrag_launches': (C.c_int64, []),
     'pvr_op_conv_wfrag_pool': (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),

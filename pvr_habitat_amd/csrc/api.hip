@@ -57,6 +57,10 @@ pvr_status launch_pack_frag_weights(const void *w, void *out, int rows, int K, h
 pvr_status launch_bneck_frame(const void *t1, const void *w2, const float *b2, const void *w3, const float *b3, const void *res, void *y,
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps = nullptr,
                               const void *w1np = nullptr, const float *b1n = nullptr, void *t1n = nullptr, const void *w1fp = nullptr, const float *b1f = nullptr);
+pvr_status launch_bneck_frame64(const void *w1p, const float *b1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *x, void *y, int n,
+                                int dtype, hipStream_t stream, unsigned long long *stamps);
+void set_frame64(int mode);
+long long bneck_frame64_launches();
 long long pp_persistent_launches();
 pvr_status launch_conv_pp256(const void *in, const void *wgt, const float *bias, const void *res, void *out, int n, int h, int w, int cin,
                              int cout, int kh, int kw, int stride, int pad, int act, int out_f32, int res_f32, int dtype, int bm, hipStream_t stream,
@@ -115,6 +119,21 @@ pvr_status pvr_debug_bneck_frame_stamps(const void *t1, const void *w2, const fl
     PVR_REQUIRE(stamps_dev && n > 8, "pvr_debug_bneck_frame_stamps: needs a stamp buffer and more than 8 frames");
     return launch_bneck_frame(t1, w2, b2, w3, b3, residual, y, nullptr, n, (w1n ? 7 : 3) | (w1f ? 8 : 0), dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev,
                               w1n, b1n, t1n, w1f, b1f);
+}
+// round 6: which kernel runs the whole-bottleneck frame launches (pvr_op_bneck_frame with w1f, the plan's bneck_frame(front1) launches): 1 the 64-channel tiling
+// (bneck_frame64.hip), 0 bneck_frame_kernel<.., FRONT1>, -1 back to the environment (PVR_FRAME64, default 0: bit-identical, measured slower).  Same bits either way.  Process-global.
+pvr_status pvr_debug_set_frame64(int32_t mode) {
+    PVR_REQUIRE(mode >= -1 && mode <= 1, "pvr_debug_set_frame64: -1 (environment: PVR_FRAME64, default off), 0 or 1");
+    set_frame64(mode);
+    return PVR_OK;
+}
+int64_t pvr_debug_bneck_frame64_launches(void) { return (int64_t)bneck_frame64_launches(); }
+// the 64-channel tiling with s_memtime stamps of workgroup 8, wave 0 (8 x uint64: start, front conv1 done, conv2 loop done, t2 written, chunk 0 K loop, chunk 0
+// epilogue, all issued, stores drained) - diagnostics only
+pvr_status pvr_debug_bneck_frame64_stamps(const void *w1f, const float *b1f, const void *w2, const float *b2, const void *w3, const float *b3, const void *x, void *y,
+                                          int32_t n, int32_t dtype, uint64_t *stamps_dev, void *stream) {
+    PVR_REQUIRE(stamps_dev && n > 8, "pvr_debug_bneck_frame64_stamps: needs a stamp buffer and more than 8 frames");
+    return launch_bneck_frame64(w1f, b1f, w2, b2, w3, b3, x, y, n, dtype, (hipStream_t)stream, (unsigned long long *)stamps_dev);
 }
 // single-operator entry point of the small-M implicit-GEMM kernel with weights as L2 fragments (conv_wfrag.hip), for the op-level parity tests
 pvr_status pvr_op_conv_wfrag(const void *in, const void *wgt_packed, const float *bias, const void *residual, void *out, int32_t n, int32_t h, int32_t w,

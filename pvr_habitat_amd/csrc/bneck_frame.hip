@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int n = blockIdx.x;
     unsigned long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] unsigned long long fs_vm = 0, fs_bar = 0;     // (BF_FRONT_STAMPS builds: cycles the front phase spent in vmcnt waits / in its barriers)
 #define BF_TS(k_) { if (p.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_[k_]) :: "memory"); }
 #define BF_TS_OUT() { if (p.stamps && blockIdx.x == 8 && lane0 == 0 && (wave0 & 3) == 0) { _Pragma("unroll") for (int k = 0; k < 10; ++k) p.stamps[(wave0 >> 2) * 10 + k] = ts_[k]; } }
     if (p.stagger) {
@@ -274,7 +275,17 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
             BF_SLICE_I(0, WA_, N0_, N1_, RS_, KC_, KT_, H_)                                                     \
             BF_SLICE_I(1, WB_, N0_, N1_, RS_, KC_, KT_, H_)                                                     \
         }
+#ifdef BF_FRONT_STAMPS      // (experiment build: where does a half chunk of the front phase wait - for its pixels / weights, or for the other waves?)
+#define BF_CHUNK_DONE(n_) { unsigned long long a_, b_, c_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_) :: "memory");                                                 \
+        asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b_) :: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory");                                                 \
+        fs_vm += b_ - a_; fs_bar += c_ - b_; __builtin_amdgcn_sched_barrier(0); }
+#else
 #define BF_CHUNK_DONE(n_) { asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#endif
         if (tid < 16) *reinterpret_cast<u32x4 *>(smem + (4 + (tid >> 3)) * SLICE + ZROW * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};   // (the third region's unused last rows: defined)
         BF_LOAD_W(wa, rs_w1, 2 * wave, CO / 8, 0);
         BF_LOAD_W(wb, rs_w1, 2 * wave, CO / 8, 1);
@@ -576,6 +587,9 @@ __global__ __launch_bounds__(512, 1) void bneck_frame_kernel(BFP p) {
     if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BF_TS(9);
     BF_TS_OUT();
+#ifdef BF_FRONT_STAMPS
+    if (p.stamps && blockIdx.x == 8 && lane0 == 0 && (wave0 & 3) == 0) { p.stamps[20 + (wave0 >> 2) * 2] = fs_vm; p.stamps[21 + (wave0 >> 2) * 2] = fs_bar; }
+#endif
 #undef BF_TS_OUT
 #undef BF_TS
 #undef BF_BARRIER
@@ -628,6 +642,11 @@ pvr_status launch_bneck_frame(const void *t1, const void *w2p, const float *b2, 
                               void *t2_out, int n, int phases, int dtype, hipStream_t stream, unsigned long long *stamps, const void *w1np,
                               const float *b1n, void *t1n, const void *w1fp, const float *b1f) {
     const int ph = phases & 7, front = (phases & 8) != 0;
+    // the whole bottleneck (own conv1 in front) in the 64-channel tiling (bneck_frame64.hip, round 6) unless switched off or a diagnostic form is asked for
+    if (front && ph == 3 && !(phases & ~15) && !t2_out && !stamps && !w1np && w1fp && b1f && w2p && b2 && w3p && b3 && res && y && frame64_on()) {
+        ++g_bneck_frame_launches;                                 // (a per-frame bottleneck launch either way; bneck_frame64_launches() counts this tiling)
+        return launch_bneck_frame64(w1fp, b1f, w2p, b2, w3p, b3, res, y, n, dtype, stream, nullptr);
+    }
     PVR_REQUIRE(ph == 1 || ph == 3 || ph == 7, "bneck_frame: phases must be 1, 3 or 7 (+ 8: own conv1 in front; + 16 / 32: timing knock-outs of the y stores / identity loads)");
     PVR_REQUIRE((t1 || front) && w2p && b2 && (ph <= 1 || (w3p && b3 && res && y)) && (ph > 1 || t2_out) && (ph < 7 || (w1np && b1n && t1n)) &&
                 (!front || (w1fp && b1f && res && ph == 3)), "bneck_frame: null argument (the front conv1 comes with phases 3 only)");

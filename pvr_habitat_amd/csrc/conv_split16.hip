@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void conv_split16_kernel(ConvS p) {
     const int cpt = p.Cin / 32;
     int kh = 0, kw = 0, cs = 0, tap = 0;
     f32x4 ra[RPT];
-    f16x8 a_hi, a_lo, n_hi, n_lo;
+    f16x8 a_hi, a_lo = {}, n_hi, n_lo = {};          // (the lo halves exist with TERMS == 3 only)
 #define PVR_S_LOAD(ks_)                                                                                          \
     {                                                                                                            \
         const int tap_off = ((kh * p.W + kw) * p.Cin + cs * 32) * 4;                                             \

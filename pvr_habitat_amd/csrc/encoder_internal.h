@@ -56,6 +56,12 @@ struct BFBlk {
     unsigned short *y;
 };
 pvr_status launch_bneck_frame_run(const BFBlk *blocks, int nblk, int n, int dtype, hipStream_t stream, int stagger);
+// bneck_frame64.hip (round 6): the whole bottleneck per frame with ONE wave per SIMD, 64 output channels x 13 pixel tiles per wave (half the LDS reads per MFMA)
+pvr_status launch_bneck_frame64(const void *w1p, const float *b1, const void *w2p, const float *b2, const void *w3p, const float *b3, const void *x, void *y, int n,
+                                int dtype, hipStream_t stream, unsigned long long *stamps);
+bool frame64_on();
+void set_frame64(int mode);
+long long bneck_frame64_launches();
 
 // conv_wfrag.hip: implicit GEMM in 112-pixel x 256-cout tiles with the weights read from L2 as MFMA fragments (layer4 at batch 256)
 bool conv_wfrag_supported(int64_t M, int64_t in_bytes, int cin, int cout, int kh, int kw, int pad, int act, int out_f32);

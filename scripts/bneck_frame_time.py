@@ -66,13 +66,20 @@ print('%s n=%d: separate conv1 %.1f us | conv2 %.1f us (%.0f TF) + conv3 %.1f us
       % (dt, n, sep1, sep2, gf2 / sep2 * 1e3, sep3, gf3 / sep3 * 1e3, sep2 + sep3, both, f1, gf2 / f1 * 1e3, f3, (gf2 + gf3) / f3 * 1e3, f7, (gf1 + gf2 + gf3) / f7 * 1e3, all3, same), flush=True)
 
 for mode7 in ((0, 1, 2) if n > 8 else ()):
-    stamps = torch.zeros(20, dtype=torch.int64, device='cuda')
+    stamps = torch.zeros(24, dtype=torch.int64, device='cuda')
+    cold = os.environ.get('BF_COLD', '0') == '1'        # evict the Infinity Cache in front of every stamped launch (the in-network condition: x comes from HBM)
+    flush = torch.empty(768 << 20, dtype=torch.uint8, device='cuda') if cold else None
     for _ in range(20):
+        if cold:
+            flush.add_(1)
         _lib.check(L.pvr_debug_bneck_frame_stamps(vp(x), vp(w2p), vp(b2), vp(w3p), vp(b3), vp(r), vp(y2), vp(w1p) if mode7 == 1 else None, vp(b1) if mode7 == 1 else None, vp(t1n) if mode7 == 1 else None, vp(w1p) if mode7 == 2 else None, vp(b1) if mode7 == 2 else None, n, cdt, vp(stamps), st()))
     torch.cuda.synchronize()
-    t = stamps.cpu().numpy().reshape(2, 10)
+    extra = stamps.cpu().numpy()[20:]
+    t = stamps.cpu().numpy()[:20].reshape(2, 10)
     names = ['start', 'prologue done', 'conv2 loop done', 't2 written', 'conv3 start', 'chunk/round0 K loop', 'chunk/round0 epilogue', 'chunk2/round5 done', 'all issued', 'stores drained']
     print('stamps, %s:' % ('conv2 + conv3', 'conv2 + conv3 + next conv1', 'own conv1 + conv2 + conv3')[mode7])
+    if extra.any():
+        print('front phase waits (BF_FRONT_STAMPS build): group 0 vmcnt %d barrier %d | group 1 vmcnt %d barrier %d cycles' % tuple(extra))
     for g_ in range(2):
         print('group %d cycles: ' % g_ + ', '.join('%s +%d' % (names[k], t[g_, k] - t[g_, k - 1]) for k in range(1, 10)) + ' | total %d' % (t[g_, 9] - t[g_, 0]))
 

@@ -1040,6 +1040,39 @@ def test_frame_bottleneck_plan_is_bit_identical(variant, dtype, n, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_frame64_tiling_is_bit_identical(dtype):
+    """Round 6: the whole layer3 bottleneck per frame in the 64-channel tiling (bneck_frame64.hip: ONE wave per SIMD, each 64 output channels x 13 pixel tiles,
+    accumulators in the AGPR half of the register file, MFMAs as inline asm with in-place accumulators) against round 5's 32-channel tiling and against the
+    separate launches: the plan's embedding at the bench batch and a ragged one, every element, bit for bit, three times in a row; the launch counters say
+    which kernel ran."""
+    from pvr_habitat_amd.embeddings import HipResNet50
+    L = _lib.lib()
+    sd = synth.resnet50_state_dict(12)
+    try:
+        for n in (256, 133):
+            fr = torch.from_numpy(synth.smooth_frames(90 + n, n, 64, 64)).cuda()
+            m = HipResNet50(sd, 'conv5', compute_dtype=dtype, max_batch=256)
+            _lib.check(L.pvr_debug_set_frame64(0))
+            c32 = L.pvr_debug_bneck_frame_launches(); c64 = L.pvr_debug_bneck_frame64_launches()
+            ref = m(fr).clone()
+            assert L.pvr_debug_bneck_frame_launches() - c32 == 5 and L.pvr_debug_bneck_frame64_launches() == c64
+            m.set_switch('frame_min_n', 100000)                      # separate launches (member convolutions)
+            sep = m(fr).clone()
+            m.set_switch('frame_min_n', 128)
+            assert torch.equal(ref, sep)
+            _lib.check(L.pvr_debug_set_frame64(1))
+            c64 = L.pvr_debug_bneck_frame64_launches()
+            for _ in range(3):
+                out = m(fr)
+                nd = int((out != ref).sum())
+                assert nd == 0, (n, nd, float((out - ref).abs().max()))
+            assert L.pvr_debug_bneck_frame64_launches() - c64 == 15
+            m.close()
+    finally:
+        _lib.check(L.pvr_debug_set_frame64(-1))
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
 def test_frame_run_is_bit_identical_at_the_bench_batch(dtype):
     """Round 6 (opt-in, PVR_FRAME_RUN=1: measured equal to the default): layer3.1 .. 3.5 as ONE launch that takes every frame through the five bottlenecks (bneck_frame.hip RUN: the workgroup that wrote a frame's y
     reads it back as the next x and identity; between two bottlenecks: stores retired + a workgroup barrier) against one launch per
