@@ -170,31 +170,38 @@ __global__ __launch_bounds__(256) void attention_kernel(const u16 *__restrict__ 
     const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(base), 0, (unsigned)((size_t)T * rs * 2), 0x00020000);
     constexpr int OOB = 0x7ffffff0;
     auto kaddr = [&](int row, int ch) { return HD == 64 ? row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) : row * KS + (ch << 4); };
-    // K / V fill: all global loads of a batch are issued before the first LDS write, so a wave pays the load latency once per
-    // batch instead of once per 16-byte chunk (the kernel is latency-bound: SQ_WAIT_ANY 53 %, MFMA busy 6 %)
-    constexpr int NIT = (MAXNT * 16 * KCH + 255) / 256, FB = 7;
+    // K / V fill.  A thread owns FOUR consecutive key rows x one 16-byte chunk: the four K chunks go to LDS as they are, the four V chunks are transposed in
+    // registers (v_perm) and leave as eight 8-byte stores of four keys each - until round 5 every V element was its own 2-byte store (32 per item instead of
+    // 8; round 6: no measurable change of the launch, 106 us per layer either way - the fill is not what the kernel waits for).  All global loads of a thread are issued before its first LDS write, so a wave pays the load latency once (the kernel is latency-bound:
+    // SQ_WAIT_ANY 53 %, MFMA busy 6 %).
+    constexpr int NG = MAXNT * 4, NITEM = NG * KCH, NIT = (NITEM + 255) / 256;      // row groups of 4 (TK <= 16 MAXNT), items, items per thread
+    {
+        u32x4 kv[NIT][4], vv[NIT][4];
 #pragma unroll
-    for (int i0 = 0; i0 < NIT; i0 += FB) {
-        u32x4 kv[FB], vv[FB];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it, rg = idx / KCH, ch = idx % KCH;
 #pragma unroll
-        for (int i = 0; i < FB; ++i) {
-            const int idx = tid + 256 * (i0 + i);
-            const int row = idx / KCH, ch = idx % KCH;
-            const bool okl = i0 + i < NIT && idx < TK * KCH && row < T && ch * 8 < HD;
-            const int off = okl ? (int)(((size_t)row * rs + W + ch * 8) * 2) : OOB;
-            kv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, off, 0, 0));
-            vv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, okl ? off + W * 2 : OOB, 0, 0));
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rg + r;
+                const bool okl = idx < NITEM && row < T && row < TK && ch * 8 < HD;
+                const int off = okl ? (int)(((size_t)row * rs + W + ch * 8) * 2) : OOB;
+                kv[it][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, off, 0, 0));
+                vv[it][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, okl ? off + W * 2 : OOB, 0, 0));
+            }
         }
 #pragma unroll
-        for (int i = 0; i < FB; ++i) {
-            const int idx = tid + 256 * (i0 + i);
-            if (i0 + i >= NIT || idx >= TK * KCH) continue;
-            const int row = idx / KCH, ch = idx % KCH;
-            *reinterpret_cast<u32x4 *>(Ks + kaddr(row, ch)) = kv[i];
-            if (ch * 8 < HD) {
-                const u16 *ve = reinterpret_cast<const u16 *>(&vv[i]);
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it, rg = idx / KCH, ch = idx % KCH;
+            if (idx >= NITEM || 4 * rg >= TK) continue;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = ve[e];
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<u32x4 *>(Ks + kaddr(4 * rg + r, ch)) = kv[it][r];
+            if (ch * 8 < HD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;          // the odd / even halfword of both dwords
+                    const uint2 o = {__builtin_amdgcn_perm(vv[it][1][e >> 1], vv[it][0][e >> 1], sel), __builtin_amdgcn_perm(vv[it][3][e >> 1], vv[it][2][e >> 1], sel)};
+                    *reinterpret_cast<uint2 *>(Vt + (size_t)(ch * 8 + e) * VS + 4 * rg) = o;
+                }
             }
         }
     }
