@@ -332,9 +332,17 @@ def finetune_bench(steps, warmup):
         opt.scheduler_step(); loss, gn = opt.step(o, d, a)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # algorithmic work of one iteration (SURVEY 8d conventions: forward MACs x 2 FLOP x 3 for forward + both backward products): the conv stack is
+    # 4.02 MMAC per 64x64x3 frame x 3200 frames; the policy behind it is PolicyNet's 22.02 MMAC per sample with a 256-wide first layer
+    # instead of 4096 (-3.93 MMAC) x 1600 samples
+    gflop = (4.02 * T * B * 2 + (22.02 - 3.93) * T * B) * 2 * 3 / 1e3
+    tf = gflop * steps / el / 1e3
     return {'metric': 'finetune steps/sec (PolicyNetWithConv T=100 B=16, 64x64x6 uint8, BN, fp32)', 'value': round(steps / el, 2), 'unit': 'steps/s',
             'ms_per_step': round(el / steps * 1e3, 3), 'frames_per_s_through_conv_stack': round(steps * T * B * 2 / el), 'dtype': 'f32',
-            'final_loss': round(float(loss), 5)}
+            'final_loss': round(float(loss), 5),
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'whole iteration (direct-conv forward / backward kernels + f32-input MFMA GEMMs + recurrences), algorithmic %.1f GFLOP/step; '
+                                   'like the BC step it is a chain of dependent launches (T = 100 sequential BPTT steps at the launch floor), not a kernel on a roof' % gflop}}
 
 
 VIT_GFLOP = {'clip_b32': 8.82, 'clip_b16': 35.13}      # per frame
