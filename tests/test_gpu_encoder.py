@@ -183,6 +183,18 @@ def test_frame_bottleneck_op_is_bit_identical(dt, n):
     torch.cuda.synchronize()
     assert same(t2b, t2f_ref), diff(t2b, t2f_ref)
     assert torch.isfinite(y.float()).all() and same(y, yf_ref), diff(y, yf_ref)
+    # the same launch in both tilings (round 6: bneck_frame64.hip, one wave per SIMD x 64 output channels; it has no t2 tap)
+    try:
+        for mode in (0, 1):
+            _lib.check(L.pvr_debug_set_frame64(mode))
+            c64 = L.pvr_debug_bneck_frame64_launches()
+            y2 = torch.full((n, 14, 14, 1024), float('nan'), dtype=tdt, device='cuda')
+            _lib.check(L.pvr_op_bneck_frame(None, vp(w2), vp(b2), vp(w3), vp(b3), vp(r), vp(y2), None, None, None, None, vp(w1), vp(b1), n, 3 | 8, cdt, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert L.pvr_debug_bneck_frame64_launches() - c64 == mode
+            assert torch.isfinite(y2.float()).all() and same(y2, yf_ref), (mode, diff(y2, yf_ref))
+    finally:
+        _lib.check(L.pvr_debug_set_frame64(-1))
 
 
 WF_CASES = [
@@ -1099,6 +1111,14 @@ def test_frame_run_is_bit_identical_at_the_bench_batch(dtype):
                     assert torch.equal(out, ref)
                 assert L.pvr_debug_bneck_frame_launches() - before == 5
         m.set_switch('frame_stagger', 0)
+        # a handful of frames (below the plan's threshold the member convolutions run; forced here): one workgroup per frame, most CUs idle
+        fr = torch.from_numpy(synth.smooth_frames(77, 5, 64, 64)).cuda()
+        m.set_switch('frame_run', 0)
+        ref = m(fr).clone()
+        m.set_switch('frame_min_n', 1)
+        m.set_switch('frame_run', 1)
+        assert m.kernel_names(5).count('bneck_frame(run)') == 1
+        assert torch.equal(m(fr), ref)
     finally:
         m.close()
 
